@@ -1,0 +1,808 @@
+/*
+ * kvz_oracle.c -- CPU restatement of Kvazaar's `generic` block kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY (see kvz_oracle.h).  Plain C99, scalar, one thread.
+ * All paths cited are relative to /root/reference/src.
+ */
+#include "kvz_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_CLIP(lo, hi, v) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
+
+/* ------------------------------------------------------------------ */
+/* picture group                                                      */
+/* ------------------------------------------------------------------ */
+
+/* picture-generic.c:30-48.  The argument is an int16: callers that pass a
+ * wider value get it truncated first.  Any bit outside 0..255 set => the
+ * result is the low byte of (-v >> 15): v < 0 gives 0, v > 255 gives -1 i.e.
+ * 255.  v == -32768 negates to +32768 in int arithmetic, >> 15 == 1: byte 1. */
+orc_pixel orc_fast_clip_16bit_to_pixel(int16_t value)
+{
+  if (value & ~255) {
+    int16_t t = (int16_t)((-(int)value) >> 15);
+    return (orc_pixel)t;
+  }
+  return (orc_pixel)value;
+}
+
+/* picture-generic.c:52-70.  -INT32_MIN is evaluated with wrap-around (the
+ * reference relies on two's complement): result byte 0xFF. */
+orc_pixel orc_fast_clip_32bit_to_pixel(int32_t value)
+{
+  if (value & ~255) {
+    int32_t neg = (int32_t)(0u - (uint32_t)value);
+    return (orc_pixel)(neg >> 31);
+  }
+  return (orc_pixel)value;
+}
+
+/* picture-generic.c:86-99 */
+unsigned orc_reg_sad(const orc_pixel *d1, const orc_pixel *d2, int w, int h,
+                     unsigned stride1, unsigned stride2)
+{
+  unsigned sad = 0;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x)
+      sad += (unsigned)abs((int)d1[(size_t)y * stride1 + x] - (int)d2[(size_t)y * stride2 + x]);
+  return sad;
+}
+
+/* picture-generic.c:460-486 (SAD_NXN); >> (bitdepth-8) == >> 0 */
+unsigned orc_sad_nxn(int n, const orc_pixel *b1, const orc_pixel *b2)
+{
+  unsigned sum = 0;
+  for (int i = 0; i < n * n; ++i) sum += (unsigned)abs((int)b1[i] - (int)b2[i]);
+  return sum;
+}
+
+/* Sum of |H * D * H^T| for an order-N Hadamard matrix.  The reference's
+ * butterflies (picture-generic.c:105-184, :240-328) compute the same set of
+ * coefficients in a different (sequency) order and sign; the absolute sum is
+ * invariant to both. */
+static int32_t hadamard_abs_sum(const int32_t *d, int n)
+{
+  int32_t t[64], sum = 0;
+  /* rows: t = D * H^T  (H[k][i] = (-1)^popcount(k & i)) */
+  for (int y = 0; y < n; ++y)
+    for (int k = 0; k < n; ++k) {
+      int32_t acc = 0;
+      for (int x = 0; x < n; ++x)
+        acc += (__builtin_popcount(k & x) & 1) ? -d[y * n + x] : d[y * n + x];
+      t[y * n + k] = acc;
+    }
+  /* columns */
+  for (int k = 0; k < n; ++k)
+    for (int x = 0; x < n; ++x) {
+      int32_t acc = 0;
+      for (int y = 0; y < n; ++y)
+        acc += (__builtin_popcount(k & y) & 1) ? -t[y * n + x] : t[y * n + x];
+      sum += abs(acc);
+    }
+  return sum;
+}
+
+/* picture-generic.c:201-213 + :105-184: (sum + 1) >> 1 */
+unsigned orc_satd_4x4_subblock(const orc_pixel *b1, int s1, const orc_pixel *b2, int s2)
+{
+  int32_t d[16];
+  for (int y = 0; y < 4; ++y)
+    for (int x = 0; x < 4; ++x) d[y * 4 + x] = (int)b1[y * s1 + x] - (int)b2[y * s2 + x];
+  return (unsigned)((hadamard_abs_sum(d, 4) + 1) >> 1);
+}
+
+/* picture-generic.c:189-196 */
+unsigned orc_satd_4x4(const orc_pixel *b1, const orc_pixel *b2)
+{
+  return orc_satd_4x4_subblock(b1, 4, b2, 4);
+}
+
+/* picture-generic.c:240-328: (sum + 2) >> 2 per 8x8 */
+unsigned orc_satd_8x8_subblock(const orc_pixel *b1, int s1, const orc_pixel *b2, int s2)
+{
+  int32_t d[64];
+  for (int y = 0; y < 8; ++y)
+    for (int x = 0; x < 8; ++x) d[y * 8 + x] = (int)b1[y * s1 + x] - (int)b2[y * s2 + x];
+  return (unsigned)((hadamard_abs_sum(d, 8) + 2) >> 2);
+}
+
+/* strategies-picture.h:40-56 (SATD_NxN) and picture-generic.c:189 for n==4 */
+unsigned orc_satd_nxn(int n, const orc_pixel *b1, const orc_pixel *b2)
+{
+  if (n == 4) return orc_satd_4x4(b1, b2);
+  unsigned sum = 0;
+  for (int y = 0; y < n; y += 8)
+    for (int x = 0; x < n; x += 8)
+      sum += orc_satd_8x8_subblock(&b1[y * n + x], n, &b2[y * n + x], n);
+  return sum;
+}
+
+/* strategies-picture.h:62-100 (SATD_ANY_SIZE) */
+unsigned orc_satd_any_size(int w, int h, const orc_pixel *b1, int s1,
+                           const orc_pixel *b2, int s2)
+{
+  unsigned sum = 0;
+  if (w % 8 != 0) {               /* first 4-px column in 4x4s */
+    for (int y = 0; y < h; y += 4)
+      sum += orc_satd_4x4_subblock(&b1[y * s1], s1, &b2[y * s2], s2);
+    b1 += 4; b2 += 4; w -= 4;
+  }
+  if (h % 8 != 0) {               /* first 4-px row of what is left */
+    for (int x = 0; x < w; x += 4)
+      sum += orc_satd_4x4_subblock(&b1[x], s1, &b2[x], s2);
+    b1 += 4 * s1; b2 += 4 * s2; h -= 4;
+  }
+  for (int y = 0; y < h; y += 8)
+    for (int x = 0; x < w; x += 8)
+      sum += orc_satd_8x8_subblock(&b1[y * s1 + x], s1, &b2[y * s2 + x], s2);
+  return sum;
+}
+
+/* picture-generic.c:497-519 */
+void orc_sad_nxn_dual(int n, const orc_pixel *preds, size_t pred_stride,
+                      const orc_pixel *orig, unsigned costs[2])
+{
+  costs[0] = orc_sad_nxn(n, preds, orig);
+  costs[1] = orc_sad_nxn(n, preds + pred_stride, orig);
+}
+
+/* picture-generic.c:357-390 */
+void orc_satd_nxn_dual(int n, const orc_pixel *preds, size_t pred_stride,
+                       const orc_pixel *orig, unsigned costs[2])
+{
+  costs[0] = orc_satd_nxn(n, preds, orig);
+  costs[1] = orc_satd_nxn(n, preds + pred_stride, orig);
+}
+
+/* picture-generic.c:392-456.  The 4x4 stages of the reference write a scratch
+ * `sums[]` that is never accumulated, and the 8x8 loop re-bases its pointers to
+ * the block origin, so their only effect is `width -= 4` / `height -= 4`.
+ * What is summed is therefore the 8x8 grid over [0,w') x [0,h') from the
+ * ORIGIN (w' = w-4 if w%8 else w), each 8x8 read in full. */
+void orc_satd_any_size_quad(int w, int h, const orc_pixel *const preds[4], int stride,
+                            const orc_pixel *orig, int orig_stride, unsigned costs[4])
+{
+  if (w % 8 != 0) w -= 4;
+  if (h % 8 != 0) h -= 4;
+  for (int k = 0; k < 4; ++k) {
+    unsigned sum = 0;
+    for (int y = 0; y < h; y += 8)
+      for (int x = 0; x < w; x += 8)
+        sum += orc_satd_8x8_subblock(&orig[y * orig_stride + x], orig_stride,
+                                     &preds[k][y * stride + x], stride);
+    costs[k] = sum;
+  }
+}
+
+/* picture-generic.c:521-536 */
+unsigned orc_pixels_calc_ssd(const orc_pixel *ref, const orc_pixel *rec,
+                             int ref_stride, int rec_stride, int width)
+{
+  int ssd = 0;
+  for (int y = 0; y < width; ++y)
+    for (int x = 0; x < width; ++x) {
+      int d = (int)ref[x + y * ref_stride] - (int)rec[x + y * rec_stride];
+      ssd += d * d;
+    }
+  return (unsigned)ssd;
+}
+
+/* picture-generic.c:538-588 for one plane: samples are held in int16,
+ * shift = 15 - 8 = 7, offset = 64. */
+void orc_bipred_blend_plane(int w, int h,
+                            int hi_prec0, const int16_t *hp0, const orc_pixel *px0, int stride0,
+                            int hi_prec1, const int16_t *hp1, const orc_pixel *px1, int stride1,
+                            orc_pixel *dst, int dst_stride)
+{
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int16_t s0 = hi_prec0 ? hp0[y * stride0 + x] : (int16_t)(px0[y * stride0 + x] << 6);
+      int16_t s1 = hi_prec1 ? hp1[y * stride1 + x] : (int16_t)(px1[y * stride1 + x] << 6);
+      dst[y * dst_stride + x] = orc_fast_clip_32bit_to_pixel((s0 + s1 + 64) >> 7);
+    }
+}
+
+/* image.c:455-486 with :320-444: the branchy cor/ver/hor_sad decomposition is
+ * exactly a SAD against the edge-replicated reference (coordinates clamped to
+ * the frame), which is what is restated here. */
+unsigned orc_image_calc_sad(const orc_pixel *pic, int pic_stride,
+                            const orc_pixel *ref, int ref_stride, int ref_w, int ref_h,
+                            int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh)
+{
+  unsigned sad = 0;
+  for (int y = 0; y < bh; ++y) {
+    int ry = ORC_CLIP(0, ref_h - 1, ref_y + y);
+    for (int x = 0; x < bw; ++x) {
+      int rx = ORC_CLIP(0, ref_w - 1, ref_x + x);
+      sad += (unsigned)abs((int)pic[(pic_y + y) * pic_stride + pic_x + x] - (int)ref[ry * ref_stride + rx]);
+    }
+  }
+  return sad;
+}
+
+/* image.c:488-545: inside => satd_any_size on the frame; else on an
+ * edge-replicated copy (kvz_get_extended_block with filter_size 0). */
+unsigned orc_image_calc_satd(const orc_pixel *pic, int pic_stride,
+                             const orc_pixel *ref, int ref_stride, int ref_w, int ref_h,
+                             int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh)
+{
+  orc_pixel *tmp = (orc_pixel *)malloc((size_t)bw * bh);
+  for (int y = 0; y < bh; ++y) {
+    int ry = ORC_CLIP(0, ref_h - 1, ref_y + y);
+    for (int x = 0; x < bw; ++x) {
+      int rx = ORC_CLIP(0, ref_w - 1, ref_x + x);
+      tmp[y * bw + x] = ref[ry * ref_stride + rx];
+    }
+  }
+  unsigned r = orc_satd_any_size(bw, bh, &pic[pic_y * pic_stride + pic_x], pic_stride, tmp, bw);
+  free(tmp);
+  return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* dct group                                                          */
+/* ------------------------------------------------------------------ */
+
+/* HEVC core transform (dct-generic.c:34-108): first column of the 32-point
+ * matrix; entry (k,n) = +-c[m] with m folded from k*(2n+1) mod 128 by the
+ * cosine symmetries.  The 16/8/4-point matrices are the even rows of the next
+ * larger one restricted to the first half of the columns. */
+static const int16_t c32[32] = {
+  64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+  64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4 };
+
+static int16_t g_mat[4][32 * 32];   /* [log2n - 2][k*n + i] */
+static int g_mat_ready = 0;
+
+static void build_matrices(void)
+{
+  int16_t m32[32][32];
+  for (int k = 0; k < 32; ++k)
+    for (int n = 0; n < 32; ++n) {
+      int m = (k * (2 * n + 1)) % 128, sign = 1;
+      if (m > 64) m = 128 - m;            /* cos(2pi - a) = cos a  */
+      if (m > 32) { m = 64 - m; sign = -1; }  /* cos(pi - a) = -cos a */
+      m32[k][n] = (int16_t)((m == 32) ? 0 : sign * c32[m]);
+    }
+  for (int l = 0; l < 4; ++l) {
+    int n = 4 << l, step = 32 / n;
+    for (int k = 0; k < n; ++k)
+      for (int i = 0; i < n; ++i) g_mat[l][k * n + i] = m32[k * step][i];
+  }
+  g_mat_ready = 1;
+}
+
+/* HEVC 4x4 DST-VII (dct-generic.c:26-32) */
+static const int16_t dst4[16] = {
+  29, 55, 74, 84,
+  74, 74, 0, -74,
+  84, -29, -74, 55,
+  55, -84, 74, -29 };
+
+const int16_t *orc_dct_matrix(int n)
+{
+  if (!g_mat_ready) build_matrices();
+  switch (n) { case 4: return g_mat[0]; case 8: return g_mat[1];
+               case 16: return g_mat[2]; case 32: return g_mat[3]; }
+  return NULL;
+}
+const int16_t *orc_dst4_matrix(void) { return dst4; }
+
+/* forward pass (partial_butterfly_N_generic, dct-generic.c:243-266 etc.):
+ * dst[k][j] = (short)((sum_i M[k][i] * src[j][i] + add) >> shift) -- the cast
+ * truncates (wraps), it does not clip. */
+static void fwd_pass(const int16_t *M, int n, const int16_t *src, int16_t *dst, int shift)
+{
+  int32_t add = 1 << (shift - 1);
+  for (int j = 0; j < n; ++j)
+    for (int k = 0; k < n; ++k) {
+      int32_t acc = 0;
+      for (int i = 0; i < n; ++i) acc += (int32_t)M[k * n + i] * src[j * n + i];
+      dst[k * n + j] = (int16_t)((acc + add) >> shift);
+    }
+}
+
+/* inverse pass (partial_butterfly_inverse_N_generic, :269-293 etc.):
+ * dst[j][i] = clip16((sum_k M[k][i] * src[k][j] + add) >> shift) */
+static void inv_pass(const int16_t *M, int n, const int16_t *src, int16_t *dst, int shift)
+{
+  int32_t add = 1 << (shift - 1);
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) {
+      int32_t acc = 0;
+      for (int k = 0; k < n; ++k) acc += (int32_t)M[k * n + i] * src[k * n + j];
+      int32_t v = (acc + add) >> shift;
+      dst[j * n + i] = (int16_t)ORC_CLIP(-32768, 32767, v);
+    }
+}
+
+/* dct-generic.c:567-617.  bitdepth 8: forward shifts log2(n)-1 and log2(n)+6,
+ * inverse shifts 7 and 12. */
+void orc_transform(int kind, int n, const int16_t *in, int16_t *out)
+{
+  int16_t tmp[32 * 32];
+  int log2n = (n == 4) ? 2 : (n == 8) ? 3 : (n == 16) ? 4 : 5;
+  const int16_t *M = (kind == ORC_DST || kind == ORC_IDST) ? dst4 : orc_dct_matrix(n);
+  if (kind == ORC_DCT || kind == ORC_DST) {
+    fwd_pass(M, n, in, tmp, log2n - 1);
+    fwd_pass(M, n, tmp, out, log2n + 6);
+  } else {
+    inv_pass(M, n, in, tmp, 7);
+    inv_pass(M, n, tmp, out, 12);
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* quant group                                                        */
+/* ------------------------------------------------------------------ */
+
+static const uint8_t chroma_scale[58] = {           /* transform.c:44-50 */
+   0, 1, 2, 3, 4, 5, 6, 7, 8, 9,10,11,12,13,14,15,16,
+  17,18,19,20,21,22,23,24,25,26,27,28,29,29,30,31,32,
+  33,33,34,34,35,35,36,36,37,37,38,39,40,41,42,43,44,
+  45,46,47,48,49,50,51 };
+static const int16_t quant_scales[6]     = { 26214, 23302, 20560, 18396, 16384, 14564 }; /* scalinglist.c:66 */
+static const int16_t inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };                    /* scalinglist.c:67 */
+
+/* transform.c:129-143 */
+int32_t orc_get_scaled_qp(int type, int qp, int qp_offset)
+{
+  if (type == 0) return qp + qp_offset;
+  int32_t q = ORC_CLIP(-qp_offset, 57, qp);
+  return (q < 0) ? q + qp_offset : chroma_scale[q] + qp_offset;
+}
+
+/* kvz_g_sig_last_scan[scan_idx][log2_size - 1] (tables.c, generated by
+ * tools/generate_tables.c): scan_idx 0 = up-right diagonal, 1 = horizontal,
+ * 2 = vertical; blocks >= 8x8 are scanned in 4x4 coefficient groups, groups
+ * and positions inside a group both following the pattern. */
+static uint32_t g_scan[3][6][32 * 32];
+static int g_scan_ready = 0;
+
+static int pattern_order(int scan_idx, int n, int *xs, int *ys)
+{
+  int c = 0;
+  if (scan_idx == 1) { for (int y = 0; y < n; ++y) for (int x = 0; x < n; ++x) { xs[c] = x; ys[c] = y; ++c; } }
+  else if (scan_idx == 2) { for (int x = 0; x < n; ++x) for (int y = 0; y < n; ++y) { xs[c] = x; ys[c] = y; ++c; } }
+  else {
+    for (int d = 0; d < 2 * n - 1; ++d)       /* anti-diagonals, bottom-left to top-right */
+      for (int y = (d < n ? d : n - 1); y >= 0 && d - y < n; --y) { xs[c] = d - y; ys[c] = y; ++c; }
+  }
+  return c;
+}
+
+static void build_scans(void)
+{
+  for (int s = 0; s < 3; ++s)
+    for (int l = 1; l <= 5; ++l) {
+      int n = 1 << l, c = 0;
+      uint32_t *out = g_scan[s][l];
+      int xs[64], ys[64];
+      if (n <= 4) {
+        int cnt = pattern_order(s, n, xs, ys);
+        for (int i = 0; i < cnt; ++i) out[c++] = (uint32_t)(ys[i] * n + xs[i]);
+      } else {
+        int gx[64], gy[64], g = n / 4;
+        int ng = pattern_order(s, g, gx, gy);
+        int np = pattern_order(s, 4, xs, ys);
+        for (int i = 0; i < ng; ++i)
+          for (int j = 0; j < np; ++j)
+            out[c++] = (uint32_t)((gy[i] * 4 + ys[j]) * n + gx[i] * 4 + xs[j]);
+      }
+    }
+  g_scan_ready = 1;
+}
+
+const uint32_t *orc_scan_order(int scan_idx, int log2_size)
+{
+  if (!g_scan_ready) build_scans();
+  return g_scan[scan_idx][log2_size];
+}
+
+static int log2_of(int w) { int l = 0; while ((1 << l) < w) ++l; return l; }
+
+/* quant-generic.c:37-163 */
+void orc_quant(const orc_quant_params *p, const orc_coeff *coef, orc_coeff *q_coef,
+               int w, int h, int type, int scan_idx, int block_is_intra)
+{
+  (void)block_is_intra;   /* only selects the scaling list, which the caller resolved */
+  const int log2_tr = log2_of(w);
+  const uint32_t *scan = orc_scan_order(scan_idx, log2_tr);
+  const int32_t qp_scaled = orc_get_scaled_qp(type, p->qp, 0);
+  const int32_t transform_shift = 15 - 8 - log2_tr;
+  const int32_t q_bits = 14 + qp_scaled / 6 + transform_shift;
+  const int32_t add = (p->slice_is_intra ? 171 : 85) << (q_bits - 9);
+  const int32_t q_bits8 = q_bits - 8;
+  const int32_t flat = quant_scales[qp_scaled % 6];
+  const int n_coef = w * h;
+  uint32_t ac_sum = 0;
+
+  for (int n = 0; n < n_coef; ++n) {
+    int32_t qc = (p->scaling_list && p->quant_coeff) ? p->quant_coeff[n] : flat;
+    int32_t level = coef[n];
+    int32_t sign = level < 0 ? -1 : 1;
+    level = (int32_t)(((int64_t)abs(level) * qc + add) >> q_bits);
+    ac_sum += (uint32_t)level;
+    level *= sign;
+    q_coef[n] = (orc_coeff)ORC_CLIP(-32768, 32767, level);
+  }
+  if (!p->signhide || ac_sum < 2) return;
+
+  /* sign bit hiding, :69-162 */
+  int32_t delta_u[32 * 32];
+  for (int n = 0; n < n_coef; ++n) {
+    int32_t qc = (p->scaling_list && p->quant_coeff) ? p->quant_coeff[n] : flat;
+    int64_t prod = (int64_t)abs((int)coef[n]) * qc;
+    int32_t level = (int32_t)((prod + add) >> q_bits);
+    delta_u[n] = (int32_t)((prod - ((int64_t)(int32_t)((uint32_t)level << q_bits))) >> q_bits8);
+  }
+
+  int32_t last_cg = -1;
+  for (int subset = (n_coef - 1) >> 4; subset >= 0; --subset) {
+    const int subpos = subset << 4;
+    int first_nz = 16, last_nz = -1, abssum = 0, n;
+    for (n = 15; n >= 0; --n) if (q_coef[scan[n + subpos]]) { last_nz = n; break; }
+    for (n = 0; n < 16; ++n)  if (q_coef[scan[n + subpos]]) { first_nz = n; break; }
+    for (n = first_nz; n <= last_nz; ++n) abssum += q_coef[scan[n + subpos]];
+    if (last_nz >= 0 && last_cg == -1) last_cg = 1;
+
+    if (last_nz - first_nz >= 4) {
+      int32_t signbit = q_coef[scan[subpos + first_nz]] > 0 ? 0 : 1;
+      if (signbit != (abssum & 1)) {
+        int32_t min_cost_inc = 0x7fffffff, min_pos = -1, cur_cost = 0x7fffffff;
+        int16_t final_change = 0, cur_change = 0;
+        for (n = (last_cg == 1 ? last_nz : 15); n >= 0; --n) {
+          uint32_t pos = scan[n + subpos];
+          if (q_coef[pos] != 0) {
+            if (delta_u[pos] > 0) { cur_cost = -delta_u[pos]; cur_change = 1; }
+            else if (n == first_nz && abs((int)q_coef[pos]) == 1) { cur_cost = 0x7fffffff; }
+            else { cur_cost = delta_u[pos]; cur_change = -1; }
+          } else if (n < first_nz && ((coef[pos] >= 0) ? 0 : 1) != signbit) {
+            cur_cost = 0x7fffffff;
+          } else { cur_cost = -delta_u[pos]; cur_change = 1; }
+          if (cur_cost < min_cost_inc) { min_cost_inc = cur_cost; final_change = cur_change; min_pos = (int32_t)pos; }
+        }
+        if (q_coef[min_pos] == 32767 || q_coef[min_pos] == -32768) final_change = -1;
+        if (coef[min_pos] >= 0) q_coef[min_pos] = (orc_coeff)(q_coef[min_pos] + final_change);
+        else                    q_coef[min_pos] = (orc_coeff)(q_coef[min_pos] - final_change);
+      }
+    }
+    if (last_cg == 1) last_cg = 0;
+  }
+}
+
+/* quant-generic.c:279-321 */
+void orc_dequant(const orc_quant_params *p, const orc_coeff *q_coef, orc_coeff *coef,
+                 int w, int h, int type, int block_is_intra)
+{
+  (void)block_is_intra;
+  const int log2_tr = log2_of(w);
+  const int32_t transform_shift = 15 - 8 - log2_tr;
+  const int32_t qp_scaled = orc_get_scaled_qp(type, p->qp, 0);
+  int32_t shift = 20 - 14 - transform_shift;
+  const int n_coef = w * h;
+
+  if (p->scaling_list && p->dequant_coeff) {
+    shift += 4;
+    if (shift > qp_scaled / 6) {
+      int32_t add = 1 << (shift - qp_scaled / 6 - 1);
+      for (int n = 0; n < n_coef; ++n) {
+        int32_t v = (q_coef[n] * p->dequant_coeff[n] + add) >> (shift - qp_scaled / 6);
+        coef[n] = (orc_coeff)ORC_CLIP(-32768, 32767, v);
+      }
+    } else {
+      for (int n = 0; n < n_coef; ++n) {
+        int32_t v = ORC_CLIP(-32768, 32767, q_coef[n] * p->dequant_coeff[n]);
+        v = (int32_t)((uint32_t)v << (qp_scaled / 6 - shift));
+        coef[n] = (orc_coeff)ORC_CLIP(-32768, 32767, v);
+      }
+    }
+  } else {
+    int32_t scale = inv_quant_scales[qp_scaled % 6] << (qp_scaled / 6);
+    int32_t add = 1 << (shift - 1);
+    for (int n = 0; n < n_coef; ++n) {
+      int32_t v = (int32_t)((uint32_t)((int32_t)q_coef[n] * scale) + (uint32_t)add) >> shift;
+      coef[n] = (orc_coeff)ORC_CLIP(-32768, 32767, v);
+    }
+  }
+}
+
+/* quant-generic.c:323-330 */
+uint32_t orc_coeff_abs_sum(const orc_coeff *c, size_t len)
+{
+  uint32_t sum = 0;
+  for (size_t i = 0; i < len; ++i) sum += (uint32_t)abs((int)c[i]);
+  return sum;
+}
+
+/* quant-generic.c:180-273, rdoq disabled.  transform choice: strategies-dct.c:66-85
+ * (4x4 intra luma => DST).  trskip: transform.c:150-180. */
+int orc_quantize_residual(const orc_quant_params *p, int cu_is_intra, int width, int color,
+                          int scan_order, int use_trskip, int in_stride, int out_stride,
+                          const orc_pixel *ref_in, const orc_pixel *pred_in,
+                          orc_pixel *rec_out, orc_coeff *coeff_out)
+{
+  int16_t residual[32 * 32];
+  orc_coeff coeff[32 * 32];
+  const int log2_tr = log2_of(width);
+  const int ts_shift = 15 - 8 - log2_tr;
+  const int use_dst = (width == 4 && color == 0 && cu_is_intra);
+  int has_coeffs = 0;
+
+  for (int y = 0; y < width; ++y)
+    for (int x = 0; x < width; ++x)
+      residual[x + y * width] = (int16_t)((int)ref_in[x + y * in_stride] - (int)pred_in[x + y * in_stride]);
+
+  if (use_trskip) {
+    for (int i = 0; i < width * width; ++i) coeff[i] = (orc_coeff)((int)residual[i] << ts_shift);
+  } else {
+    orc_transform(use_dst ? ORC_DST : ORC_DCT, width, residual, coeff);
+  }
+
+  orc_quant(p, coeff, coeff_out, width, width, color == 0 ? 0 : 2, scan_order, cu_is_intra);
+
+  for (int i = 0; i < width * width; ++i) if (coeff_out[i] != 0) { has_coeffs = 1; break; }
+
+  if (has_coeffs) {
+    orc_dequant(p, coeff_out, coeff, width, width, color == 0 ? 0 : (color == 1 ? 2 : 3), cu_is_intra);
+    if (use_trskip) {
+      int32_t offset = 1 << (ts_shift - 1);
+      for (int i = 0; i < width * width; ++i) residual[i] = (int16_t)((coeff[i] + offset) >> ts_shift);
+    } else {
+      orc_transform(use_dst ? ORC_IDST : ORC_IDCT, width, coeff, residual);
+    }
+    for (int y = 0; y < width; ++y)
+      for (int x = 0; x < width; ++x) {
+        int16_t val = (int16_t)(residual[x + y * width] + pred_in[x + y * in_stride]);
+        rec_out[x + y * out_stride] = (orc_pixel)ORC_CLIP(0, 255, val);
+      }
+  } else if (rec_out != pred_in) {
+    for (int y = 0; y < width; ++y)
+      for (int x = 0; x < width; ++x) rec_out[x + y * out_stride] = pred_in[x + y * in_stride];
+  }
+  return has_coeffs;
+}
+
+/* ------------------------------------------------------------------ */
+/* ipol group                                                         */
+/* ------------------------------------------------------------------ */
+
+const int8_t orc_luma_filter[4][8] = {          /* filter.c:54-60 */
+  {  0, 0,   0, 64,  0,   0, 0,  0 },
+  { -1, 4, -10, 58, 17,  -5, 1,  0 },
+  { -1, 4, -11, 40, 40, -11, 4, -1 },
+  {  0, 1,  -5, 17, 58, -10, 4, -1 } };
+const int8_t orc_chroma_filter[8][4] = {        /* filter.c:62-72 */
+  {  0, 64,  0,  0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+  { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+
+static int32_t fir_px(const int8_t *f, int taps, const orc_pixel *d, int step)
+{
+  int32_t t = 0;
+  for (int i = 0; i < taps; ++i) t += f[i] * d[i * step];
+  return t;
+}
+static int32_t fir_s16(const int8_t *f, int taps, const int16_t *d, int step)
+{
+  int32_t t = 0;
+  for (int i = 0; i < taps; ++i) t += f[i] * d[i * step];
+  return t;
+}
+
+/* Two-pass separable filter shared by ipol-generic.c:122-190 and :660-728:
+ * horizontal pass over h+taps-1 rows into int16, vertical pass >> 6. */
+static void sample_two_pass(const int8_t *hf, const int8_t *vf, int taps,
+                            const orc_pixel *src, int src_stride, int w, int h,
+                            orc_pixel *dst8, int16_t *dst16, int dst_stride)
+{
+  const int off = taps / 2 - 1;                /* 3 luma, 1 chroma */
+  int16_t *hor = (int16_t *)malloc(sizeof(int16_t) * (size_t)(h + taps - 1) * (size_t)w);
+  for (int y = 0; y < h + taps - 1; ++y)
+    for (int x = 0; x < w; ++x)
+      hor[y * w + x] = (int16_t)fir_px(hf, taps, &src[src_stride * (y - off) + (x - off)], 1);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      int32_t v = fir_s16(vf, taps, &hor[y * w + x], w) >> 6;
+      if (dst16) dst16[y * dst_stride + x] = (int16_t)v;
+      else       dst8[y * dst_stride + x] = orc_fast_clip_32bit_to_pixel((v + 32) >> 6);
+    }
+  free(hor);
+}
+
+void orc_sample_quarterpel_luma(const orc_pixel *src, int src_stride, int w, int h,
+                                orc_pixel *dst, int dst_stride, const int16_t mv[2])
+{
+  sample_two_pass(orc_luma_filter[mv[0] & 3], orc_luma_filter[mv[1] & 3], 8,
+                  src, src_stride, w, h, dst, NULL, dst_stride);
+}
+void orc_sample_14bit_quarterpel_luma(const orc_pixel *src, int src_stride, int w, int h,
+                                      int16_t *dst, int dst_stride, const int16_t mv[2])
+{
+  sample_two_pass(orc_luma_filter[mv[0] & 3], orc_luma_filter[mv[1] & 3], 8,
+                  src, src_stride, w, h, NULL, dst, dst_stride);
+}
+void orc_sample_octpel_chroma(const orc_pixel *src, int src_stride, int w, int h,
+                              orc_pixel *dst, int dst_stride, const int16_t mv[2])
+{
+  sample_two_pass(orc_chroma_filter[mv[0] & 7], orc_chroma_filter[mv[1] & 7], 4,
+                  src, src_stride, w, h, dst, NULL, dst_stride);
+}
+void orc_sample_14bit_octpel_chroma(const orc_pixel *src, int src_stride, int w, int h,
+                                    int16_t *dst, int dst_stride, const int16_t mv[2])
+{
+  sample_two_pass(orc_chroma_filter[mv[0] & 7], orc_chroma_filter[mv[1] & 7], 4,
+                  src, src_stride, w, h, NULL, dst, dst_stride);
+}
+
+/* (int16 sample + 32) >> 6 through the int16-argument clip */
+static orc_pixel round_clip16(int16_t sample)
+{
+  return orc_fast_clip_16bit_to_pixel((int16_t)((sample + 32) >> 6));
+}
+
+#define HS ORC_LCU_WIDTH   /* hor_stride == dst_stride == 64 */
+
+/* horizontal 8-tap of `fir` on rows y0..rows-1 of the (h+8)-row window:
+ * hor[y][x] = fir . src[y-3][x-2 .. x+5], col[y] = fir . src[y-3][-3 .. 4] */
+static void hor_plane(const int8_t *fir, const orc_pixel *src, int ss, int w, int rows, int y0,
+                      int16_t *hor, int16_t *col)
+{
+  for (int y = y0; y < rows; ++y) {
+    for (int x = 0; x < w; ++x)
+      hor[y * HS + x] = (int16_t)fir_px(fir, 8, &src[ss * (y - 3) + (x - 3 + 1)], 1);
+    col[y] = (int16_t)fir_px(fir, 8, &src[ss * (y - 3) + (0 - 3)], 1);
+  }
+}
+
+/* One output block of the qpel steps (ipol-generic.c:480-545 and :595-657):
+ * vertical filter `vf` on plane `hor` from row y+yo; when !xo the first column
+ * comes from the contiguous column array and the rest is shifted one to the
+ * right. */
+static void qpel_block(const int8_t *vf, const int16_t *hor, const int16_t *col, int xo, int yo,
+                       int w, int h, orc_pixel *out)
+{
+  for (int y = 0; y < h; ++y) {
+    if (!xo) out[y * HS] = round_clip16((int16_t)(fir_s16(vf, 8, &col[y + yo], 1) >> 6));
+    for (int x = !xo; x < w; ++x)
+      out[y * HS + x] = round_clip16((int16_t)(fir_s16(vf, 8, &hor[(y + yo) * HS + x - !xo], HS) >> 6));
+  }
+}
+
+void orc_filter_frac_blocks(int step, const orc_pixel *src, int ss, int w, int h,
+                            orc_pixel *filtered, orc_ipol_state *st,
+                            int fme_level, int hpel_off_x, int hpel_off_y)
+{
+  orc_pixel *f0 = filtered, *f1 = filtered + 64 * 64, *f2 = filtered + 2 * 64 * 64, *f3 = filtered + 3 * 64 * 64;
+  const int8_t *fir0 = orc_luma_filter[0], *fir1 = orc_luma_filter[1];
+  const int8_t *fir2 = orc_luma_filter[2], *fir3 = orc_luma_filter[3];
+  const int rows = h + 8;        /* height + KVZ_EXT_PADDING_LUMA + 1 */
+  int x, y;
+
+  if (step == 0) {               /* :192-305 hpel left/right/top/bottom */
+    hor_plane(fir0, src, ss, w, rows, 0, st->hor[0], st->cols[0]);
+    hor_plane(fir2, src, ss, w, rows, fme_level > 1 ? 0 : 1, st->hor[1], st->cols[2]);
+    for (y = 0; y < h; ++y)      /* right: horizontal only */
+      for (x = 0; x < w; ++x) f1[y * HS + x] = round_clip16(st->hor[1][(y + 4) * HS + x]);
+    for (y = 0; y < h; ++y) {    /* left */
+      f0[y * HS] = round_clip16(st->cols[2][y + 4]);
+      for (x = 1; x < w; ++x) f0[y * HS + x] = f1[y * HS + x - 1];
+    }
+    for (y = 0; y < h; ++y)      /* top: vertical only, on pixels */
+      for (x = 0; x < w; ++x)
+        f2[y * HS + x] = round_clip16((int16_t)fir_px(fir2, 8, &src[ss * (y - 3) + x + 1], ss));
+    for (y = 0; y < h - 1; ++y)  /* bottom */
+      for (x = 0; x < w; ++x) f3[y * HS + x] = f2[(y + 1) * HS + x];
+    for (x = 0; x < w; ++x)
+      f3[y * HS + x] = round_clip16((int16_t)fir_px(fir2, 8, &src[ss * (y - 3 + 1) + x + 1], ss));
+  } else if (step == 1) {        /* :307-386 hpel diagonals */
+    const int16_t *h1 = st->hor[1], *c2 = st->cols[2];
+    for (y = 0; y < h; ++y)      /* top-right */
+      for (x = 0; x < w; ++x) f1[y * HS + x] = round_clip16((int16_t)(fir_s16(fir2, 8, &h1[y * HS + x], HS) >> 6));
+    for (y = 0; y < h; ++y) {    /* top-left */
+      f0[y * HS] = round_clip16((int16_t)(fir_s16(fir2, 8, &c2[y], 1) >> 6));
+      for (x = 1; x < w; ++x) f0[y * HS + x] = f1[y * HS + x - 1];
+    }
+    for (y = 0; y < h - 1; ++y)  /* bottom-right */
+      for (x = 0; x < w; ++x) f3[y * HS + x] = f1[(y + 1) * HS + x];
+    for (x = 0; x < w; ++x) f3[y * HS + x] = round_clip16((int16_t)(fir_s16(fir2, 8, &h1[(y + 1) * HS + x], HS) >> 6));
+    for (y = 0; y < h - 1; ++y)  /* bottom-left */
+      for (x = 0; x < w; ++x) f2[y * HS + x] = f0[(y + 1) * HS + x];
+    for (x = 1; x < w; ++x) f2[y * HS + x] = f3[y * HS + x - 1];
+    f2[y * HS] = round_clip16((int16_t)(fir_s16(fir2, 8, &c2[y + 1], 1) >> 6));
+  } else {
+    const int off_x_fir_l = hpel_off_x < 1 ? 0 : 1, off_x_fir_r = hpel_off_x < 0 ? 0 : 1;
+    const int off_y_fir_t = hpel_off_y < 1 ? 0 : 1, off_y_fir_b = hpel_off_y < 0 ? 0 : 1;
+    const int8_t *ver_fir_t = hpel_off_y != 0 ? fir1 : fir3;
+    const int8_t *ver_fir_b = hpel_off_y != 0 ? fir3 : fir1;
+    if (step == 2) {             /* :388-546 qpel left/right/top/bottom */
+      const int8_t *hor_fir_l = hpel_off_x != 0 ? fir1 : fir3;
+      const int8_t *hor_fir_r = hpel_off_x != 0 ? fir3 : fir1;
+      const int8_t *ver_fir_lr = hpel_off_y != 0 ? fir2 : fir0;
+      const int16_t *hor_hpel = hpel_off_x != 0 ? st->hor[1] : st->hor[0];
+      const int16_t *col_hor = hpel_off_x != 0 ? st->cols[2] : st->cols[0];
+      const int sample_off_y = hpel_off_y < 0 ? 0 : 1;
+      const int sample_off_x = hpel_off_x > -1 ? 1 : 0;
+      hor_plane(hor_fir_l, src, ss, w, rows, 0, st->hor[3], st->cols[1]);
+      hor_plane(hor_fir_r, src, ss, w, rows, 0, st->hor[4], st->cols[3]);
+      qpel_block(ver_fir_lr, st->hor[3], st->cols[1], off_x_fir_l, sample_off_y, w, h, f0);
+      qpel_block(ver_fir_lr, st->hor[4], st->cols[3], off_x_fir_r, sample_off_y, w, h, f1);
+      qpel_block(ver_fir_t, hor_hpel, col_hor, sample_off_x, off_y_fir_t, w, h, f2);
+      qpel_block(ver_fir_b, hor_hpel, col_hor, sample_off_x, off_y_fir_b, w, h, f3);
+    } else {                     /* :548-658 qpel diagonals */
+      qpel_block(ver_fir_t, st->hor[3], st->cols[1], off_x_fir_l, off_y_fir_t, w, h, f0);
+      qpel_block(ver_fir_t, st->hor[4], st->cols[3], off_x_fir_r, off_y_fir_t, w, h, f1);
+      qpel_block(ver_fir_b, st->hor[3], st->cols[1], off_x_fir_l, off_y_fir_b, w, h, f2);
+      qpel_block(ver_fir_b, st->hor[4], st->cols[3], off_x_fir_r, off_y_fir_b, w, h, f3);
+    }
+  }
+}
+
+/* ipol-generic.c:731-784 */
+int orc_get_extended_block(int xpos, int ypos, int mv_x, int mv_y, int off_x, int off_y,
+                           const orc_pixel *ref, int ref_w, int ref_h, int filter_size,
+                           int w, int h, orc_pixel *out, long *inside_off)
+{
+  const int half = filter_size >> 1;
+  const int min_y = ypos - half + off_y + mv_y, max_y = min_y + h + filter_size;
+  const int min_x = xpos - half + off_x + mv_x, max_x = min_x + w + filter_size;
+  const int oob_y = (min_y < 0) || (max_y >= ref_h);
+  const int oob_x = (min_x < 0) || (max_x >= ref_w);
+  if (inside_off) *inside_off = (long)min_y * ref_w + min_x;
+  if (!(oob_y || oob_x)) return 0;
+  const int stride = w + filter_size;
+  for (int dy = 0, y = ypos - half; y < ypos + h + half; ++dy, ++y) {
+    int cy = ORC_CLIP(0, ref_h - 1, y + off_y + mv_y);
+    for (int dx = 0, x = xpos - half; x < xpos + w + half; ++dx, ++x) {
+      int cx = ORC_CLIP(0, ref_w - 1, x + off_x + mv_x);
+      out[dy * stride + dx] = ref[cy * ref_w + cx];
+    }
+  }
+  return 1;
+}
+
+/* search_inter.c:965-1128 without MV bit costs / tile constraints */
+void orc_search_frac_costs(const orc_pixel *pic, int pic_stride,
+                           const orc_pixel *ref, int ref_w, int ref_h,
+                           int x, int y, int w, int h, int mvx, int mvy,
+                           unsigned costs_out[17], int best_out[2])
+{
+  static const int sq[9][2] = { {0,0}, {-1,0}, {1,0}, {0,-1}, {0,1}, {-1,-1}, {1,-1}, {-1,1}, {1,1} };
+  const int iw = ((w + 7) >> 3) << 3, ih = ((h + 7) >> 3) << 3;
+  const int es = iw + 1 + 8;                         /* extended block stride */
+  orc_pixel *ext = (orc_pixel *)malloc((size_t)es * (size_t)(ih + 1 + 8));
+  orc_pixel *filtered = (orc_pixel *)malloc(4 * 64 * 64);
+  orc_ipol_state *st = (orc_ipol_state *)calloc(1, sizeof(*st));
+  const orc_pixel *src_tl; int src_stride; long off;
+
+  if (orc_get_extended_block(x, y, mvx - 1, mvy - 1, 0, 0, ref, ref_w, ref_h, 8, iw + 1, ih + 1, ext, &off)) {
+    src_tl = ext + es * 4 + 4; src_stride = es;
+  } else {
+    src_tl = ref + off + (long)ref_w * 4 + 4; src_stride = ref_w;
+  }
+  const orc_pixel *cur = pic + (long)y * pic_stride + x;
+
+  unsigned best_cost = orc_satd_any_size(w, h, cur, pic_stride, src_tl + src_stride + 1, src_stride);
+  costs_out[0] = best_cost;
+  int best_index = 0, i = 1, offx = 0, offy = 0;
+  memset(filtered, 0, 4 * 64 * 64);
+  for (int step = 0; step < 4; ++step) {
+    unsigned c[4];
+    const orc_pixel *fp[4] = { filtered, filtered + 4096, filtered + 8192, filtered + 12288 };
+    orc_filter_frac_blocks(step, src_tl, src_stride, iw, ih, filtered, st, 4, offx, offy);
+    orc_satd_any_size_quad(w, h, fp, 64, cur, pic_stride, c);
+    for (int j = 0; j < 4; ++j) {
+      costs_out[(step >= 2 ? 8 : 0) + i + j] = c[j];
+      if (c[j] < best_cost) { best_cost = c[j]; best_index = i + j; }
+    }
+    i += 4;
+    if (step == 1) {
+      best_out[0] = best_index; offx = sq[best_index][0]; offy = sq[best_index][1];
+      best_index = 0; i = 1;
+    } else if (step == 3) {
+      best_out[1] = best_index;
+    }
+  }
+  free(st); free(filtered); free(ext);
+}

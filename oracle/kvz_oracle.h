@@ -1,0 +1,152 @@
+/*
+ * kvz_oracle.h -- CPU restatement of Kvazaar's `generic` block kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under kvazaar_amd/ (the product) may
+ * include, link or call this.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * Every function cites the reference file:line (relative to
+ * /root/reference/src) whose semantics it restates.  The arithmetic is
+ * re-derived (e.g. the DCT is a plain integer matrix product, the Hadamard
+ * transforms are H*D*H^T), not transcribed; bit-exactness against the
+ * compiled reference is pinned by tests/test_oracle_vs_ref.py (in the build
+ * container, via oracle/_ref) and by the golden fixtures under tests/golden/.
+ *
+ * PARITY PINNED: by (1) the reference's own known-answer values
+ * (tests/satd_tests.c:109,127,146; tests/sad_tests.c:121-259;
+ * tests/coeff_sum_tests.c:29-43) and (2) outputs of the reference's generic
+ * strategy compiled from /root/reference by oracle/Makefile (oracle/_ref).
+ */
+#ifndef KVZ_ORACLE_H_
+#define KVZ_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint8_t orc_pixel;   /* kvz_pixel, KVZ_BIT_DEPTH == 8 (kvazaar.h:72-77) */
+typedef int16_t orc_coeff;   /* coeff_t (global.h:99) */
+
+#define ORC_LCU_WIDTH 64
+#define ORC_EXT_BLOCK_W_LUMA 71   /* search_inter.h:46 */
+#define ORC_IPOL_ROWS (ORC_EXT_BLOCK_W_LUMA + 1)
+
+/* ---- picture group (strategies/generic/picture-generic.c) ---- */
+orc_pixel orc_fast_clip_16bit_to_pixel(int16_t value);             /* :30-48 */
+orc_pixel orc_fast_clip_32bit_to_pixel(int32_t value);             /* :52-70 */
+unsigned orc_reg_sad(const orc_pixel *d1, const orc_pixel *d2, int w, int h,
+                     unsigned stride1, unsigned stride2);          /* :86-99 */
+unsigned orc_sad_nxn(int n, const orc_pixel *b1, const orc_pixel *b2);   /* :460-486 */
+unsigned orc_satd_4x4(const orc_pixel *b1, const orc_pixel *b2);         /* :189-196 */
+unsigned orc_satd_4x4_subblock(const orc_pixel *b1, int s1,
+                               const orc_pixel *b2, int s2);       /* :201-213 */
+unsigned orc_satd_8x8_subblock(const orc_pixel *b1, int s1,
+                               const orc_pixel *b2, int s2);       /* :240-328 */
+unsigned orc_satd_nxn(int n, const orc_pixel *b1, const orc_pixel *b2);  /* strategies-picture.h:40-56 */
+unsigned orc_satd_any_size(int w, int h, const orc_pixel *b1, int s1,
+                           const orc_pixel *b2, int s2);           /* strategies-picture.h:62-100 */
+/* preds[k] lives at preds + k*pred_stride (1024 in the reference: pred_buffer) */
+void orc_sad_nxn_dual(int n, const orc_pixel *preds, size_t pred_stride,
+                      const orc_pixel *orig, unsigned costs[2]);   /* :497-519 */
+void orc_satd_nxn_dual(int n, const orc_pixel *preds, size_t pred_stride,
+                       const orc_pixel *orig, unsigned costs[2]);  /* :357-390 */
+void orc_satd_any_size_quad(int w, int h, const orc_pixel *const preds[4], int stride,
+                            const orc_pixel *orig, int orig_stride,
+                            unsigned costs[4]);                    /* :392-456 */
+unsigned orc_pixels_calc_ssd(const orc_pixel *ref, const orc_pixel *rec,
+                             int ref_stride, int rec_stride, int width); /* :521-536 */
+/* bipred blend, flattened: one plane of w x h; s0/s1 are either 14-bit
+ * samples (hi_prec != 0) or pixels (hi_prec == 0, shifted << 6).  :538-588 */
+void orc_bipred_blend_plane(int w, int h,
+                            int hi_prec0, const int16_t *hp0, const orc_pixel *px0, int stride0,
+                            int hi_prec1, const int16_t *hp1, const orc_pixel *px1, int stride1,
+                            orc_pixel *dst, int dst_stride);
+
+/* kvz_image_calc_sad / kvz_image_calc_satd (image.c:455-486, :488-545):
+ * the reference block may lie (partly) outside the frame; outside pixels are
+ * edge replicated (image.c:320-444 / ipol-generic.c:731-784).               */
+unsigned orc_image_calc_sad(const orc_pixel *pic, int pic_stride,
+                            const orc_pixel *ref, int ref_stride, int ref_w, int ref_h,
+                            int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh);
+unsigned orc_image_calc_satd(const orc_pixel *pic, int pic_stride,
+                             const orc_pixel *ref, int ref_stride, int ref_w, int ref_h,
+                             int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh);
+
+/* ---- dct group (strategies/generic/dct-generic.c) ---- */
+enum orc_tr_kind { ORC_DCT = 0, ORC_IDCT = 1, ORC_DST = 2, ORC_IDST = 3 };
+/* n in {4,8,16,32}; DST only for n==4.  :567-617 */
+void orc_transform(int kind, int n, const int16_t *in, int16_t *out);
+/* the integer transform matrix row-major [n][n] (dct-generic.c:26-108) */
+const int16_t *orc_dct_matrix(int n);
+const int16_t *orc_dst4_matrix(void);
+
+/* ---- quant group (strategies/generic/quant-generic.c) ---- */
+typedef struct {
+  int32_t qp;              /* state->qp */
+  int32_t slice_is_intra;  /* state->frame->slicetype == KVZ_SLICE_I */
+  int32_t signhide;        /* encoder->cfg.signhide_enable */
+  int32_t scaling_list;    /* encoder->scaling_list.enable (0 = flat) */
+  const int32_t *quant_coeff;    /* [w*h] when scaling_list, else NULL */
+  const int32_t *dequant_coeff;  /* [w*h] when scaling_list, else NULL */
+} orc_quant_params;
+int32_t orc_get_scaled_qp(int type, int qp, int qp_offset);        /* transform.c:129-143 */
+const uint32_t *orc_scan_order(int scan_idx, int log2_size);       /* tables.c kvz_g_sig_last_scan */
+void orc_quant(const orc_quant_params *p, const orc_coeff *coef, orc_coeff *q_coef,
+               int w, int h, int type, int scan_idx, int block_is_intra);  /* :37-163 */
+void orc_dequant(const orc_quant_params *p, const orc_coeff *q_coef, orc_coeff *coef,
+                 int w, int h, int type, int block_is_intra);       /* :279-321 */
+uint32_t orc_coeff_abs_sum(const orc_coeff *c, size_t len);         /* :323-330 */
+/* rdoq disabled path of kvz_quantize_residual_generic (:180-273).
+ * color: 0 Y, 1 U, 2 V.  Returns has_coeffs. */
+int orc_quantize_residual(const orc_quant_params *p, int cu_is_intra, int width, int color,
+                          int scan_order, int use_trskip, int in_stride, int out_stride,
+                          const orc_pixel *ref_in, const orc_pixel *pred_in,
+                          orc_pixel *rec_out, orc_coeff *coeff_out);
+
+/* ---- ipol group (strategies/generic/ipol-generic.c) ---- */
+extern const int8_t orc_luma_filter[4][8];    /* filter.c:54-60 */
+extern const int8_t orc_chroma_filter[8][4];  /* filter.c:62-72 */
+void orc_sample_quarterpel_luma(const orc_pixel *src, int src_stride, int w, int h,
+                                orc_pixel *dst, int dst_stride, const int16_t mv[2]);   /* :122-157 */
+void orc_sample_14bit_quarterpel_luma(const orc_pixel *src, int src_stride, int w, int h,
+                                      int16_t *dst, int dst_stride, const int16_t mv[2]); /* :159-190 */
+void orc_sample_octpel_chroma(const orc_pixel *src, int src_stride, int w, int h,
+                              orc_pixel *dst, int dst_stride, const int16_t mv[2]);     /* :660-695 */
+void orc_sample_14bit_octpel_chroma(const orc_pixel *src, int src_stride, int w, int h,
+                                    int16_t *dst, int dst_stride, const int16_t mv[2]); /* :697-728 */
+
+typedef struct {
+  int16_t hor[5][ORC_IPOL_ROWS * ORC_LCU_WIDTH];   /* hor_intermediate */
+  int16_t cols[5][ORC_IPOL_ROWS];                   /* hor_first_cols */
+} orc_ipol_state;
+/* step 0..3 = hpel hor/ver, hpel diag, qpel hor/ver, qpel diag (:192-658).
+ * filtered = 4 blocks of 64*64 pixels (stride 64). */
+void orc_filter_frac_blocks(int step, const orc_pixel *src, int src_stride, int w, int h,
+                            orc_pixel *filtered /*[4][64*64]*/, orc_ipol_state *st,
+                            int fme_level, int hpel_off_x, int hpel_off_y);
+/* kvz_get_extended_block_generic (:731-784) into a caller buffer of
+ * (w+filter_size)*(h+filter_size) bytes; returns 1 if the copy was needed
+ * (malloc_used in the reference), 0 if the window was inside the frame (then
+ * nothing is written).  *inside_off receives the offset of `buffer` in ref. */
+int orc_get_extended_block(int xpos, int ypos, int mv_x, int mv_y, int off_x, int off_y,
+                           const orc_pixel *ref, int ref_w, int ref_h, int filter_size,
+                           int w, int h, orc_pixel *out, long *inside_off);
+
+/* ---- caller-level composite used by the fused GPU kernel's parity test:
+ * search_frac's (search_inter.c:965-1128) filter + quad-SATD sequence without
+ * the MV bit costs: returns the 1+16 SATD costs it evaluates for the block at
+ * (x,y) size w x h with integer mv (mvx,mvy) (full-pel units), choosing the
+ * best hpel offset by SATD alone.  costs_out[0] = integer position,
+ * [1..8] hpel, [9..16] qpel.  best_out = {best hpel index 0..8, best qpel 0..8}. */
+void orc_search_frac_costs(const orc_pixel *pic, int pic_stride,
+                           const orc_pixel *ref, int ref_w, int ref_h,
+                           int x, int y, int w, int h, int mvx, int mvy,
+                           unsigned costs_out[17], int best_out[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

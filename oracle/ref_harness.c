@@ -1,0 +1,310 @@
+/*
+ * ref_harness.c -- glue that exposes the COMPILED REFERENCE (Kvazaar built from
+ * /root/reference by oracle/Makefile into oracle/_ref/) to the tests and to
+ * bench.py's cpu_baseline leg.  TEST INFRASTRUCTURE ONLY; this file contains
+ * no reference code, it only calls it through the reference's own headers and
+ * strategy registry (src/strategyselector.h:86-87, tests/test_strategies.c:29-52
+ * is the model for walking the registry).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "strategyselector.h"
+#include "encoder.h"
+#include "encoderstate.h"
+#include "image.h"
+#include "scalinglist.h"
+#include "cu.h"
+#include "search_inter.h"
+
+static strategy_list_t g_list;
+static int g_ready = 0;
+
+static encoder_control_t g_ctrl;
+static encoder_state_t g_state;
+static encoder_state_config_frame_t g_frame;
+
+int ref_init(void)
+{
+  if (g_ready) return 1;
+  /* selects the best registered strategy into the kvz_* globals (avx2/sse41..) */
+  if (!kvz_strategyselector_init(1, 8)) return 0;
+  memset(&g_list, 0, sizeof(g_list));
+  if (!kvz_strategy_register_picture(&g_list, 8)) return 0;
+  if (!kvz_strategy_register_dct(&g_list, 8)) return 0;
+  if (!kvz_strategy_register_quant(&g_list, 8)) return 0;
+  if (!kvz_strategy_register_ipol(&g_list, 8)) return 0;
+
+  memset(&g_ctrl, 0, sizeof(g_ctrl));
+  memset(&g_state, 0, sizeof(g_state));
+  memset(&g_frame, 0, sizeof(g_frame));
+  g_ctrl.bitdepth = 8;
+  kvz_scalinglist_init(&g_ctrl.scaling_list);
+  kvz_scalinglist_process(&g_ctrl.scaling_list, 8);
+  g_state.encoder_control = &g_ctrl;
+  g_state.frame = &g_frame;
+  g_ready = 1;
+  return 1;
+}
+
+int ref_strategy_count(void) { return (int)g_list.count; }
+const char *ref_strategy_type(int i) { return g_list.strategies[i].type; }
+const char *ref_strategy_name(int i) { return g_list.strategies[i].strategy_name; }
+int ref_strategy_priority(int i) { return (int)g_list.strategies[i].priority; }
+
+/* function pointer of (type, name); name NULL/"best" => highest priority */
+void *ref_strategy(const char *type, const char *name)
+{
+  void *best = NULL; unsigned best_prio = 0;
+  for (unsigned i = 0; i < g_list.count; ++i) {
+    const strategy_t *s = &g_list.strategies[i];
+    if (strcmp(s->type, type)) continue;
+    if (name && strcmp(name, "best")) { if (!strcmp(s->strategy_name, name)) return s->fptr; }
+    else if (!best || s->priority >= best_prio) { best = s->fptr; best_prio = s->priority; }
+  }
+  return best;
+}
+
+/* register an external implementation (the hip strategy under test) into the
+ * harness list, exactly as strategies-*.c would. */
+strategy_list_t *ref_list(void) { return &g_list; }
+
+/* ---- thin typed call-throughs (ctypes cannot call raw fptrs portably) ---- */
+unsigned ref_reg_sad(const char *name, const kvz_pixel *a, const kvz_pixel *b, int w, int h, unsigned s1, unsigned s2)
+{ return ((reg_sad_func *)ref_strategy("reg_sad", name))(a, b, w, h, s1, s2); }
+
+unsigned ref_cost_nxn(const char *type, const char *name, const kvz_pixel *a, const kvz_pixel *b)
+{ return ((cost_pixel_nxn_func *)ref_strategy(type, name))(a, b); }
+
+void ref_cost_nxn_dual(const char *type, const char *name, const kvz_pixel *preds, const kvz_pixel *orig, unsigned *costs)
+{ ((cost_pixel_nxn_multi_func *)ref_strategy(type, name))((pred_buffer)preds, orig, 2, costs); }
+
+unsigned ref_satd_any_size(const char *name, int w, int h, const kvz_pixel *a, int s1, const kvz_pixel *b, int s2)
+{ return ((cost_pixel_any_size_func *)ref_strategy("satd_any_size", name))(w, h, a, s1, b, s2); }
+
+void ref_satd_any_size_quad(const char *name, int w, int h, const kvz_pixel *p0, const kvz_pixel *p1,
+                            const kvz_pixel *p2, const kvz_pixel *p3, int stride,
+                            const kvz_pixel *orig, int orig_stride, unsigned *costs)
+{
+  const kvz_pixel *preds[4] = { p0, p1, p2, p3 };
+  int8_t valid[4] = { 1, 1, 1, 1 };
+  ((cost_pixel_any_size_multi_func *)ref_strategy("satd_any_size_quad", name))(w, h, preds, stride, orig, orig_stride, 4, costs, valid);
+}
+
+unsigned ref_pixels_calc_ssd(const char *name, const kvz_pixel *a, const kvz_pixel *b, int s1, int s2, int w)
+{ return ((pixels_calc_ssd_func *)ref_strategy("pixels_calc_ssd", name))(a, b, s1, s2, w); }
+
+void ref_transform(const char *type, const char *name, const int16_t *in, int16_t *out)
+{ ((dct_func *)ref_strategy(type, name))(8, in, out); }
+
+uint32_t ref_coeff_abs_sum(const char *name, const coeff_t *c, size_t n)
+{ return ((coeff_abs_sum_func *)ref_strategy("coeff_abs_sum", name))(c, n); }
+
+static void set_state(int qp, int slice_is_intra, int signhide, int scaling_list_default)
+{
+  g_state.qp = (int8_t)qp;
+  g_frame.slicetype = slice_is_intra ? KVZ_SLICE_I : KVZ_SLICE_P;
+  g_ctrl.cfg.signhide_enable = signhide;
+  g_ctrl.cfg.rdoq_enable = 0;
+  if ((int)g_ctrl.scaling_list.enable != scaling_list_default) {
+    kvz_scalinglist_destroy(&g_ctrl.scaling_list);
+    kvz_scalinglist_init(&g_ctrl.scaling_list);
+    if (scaling_list_default) { g_ctrl.scaling_list.enable = 1; g_ctrl.scaling_list.use_default_list = 1; }
+    kvz_scalinglist_process(&g_ctrl.scaling_list, 8);
+  }
+}
+
+/* expose the processed scaling-list tables so the flattened C-ABI can be fed
+ * the same per-coefficient factors the reference uses */
+const int32_t *ref_quant_coeff_table(int log2_tr, int list_type, int qp_rem)
+{ return g_ctrl.scaling_list.quant_coeff[log2_tr - 2][list_type][qp_rem]; }
+const int32_t *ref_dequant_coeff_table(int log2_tr, int list_type, int qp_rem)
+{ return g_ctrl.scaling_list.de_quant_coeff[log2_tr - 2][list_type][qp_rem]; }
+
+void ref_quant(const char *name, int qp, int slice_is_intra, int signhide, int sl,
+               coeff_t *coef, coeff_t *q_coef, int w, int h, int type, int scan_idx, int block_type)
+{
+  set_state(qp, slice_is_intra, signhide, sl);
+  ((quant_func *)ref_strategy("quant", name))(&g_state, coef, q_coef, w, h, (int8_t)type, (int8_t)scan_idx, (int8_t)block_type);
+}
+
+void ref_dequant(const char *name, int qp, int sl, coeff_t *q_coef, coeff_t *coef, int w, int h, int type, int block_type)
+{
+  set_state(qp, 0, 0, sl);
+  ((dequant_func *)ref_strategy("dequant", name))(&g_state, q_coef, coef, w, h, (int8_t)type, (int8_t)block_type);
+}
+
+int ref_quantize_residual(const char *name, int qp, int slice_is_intra, int signhide, int sl,
+                          int cu_is_intra, int width, int color, int scan_order, int use_trskip,
+                          int in_stride, int out_stride, const kvz_pixel *ref_in, const kvz_pixel *pred_in,
+                          kvz_pixel *rec_out, coeff_t *coeff_out)
+{
+  cu_info_t cu; memset(&cu, 0, sizeof(cu));
+  cu.type = cu_is_intra ? CU_INTRA : CU_INTER;
+  cu.part_size = SIZE_2Nx2N;
+  set_state(qp, slice_is_intra, signhide, sl);
+  return (int)((quant_residual_func *)ref_strategy("quantize_residual", name))(
+      &g_state, &cu, width, (color_t)color, (coeff_scan_order_t)scan_order, use_trskip,
+      in_stride, out_stride, ref_in, pred_in, rec_out, coeff_out);
+}
+
+void ref_sample_luma(const char *name, kvz_pixel *src, int src_stride, int w, int h, kvz_pixel *dst, int dst_stride, int mvx, int mvy)
+{
+  int16_t mv[2] = { (int16_t)mvx, (int16_t)mvy };
+  ((kvz_sample_quarterpel_luma_func *)ref_strategy("sample_quarterpel_luma", name))(&g_ctrl, src, (int16_t)src_stride, w, h, dst, (int16_t)dst_stride, 0, 0, mv);
+}
+void ref_sample_luma_14bit(const char *name, kvz_pixel *src, int src_stride, int w, int h, int16_t *dst, int dst_stride, int mvx, int mvy)
+{
+  int16_t mv[2] = { (int16_t)mvx, (int16_t)mvy };
+  ((kvz_sample_14bit_quarterpel_luma_func *)ref_strategy("sample_14bit_quarterpel_luma", name))(&g_ctrl, src, (int16_t)src_stride, w, h, dst, (int16_t)dst_stride, 0, 0, mv);
+}
+void ref_sample_chroma(const char *name, kvz_pixel *src, int src_stride, int w, int h, kvz_pixel *dst, int dst_stride, int mvx, int mvy)
+{
+  int16_t mv[2] = { (int16_t)mvx, (int16_t)mvy };
+  ((kvz_sample_octpel_chroma_func *)ref_strategy("sample_octpel_chroma", name))(&g_ctrl, src, (int16_t)src_stride, w, h, dst, (int16_t)dst_stride, 0, 0, mv);
+}
+void ref_sample_chroma_14bit(const char *name, kvz_pixel *src, int src_stride, int w, int h, int16_t *dst, int dst_stride, int mvx, int mvy)
+{
+  int16_t mv[2] = { (int16_t)mvx, (int16_t)mvy };
+  ((kvz_sample_14bit_octpel_chroma_func *)ref_strategy("sample_14bit_octpel_chroma", name))(&g_ctrl, src, (int16_t)src_stride, w, h, dst, (int16_t)dst_stride, 0, 0, mv);
+}
+
+/* kvz_image_calc_sad / _satd (image.c:455,488) on raw luma planes, with the
+ * named reg_sad / satd_any_size strategy installed in the globals. */
+static void wrap_pic(kvz_picture *p, kvz_pixel *y, int w, int h)
+{
+  memset(p, 0, sizeof(*p));
+  p->y = y; p->data[0] = y; p->width = w; p->height = h; p->stride = w;
+}
+unsigned ref_image_calc_sad(const char *name, kvz_pixel *pic, int pw, int ph, kvz_pixel *ref, int rw, int rh,
+                            int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh)
+{
+  kvz_picture a, b; wrap_pic(&a, pic, pw, ph); wrap_pic(&b, ref, rw, rh);
+  kvz_reg_sad = (reg_sad_func *)ref_strategy("reg_sad", name);
+  return kvz_image_calc_sad(&a, &b, pic_x, pic_y, ref_x, ref_y, bw, bh);
+}
+unsigned ref_image_calc_satd(const char *name, kvz_pixel *pic, int pw, int ph, kvz_pixel *ref, int rw, int rh,
+                             int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh)
+{
+  kvz_picture a, b; wrap_pic(&a, pic, pw, ph); wrap_pic(&b, ref, rw, rh);
+  kvz_satd_any_size = (cost_pixel_any_size_func *)ref_strategy("satd_any_size", name);
+  kvz_get_extended_block = (epol_func *)ref_strategy("get_extended_block", "generic");
+  return kvz_image_calc_satd(&a, &b, pic_x, pic_y, ref_x, ref_y, bw, bh);
+}
+
+/* The filter + quad-SATD sequence of search_frac (search_inter.c:965-1128),
+ * driven through the reference's strategy functions, without MV bit costs:
+ * validates orc_search_frac_costs. */
+void ref_search_frac_costs(const char *name, kvz_pixel *pic, int pic_stride, kvz_pixel *ref, int ref_w, int ref_h,
+                           int x, int y, int w, int h, int mvx, int mvy, unsigned costs_out[17], int best_out[2])
+{
+  static const int sq[9][2] = { {0,0}, {-1,0}, {1,0}, {0,-1}, {0,1}, {-1,-1}, {1,-1}, {-1,1}, {1,1} };
+  ipol_blocks_func *steps[4] = {
+    (ipol_blocks_func *)ref_strategy("filter_hpel_blocks_hor_ver_luma", name),
+    (ipol_blocks_func *)ref_strategy("filter_hpel_blocks_diag_luma", name),
+    (ipol_blocks_func *)ref_strategy("filter_qpel_blocks_hor_ver_luma", name),
+    (ipol_blocks_func *)ref_strategy("filter_qpel_blocks_diag_luma", name) };
+  cost_pixel_any_size_func *satd = (cost_pixel_any_size_func *)ref_strategy("satd_any_size", name);
+  cost_pixel_any_size_multi_func *quad = (cost_pixel_any_size_multi_func *)ref_strategy("satd_any_size_quad", name);
+  epol_func *ext = (epol_func *)ref_strategy("get_extended_block", "generic");
+
+  kvz_pixel (*filtered)[LCU_WIDTH * LCU_WIDTH] = aligned_alloc(64, 4 * LCU_WIDTH * LCU_WIDTH);
+  int16_t (*inter)[(KVZ_EXT_BLOCK_W_LUMA + 1) * LCU_WIDTH] = aligned_alloc(64, sizeof(int16_t) * 5 * (KVZ_EXT_BLOCK_W_LUMA + 1) * LCU_WIDTH);
+  int16_t cols[5][KVZ_EXT_BLOCK_W_LUMA + 1];
+  memset(filtered, 0, 4 * LCU_WIDTH * LCU_WIDTH);
+  memset(inter, 0, sizeof(int16_t) * 5 * (KVZ_EXT_BLOCK_W_LUMA + 1) * LCU_WIDTH);
+  memset(cols, 0, sizeof(cols));
+
+  const int iw = ((w + 7) >> 3) << 3, ih = ((h + 7) >> 3) << 3;
+  kvz_extended_block src = { 0, 0, 0, 0 };
+  ext(x, y, mvx - 1, mvy - 1, 0, 0, ref, ref_w, ref_h, KVZ_LUMA_FILTER_TAPS, iw + 1, ih + 1, &src);
+  kvz_pixel *cur = pic + y * pic_stride + x;
+  unsigned best = satd(w, h, cur, pic_stride, src.orig_topleft + src.stride + 1, src.stride);
+  costs_out[0] = best;
+  int best_index = 0, i = 1; int8_t offx = 0, offy = 0;
+  for (int step = 0; step < 4; ++step) {
+    unsigned c[4]; int8_t valid[4] = { 1, 1, 1, 1 };
+    const kvz_pixel *fp[4] = { filtered[0], filtered[1], filtered[2], filtered[3] };
+    steps[step](&g_ctrl, src.orig_topleft, (int16_t)src.stride, iw, ih, filtered, inter, 4, cols, offx, offy);
+    quad(w, h, fp, LCU_WIDTH, cur, pic_stride, 4, c, valid);
+    for (int j = 0; j < 4; ++j) {
+      costs_out[(step >= 2 ? 8 : 0) + i + j] = c[j];
+      if (c[j] < best) { best = c[j]; best_index = i + j; }
+    }
+    i += 4;
+    if (step == 1) { best_out[0] = best_index; offx = (int8_t)sq[best_index][0]; offy = (int8_t)sq[best_index][1]; best_index = 0; i = 1; }
+    else if (step == 3) best_out[1] = best_index;
+  }
+  if (src.malloc_used) free(src.buffer);
+  free(filtered); free(inter);
+}
+
+/* One frac-search filter step through the reference (for block-level parity
+ * of the 4 filtered blocks).  State arrays are caller provided so that the
+ * four steps can be chained. */
+void ref_filter_step(const char *name, int step, kvz_pixel *src, int src_stride, int w, int h,
+                     kvz_pixel *filtered, int16_t *inter, int16_t *cols, int fme_level, int offx, int offy)
+{
+  static const char *types[4] = { "filter_hpel_blocks_hor_ver_luma", "filter_hpel_blocks_diag_luma",
+                                  "filter_qpel_blocks_hor_ver_luma", "filter_qpel_blocks_diag_luma" };
+  ((ipol_blocks_func *)ref_strategy(types[step], name))(&g_ctrl, src, (int16_t)src_stride, w, h,
+      (kvz_pixel (*)[LCU_WIDTH * LCU_WIDTH])filtered,
+      (int16_t (*)[(KVZ_EXT_BLOCK_W_LUMA + 1) * LCU_WIDTH])inter, (int8_t)fme_level,
+      (int16_t (*)[KVZ_EXT_BLOCK_W_LUMA + 1])cols, (int8_t)offx, (int8_t)offy);
+}
+
+/* ---- CPU baseline timing loops (speed_tests.c:117-154 is the model: call a
+ * strategy over a working set for a wall-clock budget, report calls/s) ---- */
+static double now_s(void)
+{
+  struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* blocks/s of a cost_pixel_nxn_func over `count` contiguous block pairs */
+double ref_bench_cost_nxn(const char *type, const char *name, int n, const kvz_pixel *a, const kvz_pixel *b,
+                          size_t count, double budget_s, unsigned *checksum)
+{
+  cost_pixel_nxn_func *f = (cost_pixel_nxn_func *)ref_strategy(type, name);
+  if (!f) return -1.0;
+  size_t done = 0; unsigned acc = 0; const size_t bs = (size_t)n * n;
+  double t0 = now_s(), t1;
+  do {
+    for (size_t i = 0; i < count; ++i) acc += f(a + i * bs, b + i * bs);
+    done += count; t1 = now_s();
+  } while (t1 - t0 < budget_s);
+  if (checksum) *checksum = acc;
+  return (double)done / (t1 - t0);
+}
+
+double ref_bench_transform(const char *type, const char *name, int n, const int16_t *in, int16_t *out,
+                           size_t count, double budget_s)
+{
+  dct_func *f = (dct_func *)ref_strategy(type, name);
+  if (!f) return -1.0;
+  size_t done = 0; const size_t bs = (size_t)n * n;
+  double t0 = now_s(), t1;
+  do {
+    for (size_t i = 0; i < count; ++i) f(8, in + i * bs, out + i * bs);
+    done += count; t1 = now_s();
+  } while (t1 - t0 < budget_s);
+  return (double)done / (t1 - t0);
+}
+
+double ref_bench_reg_sad(const char *name, const kvz_pixel *a, const kvz_pixel *b, int stride, int fw, int fh,
+                         int bw, int bh, double budget_s, unsigned *checksum)
+{
+  reg_sad_func *f = (reg_sad_func *)ref_strategy("reg_sad", name);
+  if (!f) return -1.0;
+  size_t done = 0; unsigned acc = 0;
+  double t0 = now_s(), t1;
+  do {
+    for (int y = 0; y + bh <= fh; y += bh)
+      for (int x = 0; x + bw <= fw; x += bw) { acc += f(a + y * stride + x, b + y * stride + x, bw, bh, stride, stride); ++done; }
+    t1 = now_s();
+  } while (t1 - t0 < budget_s);
+  if (checksum) *checksum = acc;
+  return (double)done / (t1 - t0);
+}

@@ -1,0 +1,286 @@
+"""ctypes binding of oracle/libkvzoracle.so (our CPU restatement of the
+reference's generic strategy).  TEST INFRASTRUCTURE: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+i16p = C.POINTER(C.c_int16)
+u32p = C.POINTER(C.c_uint32)
+
+
+class QuantParams(C.Structure):
+    _fields_ = [("qp", C.c_int32), ("slice_is_intra", C.c_int32), ("signhide", C.c_int32),
+                ("scaling_list", C.c_int32), ("quant_coeff", C.POINTER(C.c_int32)),
+                ("dequant_coeff", C.POINTER(C.c_int32))]
+
+
+def build():
+    so = os.path.join(ORACLE_DIR, "libkvzoracle.so")
+    src = os.path.join(ORACLE_DIR, "kvz_oracle.c")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_reg_sad.restype = C.c_uint
+        L.orc_reg_sad.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_uint, C.c_uint]
+        for f in ("orc_sad_nxn", "orc_satd_nxn"):
+            getattr(L, f).restype = C.c_uint
+            getattr(L, f).argtypes = [C.c_int, u8p, u8p]
+        L.orc_satd_any_size.restype = C.c_uint
+        L.orc_satd_any_size.argtypes = [C.c_int, C.c_int, u8p, C.c_int, u8p, C.c_int]
+        for f in ("orc_sad_nxn_dual", "orc_satd_nxn_dual"):
+            getattr(L, f).restype = None
+            getattr(L, f).argtypes = [C.c_int, u8p, C.c_size_t, u8p, u32p]
+        L.orc_satd_any_size_quad.restype = None
+        L.orc_satd_any_size_quad.argtypes = [C.c_int, C.c_int, C.POINTER(u8p), C.c_int, u8p, C.c_int, u32p]
+        L.orc_pixels_calc_ssd.restype = C.c_uint
+        L.orc_pixels_calc_ssd.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int]
+        L.orc_bipred_blend_plane.restype = None
+        L.orc_bipred_blend_plane.argtypes = [C.c_int, C.c_int, C.c_int, i16p, u8p, C.c_int,
+                                             C.c_int, i16p, u8p, C.c_int, u8p, C.c_int]
+        for f in ("orc_image_calc_sad", "orc_image_calc_satd"):
+            getattr(L, f).restype = C.c_uint
+            getattr(L, f).argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int] + [C.c_int] * 6
+        L.orc_transform.restype = None
+        L.orc_transform.argtypes = [C.c_int, C.c_int, i16p, i16p]
+        L.orc_dct_matrix.restype = i16p
+        L.orc_dct_matrix.argtypes = [C.c_int]
+        L.orc_scan_order.restype = u32p
+        L.orc_scan_order.argtypes = [C.c_int, C.c_int]
+        L.orc_get_scaled_qp.restype = C.c_int32
+        L.orc_get_scaled_qp.argtypes = [C.c_int] * 3
+        L.orc_quant.restype = None
+        L.orc_quant.argtypes = [C.POINTER(QuantParams), i16p, i16p] + [C.c_int] * 5
+        L.orc_dequant.restype = None
+        L.orc_dequant.argtypes = [C.POINTER(QuantParams), i16p, i16p] + [C.c_int] * 4
+        L.orc_coeff_abs_sum.restype = C.c_uint32
+        L.orc_coeff_abs_sum.argtypes = [i16p, C.c_size_t]
+        L.orc_quantize_residual.restype = C.c_int
+        L.orc_quantize_residual.argtypes = [C.POINTER(QuantParams)] + [C.c_int] * 7 + [u8p, u8p, u8p, i16p]
+        for f, dt in (("orc_sample_quarterpel_luma", u8p), ("orc_sample_14bit_quarterpel_luma", i16p),
+                      ("orc_sample_octpel_chroma", u8p), ("orc_sample_14bit_octpel_chroma", i16p)):
+            getattr(L, f).restype = None
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, dt, C.c_int, i16p]
+        L.orc_filter_frac_blocks.restype = None
+        L.orc_filter_frac_blocks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, u8p,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_search_frac_costs.restype = None
+        L.orc_search_frac_costs.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int] + [C.c_int] * 6 + \
+            [u32p, C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+# ---------------------------------------------------------------- picture
+def reg_sad(a, b, off1, off2, w, h, s1, s2):
+    a, b = _u8(a).ravel(), _u8(b).ravel()
+    pa = C.cast(a.ctypes.data + off1, u8p)
+    pb = C.cast(b.ctypes.data + off2, u8p)
+    return lib().orc_reg_sad(pa, pb, w, h, s1, s2)
+
+
+def cost_nxn_batch(kind, n, blk1, blk2):
+    """kind 'sad'|'satd'; blk1/blk2: uint8 [count, n*n] -> uint32[count]"""
+    blk1, blk2 = _u8(blk1).reshape(-1, n * n), _u8(blk2).reshape(-1, n * n)
+    f = lib().orc_sad_nxn if kind == "sad" else lib().orc_satd_nxn
+    out = np.empty(blk1.shape[0], dtype=np.uint32)
+    for i in range(blk1.shape[0]):
+        out[i] = f(n, _p(blk1[i], u8p), _p(blk2[i], u8p))
+    return out
+
+
+def cost_nxn_dual_batch(kind, n, preds, orig, pred_stride=1024):
+    """preds: uint8 [count, 2*pred_stride] (pred k at k*pred_stride); orig [count, n*n]"""
+    preds = _u8(preds).reshape(orig.shape[0], -1)
+    orig = _u8(orig).reshape(-1, n * n)
+    f = lib().orc_sad_nxn_dual if kind == "sad" else lib().orc_satd_nxn_dual
+    out = np.empty((orig.shape[0], 2), dtype=np.uint32)
+    for i in range(orig.shape[0]):
+        f(n, _p(preds[i], u8p), pred_stride, _p(orig[i], u8p), _p(out[i], u32p))
+    return out
+
+
+def satd_any_size(w, h, a, off1, s1, b, off2, s2):
+    a, b = _u8(a).ravel(), _u8(b).ravel()
+    return lib().orc_satd_any_size(w, h, C.cast(a.ctypes.data + off1, u8p), s1,
+                                   C.cast(b.ctypes.data + off2, u8p), s2)
+
+
+def satd_any_size_quad(w, h, preds4, stride, orig, orig_off, orig_stride):
+    """preds4: list of 4 uint8 arrays (each at least h*stride); orig uint8 array"""
+    ps = [_u8(p).ravel() for p in preds4]
+    arr = (u8p * 4)(*[_p(p, u8p) for p in ps])
+    orig = _u8(orig).ravel()
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_satd_any_size_quad(w, h, arr, stride, C.cast(orig.ctypes.data + orig_off, u8p), orig_stride,
+                                 _p(out, u32p))
+    return out
+
+
+def pixels_calc_ssd(a, off1, b, off2, s1, s2, w):
+    a, b = _u8(a).ravel(), _u8(b).ravel()
+    return lib().orc_pixels_calc_ssd(C.cast(a.ctypes.data + off1, u8p), C.cast(b.ctypes.data + off2, u8p), s1, s2, w)
+
+
+def image_calc(kind, pic, ref, pic_x, pic_y, ref_x, ref_y, bw, bh):
+    pic, ref = _u8(pic), _u8(ref)
+    f = lib().orc_image_calc_sad if kind == "sad" else lib().orc_image_calc_satd
+    return f(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[1], ref.shape[0],
+             pic_x, pic_y, ref_x, ref_y, bw, bh)
+
+
+def bipred_blend_plane(w, h, hi0, s0, hi1, s1):
+    """s0/s1: int16 [h,w] when hi, else uint8 [h,w]"""
+    dst = np.zeros((h, w), dtype=np.uint8)
+    z16 = np.zeros(1, dtype=np.int16)
+    z8 = np.zeros(1, dtype=np.uint8)
+    a16 = np.ascontiguousarray(s0, dtype=np.int16) if hi0 else z16
+    a8 = z8 if hi0 else _u8(s0)
+    b16 = np.ascontiguousarray(s1, dtype=np.int16) if hi1 else z16
+    b8 = z8 if hi1 else _u8(s1)
+    lib().orc_bipred_blend_plane(w, h, int(hi0), _p(a16, i16p), _p(a8, u8p), w,
+                                 int(hi1), _p(b16, i16p), _p(b8, u8p), w, _p(dst, u8p), w)
+    return dst
+
+
+# ---------------------------------------------------------------- dct
+KINDS = {"dct": 0, "idct": 1, "dst": 2, "idst": 3}
+
+
+def transform_batch(kind, n, blocks):
+    blocks = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, n * n)
+    out = np.empty_like(blocks)
+    k = KINDS[kind]
+    for i in range(blocks.shape[0]):
+        lib().orc_transform(k, n, _p(blocks[i], i16p), _p(out[i], i16p))
+    return out
+
+
+def dct_matrix(n):
+    p = lib().orc_dct_matrix(n)
+    return np.ctypeslib.as_array(p, shape=(n, n)).copy()
+
+
+def scan_order(scan_idx, log2):
+    p = lib().orc_scan_order(scan_idx, log2)
+    return np.ctypeslib.as_array(p, shape=(1 << (2 * log2),)).copy()
+
+
+# ---------------------------------------------------------------- quant
+def _qp(qp, slice_is_intra=0, signhide=0, quant_coeff=None, dequant_coeff=None):
+    p = QuantParams()
+    p.qp, p.slice_is_intra, p.signhide = qp, int(slice_is_intra), int(signhide)
+    keep = []
+    if quant_coeff is not None or dequant_coeff is not None:
+        p.scaling_list = 1
+        if quant_coeff is not None:
+            q = np.ascontiguousarray(quant_coeff, dtype=np.int32); keep.append(q)
+            p.quant_coeff = _p(q, C.POINTER(C.c_int32))
+        if dequant_coeff is not None:
+            d = np.ascontiguousarray(dequant_coeff, dtype=np.int32); keep.append(d)
+            p.dequant_coeff = _p(d, C.POINTER(C.c_int32))
+    return p, keep
+
+
+def quant_batch(coef, w, qp, type_, scan_idx, slice_is_intra=0, signhide=0, block_is_intra=0, quant_coeff=None):
+    coef = np.ascontiguousarray(coef, dtype=np.int16).reshape(-1, w * w)
+    out = np.empty_like(coef)
+    p, keep = _qp(qp, slice_is_intra, signhide, quant_coeff=quant_coeff)
+    for i in range(coef.shape[0]):
+        lib().orc_quant(C.byref(p), _p(coef[i], i16p), _p(out[i], i16p), w, w, type_, scan_idx, block_is_intra)
+    return out
+
+
+def dequant_batch(q_coef, w, qp, type_, block_is_intra=0, dequant_coeff=None):
+    q_coef = np.ascontiguousarray(q_coef, dtype=np.int16).reshape(-1, w * w)
+    out = np.empty_like(q_coef)
+    p, keep = _qp(qp, dequant_coeff=dequant_coeff)
+    for i in range(q_coef.shape[0]):
+        lib().orc_dequant(C.byref(p), _p(q_coef[i], i16p), _p(out[i], i16p), w, w, type_, block_is_intra)
+    return out
+
+
+def coeff_abs_sum(c):
+    c = np.ascontiguousarray(c, dtype=np.int16).ravel()
+    return lib().orc_coeff_abs_sum(_p(c, i16p), c.size)
+
+
+def quantize_residual_batch(ref_in, pred_in, w, qp, color, scan_order_, cu_is_intra, slice_is_intra=0,
+                            signhide=0, use_trskip=0):
+    """ref_in/pred_in uint8 [count, w*w] (stride w) -> (rec [count,w*w], coeff [count,w*w], has [count])"""
+    ref_in, pred_in = _u8(ref_in).reshape(-1, w * w), _u8(pred_in).reshape(-1, w * w)
+    rec = np.zeros_like(ref_in)
+    coeff = np.zeros(ref_in.shape, dtype=np.int16)
+    has = np.zeros(ref_in.shape[0], dtype=np.int32)
+    p, keep = _qp(qp, slice_is_intra, signhide)
+    for i in range(ref_in.shape[0]):
+        has[i] = lib().orc_quantize_residual(C.byref(p), int(cu_is_intra), w, color, scan_order_, int(use_trskip),
+                                             w, w, _p(ref_in[i], u8p), _p(pred_in[i], u8p), _p(rec[i], u8p),
+                                             _p(coeff[i], i16p))
+    return rec, coeff, has
+
+
+# ---------------------------------------------------------------- ipol
+def sample(kind, frame, x, y, w, h, mvx, mvy):
+    """kind: luma|luma14|chroma|chroma14.  src = &frame[y][x] (window around it must be inside)."""
+    frame = _u8(frame)
+    stride = frame.shape[1]
+    src = frame.ctypes.data + y * stride + x
+    mv = np.array([mvx, mvy], dtype=np.int16)
+    if kind in ("luma", "chroma"):
+        dst = np.zeros((h, w), dtype=np.uint8)
+        f = lib().orc_sample_quarterpel_luma if kind == "luma" else lib().orc_sample_octpel_chroma
+        f(src, stride, w, h, _p(dst, u8p), w, _p(mv, i16p))
+    else:
+        dst = np.zeros((h, w), dtype=np.int16)
+        f = lib().orc_sample_14bit_quarterpel_luma if kind == "luma14" else lib().orc_sample_14bit_octpel_chroma
+        f(src, stride, w, h, _p(dst, i16p), w, _p(mv, i16p))
+    return dst
+
+
+IPOL_STATE_BYTES = 2 * (5 * 72 * 64 + 5 * 72)
+
+
+def filter_frac_steps(frame, x, y, w, h, offs, fme_level=4):
+    """Runs steps 0..3 with src = &frame[y][x]; offs = (hpel_off_x, hpel_off_y) for the
+    qpel steps.  Returns uint8 [4 steps, 4 blocks, 64, 64] (only [:h,:w] defined)."""
+    frame = _u8(frame)
+    stride = frame.shape[1]
+    src = frame.ctypes.data + y * stride + x
+    st = np.zeros(IPOL_STATE_BYTES, dtype=np.uint8)
+    out = np.zeros((4, 4, 64, 64), dtype=np.uint8)
+    for step in range(4):
+        ox, oy = (0, 0) if step < 2 else offs
+        lib().orc_filter_frac_blocks(step, src, stride, w, h, _p(out[step], u8p), st.ctypes.data, fme_level, ox, oy)
+    return out
+
+
+def search_frac_costs(pic, ref, x, y, w, h, mvx, mvy):
+    pic, ref = _u8(pic), _u8(ref)
+    costs = np.zeros(17, dtype=np.uint32)
+    best = (C.c_int * 2)()
+    lib().orc_search_frac_costs(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],
+                                x, y, w, h, mvx, mvy, _p(costs, u32p), best)
+    return costs, (best[0], best[1])

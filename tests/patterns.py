@@ -1,0 +1,98 @@
+"""Deterministic input patterns shared by tests, bench and the golden generator.
+The patterns restate the reference's own test inputs (cited per function)."""
+import numpy as np
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def lcg_bytes(n, seed=12345):
+    """x = 1664525*x + 1013904223 (mod 2^32), byte = bits 8..15"""
+    out = np.empty(n, dtype=np.uint8)
+    # vectorised LCG via jump-ahead is overkill here; chunked python loop is fine for test sizes
+    x = seed & 0xFFFFFFFF
+    a, c = 1664525, 1013904223
+    for i in range(n):
+        x = (a * x + c) & 0xFFFFFFFF
+        out[i] = (x >> 8) & 0xFF
+    return out
+
+
+def satd_test_bufs(log_w):
+    """tests/satd_tests.c:61-90: (black/white, checkers, gradient) buffer pairs for width 1<<log_w"""
+    w = 1 << log_w
+    size = w * w
+    i = np.arange(size)
+    bw = (np.zeros(size, np.uint8), np.full(size, 255, np.uint8))
+    c0 = (255 * ((((i >> log_w) % 2) + (i % 2)) % 2)).astype(np.uint8)
+    c1 = ((c0.astype(np.int32) + 1) % 2).astype(np.uint8)
+    col, row = i % w, i // w
+    r = np.sqrt(row * row + col * col).astype(np.int64)       # int r = sqrt(...)
+    g0 = (255 // (r + 1)).astype(np.uint8)
+    g1 = (255 - 255 // (r + 1)).astype(np.uint8)
+    return bw, (c0, c1), (g0, g1)
+
+
+SATD_GOLDEN_BW = {2: 2040, 3: 4080, 4: 16320, 5: 65280, 6: 261120}          # satd_tests.c:109,127
+SATD_GOLDEN_GRADIENT = {2: 3140, 3: 9004, 4: 20481, 5: 67262, 6: 258672}    # satd_tests.c:146
+
+
+def intra_sad_gradient(width):
+    """tests/intra_sad_tests.c:48-58 init_gradient(3, 1, width, 1, buf) vs a flat 128 buffer (:91-96)"""
+    y, x = np.mgrid[0:width, 0:width]
+    val = (np.sqrt((3 - x) ** 2 + (1 - y) ** 2) + 0.5 + 1).astype(np.int64)
+    return np.clip(val, 0, 255).astype(np.uint8).ravel(), np.full(width * width, 128, np.uint8)
+
+
+def sad_test_frames():
+    """tests/sad_tests.c:38-58,77-105: the 8x8 pic/ref pair (+48) and the 64x64 big pair"""
+    ref = np.array([1, 2, 2, 2, 2, 2, 2, 3] + [4, 5, 5, 5, 5, 5, 5, 6] * 6 + [7, 8, 8, 8, 8, 8, 8, 9],
+                   dtype=np.uint8).reshape(8, 8) + 48
+    pic = np.ones((8, 8), np.uint8) + 48
+    i = np.arange(64 * 64, dtype=np.int64)
+    big_pic = ((i * i // 32 + i) % 255).astype(np.uint8).reshape(64, 64)
+    big_ref = ((i * i // 16 + i) % 255).astype(np.uint8).reshape(64, 64)
+    return pic, ref, big_pic, big_ref
+
+
+# tests/sad_tests.c:121-259: (mv_x, mv_y) -> closed-form expected kvz_image_calc_sad(pic, ref, 0,0, x,y, 8,8)
+SAD_EDGE_KAT = {
+    (-3, -3): 1 * 16 + (2 + 4) * 16 + 5 * 16 - 64,
+    (0, -3): (1 + 3) * 4 + 2 * 24 + (4 + 6) * 4 + 5 * 24 - 64,
+    (3, -3): 3 * 16 + (2 + 6) * 16 + 5 * 16 - 64,
+    (-3, 0): (1 + 7) * 4 + 4 * 24 + (2 + 8) * 4 + 5 * 24 - 64,
+    (0, 0): (1 + 3 + 7 + 9) + (2 + 4 + 6 + 8) * 6 + 5 * 36 - 64,
+    (3, 0): (3 + 9) * 4 + 6 * 24 + (2 + 8) * 4 + 5 * 24 - 64,
+    (-3, 3): 7 * 16 + (4 + 8) * 16 + 5 * 16 - 64,
+    (0, 3): (7 + 9) * 4 + 8 * 24 + (4 + 6) * 4 + 5 * 24 - 64,
+    (3, 3): 9 * 16 + (6 + 8) * 16 + 5 * 16 - 64,
+    (-10, -10): 1 * 64 - 64,
+    (0, -10): (1 + 3) * 8 + 2 * 48 - 64,
+    (10, -10): 3 * 64 - 64,
+    (-10, 0): (1 + 7) * 8 + 4 * 48 - 64,
+    (10, 0): (3 + 9) * 8 + 6 * 48 - 64,
+    (-10, 10): 7 * 64 - 64,
+    (0, 10): (7 + 9) * 8 + 8 * 48 - 64,
+    (10, 10): 9 * 64 - 64,
+}
+
+# tests/sad_tests.c:369-376
+REG_SAD_DIMS = [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (32, 64), (32, 16), (16, 32), (16, 8), (8, 16),
+                (8, 4), (4, 8), (48, 16), (16, 48), (24, 16), (16, 24), (12, 4), (4, 12)]
+
+
+def dct_test_input():
+    """tests/dct_tests.c:55-79: 64x64 radial gradient init_gradient(64, 64, 64, 255/64, buf); the
+    dct of size N reads its first N*N int16."""
+    y, x = np.mgrid[0:64, 0:64]
+    slope = 255 // 64
+    val = (slope * np.sqrt((64 - x) ** 2 + (64 - y) ** 2) + 0.5).astype(np.int64)
+    return np.clip(val, 0, 255).astype(np.int16).ravel()
+
+
+def coeff_sum_input():
+    """tests/coeff_sum_tests.c:29-43"""
+    c = (np.arange(64 * 64, dtype=np.int64) * 16 - 32768).astype(np.int16)
+    expected = 2048 * (16 + 32768) // 2 + 2048 * 2047 * 16 // 2
+    return c, expected

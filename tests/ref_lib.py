@@ -1,0 +1,262 @@
+"""ctypes binding of oracle/_ref/libkvzref.so -- the REFERENCE compiled from
+/root/reference by oracle/Makefile plus our harness glue (oracle/ref_harness.c).
+TEST INFRASTRUCTURE: used to pin the oracle, to generate tests/golden/, and as
+bench.py's cpu_baseline (kind "reference").  The .so is prebuilt in the build
+container and travels to the GPU box; /root/reference itself is never read at
+run time."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SO = os.path.join(os.path.dirname(_HERE), "oracle", "_ref", "libkvzref.so")
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+i16p = C.POINTER(C.c_int16)
+u32p = C.POINTER(C.c_uint32)
+S = C.c_char_p
+
+
+def available():
+    return os.path.exists(REF_SO)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(REF_SO, mode=C.RTLD_GLOBAL)
+        L.ref_init.restype = C.c_int
+        L.ref_strategy.restype = C.c_void_p
+        L.ref_strategy.argtypes = [S, S]
+        L.ref_list.restype = C.c_void_p
+        L.ref_strategy_type.restype = S
+        L.ref_strategy_name.restype = S
+        L.ref_reg_sad.restype = C.c_uint
+        L.ref_reg_sad.argtypes = [S, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_uint]
+        L.ref_cost_nxn.restype = C.c_uint
+        L.ref_cost_nxn.argtypes = [S, S, C.c_void_p, C.c_void_p]
+        L.ref_cost_nxn_dual.restype = None
+        L.ref_cost_nxn_dual.argtypes = [S, S, C.c_void_p, C.c_void_p, u32p]
+        L.ref_satd_any_size.restype = C.c_uint
+        L.ref_satd_any_size.argtypes = [S, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.ref_satd_any_size_quad.restype = None
+        L.ref_satd_any_size_quad.argtypes = [S, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int, u32p]
+        L.ref_pixels_calc_ssd.restype = C.c_uint
+        L.ref_pixels_calc_ssd.argtypes = [S, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ref_transform.restype = None
+        L.ref_transform.argtypes = [S, S, i16p, i16p]
+        L.ref_coeff_abs_sum.restype = C.c_uint32
+        L.ref_coeff_abs_sum.argtypes = [S, i16p, C.c_size_t]
+        L.ref_quant.restype = None
+        L.ref_quant.argtypes = [S] + [C.c_int] * 4 + [i16p, i16p] + [C.c_int] * 5
+        L.ref_dequant.restype = None
+        L.ref_dequant.argtypes = [S, C.c_int, C.c_int, i16p, i16p] + [C.c_int] * 4
+        L.ref_quantize_residual.restype = C.c_int
+        L.ref_quantize_residual.argtypes = [S] + [C.c_int] * 11 + [u8p, u8p, u8p, i16p]
+        L.ref_quant_coeff_table.restype = C.POINTER(C.c_int32)
+        L.ref_quant_coeff_table.argtypes = [C.c_int] * 3
+        L.ref_dequant_coeff_table.restype = C.POINTER(C.c_int32)
+        L.ref_dequant_coeff_table.argtypes = [C.c_int] * 3
+        for f, dt in (("ref_sample_luma", u8p), ("ref_sample_luma_14bit", i16p),
+                      ("ref_sample_chroma", u8p), ("ref_sample_chroma_14bit", i16p)):
+            getattr(L, f).restype = None
+            getattr(L, f).argtypes = [S, C.c_void_p, C.c_int, C.c_int, C.c_int, dt, C.c_int, C.c_int, C.c_int]
+        for f in ("ref_image_calc_sad", "ref_image_calc_satd"):
+            getattr(L, f).restype = C.c_uint
+            getattr(L, f).argtypes = [S, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int] + [C.c_int] * 6
+        L.ref_search_frac_costs.restype = None
+        L.ref_search_frac_costs.argtypes = [S, u8p, C.c_int, u8p, C.c_int, C.c_int] + [C.c_int] * 6 + \
+            [u32p, C.POINTER(C.c_int)]
+        L.ref_filter_step.restype = None
+        L.ref_filter_step.argtypes = [S, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, u8p, i16p, i16p,
+                                      C.c_int, C.c_int, C.c_int]
+        L.ref_bench_cost_nxn.restype = C.c_double
+        L.ref_bench_cost_nxn.argtypes = [S, S, C.c_int, u8p, u8p, C.c_size_t, C.c_double, u32p]
+        L.ref_bench_transform.restype = C.c_double
+        L.ref_bench_transform.argtypes = [S, S, C.c_int, i16p, i16p, C.c_size_t, C.c_double]
+        L.ref_bench_reg_sad.restype = C.c_double
+        L.ref_bench_reg_sad.argtypes = [S, u8p, u8p] + [C.c_int] * 5 + [C.c_double, u32p]
+        # the selector prints its "Available/In use" banner on stderr
+        if not L.ref_init():
+            raise RuntimeError("reference strategyselector init failed")
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _aligned(a, align=64):
+    """copy into a 64-byte aligned buffer (avx2 sad_NxN uses aligned loads, picture-avx2.c:44)"""
+    a = np.ascontiguousarray(a)
+    raw = np.empty(a.nbytes + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    out = raw[off:off + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def has_strategy(type_, name):
+    return bool(lib().ref_strategy(type_.encode(), name.encode()))
+
+
+def strategies():
+    L = lib()
+    return [(L.ref_strategy_type(i).decode(), L.ref_strategy_name(i).decode(), L.ref_strategy_priority(i))
+            for i in range(L.ref_strategy_count())]
+
+
+def reg_sad(a, b, off1, off2, w, h, s1, s2, name="generic"):
+    a, b = _u8(a).ravel(), _u8(b).ravel()
+    return lib().ref_reg_sad(name.encode(), a.ctypes.data + off1, b.ctypes.data + off2, w, h, s1, s2)
+
+
+def cost_nxn_batch(kind, n, blk1, blk2, name="generic"):
+    blk1 = _aligned(_u8(blk1).reshape(-1, n * n))
+    blk2 = _aligned(_u8(blk2).reshape(-1, n * n))
+    t = ("%s_%dx%d" % (kind, n, n)).encode()
+    out = np.empty(blk1.shape[0], dtype=np.uint32)
+    for i in range(blk1.shape[0]):
+        out[i] = lib().ref_cost_nxn(t, name.encode(), blk1[i].ctypes.data, blk2[i].ctypes.data)
+    return out
+
+
+def cost_nxn_dual_batch(kind, n, preds, orig, name="generic"):
+    """preds uint8 [count, 2048] (pred_buffer: pred k at k*1024)"""
+    orig = _aligned(_u8(orig).reshape(-1, n * n))
+    preds = _aligned(_u8(preds).reshape(orig.shape[0], 2048))
+    t = ("%s_%dx%d_dual" % (kind, n, n)).encode()
+    out = np.empty((orig.shape[0], 2), dtype=np.uint32)
+    for i in range(orig.shape[0]):
+        lib().ref_cost_nxn_dual(t, name.encode(), preds[i].ctypes.data, orig[i].ctypes.data, _p(out[i], u32p))
+    return out
+
+
+def satd_any_size(w, h, a, off1, s1, b, off2, s2, name="generic"):
+    a, b = _u8(a).ravel(), _u8(b).ravel()
+    return lib().ref_satd_any_size(name.encode(), w, h, a.ctypes.data + off1, s1, b.ctypes.data + off2, s2)
+
+
+def satd_any_size_quad(w, h, preds4, stride, orig, orig_off, orig_stride, name="generic"):
+    ps = [_u8(p).ravel() for p in preds4]
+    orig = _u8(orig).ravel()
+    out = np.zeros(4, dtype=np.uint32)
+    lib().ref_satd_any_size_quad(name.encode(), w, h, *[p.ctypes.data for p in ps], stride,
+                                 orig.ctypes.data + orig_off, orig_stride, _p(out, u32p))
+    return out
+
+
+def pixels_calc_ssd(a, off1, b, off2, s1, s2, w, name="generic"):
+    a, b = _u8(a).ravel(), _u8(b).ravel()
+    return lib().ref_pixels_calc_ssd(name.encode(), a.ctypes.data + off1, b.ctypes.data + off2, s1, s2, w)
+
+
+def image_calc(kind, pic, ref, pic_x, pic_y, ref_x, ref_y, bw, bh, name="generic"):
+    pic, ref = _u8(pic), _u8(ref)
+    f = lib().ref_image_calc_sad if kind == "sad" else lib().ref_image_calc_satd
+    return f(name.encode(), _p(pic, u8p), pic.shape[1], pic.shape[0], _p(ref, u8p), ref.shape[1], ref.shape[0],
+             pic_x, pic_y, ref_x, ref_y, bw, bh)
+
+
+_TR_TYPE = {("dct", 4): "dct_4x4", ("dct", 8): "dct_8x8", ("dct", 16): "dct_16x16", ("dct", 32): "dct_32x32",
+            ("idct", 4): "idct_4x4", ("idct", 8): "idct_8x8", ("idct", 16): "idct_16x16", ("idct", 32): "idct_32x32",
+            ("dst", 4): "fast_forward_dst_4x4", ("idst", 4): "fast_inverse_dst_4x4"}
+
+
+def transform_batch(kind, n, blocks, name="generic"):
+    blocks = _aligned(np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, n * n))
+    out = _aligned(np.zeros_like(blocks))
+    t = _TR_TYPE[(kind, n)].encode()
+    for i in range(blocks.shape[0]):
+        lib().ref_transform(t, name.encode(), _p(blocks[i], i16p), _p(out[i], i16p))
+    return np.array(out)
+
+
+def coeff_abs_sum(c, name="generic"):
+    c = _aligned(np.ascontiguousarray(c, dtype=np.int16).ravel())
+    return lib().ref_coeff_abs_sum(name.encode(), _p(c, i16p), c.size)
+
+
+def quant_batch(coef, w, qp, type_, scan_idx, slice_is_intra=0, signhide=0, block_is_intra=0, sl=0, name="generic"):
+    coef = _aligned(np.ascontiguousarray(coef, dtype=np.int16).reshape(-1, w * w))
+    out = _aligned(np.zeros_like(coef))
+    bt = 1 if block_is_intra else 2   # CU_INTRA = 1, CU_INTER = 2 (cu.h:39-41)
+    for i in range(coef.shape[0]):
+        lib().ref_quant(name.encode(), qp, int(slice_is_intra), int(signhide), sl, _p(coef[i], i16p), _p(out[i], i16p),
+                        w, w, type_, scan_idx, bt)
+    return np.array(out)
+
+
+def dequant_batch(q_coef, w, qp, type_, block_is_intra=0, sl=0, name="generic"):
+    q_coef = _aligned(np.ascontiguousarray(q_coef, dtype=np.int16).reshape(-1, w * w))
+    out = _aligned(np.zeros_like(q_coef))
+    bt = 1 if block_is_intra else 2
+    for i in range(q_coef.shape[0]):
+        lib().ref_dequant(name.encode(), qp, sl, _p(q_coef[i], i16p), _p(out[i], i16p), w, w, type_, bt)
+    return np.array(out)
+
+
+def scaling_tables(log2_tr, list_type, qp_rem, n):
+    L = lib()
+    q = np.ctypeslib.as_array(L.ref_quant_coeff_table(log2_tr, list_type, qp_rem), shape=(n * n,)).copy()
+    d = np.ctypeslib.as_array(L.ref_dequant_coeff_table(log2_tr, list_type, qp_rem), shape=(n * n,)).copy()
+    return q, d
+
+
+def quantize_residual_batch(ref_in, pred_in, w, qp, color, scan_order_, cu_is_intra, slice_is_intra=0,
+                            signhide=0, use_trskip=0, name="generic"):
+    ref_in, pred_in = _u8(ref_in).reshape(-1, w * w), _u8(pred_in).reshape(-1, w * w)
+    rec = np.zeros_like(ref_in)
+    coeff = _aligned(np.zeros(ref_in.shape, dtype=np.int16))
+    has = np.zeros(ref_in.shape[0], dtype=np.int32)
+    for i in range(ref_in.shape[0]):
+        has[i] = lib().ref_quantize_residual(name.encode(), qp, int(slice_is_intra), int(signhide), 0,
+                                             int(cu_is_intra), w, color, scan_order_, int(use_trskip), w, w,
+                                             _p(ref_in[i], u8p), _p(pred_in[i], u8p), _p(rec[i], u8p),
+                                             _p(coeff[i], i16p))
+    return rec, np.array(coeff), has
+
+
+def sample(kind, frame, x, y, w, h, mvx, mvy, name="generic"):
+    frame = _u8(frame)
+    stride = frame.shape[1]
+    src = frame.ctypes.data + y * stride + x
+    if kind in ("luma", "chroma"):
+        dst = np.zeros((h, w), dtype=np.uint8)
+        f = lib().ref_sample_luma if kind == "luma" else lib().ref_sample_chroma
+        f(name.encode(), src, stride, w, h, _p(dst, u8p), w, mvx, mvy)
+    else:
+        dst = np.zeros((h, w), dtype=np.int16)
+        f = lib().ref_sample_luma_14bit if kind == "luma14" else lib().ref_sample_chroma_14bit
+        f(name.encode(), src, stride, w, h, _p(dst, i16p), w, mvx, mvy)
+    return dst
+
+
+def filter_frac_steps(frame, x, y, w, h, offs, fme_level=4, name="generic"):
+    frame = _u8(frame)
+    stride = frame.shape[1]
+    src = frame.ctypes.data + y * stride + x
+    inter = _aligned(np.zeros(5 * 72 * 64, dtype=np.int16))
+    cols = np.zeros(5 * 72, dtype=np.int16)
+    out = _aligned(np.zeros((4, 4, 64, 64), dtype=np.uint8))
+    for step in range(4):
+        ox, oy = (0, 0) if step < 2 else offs
+        lib().ref_filter_step(name.encode(), step, src, stride, w, h, _p(out[step], u8p), _p(inter, i16p),
+                              _p(cols, i16p), fme_level, ox, oy)
+    return np.array(out)
+
+
+def search_frac_costs(pic, ref, x, y, w, h, mvx, mvy, name="generic"):
+    pic, ref = _u8(pic), _u8(ref)
+    costs = np.zeros(17, dtype=np.uint32)
+    best = (C.c_int * 2)()
+    lib().ref_search_frac_costs(name.encode(), _p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],
+                                x, y, w, h, mvx, mvy, _p(costs, u32p), best)
+    return costs, (best[0], best[1])

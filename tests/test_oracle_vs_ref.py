@@ -1,0 +1,254 @@
+"""Pins the oracle (oracle/kvz_oracle.c) against the COMPILED REFERENCE
+(oracle/_ref/libkvzref.so = /root/reference built by oracle/Makefile), function
+by function, on the reference's own test patterns plus random and adversarial
+inputs.  CPU only.  Skipped when the prebuilt reference library is absent."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_lib as R
+from patterns import lcg_bytes, rng
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+
+SIZES = (4, 8, 16, 32, 64)
+
+
+def _blocks(n, count, seed, mode):
+    g = rng(seed)
+    if mode == "random":
+        a = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+        b = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+    elif mode == "extreme":
+        a = np.zeros((count, n * n), np.uint8)
+        b = np.full((count, n * n), 255, np.uint8)
+        a[1::2], b[1::2] = 255, 0
+    else:  # near: small differences (typical ME residual)
+        a = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + g.integers(-6, 7, a.shape), 0, 255).astype(np.uint8)
+    return a, b
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("mode", ["random", "extreme", "near"])
+@pytest.mark.parametrize("kind", ["sad", "satd"])
+def test_cost_nxn(kind, n, mode):
+    a, b = _blocks(n, 24, 100 + n, mode)
+    np.testing.assert_array_equal(O.cost_nxn_batch(kind, n, a, b), R.cost_nxn_batch(kind, n, a, b))
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("kind", ["sad", "satd"])
+def test_cost_nxn_dual(kind, n):
+    g = rng(7 + n)
+    if n > 32:
+        pytest.skip("pred_buffer holds 32x32 (strategies-picture.h:34); 64x64_dual overlaps it")
+    orig = g.integers(0, 256, (16, n * n), dtype=np.uint8)
+    preds = g.integers(0, 256, (16, 2048), dtype=np.uint8)
+    np.testing.assert_array_equal(O.cost_nxn_dual_batch(kind, n, preds, orig),
+                                  R.cost_nxn_dual_batch(kind, n, preds, orig))
+
+
+def test_reg_sad_shapes():
+    g = rng(3)
+    a = g.integers(0, 256, 64 * 80, dtype=np.uint8)
+    b = g.integers(0, 256, 96 * 80, dtype=np.uint8)
+    dims = [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (32, 64), (32, 16), (16, 32), (16, 8), (8, 16),
+            (8, 4), (4, 8), (48, 16), (16, 48), (24, 16), (16, 24), (12, 4), (4, 12), (64, 63), (1, 1), (7, 3)]
+    for (w, h) in dims:
+        for (o1, o2) in ((0, 0), (5, 9), (64 * 3 + 1, 96 * 7 + 13)):
+            assert O.reg_sad(a, b, o1, o2, w, h, 64, 96) == R.reg_sad(a, b, o1, o2, w, h, 64, 96)
+
+
+def test_satd_any_size_shapes():
+    g = rng(4)
+    a = g.integers(0, 256, 80 * 80, dtype=np.uint8)
+    b = g.integers(0, 256, 100 * 80, dtype=np.uint8)
+    for w in (4, 8, 12, 16, 24, 32, 48, 64):
+        for h in (4, 8, 12, 16, 24, 32, 48, 64):
+            assert O.satd_any_size(w, h, a, 3, 80, b, 7, 100) == R.satd_any_size(w, h, a, 3, 80, b, 7, 100)
+
+
+def test_satd_any_size_quad_incl_quirk():
+    g = rng(5)
+    preds = [g.integers(0, 256, 64 * 72, dtype=np.uint8) for _ in range(4)]
+    orig = g.integers(0, 256, 100 * 80, dtype=np.uint8)
+    for w in (4, 8, 12, 16, 24, 32, 64):
+        for h in (4, 8, 12, 16, 24, 32, 64):
+            o = O.satd_any_size_quad(w, h, preds, 64, orig, 11, 100)
+            r = R.satd_any_size_quad(w, h, preds, 64, orig, 11, 100)
+            np.testing.assert_array_equal(o, r, err_msg="w=%d h=%d" % (w, h))
+
+
+def test_pixels_calc_ssd():
+    g = rng(6)
+    a = g.integers(0, 256, 70 * 70, dtype=np.uint8)
+    b = g.integers(0, 256, 70 * 70, dtype=np.uint8)
+    for w in (4, 8, 16, 32, 64):
+        assert O.pixels_calc_ssd(a, 2, b, 5, 70, 66, w) == R.pixels_calc_ssd(a, 2, b, 5, 70, 66, w)
+    z, m = np.zeros(64 * 64, np.uint8), np.full(64 * 64, 255, np.uint8)
+    assert O.pixels_calc_ssd(z, 0, m, 0, 64, 64, 64) == R.pixels_calc_ssd(z, 0, m, 0, 64, 64, 64)
+
+
+def test_image_calc_sad_and_satd_edges():
+    g = rng(8)
+    pic = g.integers(0, 256, (48, 64), dtype=np.uint8)
+    ref = g.integers(0, 256, (48, 64), dtype=np.uint8)
+    for (bw, bh) in ((8, 8), (16, 16), (16, 8), (32, 32)):
+        for (px, py) in ((0, 0), (16, 8), (64 - bw, 48 - bh)):
+            for (dx, dy) in ((0, 0), (-3, -3), (5, -70), (-100, 2), (70, 70), (3, 0), (0, 60), (-bw, -bh),
+                             (64, 48), (63 - px, 47 - py)):
+                args = (pic, ref, px, py, px + dx, py + dy, bw, bh)
+                assert O.image_calc("sad", *args) == R.image_calc("sad", *args), args[2:]
+                assert O.image_calc("satd", *args) == R.image_calc("satd", *args), args[2:]
+
+
+@pytest.mark.parametrize("kind,n", [("dct", 4), ("dct", 8), ("dct", 16), ("dct", 32), ("idct", 4), ("idct", 8),
+                                     ("idct", 16), ("idct", 32), ("dst", 4), ("idst", 4)])
+def test_transform(kind, n):
+    g = rng(20 + n)
+    res = g.integers(-255, 256, (16, n * n)).astype(np.int16)          # encoder's residual domain
+    full = g.integers(-32768, 32768, (16, n * n)).astype(np.int16)     # wrap / clip behaviour
+    edge = np.array([[32767] * (n * n), [-32768] * (n * n),
+                     [32767 if (i + i // n) % 2 else -32768 for i in range(n * n)]], dtype=np.int16)
+    for x in (res, full, edge):
+        np.testing.assert_array_equal(O.transform_batch(kind, n, x), R.transform_batch(kind, n, x))
+
+
+def test_dct_matrix_generation_is_orthogonal_like():
+    for n in (4, 8, 16, 32):
+        M = O.dct_matrix(n).astype(np.int64)
+        assert (M[0] == 64).all()
+        G = M @ M.T
+        off = G - np.diag(np.diag(G))
+        assert np.abs(off).max() < 64 * 64 * n * 0.02   # HEVC matrices are near-orthogonal
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+@pytest.mark.parametrize("signhide", [0, 1])
+def test_quant(w, signhide):
+    g = rng(30 + w)
+    coef = g.integers(-2000, 2001, (12, w * w)).astype(np.int16)
+    coef[3] = g.integers(-32768, 32768, w * w)
+    coef[4] = 0
+    coef[5, ::7] = 1
+    for qp in (0, 5, 22, 27, 37, 51):
+        # 32x32 chroma TUs do not exist (4:2:0, max TU 32) and the reference has no
+        # scaling-list table for them (scalinglist.c:72-93): luma only at w == 32
+        for type_ in ((0,) if w == 32 else (0, 2)):
+            for scan in (0, 1, 2):
+                for intra_slice in (0, 1):
+                    o = O.quant_batch(coef, w, qp, type_, scan, intra_slice, signhide)
+                    r = R.quant_batch(coef, w, qp, type_, scan, intra_slice, signhide)
+                    np.testing.assert_array_equal(o, r, err_msg="qp=%d type=%d scan=%d" % (qp, type_, scan))
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_dequant(w):
+    g = rng(40 + w)
+    q = g.integers(-300, 301, (8, w * w)).astype(np.int16)
+    q[2] = g.integers(-32768, 32768, w * w)
+    for qp in (0, 7, 22, 36, 51):
+        for type_ in ((0,) if w == 32 else (0, 2, 3)):
+            np.testing.assert_array_equal(O.dequant_batch(q, w, qp, type_), R.dequant_batch(q, w, qp, type_))
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_quant_dequant_scaling_list(w):
+    """default (non-flat) scaling list: the oracle is fed the reference's processed tables"""
+    g = rng(45 + w)
+    log2 = {4: 2, 8: 3, 16: 4, 32: 5}[w]
+    coef = g.integers(-3000, 3001, (6, w * w)).astype(np.int16)
+    for qp in (10, 22, 33):
+        for intra in (0, 1):
+            list_type = (0 if intra else 3) + 0        # luma
+            if log2 == 5:
+                list_type = 0 if intra else 1          # 32x32: list 3 aliases list 1 (scalinglist.c:88-92)
+            qt, dt = R.scaling_tables(log2, list_type, qp % 6, w)
+            r = R.quant_batch(coef, w, qp, 0, 0, 0, 0, intra, sl=1)
+            o = O.quant_batch(coef, w, qp, 0, 0, 0, 0, intra, quant_coeff=qt)
+            np.testing.assert_array_equal(o, r)
+            rd = R.dequant_batch(r, w, qp, 0, intra, sl=1)
+            od = O.dequant_batch(r, w, qp, 0, intra, dequant_coeff=dt)
+            np.testing.assert_array_equal(od, rd)
+
+
+def test_coeff_abs_sum_kat():
+    # tests/coeff_sum_tests.c:29-43
+    c = (np.arange(64 * 64, dtype=np.int64) * 16 - 32768).astype(np.int16)
+    expected = 2048 * (16 + 32768) // 2 + 2048 * 2047 * 16 // 2
+    assert O.coeff_abs_sum(c) == expected == R.coeff_abs_sum(c)
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_quantize_residual(w):
+    g = rng(50 + w)
+    ref_in = g.integers(0, 256, (10, w * w), dtype=np.uint8)
+    pred = np.clip(ref_in.astype(np.int32) + g.integers(-40, 41, ref_in.shape), 0, 255).astype(np.uint8)
+    pred[0] = ref_in[0]                  # zero residual => no coeffs path
+    pred[1] = 255 - ref_in[1]            # large residual
+    for qp in (12, 22, 32, 45):
+        for color in ((0,) if w == 32 else (0, 1, 2)):
+            for intra in (0, 1):
+                for trskip in ((0, 1) if w == 4 else (0,)):
+                    o = O.quantize_residual_batch(ref_in, pred, w, qp, color, 0, intra, intra, 0, trskip)
+                    r = R.quantize_residual_batch(ref_in, pred, w, qp, color, 0, intra, intra, 0, trskip)
+                    for a, b, nm in zip(o, r, ("rec", "coeff", "has")):
+                        np.testing.assert_array_equal(a, b, err_msg="%s qp=%d color=%d intra=%d" % (nm, qp, color, intra))
+
+
+@pytest.mark.parametrize("kind", ["luma", "luma14", "chroma", "chroma14"])
+def test_sample_filters(kind):
+    g = rng(60)
+    frame = g.integers(0, 256, (96, 96), dtype=np.uint8)
+    frame[40:60, 40:60] = np.where(g.integers(0, 2, (20, 20)) > 0, 255, 0)   # adversarial extremes
+    nfrac = 4 if kind.startswith("luma") else 8
+    sizes = ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 4)) if kind.startswith("luma") else \
+            ((4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (2, 2))
+    for (w, h) in sizes:
+        for fx in range(nfrac):
+            for fy in range(nfrac):
+                o = O.sample(kind, frame, 12, 10, w, h, fx, fy)
+                r = R.sample(kind, frame, 12, 10, w, h, fx, fy)
+                np.testing.assert_array_equal(o, r, err_msg="%s %dx%d frac=(%d,%d)" % (kind, w, h, fx, fy))
+
+
+@pytest.mark.parametrize("pattern", ["random", "extreme"])
+def test_frac_block_filters(pattern):
+    g = rng(70)
+    frame = g.integers(0, 256, (96, 96), dtype=np.uint8)
+    if pattern == "extreme":
+        frame = np.where(g.integers(0, 2, (96, 96)) > 0, 255, 0).astype(np.uint8)
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8)):
+        for ox in (-1, 0, 1):
+            for oy in (-1, 0, 1):
+                o = O.filter_frac_steps(frame, 10, 9, w, h, (ox, oy))
+                r = R.filter_frac_steps(frame, 10, 9, w, h, (ox, oy))
+                np.testing.assert_array_equal(o[:, :, :h, :w], r[:, :, :h, :w],
+                                              err_msg="%dx%d off=(%d,%d)" % (w, h, ox, oy))
+
+
+def test_search_frac_costs():
+    g = rng(80)
+    ref = g.integers(0, 256, (72, 96), dtype=np.uint8)
+    # pic = ref shifted by a sub-pel-ish blend so that fractional positions matter
+    pic = ((ref.astype(np.int32) + np.roll(ref, 1, axis=1)) // 2).astype(np.uint8)
+    for (w, h) in ((8, 8), (16, 16), (32, 32)):
+        for (x, y) in ((0, 0), (32, 24), (96 - w, 72 - h)):
+            for (mvx, mvy) in ((0, 0), (-2, 1), (5, -3), (-40, -40), (90, 70)):
+                o = O.search_frac_costs(pic, ref, x, y, w, h, mvx, mvy)
+                r = R.search_frac_costs(pic, ref, x, y, w, h, mvx, mvy)
+                np.testing.assert_array_equal(o[0], r[0], err_msg=str((w, h, x, y, mvx, mvy)))
+                assert o[1] == r[1]
+
+
+def test_avx2_agrees_where_survey_says_so():
+    """avx2 == generic for IDCT on any input and for forward DCT on 9-bit residuals."""
+    if not R.has_strategy("dct_32x32", "avx2"):
+        pytest.skip("host has no avx2")
+    g = rng(90)
+    for n in (4, 8, 16, 32):
+        res = g.integers(-255, 256, (8, n * n)).astype(np.int16)
+        np.testing.assert_array_equal(R.transform_batch("dct", n, res, "avx2"), O.transform_batch("dct", n, res))
+        full = g.integers(-32768, 32768, (8, n * n)).astype(np.int16)
+        np.testing.assert_array_equal(R.transform_batch("idct", n, full, "avx2"), O.transform_batch("idct", n, full))
