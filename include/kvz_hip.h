@@ -1,0 +1,272 @@
+/*
+ * kvz_hip.h -- C ABI of libkvzhip.so: Kvazaar's per-CTU block kernels as
+ * hand-written HIP kernels for MI355X (gfx950), exposed
+ *
+ *   (1) as a "hip" strategy for Kvazaar's strategyselector plugin API
+ *       (reference: src/strategyselector.h:86-87 and the per-group
+ *       registration hooks kvz_strategy_register_<group>_<isa>, e.g.
+ *       src/strategies/avx2/picture-avx2.c:1224-1258), and
+ *   (2) as batched entry points on device-resident buffers -- the form the
+ *       kernels really implement and the one that is measured.
+ *
+ * All paths cited below are relative to the reference's src/ directory.
+ * Plain C: pointers and sizes only.  Every extern symbol is kvz_-prefixed
+ * (reference rule: tests/test_external_symbols.sh:7).
+ *
+ * Conventions
+ *   kvz_pixel = uint8_t (KVZ_BIT_DEPTH 8, kvazaar.h:72-77), coeff_t = int16_t
+ *   (global.h:99).  Batched entries take DEVICE pointers and a stream; they are
+ *   asynchronous (enqueue only) and return KVZ_HIP_OK or a negative error code.
+ *   Strategy (per-call) entries take HOST pointers exactly like the reference's
+ *   typedefs and are complete (results visible to the host) on return.
+ *   There is no CPU fallback anywhere: without a usable GPU kvz_hip_init fails,
+ *   the registration hooks return 0 (=> kvz_strategyselector_init fails, as for
+ *   any strategy that cannot register: strategyselector.c:54-95) and the batched
+ *   entries return KVZ_HIP_ERR_NO_DEVICE.
+ */
+#ifndef KVZ_HIP_H_
+#define KVZ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define KVZ_HIP_API __attribute__((visibility("default")))
+#else
+#define KVZ_HIP_API
+#endif
+
+typedef uint8_t kvz_hip_pixel;
+typedef int16_t kvz_hip_coeff;
+typedef void *kvz_hip_stream;        /* hipStream_t; NULL = the library's default stream */
+
+enum {
+  KVZ_HIP_OK = 0,
+  KVZ_HIP_ERR_NO_DEVICE = -1,       /* no gfx950 device / runtime failed to initialise */
+  KVZ_HIP_ERR_INVALID = -2,         /* bad argument (size not supported, NULL pointer ...) */
+  KVZ_HIP_ERR_RUNTIME = -3          /* a HIP call failed; see kvz_hip_last_error() */
+};
+
+/* ------------------------------------------------------------------ */
+/* context                                                            */
+/* ------------------------------------------------------------------ */
+/* Select the device and create the library context.  Idempotent.  Called
+ * implicitly (device 0 or $KVZ_HIP_DEVICE) by the registration hooks -- the
+ * analogue of set_hardware_flags(), strategyselector.c:452. */
+KVZ_HIP_API int kvz_hip_init(int device);
+KVZ_HIP_API void kvz_hip_shutdown(void);
+KVZ_HIP_API int kvz_hip_device_count(void);
+KVZ_HIP_API const char *kvz_hip_last_error(void);
+KVZ_HIP_API const char *kvz_hip_device_name(void);
+
+/* Thin device-memory helpers so a C host needs no HIP headers. */
+KVZ_HIP_API void *kvz_hip_malloc(size_t bytes);
+KVZ_HIP_API void kvz_hip_free(void *dptr);
+KVZ_HIP_API int kvz_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_memset(void *dst, int value, size_t bytes, kvz_hip_stream s);
+KVZ_HIP_API kvz_hip_stream kvz_hip_stream_create(void);
+KVZ_HIP_API void kvz_hip_stream_destroy(kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_stream_sync(kvz_hip_stream s);
+/* HIP-event timing of the enqueued work on stream s (used by bench.py for the
+ * roofline: the event pair brackets exactly the launches issued in between). */
+KVZ_HIP_API void *kvz_hip_event_create(void);
+KVZ_HIP_API void kvz_hip_event_destroy(void *ev);
+KVZ_HIP_API int kvz_hip_event_record(void *ev, kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_event_elapsed_ms(void *start, void *stop, float *ms);  /* syncs on stop */
+
+/* ------------------------------------------------------------------ */
+/* (2) batched entries -- picture group                               */
+/*     reference typedefs: strategies/strategies-picture.h:102-130    */
+/* ------------------------------------------------------------------ */
+
+/* cost_pixel_nxn_func over `count` contiguous N*N block pairs:
+ * costs[i] = sad_NxN(blk1 + i*N*N, blk2 + i*N*N); N in {4,8,16,32,64}.
+ * Replaces sad_4x4..sad_64x64 (generic/picture-generic.c:460-486). */
+KVZ_HIP_API int kvz_hip_sad_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel *blk2,
+                                      size_t count, uint32_t *costs, kvz_hip_stream s);
+/* satd_4x4..satd_64x64 (picture-generic.c:189-196, strategies-picture.h:40-56) */
+KVZ_HIP_API int kvz_hip_satd_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel *blk2,
+                                       size_t count, uint32_t *costs, kvz_hip_stream s);
+
+/* cost_pixel_nxn_multi_func (sad_NxN_dual / satd_NxN_dual, picture-generic.c:357-390,
+ * :497-519): item i has two predictions at preds + i*item_stride + {0, pred_stride}
+ * (pred_stride = 1024 for the reference's pred_buffer, strategies-picture.h:34) and
+ * one original block at orig + i*N*N; costs[2*i + k]. */
+KVZ_HIP_API int kvz_hip_sad_nxn_dual_batch(int n, const kvz_hip_pixel *preds, size_t pred_stride, size_t item_stride,
+                                           const kvz_hip_pixel *orig, size_t count, uint32_t *costs, kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_satd_nxn_dual_batch(int n, const kvz_hip_pixel *preds, size_t pred_stride, size_t item_stride,
+                                            const kvz_hip_pixel *orig, size_t count, uint32_t *costs, kvz_hip_stream s);
+
+/* One block pair inside two planes; the unit of the frame-level entries below. */
+typedef struct {
+  int32_t x1, y1;          /* top-left of the block in plane 1 (the picture being coded) */
+  int32_t x2, y2;          /* top-left of the block in plane 2 (the reference picture)   */
+  int32_t width, height;
+} kvz_hip_block_pair;
+
+/* reg_sad_func (picture-generic.c:86-99) over a list of block pairs that lie
+ * INSIDE their planes: costs[i] = reg_sad(p1 + y1*stride1 + x1, p2 + y2*stride2 + x2, w, h, ..).
+ * Any width/height >= 1 (tests/sad_tests.c:369-376 shapes, 64x63, 1x1). */
+KVZ_HIP_API int kvz_hip_reg_sad_batch(const kvz_hip_pixel *plane1, uint32_t stride1,
+                                      const kvz_hip_pixel *plane2, uint32_t stride2,
+                                      const kvz_hip_block_pair *pairs, size_t count,
+                                      uint32_t *costs, kvz_hip_stream s);
+/* kvz_image_calc_sad (image.c:455-486): plane 2 coordinates may be outside the
+ * w2 x h2 reference frame; outside pixels are edge replicated, which is what
+ * image_interpolated_sad (image.c:320-444) computes. */
+KVZ_HIP_API int kvz_hip_image_calc_sad_batch(const kvz_hip_pixel *pic, uint32_t pic_stride,
+                                             const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                             const kvz_hip_block_pair *pairs, size_t count,
+                                             uint32_t *costs, kvz_hip_stream s);
+/* cost_pixel_any_size_func (strategies-picture.h:62-100) / kvz_image_calc_satd
+ * (image.c:488-545): width and height multiples of 4; edge replication as above. */
+KVZ_HIP_API int kvz_hip_image_calc_satd_batch(const kvz_hip_pixel *pic, uint32_t pic_stride,
+                                              const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                              const kvz_hip_block_pair *pairs, size_t count,
+                                              uint32_t *costs, kvz_hip_stream s);
+/* pixels_calc_ssd_func (picture-generic.c:521-536): square blocks, width = pairs[i].width */
+KVZ_HIP_API int kvz_hip_pixels_calc_ssd_batch(const kvz_hip_pixel *plane1, uint32_t stride1,
+                                              const kvz_hip_pixel *plane2, uint32_t stride2,
+                                              const kvz_hip_block_pair *pairs, size_t count,
+                                              uint32_t *ssd, kvz_hip_stream s);
+/* cost_pixel_any_size_multi_func (satd_any_size_quad, picture-generic.c:392-456),
+ * including its behaviour for widths/heights that are not multiples of 8:
+ * item i compares 4 candidate blocks preds + (4*i + k)*pred_item_stride
+ * (row stride pred_stride, 64 in search_inter.c:1076) with the block at
+ * (x1,y1) of `orig`; costs[4*i + k]. */
+KVZ_HIP_API int kvz_hip_satd_any_size_quad_batch(const kvz_hip_pixel *preds, uint32_t pred_stride, size_t pred_item_stride,
+                                                 const kvz_hip_pixel *orig, uint32_t orig_stride,
+                                                 const kvz_hip_block_pair *pairs, size_t count,
+                                                 uint32_t *costs, kvz_hip_stream s);
+/* inter_recon_bipred_func's blend (picture-generic.c:538-588) for `count` planes
+ * of w x h samples laid out contiguously (stride w): each source is either 14-bit
+ * int16 samples (hi_prec != 0) or pixels. */
+KVZ_HIP_API int kvz_hip_bipred_blend_batch(int w, int h, int hi_prec0, const void *src0, int hi_prec1, const void *src1,
+                                           kvz_hip_pixel *dst, size_t count, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
+/* (2) batched entries -- dct group (strategies/strategies-dct.h:31)   */
+/* ------------------------------------------------------------------ */
+enum { KVZ_HIP_DCT = 0, KVZ_HIP_IDCT = 1, KVZ_HIP_DST = 2, KVZ_HIP_IDST = 3 };
+/* dct_func over `count` contiguous N*N int16 blocks (generic/dct-generic.c:567-617).
+ * kind DCT/IDCT: n in {4,8,16,32}; DST/IDST: n == 4 (fast_forward_dst_4x4 / inverse). */
+KVZ_HIP_API int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16_t *out,
+                                        size_t count, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
+/* (2) batched entries -- quant group (strategies/strategies-quant.h)  */
+/* ------------------------------------------------------------------ */
+/* The encoder state the reference's quant functions read, flattened
+ * (generic/quant-generic.c:40-50, :283-289). */
+typedef struct {
+  int32_t qp;               /* state->qp */
+  int32_t slice_is_intra;   /* state->frame->slicetype == KVZ_SLICE_I */
+  int32_t signhide;         /* encoder->cfg.signhide_enable */
+  int32_t scaling_list;     /* encoder->scaling_list.enable; 0 = flat list */
+  const int32_t *quant_coeff;    /* DEVICE (batched) / HOST (per-call) [w*h] factors when scaling_list */
+  const int32_t *dequant_coeff;  /* likewise */
+} kvz_hip_quant_params;
+
+/* quant_func (quant-generic.c:37-163) over `count` w*w blocks.
+ * type: 0 luma, 2/3 chroma; scan_idx 0 diag / 1 hor / 2 ver. */
+KVZ_HIP_API int kvz_hip_quant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *coef, kvz_hip_coeff *q_coef,
+                                    int width, int type, int scan_idx, size_t count, kvz_hip_stream s);
+/* dequant_func (quant-generic.c:279-321) */
+KVZ_HIP_API int kvz_hip_dequant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *q_coef, kvz_hip_coeff *coef,
+                                      int width, int type, size_t count, kvz_hip_stream s);
+/* coeff_abs_sum_func (quant-generic.c:323-330) per block of `length` coeffs */
+KVZ_HIP_API int kvz_hip_coeff_abs_sum_batch(const kvz_hip_coeff *coeffs, size_t length, size_t count,
+                                            uint32_t *sums, kvz_hip_stream s);
+/* quant_residual_func, the rdoq-off path of kvz_quantize_residual_generic
+ * (quant-generic.c:180-273): residual -> transform -> quant -> dequant ->
+ * inverse -> reconstruction, one fused kernel per TU.  Blocks are contiguous
+ * (stride = width).  rec_out may alias pred_in.  has_coeffs[i] receives the
+ * function's return value.  color 0 Y / 1 U / 2 V. */
+KVZ_HIP_API int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_intra, int width, int color,
+                                                int scan_order, int use_trskip,
+                                                const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
+                                                kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
+                                                size_t count, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
+/* (2) batched entries -- ipol group (strategies/strategies-ipol.h)    */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  int32_t x, y;            /* integer-pel top-left of the block in the reference plane (may be outside) */
+  int32_t mv_frac_x, mv_frac_y;   /* mv & 3 (luma) / mv & 7 (chroma) */
+  int32_t width, height;
+} kvz_hip_ipol_block;
+
+/* kvz_sample_quarterpel_luma / kvz_sample_octpel_chroma and their 14-bit
+ * variants (generic/ipol-generic.c:122-190, :660-728), with the source window
+ * fetched like kvz_get_extended_block (ipol-generic.c:731-784: coordinates
+ * clamped to the plane).  Output block i is written contiguously (stride =
+ * width) at dst + out_offsets[i] (elements). */
+KVZ_HIP_API int kvz_hip_sample_luma_batch(const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                          const kvz_hip_ipol_block *blocks, const uint64_t *out_offsets, size_t count,
+                                          int out_14bit, void *dst, kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_sample_chroma_batch(const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                            const kvz_hip_ipol_block *blocks, const uint64_t *out_offsets, size_t count,
+                                            int out_14bit, void *dst, kvz_hip_stream s);
+
+/* Fractional motion search of search_frac (search_inter.c:965-1128): for block
+ * pair i (x1,y1 in pic; x2,y2 = integer-pel position in ref; w,h multiples of
+ * 8 up to 64) the four filter steps (filter_hpel/qpel_blocks_*_luma,
+ * ipol-generic.c:192-658) fused with satd_any_size(_quad); filtered candidates
+ * stay in LDS, only costs leave the CU.  costs[17*i + 0] integer position,
+ * [1..8] half-pel neighbours, [9..16] quarter-pel neighbours of the best
+ * half-pel position; best[2*i + {0,1}] = chosen hpel / qpel index (0 = centre),
+ * ties and order as in the reference, MV bit costs taken as zero. */
+KVZ_HIP_API int kvz_hip_search_frac_batch(const kvz_hip_pixel *pic, uint32_t pic_stride,
+                                          const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                          const kvz_hip_block_pair *pairs, size_t count,
+                                          uint32_t *costs, int32_t *best, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
+/* (1) strategy registration -- the drop-in boundary                   */
+/* ------------------------------------------------------------------ */
+/* kvz_strategyselector_register (strategyselector.h:87, strategyselector.c:216-256) */
+typedef int (*kvz_hip_register_fn)(void *opaque, const char *type, const char *strategy_name, int priority, void *fptr);
+/* By default the hooks call the process's own kvz_strategyselector_register
+ * (resolved at load time from the host encoder).  A host that links the
+ * selector with hidden visibility passes it explicitly. */
+KVZ_HIP_API void kvz_hip_set_registrar(kvz_hip_register_fn fn);
+
+/* Accessors for the opaque encoder_state_t the quant strategies receive
+ * (encoderstate.h; quant-generic.c:40-50).  Supplied by the few lines of glue
+ * compiled inside Kvazaar; without them the quant group
+ * registers only coeff_abs_sum. */
+typedef struct {
+  int (*qp)(const void *state);
+  int (*slice_is_intra)(const void *state);
+  int (*signhide_enable)(const void *state);
+  int (*scaling_list_enable)(const void *state);
+  const int32_t *(*quant_coeff)(const void *state, int log2_tr_size, int list_type, int qp_rem);
+  const int32_t *(*dequant_coeff)(const void *state, int log2_tr_size, int list_type, int qp_rem);
+  int (*rdoq_enable)(const void *state);
+  /* cu_info_t fields used by quantize_residual (quant-generic.c:197-225) */
+  int (*cu_is_intra)(const void *cur_cu);
+} kvz_hip_state_accessors;
+KVZ_HIP_API void kvz_hip_set_state_accessors(const kvz_hip_state_accessors *acc);
+
+#define KVZ_HIP_STRATEGY_NAME "hip"
+#define KVZ_HIP_STRATEGY_PRIORITY 50     /* avx2 = 40 (picture-avx2.c:1232) */
+
+/* Same shape as kvz_strategy_register_picture_avx2 (picture-avx2.c:1224):
+ * registers every function of the group under the type strings of
+ * STRATEGIES_<GROUP>_EXPORTS, name "hip", priority 50; only for bitdepth 8.
+ * Returns 1 on success, 0 on failure. */
+KVZ_HIP_API int kvz_strategy_register_picture_hip(void *opaque, uint8_t bitdepth);
+KVZ_HIP_API int kvz_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);
+KVZ_HIP_API int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);
+KVZ_HIP_API int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVZ_HIP_H_ */

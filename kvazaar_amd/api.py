@@ -1,0 +1,250 @@
+"""Host-side Python mirror of the batched C ABI (include/kvz_hip.h).
+
+Two levels:
+  * `DeviceBuffer` + the raw `*_batch` calls of `_lib.load()` work on device
+    pointers (what bench.py times);
+  * the convenience functions below take numpy arrays, stage them to HBM, run
+    the HIP kernel and copy the result back -- used by the parity tests, which
+    therefore always go through the C ABI and the GPU.
+Names follow the reference's strategy types (strategies-picture.h:174-199,
+strategies-dct.h:55-69, strategies-quant.h:58-62, strategies-ipol.h:65-74)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BlockPair, IpolBlock, QuantParams, KvzHipError, check
+
+KINDS = {"dct": 0, "idct": 1, "dst": 2, "idst": 3}
+
+
+class DeviceBuffer:
+    """HBM allocation owned through kvz_hip_malloc/kvz_hip_free."""
+
+    def __init__(self, nbytes):
+        self.lib = _lib.init()
+        self.nbytes = int(nbytes)
+        self.ptr = self.lib.kvz_hip_malloc(max(self.nbytes, 16))
+        if not self.ptr:
+            raise KvzHipError("kvz_hip_malloc(%d) failed: %s" % (nbytes, self.lib.kvz_hip_last_error().decode()))
+
+    @classmethod
+    def from_numpy(cls, a, stream=None):
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        if a.nbytes:
+            check(buf.lib.kvz_hip_memcpy_h2d(buf.ptr, a.ctypes.data, a.nbytes, stream), "memcpy_h2d")
+            check(buf.lib.kvz_hip_stream_sync(stream), "stream_sync")
+        return buf
+
+    def to_numpy(self, dtype, shape, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= max(self.nbytes, 16)
+        if out.nbytes:
+            check(self.lib.kvz_hip_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, stream), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.lib.kvz_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _pairs_array(pairs):
+    """pairs: iterable of (x1, y1, x2, y2, w, h) -> contiguous BlockPair array as numpy int32 [n,6]"""
+    a = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 6))
+    return a
+
+
+# ------------------------------------------------------------------ picture
+def cost_nxn_batch(kind, n, blk1, blk2):
+    """sad_NxN / satd_NxN over [count, n*n] uint8 block pairs -> uint32[count]"""
+    L = _lib.init()
+    blk1 = np.ascontiguousarray(blk1, dtype=np.uint8).reshape(-1, n * n)
+    blk2 = np.ascontiguousarray(blk2, dtype=np.uint8).reshape(-1, n * n)
+    count = blk1.shape[0]
+    a, b, o = DeviceBuffer.from_numpy(blk1), DeviceBuffer.from_numpy(blk2), DeviceBuffer(4 * count)
+    f = L.kvz_hip_sad_nxn_batch if kind == "sad" else L.kvz_hip_satd_nxn_batch
+    check(f(n, a.ptr, b.ptr, count, o.ptr, None), "%s_%dx%d batch" % (kind, n, n))
+    return o.to_numpy(np.uint32, (count,))
+
+
+def cost_nxn_dual_batch(kind, n, preds, orig, pred_stride=1024, item_stride=2048):
+    L = _lib.init()
+    orig = np.ascontiguousarray(orig, dtype=np.uint8).reshape(-1, n * n)
+    count = orig.shape[0]
+    preds = np.ascontiguousarray(preds, dtype=np.uint8).reshape(count, item_stride)
+    p, g, o = DeviceBuffer.from_numpy(preds), DeviceBuffer.from_numpy(orig), DeviceBuffer(8 * count)
+    f = L.kvz_hip_sad_nxn_dual_batch if kind == "sad" else L.kvz_hip_satd_nxn_dual_batch
+    check(f(n, p.ptr, pred_stride, item_stride, g.ptr, count, o.ptr, None), "%s_%dx%d_dual batch" % (kind, n, n))
+    return o.to_numpy(np.uint32, (count, 2))
+
+
+def _pair_call(fname, plane1, plane2, pairs, clamp):
+    L = _lib.init()
+    plane1 = np.ascontiguousarray(plane1, dtype=np.uint8)
+    plane2 = np.ascontiguousarray(plane2, dtype=np.uint8)
+    pa = _pairs_array(pairs)
+    count = pa.shape[0]
+    a, b, d, o = (DeviceBuffer.from_numpy(plane1), DeviceBuffer.from_numpy(plane2), DeviceBuffer.from_numpy(pa),
+                  DeviceBuffer(4 * count))
+    f = getattr(L, fname)
+    if clamp:
+        rc = f(a.ptr, plane1.shape[1], b.ptr, plane2.shape[1], plane2.shape[1], plane2.shape[0], d.ptr, count, o.ptr, None)
+    else:
+        rc = f(a.ptr, plane1.shape[1], b.ptr, plane2.shape[1], d.ptr, count, o.ptr, None)
+    check(rc, fname)
+    return o.to_numpy(np.uint32, (count,))
+
+
+def reg_sad_batch(plane1, plane2, pairs):
+    """reg_sad over (x1,y1,x2,y2,w,h) pairs inside 2-D uint8 planes"""
+    return _pair_call("kvz_hip_reg_sad_batch", plane1, plane2, pairs, False)
+
+
+def image_calc_sad_batch(pic, ref, pairs):
+    return _pair_call("kvz_hip_image_calc_sad_batch", pic, ref, pairs, True)
+
+
+def image_calc_satd_batch(pic, ref, pairs):
+    return _pair_call("kvz_hip_image_calc_satd_batch", pic, ref, pairs, True)
+
+
+def pixels_calc_ssd_batch(plane1, plane2, pairs):
+    return _pair_call("kvz_hip_pixels_calc_ssd_batch", plane1, plane2, pairs, False)
+
+
+def satd_any_size_quad_batch(preds, orig, pairs, pred_stride=64, pred_item_stride=64 * 64):
+    """preds: uint8 [count*4, pred_item_stride]; orig: 2-D plane; pairs use (x1,y1,w,h)"""
+    L = _lib.init()
+    preds = np.ascontiguousarray(preds, dtype=np.uint8)
+    orig = np.ascontiguousarray(orig, dtype=np.uint8)
+    pa = _pairs_array(pairs)
+    count = pa.shape[0]
+    p, g, d, o = (DeviceBuffer.from_numpy(preds), DeviceBuffer.from_numpy(orig), DeviceBuffer.from_numpy(pa),
+                  DeviceBuffer(16 * count))
+    check(L.kvz_hip_satd_any_size_quad_batch(p.ptr, pred_stride, pred_item_stride, g.ptr, orig.shape[1], d.ptr, count,
+                                             o.ptr, None), "satd_any_size_quad batch")
+    return o.to_numpy(np.uint32, (count, 4))
+
+
+def bipred_blend_batch(w, h, hi0, s0, hi1, s1):
+    """s0/s1: [count, h, w] int16 (hi precision) or uint8 -> uint8 [count, h, w]"""
+    L = _lib.init()
+    s0 = np.ascontiguousarray(s0, dtype=np.int16 if hi0 else np.uint8).reshape(-1, h, w)
+    s1 = np.ascontiguousarray(s1, dtype=np.int16 if hi1 else np.uint8).reshape(-1, h, w)
+    count = s0.shape[0]
+    a, b, o = DeviceBuffer.from_numpy(s0), DeviceBuffer.from_numpy(s1), DeviceBuffer(count * h * w)
+    check(L.kvz_hip_bipred_blend_batch(w, h, int(hi0), a.ptr, int(hi1), b.ptr, o.ptr, count, None), "bipred blend")
+    return o.to_numpy(np.uint8, (count, h, w))
+
+
+# ------------------------------------------------------------------ dct
+def transform_batch(kind, n, blocks):
+    L = _lib.init()
+    blocks = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, n * n)
+    count = blocks.shape[0]
+    a, o = DeviceBuffer.from_numpy(blocks), DeviceBuffer(blocks.nbytes)
+    check(L.kvz_hip_transform_batch(KINDS[kind], n, a.ptr, o.ptr, count, None), "%s %d batch" % (kind, n))
+    return o.to_numpy(np.int16, blocks.shape)
+
+
+# ------------------------------------------------------------------ quant
+def _qparams(qp, slice_is_intra=0, signhide=0, quant_coeff=None, dequant_coeff=None):
+    p = QuantParams()
+    p.qp, p.slice_is_intra, p.signhide = int(qp), int(slice_is_intra), int(signhide)
+    keep = []
+    if quant_coeff is not None or dequant_coeff is not None:
+        p.scaling_list = 1
+        if quant_coeff is not None:
+            q = DeviceBuffer.from_numpy(np.ascontiguousarray(quant_coeff, dtype=np.int32)); keep.append(q)
+            p.quant_coeff = q.ptr
+        if dequant_coeff is not None:
+            d = DeviceBuffer.from_numpy(np.ascontiguousarray(dequant_coeff, dtype=np.int32)); keep.append(d)
+            p.dequant_coeff = d.ptr
+    return p, keep
+
+
+def quant_batch(coef, w, qp, type_, scan_idx, slice_is_intra=0, signhide=0, quant_coeff=None):
+    L = _lib.init()
+    coef = np.ascontiguousarray(coef, dtype=np.int16).reshape(-1, w * w)
+    count = coef.shape[0]
+    p, keep = _qparams(qp, slice_is_intra, signhide, quant_coeff=quant_coeff)
+    a, o = DeviceBuffer.from_numpy(coef), DeviceBuffer(coef.nbytes)
+    check(L.kvz_hip_quant_batch(C.byref(p), a.ptr, o.ptr, w, type_, scan_idx, count, None), "quant batch")
+    return o.to_numpy(np.int16, coef.shape)
+
+
+def dequant_batch(q_coef, w, qp, type_, dequant_coeff=None):
+    L = _lib.init()
+    q_coef = np.ascontiguousarray(q_coef, dtype=np.int16).reshape(-1, w * w)
+    count = q_coef.shape[0]
+    p, keep = _qparams(qp, dequant_coeff=dequant_coeff)
+    a, o = DeviceBuffer.from_numpy(q_coef), DeviceBuffer(q_coef.nbytes)
+    check(L.kvz_hip_dequant_batch(C.byref(p), a.ptr, o.ptr, w, type_, count, None), "dequant batch")
+    return o.to_numpy(np.int16, q_coef.shape)
+
+
+def coeff_abs_sum_batch(coeffs, length):
+    L = _lib.init()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16).reshape(-1, length)
+    count = coeffs.shape[0]
+    a, o = DeviceBuffer.from_numpy(coeffs), DeviceBuffer(4 * count)
+    check(L.kvz_hip_coeff_abs_sum_batch(a.ptr, length, count, o.ptr, None), "coeff_abs_sum batch")
+    return o.to_numpy(np.uint32, (count,))
+
+
+def quantize_residual_batch(ref_in, pred_in, w, qp, color, scan_order, cu_is_intra, slice_is_intra=0, signhide=0,
+                            use_trskip=0, alias_rec=False):
+    L = _lib.init()
+    ref_in = np.ascontiguousarray(ref_in, dtype=np.uint8).reshape(-1, w * w)
+    pred_in = np.ascontiguousarray(pred_in, dtype=np.uint8).reshape(-1, w * w)
+    count = ref_in.shape[0]
+    p, keep = _qparams(qp, slice_is_intra, signhide)
+    r, pr = DeviceBuffer.from_numpy(ref_in), DeviceBuffer.from_numpy(pred_in)
+    rec = pr if alias_rec else DeviceBuffer(ref_in.nbytes)
+    co, has = DeviceBuffer(2 * ref_in.size), DeviceBuffer(4 * count)
+    check(L.kvz_hip_quantize_residual_batch(C.byref(p), int(cu_is_intra), w, color, scan_order, int(use_trskip),
+                                            r.ptr, pr.ptr, rec.ptr, co.ptr, has.ptr, count, None), "quantize_residual")
+    return (rec.to_numpy(np.uint8, ref_in.shape), co.to_numpy(np.int16, ref_in.shape), has.to_numpy(np.int32, (count,)))
+
+
+# ------------------------------------------------------------------ ipol
+def sample_batch(kind, ref, blocks):
+    """kind: luma|luma14|chroma|chroma14; blocks: (x, y, frac_x, frac_y, w, h); returns list of arrays"""
+    L = _lib.init()
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    b = np.ascontiguousarray(np.asarray(blocks, dtype=np.int32).reshape(-1, 6))
+    count = b.shape[0]
+    sizes = (b[:, 4].astype(np.int64) * b[:, 5])
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    out14 = kind.endswith("14")
+    esize = 2 if out14 else 1
+    r, d, o = DeviceBuffer.from_numpy(ref), DeviceBuffer.from_numpy(b), DeviceBuffer.from_numpy(offs[:-1].copy())
+    dst = DeviceBuffer(int(offs[-1]) * esize)
+    f = L.kvz_hip_sample_luma_batch if kind.startswith("luma") else L.kvz_hip_sample_chroma_batch
+    check(f(r.ptr, ref.shape[1], ref.shape[1], ref.shape[0], d.ptr, o.ptr, count, int(out14), dst.ptr, None),
+          "sample %s batch" % kind)
+    flat = dst.to_numpy(np.int16 if out14 else np.uint8, (int(offs[-1]),))
+    return [flat[int(offs[i]):int(offs[i + 1])].reshape(int(b[i, 5]), int(b[i, 4])) for i in range(count)]
+
+
+def search_frac_batch(pic, ref, pairs):
+    """pairs: (x1, y1, x2, y2, w, h) with (x2,y2) the integer-pel position in ref.
+    Returns (costs uint32 [count,17], best int32 [count,2])"""
+    L = _lib.init()
+    pic = np.ascontiguousarray(pic, dtype=np.uint8)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    pa = _pairs_array(pairs)
+    count = pa.shape[0]
+    a, b, d = DeviceBuffer.from_numpy(pic), DeviceBuffer.from_numpy(ref), DeviceBuffer.from_numpy(pa)
+    co, be = DeviceBuffer(4 * 17 * count), DeviceBuffer(8 * count)
+    check(L.kvz_hip_search_frac_batch(a.ptr, pic.shape[1], b.ptr, ref.shape[1], ref.shape[1], ref.shape[0], d.ptr,
+                                      count, co.ptr, be.ptr, None), "search_frac batch")
+    return co.to_numpy(np.uint32, (count, 17)), be.to_numpy(np.int32, (count, 2))

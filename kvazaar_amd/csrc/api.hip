@@ -1,0 +1,161 @@
+// api.hip -- library context, device-memory helpers and HIP-event timing of the
+// C ABI declared in include/kvz_hip.h.
+#include "kvz_hip_internal.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace kvzhip {
+
+static std::mutex g_mu;
+static std::atomic<bool> g_ready{false};
+static int g_device = -1;
+static int g_num_cus = 256;
+static hipStream_t g_stream = nullptr;
+static char g_err[512] = "";
+static char g_name[256] = "";
+
+bool ctx_ready() { return g_ready.load(std::memory_order_acquire); }
+hipStream_t ctx_stream(kvz_hip_stream s) { return s ? (hipStream_t)s : g_stream; }
+int num_cus() { return g_num_cus; }
+
+void set_error(const char *what, hipError_t e)
+{
+  std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+void set_error_msg(const char *what) { std::snprintf(g_err, sizeof(g_err), "%s", what); }
+
+}  // namespace kvzhip
+
+using namespace kvzhip;
+
+#define HIP_TRY(call, what)                                  \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) { set_error(what, e__); return KVZ_HIP_ERR_RUNTIME; } \
+  } while (0)
+
+extern "C" {
+
+int kvz_hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int kvz_hip_init(int device)
+{
+  if (ctx_ready()) return KVZ_HIP_OK;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (ctx_ready()) return KVZ_HIP_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error_msg("kvz_hip_init: no HIP device visible (this library has no CPU fallback)");
+    return KVZ_HIP_ERR_NO_DEVICE;
+  }
+  if (device < 0) {
+    const char *env = std::getenv("KVZ_HIP_DEVICE");
+    device = env ? std::atoi(env) : 0;
+  }
+  if (device >= n) { set_error_msg("kvz_hip_init: device index out of range"); return KVZ_HIP_ERR_INVALID; }
+  if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e); return KVZ_HIP_ERR_NO_DEVICE; }
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { set_error("hipGetDeviceProperties", e); return KVZ_HIP_ERR_NO_DEVICE; }
+  std::snprintf(g_name, sizeof(g_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::snprintf(g_err, sizeof(g_err), "kvz_hip_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return KVZ_HIP_ERR_NO_DEVICE;
+  }
+  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if ((e = hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking)) != hipSuccess) { set_error("hipStreamCreate", e); return KVZ_HIP_ERR_RUNTIME; }
+  g_device = device;
+  g_ready.store(true, std::memory_order_release);
+  return KVZ_HIP_OK;
+}
+
+void kvz_hip_shutdown(void)
+{
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!ctx_ready()) return;
+  (void)hipStreamSynchronize(g_stream);
+  (void)hipStreamDestroy(g_stream);
+  g_stream = nullptr;
+  g_ready.store(false, std::memory_order_release);
+}
+
+const char *kvz_hip_last_error(void) { return g_err; }
+const char *kvz_hip_device_name(void) { return g_name; }
+
+void *kvz_hip_malloc(size_t bytes)
+{
+  if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return nullptr;
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) { set_error("hipMalloc", e); return nullptr; }
+  return p;
+}
+void kvz_hip_free(void *dptr) { if (dptr) (void)hipFree(dptr); }
+
+int kvz_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx_stream(s)), "hipMemcpyAsync(H2D)");
+  return KVZ_HIP_OK;
+}
+int kvz_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx_stream(s)), "hipMemcpyAsync(D2H)");
+  HIP_TRY(hipStreamSynchronize(ctx_stream(s)), "hipStreamSynchronize");
+  return KVZ_HIP_OK;
+}
+int kvz_hip_memset(void *dst, int value, size_t bytes, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipMemsetAsync(dst, value, bytes, ctx_stream(s)), "hipMemsetAsync");
+  return KVZ_HIP_OK;
+}
+kvz_hip_stream kvz_hip_stream_create(void)
+{
+  if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return nullptr;
+  hipStream_t st = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e != hipSuccess) { set_error("hipStreamCreate", e); return nullptr; }
+  return (kvz_hip_stream)st;
+}
+void kvz_hip_stream_destroy(kvz_hip_stream s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+int kvz_hip_stream_sync(kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipStreamSynchronize(ctx_stream(s)), "hipStreamSynchronize");
+  return KVZ_HIP_OK;
+}
+
+void *kvz_hip_event_create(void)
+{
+  if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return nullptr;
+  hipEvent_t ev = nullptr;
+  if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+  return (void *)ev;
+}
+void kvz_hip_event_destroy(void *ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int kvz_hip_event_record(void *ev, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipEventRecord((hipEvent_t)ev, ctx_stream(s)), "hipEventRecord");
+  return KVZ_HIP_OK;
+}
+int kvz_hip_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipEventSynchronize((hipEvent_t)stop), "hipEventSynchronize");
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "hipEventElapsedTime");
+  return KVZ_HIP_OK;
+}
+
+}  // extern "C"

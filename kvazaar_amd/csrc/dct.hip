@@ -1,0 +1,100 @@
+// dct.hip -- batched 4/8/16/32 integer DCT / IDCT and the 4x4 DST for gfx950.
+// Reference: src/strategies/generic/dct-generic.c:567-617 (dct_func typedef:
+// src/strategies/strategies-dct.h:31).
+//
+// Layout: `count` contiguous row-major N x N int16 blocks in, same out.
+// One 256-thread workgroup transforms 256/N blocks per iteration: blocks are
+// staged into LDS with coalesced 16-byte loads, N threads per block run the two
+// 1-D passes in registers (exact int32 even/odd butterflies, transform_core.h)
+// exchanging the intermediate through LDS, and the result leaves with coalesced
+// 16-byte stores.  HBM traffic = 4*N*N bytes per block, the algorithmic minimum.
+#include "kvz_hip_internal.h"
+#include "transform_core.h"
+
+using namespace kvzhip;
+
+template <int N, int KIND>
+__global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
+{
+  constexpr int TPB = 256 / N;                       // blocks (TUs) per workgroup iteration
+  constexpr int LD = N >= 8 ? N + 8 : N;             // padded LDS row stride (int16), rows stay 16-byte aligned
+  constexpr int CPB = N * N / 8;                     // 16-byte chunks per block
+  constexpr int CHUNKS = TPB * CPB;                  // per iteration
+  __shared__ __attribute__((aligned(16))) i16 sa[TPB * N * LD];
+  __shared__ __attribute__((aligned(16))) i16 sb[TPB * N * LD];
+
+  const int tid = threadIdx.x;
+  const int tu = tid / N, row = tid % N;
+  const size_t ngroups = (count + TPB - 1) / TPB;
+
+  for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const size_t first = g * TPB;
+    // stage in
+#pragma unroll
+    for (int c = tid; c < CHUNKS; c += 256) {
+      const int t = c / CPB, e = (c % CPB) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (first + t < count) v = *(const uint4 *)(in + (first + t) * (size_t)(N * N) + e);
+      if (LD == N) *(uint4 *)(sa + t * N * LD + e) = v;
+      else *(uint4 *)(sa + t * N * LD + (e / N) * LD + (e % N)) = v;
+    }
+    __syncthreads();
+    transform_2d_lds<N, KIND, LD>(sa + tu * N * LD, sb + tu * N * LD, row);
+    __syncthreads();
+    // stage out
+#pragma unroll
+    for (int c = tid; c < CHUNKS; c += 256) {
+      const int t = c / CPB, e = (c % CPB) * 8;
+      if (first + t < count) {
+        uint4 v;
+        if (LD == N) v = *(const uint4 *)(sa + t * N * LD + e);
+        else v = *(const uint4 *)(sa + t * N * LD + (e / N) * LD + (e % N));
+        *(uint4 *)(out + (first + t) * (size_t)(N * N) + e) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int N, int KIND>
+static int launch_transform(const i16 *in, i16 *out, size_t count, hipStream_t st)
+{
+  constexpr int TPB = 256 / N;
+  const unsigned grid = stream_grid(count, TPB, 16);
+  hipLaunchKernelGGL((transform_kernel<N, KIND>), dim3(grid), dim3(256), 0, st, in, out, count);
+  KVZ_CHECK_LAUNCH("transform_kernel");
+  return KVZ_HIP_OK;
+}
+
+extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16_t *out, size_t count, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!in || !out || (((uintptr_t)in | (uintptr_t)out) & 15)) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  hipStream_t st = ctx_stream(s);
+  switch (kind) {
+    case KVZ_HIP_DCT:
+      switch (n) {
+        case 4: return launch_transform<4, 0>(in, out, count, st);
+        case 8: return launch_transform<8, 0>(in, out, count, st);
+        case 16: return launch_transform<16, 0>(in, out, count, st);
+        case 32: return launch_transform<32, 0>(in, out, count, st);
+      }
+      break;
+    case KVZ_HIP_IDCT:
+      switch (n) {
+        case 4: return launch_transform<4, 1>(in, out, count, st);
+        case 8: return launch_transform<8, 1>(in, out, count, st);
+        case 16: return launch_transform<16, 1>(in, out, count, st);
+        case 32: return launch_transform<32, 1>(in, out, count, st);
+      }
+      break;
+    case KVZ_HIP_DST:
+      if (n == 4) return launch_transform<4, 2>(in, out, count, st);
+      break;
+    case KVZ_HIP_IDST:
+      if (n == 4) return launch_transform<4, 3>(in, out, count, st);
+      break;
+  }
+  return KVZ_HIP_ERR_INVALID;
+}

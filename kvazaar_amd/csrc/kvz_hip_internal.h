@@ -1,0 +1,92 @@
+// Internal declarations shared by the HIP translation units of libkvzhip.so.
+// gfx950 (MI355X, CDNA4) only: wave64, 256 CUs, 160 KiB LDS/CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/kvz_hip.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef int16_t i16;
+typedef int32_t i32;
+
+namespace kvzhip {
+
+// ---- context (api.hip) ----
+bool ctx_ready();
+hipStream_t ctx_stream(kvz_hip_stream s);      // NULL -> library default stream
+void set_error(const char *what, hipError_t e);
+void set_error_msg(const char *what);
+int num_cus();
+
+#define KVZ_CHECK_CTX()                         \
+  do {                                          \
+    if (!kvzhip::ctx_ready()) {                 \
+      if (kvz_hip_init(-1) != KVZ_HIP_OK) return KVZ_HIP_ERR_NO_DEVICE; \
+    }                                           \
+  } while (0)
+
+#define KVZ_CHECK_LAUNCH(name)                               \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) {                                 \
+      kvzhip::set_error(name, e__);                          \
+      return KVZ_HIP_ERR_RUNTIME;                            \
+    }                                                        \
+  } while (0)
+
+// Grid sizing for streaming kernels: enough workgroups to fill 256 CUs several
+// times over, capped so that grid-stride loops amortise the launch.
+static inline unsigned stream_grid(size_t work_items, unsigned items_per_block, unsigned max_blocks_per_cu = 8)
+{
+  size_t need = (work_items + items_per_block - 1) / items_per_block;
+  size_t cap = (size_t)num_cus() * max_blocks_per_cu;
+  if (need < 1) need = 1;
+  return (unsigned)(need < cap ? need : cap);
+}
+
+// ---- device helpers ----
+#if defined(__HIPCC__)
+
+// DPP cross-lane moves (no LDS traffic).  quad_perm / row_half_mirror / row_mirror.
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_mov(u32 v)
+{
+  return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+
+// Sum over aligned groups of L consecutive lanes (L power of two <= 64); every
+// lane of the group ends up with the group's sum.
+template <int L>
+__device__ __forceinline__ u32 group_sum(u32 v)
+{
+  if (L >= 2) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (L >= 4) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (L >= 8) v += dpp_mov<0x141>(v);   // row_half_mirror
+  if (L >= 16) v += dpp_mov<0x140>(v);  // row_mirror
+  if (L >= 32) v += (u32)__shfl_xor((int)v, 16, 64);
+  if (L >= 64) v += (u32)__shfl_xor((int)v, 32, 64);
+  return v;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// kvz_fast_clip_16bit_to_pixel (picture-generic.c:30-48): int16 argument,
+// any bit outside 0..255 => low byte of (-v >> 15).
+__device__ __forceinline__ u8 fast_clip16(i16 v)
+{
+  int x = v;
+  return (x & ~255) ? (u8)((-x) >> 15) : (u8)x;
+}
+// kvz_fast_clip_32bit_to_pixel (picture-generic.c:52-70)
+__device__ __forceinline__ u8 fast_clip32(i32 v)
+{
+  return (v & ~255) ? (u8)(((i32)(0u - (u32)v)) >> 31) : (u8)v;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace kvzhip

@@ -1,0 +1,625 @@
+// picture.hip -- SAD / SATD / SSD / bipred-blend kernels for gfx950.
+//
+// Reference semantics: src/strategies/generic/picture-generic.c and the macros
+// of src/strategies/strategies-picture.h (cited per kernel).  Everything here is
+// integer/byte streaming work bounded by HBM bandwidth: wide coalesced loads,
+// v_sad_u8 / packed-int16 butterflies in registers, DPP reductions, one
+// coalesced store per wave.  No LDS is needed for the contiguous-block kernels
+// (there is no reuse to exploit: every byte is read exactly once).
+#include "kvz_hip_internal.h"
+
+using namespace kvzhip;
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 sad_dword(u32 a, u32 b, u32 acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+__device__ __forceinline__ u32 sad16(uint4 a, uint4 b)
+{
+  u32 s = sad_dword(a.x, b.x, 0);
+  s = sad_dword(a.y, b.y, s);
+  s = sad_dword(a.z, b.z, s);
+  return sad_dword(a.w, b.w, s);
+}
+
+// ---------------------------------------------------------------------------
+// sad_NxN over contiguous block pairs (picture-generic.c:460-486) and the dual
+// variant (:497-519).  A "chunk" is 16 bytes; a block has L = N*N/16 chunks.
+// Each wave streams 64*U consecutive chunks per iteration (1 KiB per load
+// instruction, U loads per array in flight), reduces the L lanes of a block
+// with DPP and writes the wave's results with one coalesced store.
+// ---------------------------------------------------------------------------
+template <int N, int U, bool DUAL>
+__global__ __launch_bounds__(256) void sad_nxn_kernel(const u8 *__restrict__ a, const u8 *__restrict__ b,
+                                                      u32 *__restrict__ costs, size_t count,
+                                                      size_t pred_stride, size_t item_stride)
+{
+  constexpr int L = N * N / 16;                 // chunks (lanes) per block: 1, 4, 16, 64, 256
+  constexpr int LW = L > 64 ? 64 : L;           // lanes of one wave that share a block
+  constexpr int UB = L > 64 ? L / 64 : 1;       // wave-loads that make up one block (N = 64: 4)
+  static_assert(U % UB == 0, "U must cover whole blocks");
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  const size_t total_chunks = count * L;        // count = number of (block1, block2) pairs
+  constexpr size_t CH = (size_t)64 * U;
+
+  for (size_t base = wave * CH; base < total_chunks; base += nwaves * CH) {
+    u32 s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = base + (size_t)u * 64 + lane;
+      s[u] = 0;
+      if (c < total_chunks) {
+        uint4 x, y;
+        if (DUAL) {
+          const size_t blk = c / L, within = c % L;      // blk = 2*item + k
+          x = *(const uint4 *)(a + (blk >> 1) * item_stride + (blk & 1) * pred_stride + within * 16);
+          y = *(const uint4 *)(b + (blk >> 1) * (size_t)(N * N) + within * 16);
+        } else {
+          x = *(const uint4 *)(a + c * 16);
+          y = *(const uint4 *)(b + c * 16);
+        }
+        s[u] = sad16(x, y);
+      }
+    }
+    if (L == 1) {                                // N == 4: every chunk is a whole block
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t c = base + (size_t)u * 64 + lane;
+        if (c < count) costs[c] = s[u];
+      }
+      continue;
+    }
+    // fold the UB loads of one block, then the LW lanes
+    constexpr int R = U / UB;                    // results per lane-group per iteration
+    u32 r[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      u32 t = 0;
+#pragma unroll
+      for (int j = 0; j < UB; ++j) t += s[i * UB + j];
+      r[i] = group_sum<LW>(t);
+    }
+    // lane (g = lane / LW, p = lane % LW) stores result p of group g
+    const int g = lane / LW, p = lane % LW;
+    if (p < R) {
+      u32 v = r[0];
+#pragma unroll
+      for (int i = 1; i < R; ++i) v = (p == i) ? r[i] : v;
+      // block index of (iteration-result p, group g)
+      const size_t blk = (base + (size_t)p * UB * 64) / L + g;
+      if (blk < count) costs[blk] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// SATD.  One lane owns one 8x8 sub-block (or one 4x4 block): 128 input bytes,
+// Hadamard in packed int16 registers (|coef| <= 64*255 fits), no cross-lane
+// traffic until the final per-block sum.  The last butterfly stage is folded
+// into the absolute sum: |a+b| + |a-b| = 2*max(|a|,|b|).
+// picture-generic.c:240-328 (8x8: (sum+2)>>2), :105-196 (4x4: (sum+1)>>1).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ v2s as_v2s(u32 x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ u32 as_u32(v2s x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ v2s unpack_lo(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
+__device__ __forceinline__ v2s unpack_hi(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
+
+// sum over the register's two halves of max(|lo|,|hi|)  (the folded last stage)
+__device__ __forceinline__ u32 absmax_halves(v2s x)
+{
+  v2s n = -x;
+  v2s ax = __builtin_elementwise_max(x, n);
+  u32 w = as_u32(ax);
+  u32 lo = w & 0xffffu, hi = w >> 16;
+  return lo > hi ? lo : hi;
+}
+
+// a[16], b[16]: row r of the 8x8 = dwords 2r (cols 0..3) and 2r+1 (cols 4..7).
+// Returns the reference's satd_8x8_subblock value.
+__device__ __forceinline__ u32 satd8x8_regs(const u32 *a, const u32 *b)
+{
+  v2s x[8][4];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    x[r][0] = unpack_lo(a[2 * r]) - unpack_lo(b[2 * r]);
+    x[r][1] = unpack_hi(a[2 * r]) - unpack_hi(b[2 * r]);
+    x[r][2] = unpack_lo(a[2 * r + 1]) - unpack_lo(b[2 * r + 1]);
+    x[r][3] = unpack_hi(a[2 * r + 1]) - unpack_hi(b[2 * r + 1]);
+  }
+  // horizontal, column bit 2 (distance 4) and bit 1 (distance 2)
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    v2s s0 = x[r][0] + x[r][2], s1 = x[r][1] + x[r][3];
+    v2s d0 = x[r][0] - x[r][2], d1 = x[r][1] - x[r][3];
+    x[r][0] = s0 + s1; x[r][1] = s0 - s1;
+    x[r][2] = d0 + d1; x[r][3] = d0 - d1;
+  }
+  // vertical, three stages
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v2s t[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t[r] = x[r][q] + x[r + 4][q]; t[r + 4] = x[r][q] - x[r + 4][q]; }
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      v2s u0 = t[h] + t[h + 2], u1 = t[h + 1] + t[h + 3], u2 = t[h] - t[h + 2], u3 = t[h + 1] - t[h + 3];
+      x[h][q] = u0 + u1; x[h + 1][q] = u0 - u1; x[h + 2][q] = u2 + u3; x[h + 3][q] = u2 - u3;
+    }
+  }
+  // column bit 0 (inside the register) folded into the absolute sum
+  u32 m = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m += absmax_halves(x[r][q]);
+  return (m + 1) >> 1;                 // (2m + 2) >> 2
+}
+
+// a[4], b[4]: row r of the 4x4 = dword r.  Returns satd_4x4 ((sum+1)>>1 == m).
+__device__ __forceinline__ u32 satd4x4_regs(const u32 *a, const u32 *b)
+{
+  v2s x[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    x[r][0] = unpack_lo(a[r]) - unpack_lo(b[r]);
+    x[r][1] = unpack_hi(a[r]) - unpack_hi(b[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { v2s s = x[r][0] + x[r][1], d = x[r][0] - x[r][1]; x[r][0] = s; x[r][1] = d; }
+  u32 m = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    v2s s0 = x[0][q] + x[2][q], s1 = x[1][q] + x[3][q], d0 = x[0][q] - x[2][q], d1 = x[1][q] - x[3][q];
+    m += absmax_halves(s0 + s1) + absmax_halves(s0 - s1) + absmax_halves(d0 + d1) + absmax_halves(d0 - d1);
+  }
+  return m;                            // (2m + 1) >> 1
+}
+
+// strategies-picture.h:40-56 (SATD_NxN) / picture-generic.c:357-390 (dual).
+// Lane = one 8x8 sub-block; the (N/8)^2 lanes of a block are consecutive.
+template <int N, bool DUAL>
+__global__ __launch_bounds__(256) void satd_nxn_kernel(const u8 *__restrict__ a, const u8 *__restrict__ b,
+                                                       u32 *__restrict__ costs, size_t count,
+                                                       size_t pred_stride, size_t item_stride)
+{
+  constexpr int W8 = N / 8, SB = W8 * W8;       // 1, 4, 16, 64
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const size_t total = count * SB;
+  const size_t total_up = (total + 63) & ~(size_t)63;     // keep whole waves in the loop (DPP)
+  for (size_t i = tid; i < total_up; i += nthreads) {
+    u32 v = 0;
+    const bool valid = i < total;
+    const size_t blk = i / SB;
+    const int sidx = (int)(i % SB), sy = sidx / W8, sx = sidx % W8;
+    if (valid) {
+      const u8 *pa, *pb;
+      if (DUAL) {
+        pa = a + (blk >> 1) * item_stride + (blk & 1) * pred_stride;
+        pb = b + (blk >> 1) * (size_t)(N * N);
+      } else {
+        pa = a + blk * (size_t)(N * N);
+        pb = b + blk * (size_t)(N * N);
+      }
+      pa += (size_t)(sy * 8) * N + sx * 8;
+      pb += (size_t)(sy * 8) * N + sx * 8;
+      u32 ra[16], rb[16];
+      if (N == 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint4 t = ((const uint4 *)pa)[k], w = ((const uint4 *)pb)[k];
+          ra[4 * k] = t.x; ra[4 * k + 1] = t.y; ra[4 * k + 2] = t.z; ra[4 * k + 3] = t.w;
+          rb[4 * k] = w.x; rb[4 * k + 1] = w.y; rb[4 * k + 2] = w.z; rb[4 * k + 3] = w.w;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          uint2 t = *(const uint2 *)(pa + (size_t)r * N), w = *(const uint2 *)(pb + (size_t)r * N);
+          ra[2 * r] = t.x; ra[2 * r + 1] = t.y; rb[2 * r] = w.x; rb[2 * r + 1] = w.y;
+        }
+      }
+      v = satd8x8_regs(ra, rb);
+    }
+    v = group_sum<SB>(v);
+    if (valid && sidx == 0) costs[blk] = v;
+  }
+}
+
+// satd_4x4 / satd_4x4_dual: lane = one 16-byte block pair
+template <bool DUAL>
+__global__ __launch_bounds__(256) void satd_4x4_kernel(const u8 *__restrict__ a, const u8 *__restrict__ b,
+                                                       u32 *__restrict__ costs, size_t count,
+                                                       size_t pred_stride, size_t item_stride)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid; i < count; i += nthreads) {
+    uint4 x, y;
+    if (DUAL) {
+      x = *(const uint4 *)(a + (i >> 1) * item_stride + (i & 1) * pred_stride);
+      y = *(const uint4 *)(b + (i >> 1) * 16);
+    } else {
+      x = ((const uint4 *)a)[i];
+      y = ((const uint4 *)b)[i];
+    }
+    u32 ra[4] = { x.x, x.y, x.z, x.w }, rb[4] = { y.x, y.y, y.z, y.w };
+    costs[i] = satd4x4_regs(ra, rb);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Frame-level kernels: block pairs described by kvz_hip_block_pair inside two
+// planes.  Addresses are unaligned and strided, the reference plane may be
+// addressed outside the frame (edge replication, image.c:320-444 /
+// ipol-generic.c:731-784).
+// ---------------------------------------------------------------------------
+struct plane_t {
+  const u8 *p;
+  u32 stride;
+  int w, h;          // clamp extents; w == 0 => no clamping (coordinates are inside)
+};
+
+// 8 pixels of row y starting at column x (with replication when clamping and
+// the segment is not fully inside); bytes beyond `n` valid pixels are zero.
+__device__ __forceinline__ uint2 load_seg8(const plane_t &pl, int x, int y, int n)
+{
+  uint2 r;
+  u8 v[8];
+  if (pl.w == 0 || (x >= 0 && x + 8 <= pl.w && y >= 0 && y < pl.h)) {
+    const u8 *q = pl.p + (size_t)y * pl.stride + x;
+    if (n == 8) {
+      // unaligned 8-byte load assembled from bytes by the compiler when it cannot prove alignment
+      __builtin_memcpy(&r, q, 8);
+      return r;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (i < n) ? q[i] : (u8)0;
+  } else {
+    const int yy = clampi(y, 0, pl.h - 1);
+    const u8 *row = pl.p + (size_t)yy * pl.stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (i < n) ? row[clampi(x + i, 0, pl.w - 1)] : (u8)0;
+  }
+  r.x = v[0] | (v[1] << 8) | (v[2] << 16) | ((u32)v[3] << 24);
+  r.y = v[4] | (v[5] << 8) | (v[6] << 16) | ((u32)v[7] << 24);
+  return r;
+}
+
+// reg_sad (picture-generic.c:86-99) / kvz_image_calc_sad (image.c:455-486) and
+// pixels_calc_ssd (picture-generic.c:521-536).  8 lanes share one block pair;
+// a lane takes 8-pixel row segments round robin, so the 8 lanes of a group read
+// up to 64 contiguous bytes of a row.
+template <bool SSD>
+__global__ __launch_bounds__(256) void pair_sad_kernel(plane_t p1, plane_t p2, const kvz_hip_block_pair *__restrict__ pairs,
+                                                       size_t count, u32 *__restrict__ out)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ngroups = ((size_t)gridDim.x * blockDim.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const size_t count_up = (count + 7) & ~(size_t)7;
+  for (size_t i = tid >> 3; i < count_up; i += ngroups) {
+    u32 acc = 0;
+    if (i < count) {
+      const kvz_hip_block_pair d = pairs[i];
+      const int w = d.width, h = SSD ? d.width : d.height;
+      const int spr = (w + 7) >> 3;
+      const int nseg = spr * h;
+      for (int t = sub; t < nseg; t += 8) {
+        const int y = t / spr, sx = (t - y * spr) << 3;
+        const int n = (w - sx) < 8 ? (w - sx) : 8;
+        uint2 a = load_seg8(p1, d.x1 + sx, d.y1 + y, n);
+        uint2 b = load_seg8(p2, d.x2 + sx, d.y2 + y, n);
+        if (SSD) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            int e0 = (int)((a.x >> (8 * k)) & 255) - (int)((b.x >> (8 * k)) & 255);
+            int e1 = (int)((a.y >> (8 * k)) & 255) - (int)((b.y >> (8 * k)) & 255);
+            acc += (u32)(e0 * e0 + e1 * e1);
+          }
+        } else {
+          acc = sad_dword(a.x, b.x, acc);
+          acc = sad_dword(a.y, b.y, acc);
+        }
+      }
+    }
+    acc = group_sum<8>(acc);
+    if (i < count && sub == 0) out[i] = acc;
+  }
+}
+
+// 8x8 sub-block of a pair at (ox, oy) inside the block
+__device__ __forceinline__ u32 satd8x8_planes(const plane_t &p1, const plane_t &p2, const kvz_hip_block_pair &d, int ox, int oy)
+{
+  u32 ra[16], rb[16];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    uint2 a = load_seg8(p1, d.x1 + ox, d.y1 + oy + r, 8);
+    uint2 b = load_seg8(p2, d.x2 + ox, d.y2 + oy + r, 8);
+    ra[2 * r] = a.x; ra[2 * r + 1] = a.y; rb[2 * r] = b.x; rb[2 * r + 1] = b.y;
+  }
+  return satd8x8_regs(ra, rb);
+}
+__device__ __forceinline__ u32 satd4x4_planes(const plane_t &p1, const plane_t &p2, const kvz_hip_block_pair &d, int ox, int oy)
+{
+  u32 ra[4], rb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ra[r] = load_seg8(p1, d.x1 + ox, d.y1 + oy + r, 4).x;
+    rb[r] = load_seg8(p2, d.x2 + ox, d.y2 + oy + r, 4).x;
+  }
+  return satd4x4_regs(ra, rb);
+}
+
+// SATD_ANY_SIZE (strategies-picture.h:62-100) / kvz_image_calc_satd
+// (image.c:488-545).  8 lanes share a pair and split its 8x8 sub-blocks (and
+// the 4x4 ones of a leading 4-pixel column / row when w or h is not a multiple
+// of 8).
+__global__ __launch_bounds__(256) void pair_satd_kernel(plane_t p1, plane_t p2, const kvz_hip_block_pair *__restrict__ pairs,
+                                                        size_t count, u32 *__restrict__ out)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ngroups = ((size_t)gridDim.x * blockDim.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const size_t count_up = (count + 7) & ~(size_t)7;
+  for (size_t i = tid >> 3; i < count_up; i += ngroups) {
+    u32 acc = 0;
+    if (i < count) {
+      const kvz_hip_block_pair d = pairs[i];
+      int w = d.width, h = d.height, ox = 0, oy = 0;
+      if (w & 7) {                                   // first 4-px column, full height
+        for (int y = sub * 4; y < h; y += 32) acc += satd4x4_planes(p1, p2, d, 0, y);
+        ox = 4; w -= 4;
+      }
+      if (h & 7) {                                   // first 4-px row of the rest
+        for (int x = sub * 4; x < w; x += 32) acc += satd4x4_planes(p1, p2, d, ox + x, 0);
+        oy = 4; h -= 4;
+      }
+      const int w8 = w >> 3, n8 = w8 * (h >> 3);
+      for (int t = sub; t < n8; t += 8) {
+        const int by = t / w8, bx = t - by * w8;
+        acc += satd8x8_planes(p1, p2, d, ox + bx * 8, oy + by * 8);
+      }
+    }
+    acc = group_sum<8>(acc);
+    if (i < count && sub == 0) out[i] = acc;
+  }
+}
+
+// satd_any_size_quad (picture-generic.c:392-456): 4 candidate blocks against
+// one original.  Reproduces the reference exactly, including for sizes that are
+// not multiples of 8: the 4x4 stages contribute nothing and only shrink
+// w/h by 4, the 8x8 grid then starts at the block ORIGIN.  8 lanes per item,
+// each lane evaluates its 8x8 positions for all four candidates so the
+// original's rows are loaded once.
+__global__ __launch_bounds__(256) void quad_satd_kernel(const u8 *__restrict__ preds, u32 pred_stride, size_t pred_item_stride,
+                                                        plane_t orig, const kvz_hip_block_pair *__restrict__ pairs,
+                                                        size_t count, u32 *__restrict__ out)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ngroups = ((size_t)gridDim.x * blockDim.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const size_t count_up = (count + 7) & ~(size_t)7;
+  for (size_t i = tid >> 3; i < count_up; i += ngroups) {
+    u32 acc[4] = { 0, 0, 0, 0 };
+    if (i < count) {
+      const kvz_hip_block_pair d = pairs[i];
+      int w = d.width, h = d.height;
+      if (w & 7) w -= 4;
+      if (h & 7) h -= 4;
+      const int w8 = (w + 7) >> 3, h8 = (h + 7) >> 3, n8 = (w > 0 && h > 0) ? w8 * h8 : 0;
+      for (int t = sub; t < n8; t += 8) {
+        const int by = t / w8, bx = t - by * w8;
+        u32 ro[16];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          uint2 o = load_seg8(orig, d.x1 + bx * 8, d.y1 + by * 8 + r, 8);
+          ro[2 * r] = o.x; ro[2 * r + 1] = o.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u8 *pp = preds + (i * 4 + k) * pred_item_stride + (size_t)(by * 8) * pred_stride + bx * 8;
+          u32 rp[16];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            uint2 t2;
+            __builtin_memcpy(&t2, pp + (size_t)r * pred_stride, 8);
+            rp[2 * r] = t2.x; rp[2 * r + 1] = t2.y;
+          }
+          acc[k] += satd8x8_regs(ro, rp);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = group_sum<8>(acc[k]);
+    if (i < count && sub < 4) {
+      u32 v = acc[0];
+      v = sub == 1 ? acc[1] : v; v = sub == 2 ? acc[2] : v; v = sub == 3 ? acc[3] : v;
+      out[i * 4 + sub] = v;
+    }
+  }
+}
+
+// inter_recon_bipred blend (picture-generic.c:538-588): (s0 + s1 + 64) >> 7
+// through the 32-bit clip; samples are held in int16 (pixels << 6).
+template <bool HP0, bool HP1>
+__global__ __launch_bounds__(256) void bipred_blend_kernel(const void *__restrict__ s0, const void *__restrict__ s1,
+                                                           u8 *__restrict__ dst, size_t n)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid * 4; i < n; i += nthreads * 4) {
+    u8 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < n) {
+        i16 a = HP0 ? ((const i16 *)s0)[i + k] : (i16)(((const u8 *)s0)[i + k] << 6);
+        i16 b = HP1 ? ((const i16 *)s1)[i + k] : (i16)(((const u8 *)s1)[i + k] << 6);
+        o[k] = fast_clip32(((i32)a + (i32)b + 64) >> 7);
+      }
+    }
+    if (i + 3 < n) *(u32 *)(dst + i) = o[0] | (o[1] << 8) | (o[2] << 16) | ((u32)o[3] << 24);
+    else for (int k = 0; k < 4 && i + k < n; ++k) dst[i + k] = o[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <bool DUAL>
+static int launch_sad(int n, const u8 *a, const u8 *b, size_t count, u32 *costs, size_t ps, size_t is, hipStream_t st)
+{
+  // count here = number of block pairs (2 * items for DUAL)
+  const unsigned threads = 256;
+#define KVZ_SAD_CASE(N, U)                                                                        \
+  case N: {                                                                                       \
+    size_t chunks = count * (N * N / 16);                                                         \
+    unsigned grid = stream_grid(chunks, (threads / 64) * 64 * U);                                 \
+    hipLaunchKernelGGL((sad_nxn_kernel<N, U, DUAL>), dim3(grid), dim3(threads), 0, st, a, b, costs, count, ps, is); \
+  } break;
+  switch (n) {
+    KVZ_SAD_CASE(4, 4)
+    KVZ_SAD_CASE(8, 4)
+    KVZ_SAD_CASE(16, 4)
+    KVZ_SAD_CASE(32, 4)
+    KVZ_SAD_CASE(64, 4)
+    default: return KVZ_HIP_ERR_INVALID;
+  }
+#undef KVZ_SAD_CASE
+  KVZ_CHECK_LAUNCH("sad_nxn_kernel");
+  return KVZ_HIP_OK;
+}
+
+template <bool DUAL>
+static int launch_satd(int n, const u8 *a, const u8 *b, size_t count, u32 *costs, size_t ps, size_t is, hipStream_t st)
+{
+  const unsigned threads = 256;
+  switch (n) {
+    case 4: hipLaunchKernelGGL((satd_4x4_kernel<DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    case 8: hipLaunchKernelGGL((satd_nxn_kernel<8, DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    case 16: hipLaunchKernelGGL((satd_nxn_kernel<16, DUAL>), dim3(stream_grid(count * 4, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    case 32: hipLaunchKernelGGL((satd_nxn_kernel<32, DUAL>), dim3(stream_grid(count * 16, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    case 64: hipLaunchKernelGGL((satd_nxn_kernel<64, DUAL>), dim3(stream_grid(count * 64, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    default: return KVZ_HIP_ERR_INVALID;
+  }
+  KVZ_CHECK_LAUNCH("satd_nxn_kernel");
+  return KVZ_HIP_OK;
+}
+
+extern "C" {
+
+int kvz_hip_sad_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel *blk2, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!blk1 || !blk2 || !costs || !aligned16(blk1) || !aligned16(blk2)) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  return launch_sad<false>(n, blk1, blk2, count, costs, 0, 0, ctx_stream(s));
+}
+
+int kvz_hip_satd_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel *blk2, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!blk1 || !blk2 || !costs || !aligned16(blk1) || !aligned16(blk2)) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  return launch_satd<false>(n, blk1, blk2, count, costs, 0, 0, ctx_stream(s));
+}
+
+int kvz_hip_sad_nxn_dual_batch(int n, const kvz_hip_pixel *preds, size_t pred_stride, size_t item_stride,
+                               const kvz_hip_pixel *orig, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!preds || !orig || !costs || !aligned16(preds) || !aligned16(orig) || (pred_stride & 15) || (item_stride & 15)) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  return launch_sad<true>(n, preds, orig, count * 2, costs, pred_stride, item_stride, ctx_stream(s));
+}
+
+int kvz_hip_satd_nxn_dual_batch(int n, const kvz_hip_pixel *preds, size_t pred_stride, size_t item_stride,
+                                const kvz_hip_pixel *orig, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!preds || !orig || !costs || !aligned16(preds) || !aligned16(orig) || (pred_stride & 15) || (item_stride & 15)) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  return launch_satd<true>(n, preds, orig, count * 2, costs, pred_stride, item_stride, ctx_stream(s));
+}
+
+int kvz_hip_reg_sad_batch(const kvz_hip_pixel *plane1, uint32_t stride1, const kvz_hip_pixel *plane2, uint32_t stride2,
+                          const kvz_hip_block_pair *pairs, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!plane1 || !plane2 || !pairs || !costs) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  plane_t p1 = { plane1, stride1, 0, 0 }, p2 = { plane2, stride2, 0, 0 };
+  hipLaunchKernelGGL((pair_sad_kernel<false>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
+  KVZ_CHECK_LAUNCH("pair_sad_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_image_calc_sad_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, const kvz_hip_pixel *ref, uint32_t ref_stride,
+                                 int ref_w, int ref_h, const kvz_hip_block_pair *pairs, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  plane_t p1 = { pic, pic_stride, 0, 0 }, p2 = { ref, ref_stride, ref_w, ref_h };
+  hipLaunchKernelGGL((pair_sad_kernel<false>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
+  KVZ_CHECK_LAUNCH("pair_sad_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_image_calc_satd_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, const kvz_hip_pixel *ref, uint32_t ref_stride,
+                                  int ref_w, int ref_h, const kvz_hip_block_pair *pairs, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  plane_t p1 = { pic, pic_stride, 0, 0 }, p2 = { ref, ref_stride, ref_w, ref_h };
+  hipLaunchKernelGGL(pair_satd_kernel, dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
+  KVZ_CHECK_LAUNCH("pair_satd_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_pixels_calc_ssd_batch(const kvz_hip_pixel *plane1, uint32_t stride1, const kvz_hip_pixel *plane2, uint32_t stride2,
+                                  const kvz_hip_block_pair *pairs, size_t count, uint32_t *ssd, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!plane1 || !plane2 || !pairs || !ssd) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  plane_t p1 = { plane1, stride1, 0, 0 }, p2 = { plane2, stride2, 0, 0 };
+  hipLaunchKernelGGL((pair_sad_kernel<true>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, ssd);
+  KVZ_CHECK_LAUNCH("pair_sad_kernel<ssd>");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_satd_any_size_quad_batch(const kvz_hip_pixel *preds, uint32_t pred_stride, size_t pred_item_stride,
+                                     const kvz_hip_pixel *orig, uint32_t orig_stride, const kvz_hip_block_pair *pairs,
+                                     size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!preds || !orig || !pairs || !costs) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  plane_t po = { orig, orig_stride, 0, 0 };
+  hipLaunchKernelGGL(quad_satd_kernel, dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), preds, pred_stride, pred_item_stride, po, pairs, count, costs);
+  KVZ_CHECK_LAUNCH("quad_satd_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_bipred_blend_batch(int w, int h, int hi_prec0, const void *src0, int hi_prec1, const void *src1,
+                               kvz_hip_pixel *dst, size_t count, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!src0 || !src1 || !dst || w <= 0 || h <= 0) return KVZ_HIP_ERR_INVALID;
+  const size_t n = (size_t)w * h * count;
+  if (n == 0) return KVZ_HIP_OK;
+  const unsigned grid = stream_grid(n, 1024);
+  hipStream_t st = ctx_stream(s);
+  if (hi_prec0 && hi_prec1) hipLaunchKernelGGL((bipred_blend_kernel<true, true>), dim3(grid), dim3(256), 0, st, src0, src1, dst, n);
+  else if (hi_prec0) hipLaunchKernelGGL((bipred_blend_kernel<true, false>), dim3(grid), dim3(256), 0, st, src0, src1, dst, n);
+  else if (hi_prec1) hipLaunchKernelGGL((bipred_blend_kernel<false, true>), dim3(grid), dim3(256), 0, st, src0, src1, dst, n);
+  else hipLaunchKernelGGL((bipred_blend_kernel<false, false>), dim3(grid), dim3(256), 0, st, src0, src1, dst, n);
+  KVZ_CHECK_LAUNCH("bipred_blend_kernel");
+  return KVZ_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,414 @@
+// quant.hip -- quant / dequant / coeff_abs_sum and the fused quantize_residual
+// for gfx950.  Reference: src/strategies/generic/quant-generic.c (cited per
+// kernel), transform.c:129-180 for the scaled QP and transform-skip.
+//
+// The encoder state the reference reads through `state` is flattened by the
+// host into quant_consts (kvz_hip_quant_params in the C ABI).
+#include "kvz_hip_internal.h"
+#include "transform_core.h"
+
+using namespace kvzhip;
+
+struct quant_consts {
+  int q_bits, add, flat_qc, signhide;       // quant
+  const int32_t *qtable;                     // per-coefficient factors or nullptr (flat)
+  int dq_mode;                               // 0 flat, 1 scaling list (shift > qp/6), 2 scaling list (clip + shl)
+  int dq_shift, dq_add, dq_scale;            // mode 0: (q*scale + add) >> shift; mode 1: shift/add; mode 2: shl = dq_shift
+  const int32_t *dqtable;
+};
+
+// transform.c:129-143
+static int scaled_qp(int type, int qp)
+{
+  static const unsigned char chroma_scale[58] = {
+     0, 1, 2, 3, 4, 5, 6, 7, 8, 9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,29,30,31,32,
+    33,33,34,34,35,35,36,36,37,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51 };
+  if (type == 0) return qp;
+  int q = qp < 0 ? 0 : (qp > 57 ? 57 : qp);      // CLIP(-qp_offset, 57, qp) with qp_offset 0
+  return chroma_scale[q];
+}
+static int log2i(int w) { int l = 0; while ((1 << l) < w) ++l; return l; }
+
+// quant-generic.c:40-50 and :283-320
+static bool make_consts(const kvz_hip_quant_params *p, int width, int type_q, int type_dq, quant_consts *c)
+{
+  static const int quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };     // scalinglist.c:66
+  static const int inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };                   // scalinglist.c:67
+  if (width != 4 && width != 8 && width != 16 && width != 32) return false;
+  const int log2_tr = log2i(width);
+  const int transform_shift = 15 - 8 - log2_tr;
+  {
+    const int qps = scaled_qp(type_q, p->qp);
+    if (qps < 0) return false;
+    c->q_bits = 14 + qps / 6 + transform_shift;
+    c->add = (p->slice_is_intra ? 171 : 85) << (c->q_bits - 9);
+    c->flat_qc = quant_scales[qps % 6];
+    c->signhide = p->signhide;
+    c->qtable = (p->scaling_list && p->quant_coeff) ? p->quant_coeff : nullptr;
+  }
+  {
+    const int qps = scaled_qp(type_dq, p->qp);
+    int shift = 20 - 14 - transform_shift;
+    if (p->scaling_list && p->dequant_coeff) {
+      shift += 4;
+      c->dqtable = p->dequant_coeff;
+      if (shift > qps / 6) { c->dq_mode = 1; c->dq_shift = shift - qps / 6; c->dq_add = 1 << (c->dq_shift - 1); }
+      else { c->dq_mode = 2; c->dq_shift = qps / 6 - shift; c->dq_add = 0; }
+      c->dq_scale = 0;
+    } else {
+      c->dq_mode = 0; c->dqtable = nullptr;
+      c->dq_scale = inv_quant_scales[qps % 6] << (qps / 6);
+      c->dq_shift = shift; c->dq_add = 1 << (shift - 1);
+    }
+  }
+  return true;
+}
+
+// quant-generic.c:55-67: unsigned level before sign/clip
+__device__ __forceinline__ int quant_level(int c, int qc, const quant_consts &k)
+{
+  const int a = c < 0 ? -c : c;
+  return (int)(((long long)a * qc + k.add) >> k.q_bits);
+}
+__device__ __forceinline__ int quant_one(int c, int qc, const quant_consts &k)
+{
+  int level = quant_level(c, qc, k);
+  level = c < 0 ? -level : level;
+  return clip16(level);
+}
+// quant-generic.c:290-320
+__device__ __forceinline__ int dequant_one(int q, int n, const quant_consts &k)
+{
+  if (k.dq_mode == 0) return clip16((int)((unsigned)(q * k.dq_scale) + (unsigned)k.dq_add) >> k.dq_shift);
+  const int d = k.dqtable[n];
+  if (k.dq_mode == 1) return clip16((q * d + k.dq_add) >> k.dq_shift);
+  int v = clip16(q * d);
+  return clip16((int)((unsigned)v << k.dq_shift));
+}
+
+// ---- elementwise kernels: 8 coefficients (16 bytes) per lane ----
+__global__ __launch_bounds__(256) void quant_kernel(const i16 *__restrict__ coef, i16 *__restrict__ q_coef,
+                                                    size_t total, int block_elems, quant_consts k)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid * 8; i < total; i += nthreads * 8) {
+    union { uint4 v; i16 s[8]; } in, out;
+    in.v = *(const uint4 *)(coef + i);
+    const int n0 = (int)(i % (size_t)block_elems);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int qc = k.qtable ? k.qtable[n0 + j] : k.flat_qc;
+      out.s[j] = (i16)quant_one(in.s[j], qc, k);
+    }
+    *(uint4 *)(q_coef + i) = out.v;
+  }
+}
+
+__global__ __launch_bounds__(256) void dequant_kernel(const i16 *__restrict__ q_coef, i16 *__restrict__ coef,
+                                                      size_t total, int block_elems, quant_consts k)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = tid * 8; i < total; i += nthreads * 8) {
+    union { uint4 v; i16 s[8]; } in, out;
+    in.v = *(const uint4 *)(q_coef + i);
+    const int n0 = (int)(i % (size_t)block_elems);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out.s[j] = (i16)dequant_one(in.s[j], n0 + j, k);
+    *(uint4 *)(coef + i) = out.v;
+  }
+}
+
+// ---- sign bit hiding (quant-generic.c:69-162) on one block; coef/q_coef may be
+// global or LDS pointers.  Sequential per block, exactly the reference's control
+// flow (including `abssum` being a signed sum and `cur_change` persisting across
+// iterations).  Only reached with --signhide (off at preset medium). ----
+// position of scan index `idx` for (scan_idx, log2 size): kvz_g_sig_last_scan
+// (tables.c): 4x4 coefficient groups, group order and in-group order both follow
+// the pattern (0 up-right diagonal, 1 horizontal, 2 vertical).
+__device__ __forceinline__ int pattern_pos4(int scan_idx, int i)     // i in 0..15 -> y*4 + x inside a 4x4
+{
+  if (scan_idx == 1) return i;
+  if (scan_idx == 2) return ((i & 3) << 2) | (i >> 2);
+  const unsigned char t[16] = { 0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15 };
+  return t[i];
+}
+// order of the g x g groups (g = 1, 2, 4, 8): returns gy * g + gx of the i-th group
+__device__ __forceinline__ int pattern_group(int scan_idx, int g, int i)
+{
+  if (scan_idx == 1) return i;
+  if (scan_idx == 2) return (i % g) * g + (i / g);
+  // up-right diagonal over a g x g grid: walk anti-diagonals from bottom-left to top-right
+  int c = 0;
+  for (int d = 0; d < 2 * g - 1; ++d) {
+    const int y0 = d < g ? d : g - 1;
+    const int cnt = (d < g) ? d + 1 : 2 * g - 1 - d;
+    if (i < c + cnt) { const int y = y0 - (i - c); return y * g + (d - y); }
+    c += cnt;
+  }
+  return 0;
+}
+__device__ __forceinline__ int scan_pos(int scan_idx, int log2_size, int idx)
+{
+  const int n = 1 << log2_size;
+  if (log2_size == 2) return pattern_pos4(scan_idx, idx);
+  const int g = n >> 2;
+  const int grp = pattern_group(scan_idx, g, idx >> 4);
+  const int p = pattern_pos4(scan_idx, idx & 15);
+  return ((grp / g) * 4 + (p >> 2)) * n + (grp % g) * 4 + (p & 3);
+}
+
+template <typename CP, typename QP>
+__device__ void sign_hide_block(CP coef, QP q_coef, int width, int scan_idx, const quant_consts &k)
+{
+  const int log2_size = width == 4 ? 2 : width == 8 ? 3 : width == 16 ? 4 : 5;
+  const int n_coef = width * width;
+  const int q_bits8 = k.q_bits - 8;
+  unsigned ac_sum = 0;
+  for (int n = 0; n < n_coef; ++n) ac_sum += (unsigned)quant_level(coef[n], k.qtable ? k.qtable[n] : k.flat_qc, k);
+  if (ac_sum < 2) return;
+
+  auto delta_u = [&](int pos) -> int {
+    const int qc = k.qtable ? k.qtable[pos] : k.flat_qc;
+    const int c = coef[pos];
+    const long long prod = (long long)(c < 0 ? -c : c) * qc;
+    const int level = (int)((prod + k.add) >> k.q_bits);
+    return (int)((prod - (long long)(int)((unsigned)level << k.q_bits)) >> q_bits8);
+  };
+
+  int last_cg = -1;
+  for (int subset = (n_coef - 1) >> 4; subset >= 0; --subset) {
+    const int subpos = subset << 4;
+    int pos16[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) pos16[n] = scan_pos(scan_idx, log2_size, subpos + n);
+    int first_nz = 16, last_nz = -1, abssum = 0;
+    for (int n = 15; n >= 0; --n) if (q_coef[pos16[n]]) { last_nz = n; break; }
+    for (int n = 0; n < 16; ++n) if (q_coef[pos16[n]]) { first_nz = n; break; }
+    for (int n = first_nz; n <= last_nz; ++n) abssum += q_coef[pos16[n]];
+    if (last_nz >= 0 && last_cg == -1) last_cg = 1;
+    if (last_nz - first_nz >= 4) {
+      const int signbit = q_coef[pos16[first_nz]] > 0 ? 0 : 1;
+      if (signbit != (abssum & 1)) {
+        int min_cost_inc = 0x7fffffff, min_pos = -1, cur_cost = 0x7fffffff;
+        int final_change = 0, cur_change = 0;
+        for (int n = (last_cg == 1 ? last_nz : 15); n >= 0; --n) {
+          const int pos = pos16[n];
+          const int q = q_coef[pos];
+          if (q != 0) {
+            const int du = delta_u(pos);
+            if (du > 0) { cur_cost = -du; cur_change = 1; }
+            else if (n == first_nz && (q == 1 || q == -1)) { cur_cost = 0x7fffffff; }
+            else { cur_cost = du; cur_change = -1; }
+          } else if (n < first_nz && ((coef[pos] >= 0) ? 0 : 1) != signbit) {
+            cur_cost = 0x7fffffff;
+          } else { cur_cost = -delta_u(pos); cur_change = 1; }
+          if (cur_cost < min_cost_inc) { min_cost_inc = cur_cost; final_change = cur_change; min_pos = pos; }
+        }
+        const int qm = q_coef[min_pos];
+        if (qm == 32767 || qm == -32768) final_change = -1;
+        if (coef[min_pos] >= 0) q_coef[min_pos] = (i16)(qm + final_change);
+        else q_coef[min_pos] = (i16)(qm - final_change);
+      }
+    }
+    if (last_cg == 1) last_cg = 0;
+  }
+}
+
+__global__ __launch_bounds__(64) void sign_hide_kernel(const i16 *__restrict__ coef, i16 *__restrict__ q_coef,
+                                                       size_t count, int width, int scan_idx, quant_consts k)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const size_t off = i * (size_t)(width * width);
+  sign_hide_block(coef + off, q_coef + off, width, scan_idx, k);
+}
+
+// coeff_abs_sum (quant-generic.c:323-330): one wave per block
+__global__ __launch_bounds__(256) void coeff_abs_sum_kernel(const i16 *__restrict__ c, size_t length, size_t count, u32 *__restrict__ sums)
+{
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  for (size_t b = wave; b < count; b += nwaves) {
+    const i16 *p = c + b * length;
+    u32 acc = 0;
+    for (size_t i = lane; i < length; i += 64) { int v = p[i]; acc += (u32)(v < 0 ? -v : v); }
+    acc = group_sum<64>(acc);
+    if (lane == 0) sums[b] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused kvz_quantize_residual (rdoq off), quant-generic.c:180-273.  256/N TUs per
+// workgroup, N threads per TU; everything between the loads of ref/pred and the
+// stores of rec/coeff stays in LDS and registers.
+// ---------------------------------------------------------------------------
+template <int N, int TRK>     // TRK: 0 DCT, 2 DST, 4 transform skip
+__global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__restrict__ ref_in, const u8 *pred_in,
+                                                                u8 *rec_out, i16 *__restrict__ coeff_out,
+                                                                i32 *__restrict__ has_coeffs, size_t count,
+                                                                int scan_order, quant_consts k)
+{
+  constexpr int TPB = 256 / N;
+  constexpr int LD = N >= 8 ? N + 8 : N;
+  constexpr int LOG2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+  constexpr int TS_SHIFT = 15 - 8 - LOG2N;
+  __shared__ __attribute__((aligned(16))) i16 sa[TPB * N * LD];     // residual / coefficients
+  __shared__ __attribute__((aligned(16))) i16 sb[TPB * N * LD];     // transform scratch
+  __shared__ __attribute__((aligned(16))) i16 sq[TPB * N * N];      // quantized coefficients (row-major, unpadded)
+  __shared__ int s_has[TPB];
+
+  const int tid = threadIdx.x, tu = tid / N, row = tid % N;
+  const size_t ngroups = (count + TPB - 1) / TPB;
+  i16 *a = sa + tu * N * LD, *b = sb + tu * N * LD, *q = sq + tu * N * N;
+
+  for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const size_t blk = g * TPB + tu;
+    const bool valid = blk < count;
+    const size_t base = (valid ? blk : 0) * (size_t)(N * N) + (size_t)row * N;
+    int pred[N];
+    // residual row (ref - pred) as int16
+#pragma unroll
+    for (int x = 0; x < N; ++x) {
+      const int r = ref_in[base + x], p = pred_in[base + x];
+      pred[x] = p;
+      a[row * LD + x] = (i16)(r - p);
+    }
+    if (row == 0) s_has[tu] = 0;
+    __syncthreads();
+    if constexpr (TRK == 4) {
+#pragma unroll
+      for (int x = 0; x < N; ++x) a[row * LD + x] = (i16)((int)a[row * LD + x] << TS_SHIFT);
+    } else {
+      transform_2d_lds<N, TRK, LD>(a, b, row);
+    }
+    __syncthreads();
+    // quantize own row
+    int any = 0;
+#pragma unroll
+    for (int x = 0; x < N; ++x) {
+      const int n = row * N + x;
+      const int v = quant_one(a[row * LD + x], k.qtable ? k.qtable[n] : k.flat_qc, k);
+      q[n] = (i16)v;
+      any |= v;
+    }
+    if (k.signhide) {
+      __syncthreads();
+      if (row == 0) {
+        struct lds_view { const i16 *p; int ld, n; __device__ int operator[](int i) const { return p[(i / n) * ld + (i % n)]; } };
+        lds_view cv = { a, LD, N };
+        sign_hide_block(cv, q, N, scan_order, k);
+      }
+      __syncthreads();
+      any = 0;
+#pragma unroll
+      for (int x = 0; x < N; ++x) any |= q[row * N + x];
+    }
+    if (any) atomicOr(&s_has[tu], 1);
+    __syncthreads();
+    const int has = s_has[tu];
+    // dequantize own row back into `a`, inverse transform (done for every TU so that
+    // barriers stay uniform; the result is only used when has != 0)
+#pragma unroll
+    for (int x = 0; x < N; ++x) a[row * LD + x] = (i16)dequant_one(q[row * N + x], row * N + x, k);
+    __syncthreads();
+    if constexpr (TRK == 4) {
+#pragma unroll
+      for (int x = 0; x < N; ++x) a[row * LD + x] = (i16)(((int)a[row * LD + x] + (1 << (TS_SHIFT - 1))) >> TS_SHIFT);
+    } else {
+      transform_2d_lds<N, TRK + 1, LD>(a, b, row);
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+      for (int x = 0; x < N; ++x) {
+        int out = pred[x];
+        if (has) {
+          const i16 val = (i16)((int)a[row * LD + x] + pred[x]);
+          out = val < 0 ? 0 : (val > 255 ? 255 : val);
+        }
+        rec_out[base + x] = (u8)out;
+        coeff_out[base + x] = q[row * N + x];
+      }
+      if (row == 0) has_coeffs[blk] = has;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" {
+
+int kvz_hip_quant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *coef, kvz_hip_coeff *q_coef,
+                        int width, int type, int scan_idx, size_t count, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  quant_consts k;
+  if (!p || !coef || !q_coef || scan_idx < 0 || scan_idx > 2 || !make_consts(p, width, type, type, &k)) return KVZ_HIP_ERR_INVALID;
+  if ((((uintptr_t)coef | (uintptr_t)q_coef) & 15) != 0) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  hipStream_t st = ctx_stream(s);
+  const size_t total = count * (size_t)(width * width);
+  hipLaunchKernelGGL(quant_kernel, dim3(stream_grid(total, 2048)), dim3(256), 0, st, coef, q_coef, total, width * width, k);
+  KVZ_CHECK_LAUNCH("quant_kernel");
+  if (k.signhide) {
+    hipLaunchKernelGGL(sign_hide_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, coef, q_coef, count, width, scan_idx, k);
+    KVZ_CHECK_LAUNCH("sign_hide_kernel");
+  }
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_dequant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *q_coef, kvz_hip_coeff *coef,
+                          int width, int type, size_t count, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  quant_consts k;
+  if (!p || !coef || !q_coef || !make_consts(p, width, type, type, &k)) return KVZ_HIP_ERR_INVALID;
+  if ((((uintptr_t)coef | (uintptr_t)q_coef) & 15) != 0) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  const size_t total = count * (size_t)(width * width);
+  hipLaunchKernelGGL(dequant_kernel, dim3(stream_grid(total, 2048)), dim3(256), 0, ctx_stream(s), q_coef, coef, total, width * width, k);
+  KVZ_CHECK_LAUNCH("dequant_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_coeff_abs_sum_batch(const kvz_hip_coeff *coeffs, size_t length, size_t count, uint32_t *sums, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!coeffs || !sums) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  hipLaunchKernelGGL(coeff_abs_sum_kernel, dim3(stream_grid(count, 4)), dim3(256), 0, ctx_stream(s), coeffs, length, count, sums);
+  KVZ_CHECK_LAUNCH("coeff_abs_sum_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_intra, int width, int color, int scan_order,
+                                    int use_trskip, const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
+                                    kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
+                                    size_t count, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  quant_consts k;
+  // quant uses type 0 / 2, dequant 0 / 2 / 3 (quant-generic.c:224, :244)
+  const int tq = color == 0 ? 0 : 2, tdq = color == 0 ? 0 : (color == 1 ? 2 : 3);
+  if (!p || !ref_in || !pred_in || !rec_out || !coeff_out || !has_coeffs || color < 0 || color > 2 ||
+      scan_order < 0 || scan_order > 2 || !make_consts(p, width, tq, tdq, &k)) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  hipStream_t st = ctx_stream(s);
+  const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
+#define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, 16)), dim3(256), 0, st, \
+                                          ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, scan_order, k)
+  switch (width) {
+    case 4: if (use_trskip) KVZ_QR(4, 4); else if (dst) KVZ_QR(4, 2); else KVZ_QR(4, 0); break;
+    case 8: if (use_trskip) KVZ_QR(8, 4); else KVZ_QR(8, 0); break;
+    case 16: if (use_trskip) KVZ_QR(16, 4); else KVZ_QR(16, 0); break;
+    case 32: if (use_trskip) KVZ_QR(32, 4); else KVZ_QR(32, 0); break;
+    default: return KVZ_HIP_ERR_INVALID;
+  }
+#undef KVZ_QR
+  KVZ_CHECK_LAUNCH("quantize_residual_kernel");
+  return KVZ_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// strategy.hip -- the drop-in boundary: per-call strategy functions with the
+// reference's exact typedefs (host pointers in, result visible on return) and
+// the registration hooks kvz_strategy_register_<group>_hip.
+//
+// Reference interface replaced: src/strategyselector.h:86-87,
+// strategies/strategies-picture.h:102-130, strategies-dct.h:31,
+// strategies-quant.h:36-48, strategies-ipol.h:34-47; model for the hooks:
+// strategies/avx2/picture-avx2.c:1224-1258.
+//
+// Each call stages its operands through a per-thread pinned buffer to HBM,
+// launches the same kernels as the batched entries with a batch of one on a
+// per-thread stream, and waits: correct and thread-safe (the function pointers
+// are called concurrently from all threadqueue workers, encoderstate.c:781) but
+// launch-latency bound -- throughput comes from the batched entries.
+#include "kvz_hip_internal.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace kvzhip;
+
+// the host encoder's registry function; resolved at load time when present
+extern "C" int kvz_strategyselector_register(void *opaque, const char *type, const char *strategy_name, int priority, void *fptr)
+    __attribute__((weak, visibility("default")));
+
+namespace {
+
+kvz_hip_register_fn g_registrar = nullptr;
+kvz_hip_state_accessors g_acc;
+bool g_have_acc = false;
+
+struct call_ctx {
+  hipStream_t st = nullptr;
+  u8 *h = nullptr;       // pinned host staging
+  u8 *d = nullptr;       // device staging (same layout)
+  size_t cap = 0;
+  bool ok = false;
+  call_ctx()
+  {
+    if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return;
+    cap = 1u << 20;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return;
+    if (hipHostMalloc((void **)&h, cap, hipHostMallocDefault) != hipSuccess) return;
+    if (hipMalloc((void **)&d, cap) != hipSuccess) return;
+    ok = true;
+  }
+  ~call_ctx()
+  {
+    if (d) (void)hipFree(d);
+    if (h) (void)hipHostFree(h);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+call_ctx &tls()
+{
+  static thread_local call_ctx c;
+  if (!c.ok) {
+    // A strategy function has no error channel: never return garbage.
+    std::fprintf(stderr, "kvzhip: GPU context unavailable in a strategy call: %s\n", kvz_hip_last_error());
+    std::abort();
+  }
+  return c;
+}
+
+void die(const char *what, int rc)
+{
+  std::fprintf(stderr, "kvzhip: %s failed (rc=%d): %s\n", what, rc, kvz_hip_last_error());
+  std::abort();
+}
+#define MUST(call) do { int rc__ = (call); if (rc__ != KVZ_HIP_OK) die(#call, rc__); } while (0)
+#define HMUST(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { set_error(#call, e__); die(#call, KVZ_HIP_ERR_RUNTIME); } } while (0)
+
+inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// bump allocator over the staging buffer
+struct stage {
+  call_ctx &c;
+  size_t off = 0;
+  explicit stage(call_ctx &cc) : c(cc) {}
+  size_t take(size_t bytes)
+  {
+    size_t o = off;
+    off = up16(off + bytes);
+    if (off > c.cap) die("staging buffer overflow", KVZ_HIP_ERR_INVALID);
+    return o;
+  }
+  void h2d(size_t o, size_t bytes) { HMUST(hipMemcpyAsync(c.d + o, c.h + o, bytes, hipMemcpyHostToDevice, c.st)); }
+  void d2h(size_t o, size_t bytes) { HMUST(hipMemcpyAsync(c.h + o, c.d + o, bytes, hipMemcpyDeviceToHost, c.st)); }
+  void sync() { HMUST(hipStreamSynchronize(c.st)); }
+};
+
+void pack_rows(u8 *dst, const u8 *src, int w, int h, size_t stride)
+{
+  for (int y = 0; y < h; ++y) std::memcpy(dst + (size_t)y * w, src + (size_t)y * stride, (size_t)w);
+}
+
+// ---------------- picture group ----------------
+unsigned hip_reg_sad(const kvz_hip_pixel *d1, const kvz_hip_pixel *d2, int w, int h, unsigned s1, unsigned s2)
+{
+  if (w <= 0 || h <= 0) return 0;
+  call_ctx &c = tls(); stage s(c);
+  size_t oa = s.take((size_t)w * h), ob = s.take((size_t)w * h), od = s.take(sizeof(kvz_hip_block_pair)), in_end = s.off, oc = s.take(4);
+  pack_rows(c.h + oa, d1, w, h, s1); pack_rows(c.h + ob, d2, w, h, s2);
+  kvz_hip_block_pair bp = { 0, 0, 0, 0, w, h };
+  std::memcpy(c.h + od, &bp, sizeof(bp));
+  s.h2d(0, in_end);
+  MUST(kvz_hip_reg_sad_batch(c.d + oa, (u32)w, c.d + ob, (u32)w, (const kvz_hip_block_pair *)(c.d + od), 1, (u32 *)(c.d + oc), c.st));
+  s.d2h(oc, 4); s.sync();
+  return *(u32 *)(c.h + oc);
+}
+
+template <int N, bool SATD>
+unsigned hip_cost_nxn(const kvz_hip_pixel *b1, const kvz_hip_pixel *b2)
+{
+  call_ctx &c = tls(); stage s(c);
+  size_t oa = s.take(N * N), ob = s.take(N * N), in_end = s.off, oc = s.take(4);
+  std::memcpy(c.h + oa, b1, N * N); std::memcpy(c.h + ob, b2, N * N);
+  s.h2d(0, in_end);
+  if (SATD) MUST(kvz_hip_satd_nxn_batch(N, c.d + oa, c.d + ob, 1, (u32 *)(c.d + oc), c.st));
+  else MUST(kvz_hip_sad_nxn_batch(N, c.d + oa, c.d + ob, 1, (u32 *)(c.d + oc), c.st));
+  s.d2h(oc, 4); s.sync();
+  return *(u32 *)(c.h + oc);
+}
+
+// cost_pixel_nxn_multi_func: preds is kvz_pixel (*)[32*32]; preds[1] is 1024 bytes after preds[0]
+template <int N, bool SATD>
+void hip_cost_nxn_dual(const kvz_hip_pixel (*preds)[32 * 32], const kvz_hip_pixel *orig, unsigned num_modes, unsigned *costs_out)
+{
+  (void)num_modes;
+  call_ctx &c = tls(); stage s(c);
+  // N == 64 overlaps the two predictions in the reference's buffer (64*64 > 1024); copy what the generic code reads
+  const size_t pbytes = 1024 + (size_t)N * N;
+  size_t op = s.take(pbytes), oo = s.take(N * N), in_end = s.off, oc = s.take(8);
+  std::memcpy(c.h + op, preds, pbytes); std::memcpy(c.h + oo, orig, N * N);
+  s.h2d(0, in_end);
+  if (SATD) MUST(kvz_hip_satd_nxn_dual_batch(N, c.d + op, 1024, up16(pbytes), c.d + oo, 1, (u32 *)(c.d + oc), c.st));
+  else MUST(kvz_hip_sad_nxn_dual_batch(N, c.d + op, 1024, up16(pbytes), c.d + oo, 1, (u32 *)(c.d + oc), c.st));
+  s.d2h(oc, 8); s.sync();
+  costs_out[0] = ((u32 *)(c.h + oc))[0]; costs_out[1] = ((u32 *)(c.h + oc))[1];
+}
+
+unsigned hip_satd_any_size(int w, int h, const kvz_hip_pixel *b1, int s1, const kvz_hip_pixel *b2, int s2)
+{
+  if (w <= 0 || h <= 0) return 0;
+  call_ctx &c = tls(); stage s(c);
+  size_t oa = s.take((size_t)w * h), ob = s.take((size_t)w * h), od = s.take(sizeof(kvz_hip_block_pair)), in_end = s.off, oc = s.take(4);
+  pack_rows(c.h + oa, b1, w, h, (size_t)s1); pack_rows(c.h + ob, b2, w, h, (size_t)s2);
+  kvz_hip_block_pair bp = { 0, 0, 0, 0, w, h };
+  std::memcpy(c.h + od, &bp, sizeof(bp));
+  s.h2d(0, in_end);
+  // both planes are the packed blocks themselves: clamp extents == block => never clamps
+  MUST(kvz_hip_image_calc_satd_batch(c.d + oa, (u32)w, c.d + ob, (u32)w, w, h, (const kvz_hip_block_pair *)(c.d + od), 1, (u32 *)(c.d + oc), c.st));
+  s.d2h(oc, 4); s.sync();
+  return *(u32 *)(c.h + oc);
+}
+
+void hip_satd_any_size_quad(int w, int h, const kvz_hip_pixel **preds, const int stride, const kvz_hip_pixel *orig,
+                            const int orig_stride, unsigned num_modes, unsigned *costs_out, int8_t *valid)
+{
+  (void)num_modes; (void)valid;
+  costs_out[0] = costs_out[1] = costs_out[2] = costs_out[3] = 0;
+  if (w <= 0 || h <= 0) return;
+  call_ctx &c = tls(); stage s(c);
+  const size_t bsz = up16((size_t)w * h);
+  size_t op = s.take(bsz * 4), oo = s.take((size_t)w * h), od = s.take(sizeof(kvz_hip_block_pair)), in_end = s.off, oc = s.take(16);
+  for (int k = 0; k < 4; ++k) pack_rows(c.h + op + k * bsz, preds[k], w, h, (size_t)stride);
+  pack_rows(c.h + oo, orig, w, h, (size_t)orig_stride);
+  kvz_hip_block_pair bp = { 0, 0, 0, 0, w, h };
+  std::memcpy(c.h + od, &bp, sizeof(bp));
+  s.h2d(0, in_end);
+  MUST(kvz_hip_satd_any_size_quad_batch(c.d + op, (u32)w, bsz, c.d + oo, (u32)w, (const kvz_hip_block_pair *)(c.d + od), 1, (u32 *)(c.d + oc), c.st));
+  s.d2h(oc, 16); s.sync();
+  for (int k = 0; k < 4; ++k) costs_out[k] = ((u32 *)(c.h + oc))[k];
+}
+
+unsigned hip_pixels_calc_ssd(const kvz_hip_pixel *ref, const kvz_hip_pixel *rec, const int ref_stride, const int rec_stride, const int width)
+{
+  if (width <= 0) return 0;
+  call_ctx &c = tls(); stage s(c);
+  const int w = width;
+  size_t oa = s.take((size_t)w * w), ob = s.take((size_t)w * w), od = s.take(sizeof(kvz_hip_block_pair)), in_end = s.off, oc = s.take(4);
+  pack_rows(c.h + oa, ref, w, w, (size_t)ref_stride); pack_rows(c.h + ob, rec, w, w, (size_t)rec_stride);
+  kvz_hip_block_pair bp = { 0, 0, 0, 0, w, w };
+  std::memcpy(c.h + od, &bp, sizeof(bp));
+  s.h2d(0, in_end);
+  MUST(kvz_hip_pixels_calc_ssd_batch(c.d + oa, (u32)w, c.d + ob, (u32)w, (const kvz_hip_block_pair *)(c.d + od), 1, (u32 *)(c.d + oc), c.st));
+  s.d2h(oc, 4); s.sync();
+  return *(u32 *)(c.h + oc);
+}
+
+// ---------------- dct group ----------------
+template <int KIND, int N>
+unsigned hip_transform(int8_t bitdepth, const int16_t *input, int16_t *output)
+{
+  (void)bitdepth;           // registered for bitdepth 8 only
+  call_ctx &c = tls(); stage s(c);
+  size_t oi = s.take(N * N * 2), in_end = s.off, oo = s.take(N * N * 2);
+  std::memcpy(c.h + oi, input, N * N * 2);
+  s.h2d(0, in_end);
+  MUST(kvz_hip_transform_batch(KIND, N, (const int16_t *)(c.d + oi), (int16_t *)(c.d + oo), 1, c.st));
+  s.d2h(oo, N * N * 2); s.sync();
+  std::memcpy(output, c.h + oo, N * N * 2);
+  return 0;
+}
+
+// ---------------- quant group ----------------
+// flatten encoder_state_t through the accessors supplied by the host glue
+int log2w(int w) { int l = 0; while ((1 << l) < w) ++l; return l; }
+
+// stages the per-coefficient tables when the scaling list is enabled; returns params with DEVICE table pointers
+kvz_hip_quant_params flatten_state(const void *state, int width, int type_q, int type_dq, int block_is_intra, stage &s, call_ctx &c)
+{
+  kvz_hip_quant_params p;
+  std::memset(&p, 0, sizeof(p));
+  p.qp = g_acc.qp(state);
+  p.slice_is_intra = g_acc.slice_is_intra(state);
+  p.signhide = g_acc.signhide_enable(state);
+  p.scaling_list = g_acc.scaling_list_enable ? g_acc.scaling_list_enable(state) : 0;
+  if (p.scaling_list) {
+    static const unsigned char chroma_scale[58] = {
+       0, 1, 2, 3, 4, 5, 6, 7, 8, 9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,29,30,31,32,
+      33,33,34,34,35,35,36,36,37,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51 };
+    auto sqp = [&](int type) { if (type == 0) return p.qp; int q = p.qp < 0 ? 0 : (p.qp > 57 ? 57 : p.qp); return (int)chroma_scale[q]; };
+    static const int map[4] = { 0, 3, 1, 2 };        // "\0\3\1\2"[type], quant-generic.c:46
+    const size_t bytes = (size_t)width * width * 4;
+    const int l2 = log2w(width);
+    const int32_t *qt = g_acc.quant_coeff(state, l2, (block_is_intra ? 0 : 3) + map[type_q], sqp(type_q) % 6);
+    const int32_t *dt = g_acc.dequant_coeff(state, l2, (block_is_intra ? 0 : 3) + map[type_dq], sqp(type_dq) % 6);
+    size_t oq = s.take(bytes), odq = s.take(bytes);
+    std::memcpy(c.h + oq, qt, bytes); std::memcpy(c.h + odq, dt, bytes);
+    p.quant_coeff = (const int32_t *)(c.d + oq);
+    p.dequant_coeff = (const int32_t *)(c.d + odq);
+  }
+  return p;
+}
+
+unsigned hip_quant(const void *state, kvz_hip_coeff *coef, kvz_hip_coeff *q_coef, int32_t width, int32_t height,
+                   int8_t type, int8_t scan_idx, int8_t block_type)
+{
+  (void)height;
+  call_ctx &c = tls(); stage s(c);
+  const size_t bytes = (size_t)width * width * 2;
+  const int intra = (block_type == 1);          // CU_INTRA == 1 (cu.h:39-41)
+  kvz_hip_quant_params p = flatten_state(state, width, type, type, intra, s, c);
+  size_t oi = s.take(bytes), in_end = s.off, oo = s.take(bytes);
+  std::memcpy(c.h + oi, coef, bytes);
+  s.h2d(0, in_end);
+  MUST(kvz_hip_quant_batch(&p, (const kvz_hip_coeff *)(c.d + oi), (kvz_hip_coeff *)(c.d + oo), width, type, scan_idx, 1, c.st));
+  s.d2h(oo, bytes); s.sync();
+  std::memcpy(q_coef, c.h + oo, bytes);
+  return 0;
+}
+
+unsigned hip_dequant(const void *state, kvz_hip_coeff *q_coef, kvz_hip_coeff *coef, int32_t width, int32_t height,
+                     int8_t type, int8_t block_type)
+{
+  (void)height;
+  call_ctx &c = tls(); stage s(c);
+  const size_t bytes = (size_t)width * width * 2;
+  const int intra = (block_type == 1);
+  kvz_hip_quant_params p = flatten_state(state, width, type, type, intra, s, c);
+  size_t oi = s.take(bytes), in_end = s.off, oo = s.take(bytes);
+  std::memcpy(c.h + oi, q_coef, bytes);
+  s.h2d(0, in_end);
+  MUST(kvz_hip_dequant_batch(&p, (const kvz_hip_coeff *)(c.d + oi), (kvz_hip_coeff *)(c.d + oo), width, type, 1, c.st));
+  s.d2h(oo, bytes); s.sync();
+  std::memcpy(coef, c.h + oo, bytes);
+  return 0;
+}
+
+uint32_t hip_coeff_abs_sum(const kvz_hip_coeff *coeffs, size_t length)
+{
+  if (length == 0) return 0;
+  call_ctx &c = tls(); stage s(c);
+  size_t oi = s.take(length * 2), in_end = s.off, oc = s.take(4);
+  std::memcpy(c.h + oi, coeffs, length * 2);
+  s.h2d(0, in_end);
+  MUST(kvz_hip_coeff_abs_sum_batch((const kvz_hip_coeff *)(c.d + oi), length, 1, (u32 *)(c.d + oc), c.st));
+  s.d2h(oc, 4); s.sync();
+  return *(u32 *)(c.h + oc);
+}
+
+// quant_residual_func; color_t and coeff_scan_order_t are int-sized enums
+unsigned hip_quantize_residual(void *state, const void *cur_cu, const int width, const int color, const int scan_order,
+                               const int use_trskip, const int in_stride, const int out_stride,
+                               const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in, kvz_hip_pixel *rec_out,
+                               kvz_hip_coeff *coeff_out)
+{
+  call_ctx &c = tls(); stage s(c);
+  const int w = width;
+  const int intra = g_acc.cu_is_intra(cur_cu);
+  if (g_acc.rdoq_enable && g_acc.rdoq_enable(state)) {
+    std::fprintf(stderr, "kvzhip: quantize_residual with rdoq enabled is not offloaded; select the generic strategy "
+                         "(KVAZAAR_OVERRIDE_quantize_residual=generic) or run with --no-rdoq\n");
+    std::abort();
+  }
+  const int tq = color == 0 ? 0 : 2, tdq = color == 0 ? 0 : (color == 1 ? 2 : 3);
+  kvz_hip_quant_params p = flatten_state(state, w, tq, tdq, intra, s, c);
+  size_t orf = s.take((size_t)w * w), opr = s.take((size_t)w * w), in_end = s.off;
+  size_t ore = s.take((size_t)w * w), oco = s.take((size_t)w * w * 2), oha = s.take(4), out_end = s.off;
+  pack_rows(c.h + orf, ref_in, w, w, (size_t)in_stride); pack_rows(c.h + opr, pred_in, w, w, (size_t)in_stride);
+  s.h2d(0, in_end);
+  MUST(kvz_hip_quantize_residual_batch(&p, intra, w, color, scan_order, use_trskip, c.d + orf, c.d + opr, c.d + ore,
+                                       (kvz_hip_coeff *)(c.d + oco), (int32_t *)(c.d + oha), 1, c.st));
+  s.d2h(ore, out_end - ore); s.sync();
+  const int has = *(int32_t *)(c.h + oha);
+  std::memcpy(coeff_out, c.h + oco, (size_t)w * w * 2);
+  if (has || rec_out != pred_in)
+    for (int y = 0; y < w; ++y) std::memcpy(rec_out + (size_t)y * out_stride, c.h + ore + (size_t)y * w, (size_t)w);
+  return (unsigned)has;
+}
+
+// ---------------- ipol group ----------------
+template <bool LUMA, bool OUT14>
+void hip_sample(const void *encoder, kvz_hip_pixel *src, int16_t src_stride, int width, int height, void *dst,
+                int16_t dst_stride, int8_t hor_flag, int8_t ver_flag, const int16_t mv[2])
+{
+  (void)encoder; (void)hor_flag; (void)ver_flag;
+  constexpr int TAPS = LUMA ? 8 : 4, OFF = TAPS / 2 - 1;
+  call_ctx &c = tls(); stage s(c);
+  const int ww = width + TAPS - 1, wh = height + TAPS - 1;
+  size_t ow = s.take((size_t)ww * wh), ob = s.take(sizeof(kvz_hip_ipol_block)), oof = s.take(8), in_end = s.off;
+  const size_t obytes = (size_t)width * height * (OUT14 ? 2 : 1);
+  size_t oo = s.take(obytes);
+  pack_rows(c.h + ow, src - (ptrdiff_t)OFF * src_stride - OFF, ww, wh, (size_t)src_stride);
+  kvz_hip_ipol_block b = { OFF, OFF, mv[0] & (LUMA ? 3 : 7), mv[1] & (LUMA ? 3 : 7), width, height };
+  std::memcpy(c.h + ob, &b, sizeof(b));
+  uint64_t zero = 0; std::memcpy(c.h + oof, &zero, 8);
+  s.h2d(0, in_end);
+  if (LUMA) MUST(kvz_hip_sample_luma_batch(c.d + ow, (u32)ww, ww, wh, (const kvz_hip_ipol_block *)(c.d + ob), (const uint64_t *)(c.d + oof), 1, OUT14, c.d + oo, c.st));
+  else MUST(kvz_hip_sample_chroma_batch(c.d + ow, (u32)ww, ww, wh, (const kvz_hip_ipol_block *)(c.d + ob), (const uint64_t *)(c.d + oof), 1, OUT14, c.d + oo, c.st));
+  s.d2h(oo, obytes); s.sync();
+  const size_t esz = OUT14 ? 2 : 1;
+  for (int y = 0; y < height; ++y)
+    std::memcpy((u8 *)dst + (size_t)y * dst_stride * esz, c.h + oo + (size_t)y * width * esz, (size_t)width * esz);
+}
+
+int reg(void *opaque, const char *type, void *fptr)
+{
+  kvz_hip_register_fn f = g_registrar ? g_registrar : (kvz_hip_register_fn)kvz_strategyselector_register;
+  if (!f) { set_error_msg("no strategy registrar: the host has no kvz_strategyselector_register and kvz_hip_set_registrar was not called"); return 0; }
+  return f(opaque, type, KVZ_HIP_STRATEGY_NAME, KVZ_HIP_STRATEGY_PRIORITY, fptr);
+}
+
+bool hook_ready(uint8_t bitdepth)
+{
+  if (bitdepth != 8) return false;
+  return kvz_hip_init(-1) == KVZ_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void kvz_hip_set_registrar(kvz_hip_register_fn fn) { g_registrar = fn; }
+
+void kvz_hip_set_state_accessors(const kvz_hip_state_accessors *acc)
+{
+  if (acc) { g_acc = *acc; g_have_acc = acc->qp && acc->slice_is_intra && acc->signhide_enable && acc->cu_is_intra; }
+  else g_have_acc = false;
+}
+
+// STRATEGIES_PICTURE_EXPORTS, strategies-picture.h:174-199.  inter_recon_bipred is
+// not registered: its lcu_t / hi_prec_buf_t arguments are encoder structs and the
+// function is only reached with --bipred (off at every preset up to medium); the
+// batched blend kvz_hip_bipred_blend_batch covers the arithmetic.
+int kvz_strategy_register_picture_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!hook_ready(bitdepth)) return 0;
+  int ok = 1;
+  ok &= reg(opaque, "reg_sad", (void *)&hip_reg_sad);
+  ok &= reg(opaque, "sad_4x4", (void *)&hip_cost_nxn<4, false>);
+  ok &= reg(opaque, "sad_8x8", (void *)&hip_cost_nxn<8, false>);
+  ok &= reg(opaque, "sad_16x16", (void *)&hip_cost_nxn<16, false>);
+  ok &= reg(opaque, "sad_32x32", (void *)&hip_cost_nxn<32, false>);
+  ok &= reg(opaque, "sad_64x64", (void *)&hip_cost_nxn<64, false>);
+  ok &= reg(opaque, "satd_4x4", (void *)&hip_cost_nxn<4, true>);
+  ok &= reg(opaque, "satd_8x8", (void *)&hip_cost_nxn<8, true>);
+  ok &= reg(opaque, "satd_16x16", (void *)&hip_cost_nxn<16, true>);
+  ok &= reg(opaque, "satd_32x32", (void *)&hip_cost_nxn<32, true>);
+  ok &= reg(opaque, "satd_64x64", (void *)&hip_cost_nxn<64, true>);
+  ok &= reg(opaque, "satd_any_size", (void *)&hip_satd_any_size);
+  ok &= reg(opaque, "sad_4x4_dual", (void *)&hip_cost_nxn_dual<4, false>);
+  ok &= reg(opaque, "sad_8x8_dual", (void *)&hip_cost_nxn_dual<8, false>);
+  ok &= reg(opaque, "sad_16x16_dual", (void *)&hip_cost_nxn_dual<16, false>);
+  ok &= reg(opaque, "sad_32x32_dual", (void *)&hip_cost_nxn_dual<32, false>);
+  ok &= reg(opaque, "sad_64x64_dual", (void *)&hip_cost_nxn_dual<64, false>);
+  ok &= reg(opaque, "satd_4x4_dual", (void *)&hip_cost_nxn_dual<4, true>);
+  ok &= reg(opaque, "satd_8x8_dual", (void *)&hip_cost_nxn_dual<8, true>);
+  ok &= reg(opaque, "satd_16x16_dual", (void *)&hip_cost_nxn_dual<16, true>);
+  ok &= reg(opaque, "satd_32x32_dual", (void *)&hip_cost_nxn_dual<32, true>);
+  ok &= reg(opaque, "satd_64x64_dual", (void *)&hip_cost_nxn_dual<64, true>);
+  ok &= reg(opaque, "satd_any_size_quad", (void *)&hip_satd_any_size_quad);
+  ok &= reg(opaque, "pixels_calc_ssd", (void *)&hip_pixels_calc_ssd);
+  return ok;
+}
+
+// STRATEGIES_DCT_EXPORTS, strategies-dct.h:55-69
+int kvz_strategy_register_dct_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!hook_ready(bitdepth)) return 0;
+  int ok = 1;
+  ok &= reg(opaque, "fast_forward_dst_4x4", (void *)&hip_transform<KVZ_HIP_DST, 4>);
+  ok &= reg(opaque, "dct_4x4", (void *)&hip_transform<KVZ_HIP_DCT, 4>);
+  ok &= reg(opaque, "dct_8x8", (void *)&hip_transform<KVZ_HIP_DCT, 8>);
+  ok &= reg(opaque, "dct_16x16", (void *)&hip_transform<KVZ_HIP_DCT, 16>);
+  ok &= reg(opaque, "dct_32x32", (void *)&hip_transform<KVZ_HIP_DCT, 32>);
+  ok &= reg(opaque, "fast_inverse_dst_4x4", (void *)&hip_transform<KVZ_HIP_IDST, 4>);
+  ok &= reg(opaque, "idct_4x4", (void *)&hip_transform<KVZ_HIP_IDCT, 4>);
+  ok &= reg(opaque, "idct_8x8", (void *)&hip_transform<KVZ_HIP_IDCT, 8>);
+  ok &= reg(opaque, "idct_16x16", (void *)&hip_transform<KVZ_HIP_IDCT, 16>);
+  ok &= reg(opaque, "idct_32x32", (void *)&hip_transform<KVZ_HIP_IDCT, 32>);
+  return ok;
+}
+
+// STRATEGIES_QUANT_EXPORTS, strategies-quant.h:58-62.  quant / dequant /
+// quantize_residual read encoder_state_t, so they register only when the host
+// glue supplied accessors (kvz_hip_set_state_accessors).
+int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!hook_ready(bitdepth)) return 0;
+  int ok = 1;
+  ok &= reg(opaque, "coeff_abs_sum", (void *)&hip_coeff_abs_sum);
+  if (g_have_acc) {
+    ok &= reg(opaque, "quant", (void *)&hip_quant);
+    ok &= reg(opaque, "dequant", (void *)&hip_dequant);
+    ok &= reg(opaque, "quantize_residual", (void *)&hip_quantize_residual);
+  }
+  return ok;
+}
+
+// STRATEGIES_IPOL_EXPORTS, strategies-ipol.h:65-74: the four sample filters.  The
+// filter_{hpel,qpel}_blocks_* steps are stateful across calls through caller-owned
+// scratch and are offloaded as one fused search (kvz_hip_search_frac_batch)
+// instead of four per-call shims; get_extended_block is host-side pointer logic.
+int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!hook_ready(bitdepth)) return 0;
+  int ok = 1;
+  ok &= reg(opaque, "sample_quarterpel_luma", (void *)&hip_sample<true, false>);
+  ok &= reg(opaque, "sample_octpel_chroma", (void *)&hip_sample<false, false>);
+  ok &= reg(opaque, "sample_14bit_quarterpel_luma", (void *)&hip_sample<true, true>);
+  ok &= reg(opaque, "sample_14bit_octpel_chroma", (void *)&hip_sample<false, true>);
+  return ok;
+}
+
+}  // extern "C"

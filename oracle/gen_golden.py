@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the COMPILED REFERENCE's `generic` strategy
+(oracle/_ref/libkvzref.so, built from /root/reference by oracle/Makefile).
+
+Run in the build container:  python oracle/gen_golden.py
+The fixtures are data only (seeded inputs + the reference's outputs) and are
+committed; tests/test_oracle_golden.py checks the oracle against them on any
+machine (the GPU box has no /root/reference), tests/test_gpu_golden.py checks the
+HIP kernels against them."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ref_lib as R  # noqa: E402
+from patterns import dct_test_input, rng  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 20261004
+
+
+def picture():
+    g = rng(SEED)
+    d = {}
+    for n in (4, 8, 16, 32, 64):
+        cnt = 24 if n < 64 else 6
+        a = g.integers(0, 256, (cnt, n * n), dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + g.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+        b[::3] = g.integers(0, 256, (len(b[::3]), n * n), dtype=np.uint8)
+        d["a%d" % n], d["b%d" % n] = a, b
+        d["sad%d" % n] = R.cost_nxn_batch("sad", n, a, b)
+        d["satd%d" % n] = R.cost_nxn_batch("satd", n, a, b)
+        if n <= 32:
+            preds = g.integers(0, 256, (8, 2048), dtype=np.uint8)
+            d["dual_preds%d" % n] = preds
+            d["sad_dual%d" % n] = R.cost_nxn_dual_batch("sad", n, preds, a[:8])
+            d["satd_dual%d" % n] = R.cost_nxn_dual_batch("satd", n, preds, a[:8])
+    pic = g.integers(0, 256, (48, 64), dtype=np.uint8)
+    ref = g.integers(0, 256, (48, 64), dtype=np.uint8)
+    pairs = []
+    for (bw, bh) in ((8, 8), (16, 16), (32, 16), (12, 8), (4, 4), (64, 48)):
+        for (dx, dy) in ((0, 0), (-3, -3), (5, -70), (70, 9), (3, 0)):
+            px, py = (64 - bw) // 2, (48 - bh) // 2
+            pairs.append((px, py, px + dx, py + dy, bw, bh))
+    d["frame_pic"], d["frame_ref"] = pic, ref
+    d["pairs"] = np.array(pairs, dtype=np.int32)
+    d["image_sad"] = np.array([R.image_calc("sad", pic, ref, *p) for p in pairs], dtype=np.uint32)
+    d["image_satd"] = np.array([R.image_calc("satd", pic, ref, *p) for p in pairs], dtype=np.uint32)
+    # quad incl. the non-multiple-of-8 behaviour
+    qp = g.integers(0, 256, (4, 64 * 64), dtype=np.uint8)
+    dims = [(8, 8), (16, 16), (64, 48), (12, 16), (16, 12), (4, 8), (24, 24)]
+    d["quad_preds"] = qp
+    d["quad_dims"] = np.array(dims, dtype=np.int32)
+    d["quad_costs"] = np.array([R.satd_any_size_quad(w, h, list(qp), 64, pic, 0, 64) for (w, h) in dims], dtype=np.uint32)
+    d["ssd"] = np.array([R.pixels_calc_ssd(pic, 0, ref, 0, 64, 64, w) for w in (4, 8, 16, 32)], dtype=np.uint32)
+    np.savez_compressed(os.path.join(OUT, "picture.npz"), **d)
+
+
+def dct():
+    g = rng(SEED + 1)
+    d = {"gradient": dct_test_input()}
+    for n in (4, 8, 16, 32):
+        res = g.integers(-255, 256, (6, n * n)).astype(np.int16)
+        full = g.integers(-32768, 32768, (4, n * n)).astype(np.int16)
+        x = np.concatenate([res, full, d["gradient"][:n * n][None]])
+        d["in%d" % n] = x
+        for kind in ("dct", "idct") + (("dst", "idst") if n == 4 else ()):
+            d["%s%d" % (kind, n)] = R.transform_batch(kind, n, x)
+    np.savez_compressed(os.path.join(OUT, "dct.npz"), **d)
+
+
+def quant():
+    g = rng(SEED + 2)
+    d = {}
+    for w in (4, 8, 16, 32):
+        coef = g.integers(-1500, 1501, (6, w * w)).astype(np.int16)
+        coef[0] = g.integers(-32768, 32768, w * w)
+        d["coef%d" % w] = coef
+        for qp in (22, 37):
+            for sh in (0, 1):
+                q = R.quant_batch(coef, w, qp, 0, 0, 1, sh)
+                d["quant%d_qp%d_sh%d" % (w, qp, sh)] = q
+            d["dequant%d_qp%d" % (w, qp)] = R.dequant_batch(d["quant%d_qp%d_sh0" % (w, qp)], w, qp, 0)
+        ref_in = g.integers(0, 256, (6, w * w), dtype=np.uint8)
+        pred = np.clip(ref_in.astype(np.int32) + g.integers(-30, 31, ref_in.shape), 0, 255).astype(np.uint8)
+        pred[0] = ref_in[0]
+        d["qr_ref%d" % w], d["qr_pred%d" % w] = ref_in, pred
+        for intra in (0, 1):
+            rec, co, has = R.quantize_residual_batch(ref_in, pred, w, 22, 0, 0, intra, intra, 0, 0)
+            d["qr_rec%d_i%d" % (w, intra)], d["qr_coeff%d_i%d" % (w, intra)], d["qr_has%d_i%d" % (w, intra)] = rec, co, has
+    np.savez_compressed(os.path.join(OUT, "quant.npz"), **d)
+
+
+def ipol():
+    g = rng(SEED + 3)
+    frame = g.integers(0, 256, (80, 96), dtype=np.uint8)
+    frame[30:50, 30:50] = np.where(g.integers(0, 2, (20, 20)) > 0, 255, 0)
+    d = {"frame": frame}
+    lb = [(12, 10, fx, fy, w, h) for (w, h) in ((8, 8), (16, 16), (32, 16)) for fx in range(4) for fy in range(4)]
+    cb = [(12, 10, fx, fy, w, h) for (w, h) in ((4, 4), (8, 8), (16, 8)) for fx in range(8) for fy in range(0, 8, 3)]
+    d["luma_blocks"], d["chroma_blocks"] = np.array(lb, np.int32), np.array(cb, np.int32)
+    d["luma"] = np.concatenate([R.sample("luma", frame, *b[:2], b[4], b[5], b[2], b[3]).ravel() for b in lb])
+    d["luma14"] = np.concatenate([R.sample("luma14", frame, *b[:2], b[4], b[5], b[2], b[3]).ravel() for b in lb])
+    d["chroma"] = np.concatenate([R.sample("chroma", frame, *b[:2], b[4], b[5], b[2], b[3]).ravel() for b in cb])
+    d["chroma14"] = np.concatenate([R.sample("chroma14", frame, *b[:2], b[4], b[5], b[2], b[3]).ravel() for b in cb])
+    pic = ((frame.astype(np.int32) + np.roll(frame, 1, axis=1)) // 2).astype(np.uint8)
+    sf = [(x, y, w, h, mvx, mvy) for (w, h) in ((8, 8), (16, 16), (32, 32))
+          for (x, y) in ((0, 0), (40, 32)) for (mvx, mvy) in ((0, 0), (-3, 2), (-60, -60), (80, 70))]
+    d["pic"] = pic
+    d["sf_cases"] = np.array(sf, np.int32)
+    costs, bests = [], []
+    for (x, y, w, h, mvx, mvy) in sf:
+        c, b = R.search_frac_costs(pic, frame, x, y, w, h, mvx, mvy)
+        costs.append(c); bests.append(b)
+    d["sf_costs"], d["sf_best"] = np.array(costs, np.uint32), np.array(bests, np.int32)
+    # the four filter steps' blocks for one case per hpel offset
+    fs = []
+    for (ox, oy) in ((0, 0), (-1, 1), (1, -1)):
+        fs.append(R.filter_frac_steps(frame, 20, 18, 16, 16, (ox, oy))[:, :, :16, :16])
+    d["filter_steps"] = np.array(fs)
+    np.savez_compressed(os.path.join(OUT, "ipol.npz"), **d)
+
+
+if __name__ == "__main__":
+    if not R.available():
+        sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
+    os.makedirs(OUT, exist_ok=True)
+    picture(); dct(); quant(); ipol()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))

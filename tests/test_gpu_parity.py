@@ -1,0 +1,346 @@
+"""GPU parity: every batched entry of the C ABI (HIP kernels on a real MI355X)
+against the oracle on the same seeded inputs -- bit-exact, all integer work.
+Includes the reference's own test patterns and known-answer values."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from patterns import (SAD_EDGE_KAT, SATD_GOLDEN_BW, SATD_GOLDEN_GRADIENT, REG_SAD_DIMS, coeff_sum_input,
+                      dct_test_input, intra_sad_gradient, rng, sad_test_frames, satd_test_bufs)
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (4, 8, 16, 32, 64)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from kvazaar_amd import api as a, _lib
+    _lib.init(0)
+    return a
+
+
+def _blocks(n, count, seed, mode):
+    g = rng(seed)
+    if mode == "random":
+        a = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+        b = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+    elif mode == "extreme":
+        a = np.zeros((count, n * n), np.uint8)
+        b = np.full((count, n * n), 255, np.uint8)
+        a[1::2], b[1::2] = 255, 0
+    else:
+        a = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + g.integers(-6, 7, a.shape), 0, 255).astype(np.uint8)
+    return a, b
+
+
+# ragged counts exercise the wave / group tails of every kernel
+@pytest.mark.parametrize("count", [1, 3, 63, 64, 65, 257, 1000])
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("kind", ["sad", "satd"])
+def test_cost_nxn_counts(api, kind, n, count):
+    if n == 64 and count > 300:
+        count = 300
+    a, b = _blocks(n, count, 1000 + n + count, "random")
+    np.testing.assert_array_equal(api.cost_nxn_batch(kind, n, a, b), O.cost_nxn_batch(kind, n, a, b))
+
+
+@pytest.mark.parametrize("mode", ["extreme", "near"])
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("kind", ["sad", "satd"])
+def test_cost_nxn_modes(api, kind, n, mode):
+    a, b = _blocks(n, 130, 7 + n, mode)
+    np.testing.assert_array_equal(api.cost_nxn_batch(kind, n, a, b), O.cost_nxn_batch(kind, n, a, b))
+
+
+def test_cost_nxn_empty(api):
+    assert api.cost_nxn_batch("sad", 8, np.zeros((0, 64), np.uint8), np.zeros((0, 64), np.uint8)).shape == (0,)
+
+
+@pytest.mark.parametrize("log_w", [2, 3, 4, 5, 6])
+def test_satd_reference_known_answers(api, log_w):
+    """tests/satd_tests.c:109,127,146 hard-coded golden values; symmetric in the arguments"""
+    n = 1 << log_w
+    bw, ck, gr = satd_test_bufs(log_w)
+    for (x, y), want in ((bw, SATD_GOLDEN_BW[log_w]), (ck, SATD_GOLDEN_BW[log_w]), (gr, SATD_GOLDEN_GRADIENT[log_w])):
+        assert api.cost_nxn_batch("satd", n, x[None], y[None])[0] == want
+        assert api.cost_nxn_batch("satd", n, y[None], x[None])[0] == want
+
+
+@pytest.mark.parametrize("log_w", [2, 3, 4, 5, 6])
+def test_intra_sad_reference_patterns(api, log_w):
+    """tests/intra_sad_tests.c:124-167"""
+    n = 1 << log_w
+    z, m = np.zeros(n * n, np.uint8), np.full(n * n, 255, np.uint8)
+    assert api.cost_nxn_batch("sad", n, z[None], m[None])[0] == 255 * n * n
+    assert api.cost_nxn_batch("sad", n, m[None], z[None])[0] == 255 * n * n
+    ga, gb = intra_sad_gradient(n)
+    want = int(np.abs(ga.astype(np.int64) - gb.astype(np.int64)).sum())
+    assert api.cost_nxn_batch("sad", n, ga[None], gb[None])[0] == want
+    assert api.cost_nxn_batch("sad", n, gb[None], ga[None])[0] == want
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+@pytest.mark.parametrize("kind", ["sad", "satd"])
+def test_cost_nxn_dual(api, kind, n):
+    g = rng(70 + n)
+    for count in (1, 5, 64, 129):
+        orig = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+        preds = g.integers(0, 256, (count, 2048), dtype=np.uint8)
+        np.testing.assert_array_equal(api.cost_nxn_dual_batch(kind, n, preds, orig),
+                                      O.cost_nxn_dual_batch(kind, n, preds, orig))
+
+
+def test_reg_sad_reference_shapes(api):
+    """tests/sad_tests.c:261-320,369-376: 18 (w,h) shapes on the 64x64 patterns + 0-vs-255 overflow"""
+    _, _, big_pic, big_ref = sad_test_frames()
+    dims = REG_SAD_DIMS + [(64, 63), (1, 1), (7, 3), (13, 5)]
+    pairs = [(0, 0, 0, 0, w, h) for (w, h) in dims]
+    got = api.reg_sad_batch(big_pic, big_ref, pairs)
+    for (w, h), v in zip(dims, got):
+        want = int(np.abs(big_pic[:h, :w].astype(np.int64) - big_ref[:h, :w].astype(np.int64)).sum())
+        assert v == want, (w, h)
+    z, m = np.zeros((64, 64), np.uint8), np.full((64, 64), 255, np.uint8)
+    got = api.reg_sad_batch(z, m, pairs)
+    for (w, h), v in zip(dims, got):
+        assert v == 255 * w * h
+
+
+def test_reg_sad_random_offsets(api):
+    g = rng(11)
+    p1 = g.integers(0, 256, (120, 200), dtype=np.uint8)
+    p2 = g.integers(0, 256, (90, 160), dtype=np.uint8)
+    pairs = []
+    for _ in range(300):
+        w, h = int(g.integers(1, 65)), int(g.integers(1, 65))
+        pairs.append((int(g.integers(0, 200 - w + 1)), int(g.integers(0, 120 - h + 1)),
+                      int(g.integers(0, 160 - w + 1)), int(g.integers(0, 90 - h + 1)), w, h))
+    got = api.reg_sad_batch(p1, p2, pairs)
+    for (x1, y1, x2, y2, w, h), v in zip(pairs, got):
+        assert v == O.reg_sad(p1, p2, y1 * 200 + x1, y2 * 160 + x2, w, h, 200, 160)
+
+
+def test_image_calc_sad_reference_known_answers(api):
+    """tests/sad_tests.c:121-259: 17 closed-form values for MVs overlapping / outside the frame"""
+    pic, ref, _, _ = sad_test_frames()
+    mvs = list(SAD_EDGE_KAT.keys())
+    got = api.image_calc_sad_batch(pic, ref, [(0, 0, x, y, 8, 8) for (x, y) in mvs])
+    for mv, v in zip(mvs, got):
+        assert v == SAD_EDGE_KAT[mv], mv
+
+
+def test_image_calc_sad_and_satd_edges(api):
+    g = rng(8)
+    pic = g.integers(0, 256, (48, 64), dtype=np.uint8)
+    ref = g.integers(0, 256, (48, 64), dtype=np.uint8)
+    pairs = []
+    for (bw, bh) in ((8, 8), (16, 16), (16, 8), (32, 32), (64, 48), (4, 4), (12, 16), (8, 12), (24, 32)):
+        for (px, py) in ((0, 0), (min(16, 64 - bw), min(8, 48 - bh)), (64 - bw, 48 - bh)):
+            for (dx, dy) in ((0, 0), (-3, -3), (5, -70), (-100, 2), (70, 70), (3, 0), (0, 60), (-bw, -bh), (64, 48),
+                             (63 - px, 47 - py)):
+                pairs.append((px, py, px + dx, py + dy, bw, bh))
+    sad = api.image_calc_sad_batch(pic, ref, pairs)
+    satd = api.image_calc_satd_batch(pic, ref, pairs)
+    for p, a, b in zip(pairs, sad, satd):
+        assert a == O.image_calc("sad", pic, ref, *p), p
+        assert b == O.image_calc("satd", pic, ref, *p), p
+
+
+def test_pixels_calc_ssd(api):
+    g = rng(6)
+    a = g.integers(0, 256, (70, 70), dtype=np.uint8)
+    b = g.integers(0, 256, (70, 66), dtype=np.uint8)
+    pairs = [(2, 1, 1, 3, w, w) for w in (4, 8, 16, 32, 64)]
+    got = api.pixels_calc_ssd_batch(a, b, pairs)
+    for (x1, y1, x2, y2, w, _), v in zip(pairs, got):
+        assert v == O.pixels_calc_ssd(a, y1 * 70 + x1, b, y2 * 66 + x2, 70, 66, w)
+    z, m = np.zeros((64, 64), np.uint8), np.full((64, 64), 255, np.uint8)
+    assert api.pixels_calc_ssd_batch(z, m, [(0, 0, 0, 0, 64, 64)])[0] == 64 * 64 * 255 * 255
+
+
+def test_satd_any_size_quad_incl_quirk(api):
+    g = rng(5)
+    orig = g.integers(0, 256, (80, 100), dtype=np.uint8)
+    dims = [(w, h) for w in (4, 8, 12, 16, 24, 32, 64) for h in (4, 8, 12, 16, 24, 32, 64)]
+    preds = g.integers(0, 256, (len(dims) * 4, 64 * 64), dtype=np.uint8)
+    pairs = [(11, 3, 0, 0, w, h) for (w, h) in dims]
+    got = api.satd_any_size_quad_batch(preds, orig, pairs)
+    for i, (w, h) in enumerate(dims):
+        want = O.satd_any_size_quad(w, h, [preds[4 * i + k] for k in range(4)], 64, orig, 3 * 100 + 11, 100)
+        np.testing.assert_array_equal(got[i], want, err_msg="w=%d h=%d" % (w, h))
+
+
+def test_bipred_blend(api):
+    g = rng(12)
+    for (w, h) in ((8, 8), (16, 4), (64, 64), (5, 3)):
+        hp0 = g.integers(-3000, 20000, (3, h, w)).astype(np.int16)
+        hp1 = g.integers(-3000, 20000, (3, h, w)).astype(np.int16)
+        px0 = g.integers(0, 256, (3, h, w), dtype=np.uint8)
+        px1 = g.integers(0, 256, (3, h, w), dtype=np.uint8)
+        for hi0, s0 in ((1, hp0), (0, px0)):
+            for hi1, s1 in ((1, hp1), (0, px1)):
+                got = api.bipred_blend_batch(w, h, hi0, s0, hi1, s1)
+                for k in range(3):
+                    np.testing.assert_array_equal(got[k], O.bipred_blend_plane(w, h, hi0, s0[k], hi1, s1[k]))
+
+
+# ------------------------------------------------------------------ dct
+@pytest.mark.parametrize("kind,n", [("dct", 4), ("dct", 8), ("dct", 16), ("dct", 32), ("idct", 4), ("idct", 8),
+                                     ("idct", 16), ("idct", 32), ("dst", 4), ("idst", 4)])
+def test_transform(api, kind, n):
+    g = rng(20 + n)
+    for count in (1, 7, 64, 130):
+        res = g.integers(-255, 256, (count, n * n)).astype(np.int16)
+        np.testing.assert_array_equal(api.transform_batch(kind, n, res), O.transform_batch(kind, n, res))
+    full = g.integers(-32768, 32768, (40, n * n)).astype(np.int16)          # wrap (forward) / clip (inverse)
+    np.testing.assert_array_equal(api.transform_batch(kind, n, full), O.transform_batch(kind, n, full))
+    edge = np.array([[32767] * (n * n), [-32768] * (n * n),
+                     [32767 if (i + i // n) % 2 else -32768 for i in range(n * n)]], dtype=np.int16)
+    np.testing.assert_array_equal(api.transform_batch(kind, n, edge), O.transform_batch(kind, n, edge))
+
+
+def test_transform_reference_pattern(api):
+    """tests/dct_tests.c:55-175: radial gradient, expected = generic output (here: the oracle, pinned to generic)"""
+    src = dct_test_input()
+    for n in (4, 8, 16, 32):
+        x = src[:n * n][None]
+        for kind in ("dct", "idct") + (("dst", "idst") if n == 4 else ()):
+            np.testing.assert_array_equal(api.transform_batch(kind, n, x), O.transform_batch(kind, n, x))
+
+
+# ------------------------------------------------------------------ quant
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+@pytest.mark.parametrize("signhide", [0, 1])
+def test_quant(api, w, signhide):
+    g = rng(30 + w)
+    coef = g.integers(-2000, 2001, (70, w * w)).astype(np.int16)
+    coef[3] = g.integers(-32768, 32768, w * w)
+    coef[4] = 0
+    coef[5, ::7] = 1
+    for qp in (0, 22, 37, 51):
+        for type_ in ((0,) if w == 32 else (0, 2)):
+            for scan in (0, 1, 2):
+                for intra_slice in (0, 1):
+                    got = api.quant_batch(coef, w, qp, type_, scan, intra_slice, signhide)
+                    want = O.quant_batch(coef, w, qp, type_, scan, intra_slice, signhide)
+                    np.testing.assert_array_equal(got, want, err_msg="qp=%d type=%d scan=%d" % (qp, type_, scan))
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_dequant(api, w):
+    g = rng(40 + w)
+    q = g.integers(-300, 301, (33, w * w)).astype(np.int16)
+    q[2] = g.integers(-32768, 32768, w * w)
+    for qp in (0, 7, 22, 36, 51):
+        for type_ in ((0,) if w == 32 else (0, 2, 3)):
+            np.testing.assert_array_equal(api.dequant_batch(q, w, qp, type_), O.dequant_batch(q, w, qp, type_))
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_quant_dequant_scaling_tables(api, w):
+    """per-coefficient factor tables (the scaling-list path) with synthetic tables"""
+    g = rng(45 + w)
+    coef = g.integers(-3000, 3001, (9, w * w)).astype(np.int16)
+    qt = (g.integers(800, 30000, w * w)).astype(np.int32)
+    dt = (g.integers(16, 2000, w * w)).astype(np.int32)
+    for qp in (4, 22, 40, 51):
+        got = api.quant_batch(coef, w, qp, 0, 0, 0, 0, quant_coeff=qt)
+        want = O.quant_batch(coef, w, qp, 0, 0, 0, 0, quant_coeff=qt)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(api.dequant_batch(want, w, qp, 0, dequant_coeff=dt),
+                                      O.dequant_batch(want, w, qp, 0, dequant_coeff=dt))
+
+
+def test_coeff_abs_sum(api):
+    c, expected = coeff_sum_input()        # tests/coeff_sum_tests.c:29-43
+    assert api.coeff_abs_sum_batch(c, 64 * 64)[0] == expected
+    g = rng(3)
+    x = g.integers(-32768, 32768, (37, 256)).astype(np.int16)
+    got = api.coeff_abs_sum_batch(x, 256)
+    for i in range(37):
+        assert got[i] == O.coeff_abs_sum(x[i])
+
+
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_quantize_residual(api, w):
+    g = rng(50 + w)
+    ref_in = g.integers(0, 256, (70, w * w), dtype=np.uint8)
+    pred = np.clip(ref_in.astype(np.int32) + g.integers(-40, 41, ref_in.shape), 0, 255).astype(np.uint8)
+    pred[0] = ref_in[0]
+    pred[1] = 255 - ref_in[1]
+    for qp in (12, 22, 32, 45):
+        for color in ((0,) if w == 32 else (0, 1, 2)):
+            for intra in (0, 1):
+                for signhide in (0, 1):
+                    for trskip in ((0, 1) if w == 4 else (0,)):
+                        got = api.quantize_residual_batch(ref_in, pred, w, qp, color, 0, intra, intra, signhide, trskip)
+                        want = O.quantize_residual_batch(ref_in, pred, w, qp, color, 0, intra, intra, signhide, trskip)
+                        for a, b, nm in zip(got, want, ("rec", "coeff", "has")):
+                            np.testing.assert_array_equal(a, b, err_msg="%s qp=%d color=%d intra=%d sh=%d ts=%d" %
+                                                          (nm, qp, color, intra, signhide, trskip))
+    # rec_out aliasing pred_in (transform.c:398-399)
+    got = api.quantize_residual_batch(ref_in, pred, w, 27, 0, 0, 0, alias_rec=True)
+    want = O.quantize_residual_batch(ref_in, pred, w, 27, 0, 0, 0)
+    np.testing.assert_array_equal(got[0], want[0])
+
+
+# ------------------------------------------------------------------ ipol
+@pytest.mark.parametrize("kind", ["luma", "luma14", "chroma", "chroma14"])
+def test_sample_filters(api, kind):
+    g = rng(60)
+    frame = g.integers(0, 256, (96, 96), dtype=np.uint8)
+    frame[40:60, 40:60] = np.where(g.integers(0, 2, (20, 20)) > 0, 255, 0)
+    luma = kind.startswith("luma")
+    nfrac = 4 if luma else 8
+    sizes = ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 4)) if luma else \
+            ((4, 4), (8, 8), (16, 16), (32, 32), (8, 4), (2, 2))
+    blocks = [(12, 10, fx, fy, w, h) for (w, h) in sizes for fx in range(nfrac) for fy in range(nfrac)]
+    got = api.sample_batch(kind, frame, blocks)
+    for b, o in zip(blocks, got):
+        x, y, fx, fy, w, h = b
+        np.testing.assert_array_equal(o, O.sample(kind, frame, x, y, w, h, fx, fy), err_msg=str(b))
+
+
+def test_sample_filters_edge_replication(api):
+    """blocks whose filter window leaves the frame: kvz_get_extended_block semantics"""
+    g = rng(61)
+    frame = g.integers(0, 256, (40, 56), dtype=np.uint8)
+    pad = 80
+    padded = np.pad(frame, pad, mode="edge")
+    blocks = [(x, y, fx, fy, 16, 8) for (x, y) in ((-5, -3), (50, 36), (-20, 10), (30, -9), (56, 40), (0, 0))
+              for (fx, fy) in ((1, 2), (3, 3), (0, 1))]
+    got = api.sample_batch("luma", frame, blocks)
+    for b, o in zip(blocks, got):
+        x, y, fx, fy, w, h = b
+        np.testing.assert_array_equal(o, O.sample("luma", padded, x + pad, y + pad, w, h, fx, fy), err_msg=str(b))
+
+
+def test_search_frac(api):
+    g = rng(80)
+    ref = g.integers(0, 256, (72, 96), dtype=np.uint8)
+    pic = ((ref.astype(np.int32) + np.roll(ref, 1, axis=1)) // 2).astype(np.uint8)
+    pairs, meta = [], []
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 32)):
+        for (x, y) in ((0, 0), (32 - w // 2, 24 - h // 4), (96 - w, 72 - h)):
+            for (mvx, mvy) in ((0, 0), (-2, 1), (5, -3), (-40, -40), (90, 70)):
+                pairs.append((x, y, x + mvx, y + mvy, w, h))
+                meta.append((x, y, w, h, mvx, mvy))
+    costs, best = api.search_frac_batch(pic, ref, pairs)
+    for i, (x, y, w, h, mvx, mvy) in enumerate(meta):
+        oc, ob = O.search_frac_costs(pic, ref, x, y, w, h, mvx, mvy)
+        np.testing.assert_array_equal(costs[i], oc, err_msg=str(meta[i]))
+        assert tuple(best[i]) == ob, meta[i]
+
+
+def test_search_frac_extreme_pixels(api):
+    """0/255 checkerboards drive the int16 truncation paths of the filters"""
+    g = rng(81)
+    ref = np.where(g.integers(0, 2, (64, 64)) > 0, 255, 0).astype(np.uint8)
+    pic = np.where(g.integers(0, 2, (64, 64)) > 0, 255, 0).astype(np.uint8)
+    pairs = [(8, 8, 8 + dx, 8 + dy, 16, 16) for dx in (-1, 0, 2) for dy in (-2, 0, 1)]
+    costs, best = api.search_frac_batch(pic, ref, pairs)
+    for i, p in enumerate(pairs):
+        oc, ob = O.search_frac_costs(pic, ref, p[0], p[1], 16, 16, p[2] - p[0], p[3] - p[1])
+        np.testing.assert_array_equal(costs[i], oc)
+        assert tuple(best[i]) == ob

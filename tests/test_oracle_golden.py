@@ -1,0 +1,134 @@
+"""CPU: the oracle against (1) the known-answer values the reference's own unit
+tests hard-code and (2) the committed golden fixtures generated from the compiled
+reference's generic strategy (oracle/gen_golden.py).  Runs anywhere -- does not
+need /root/reference or oracle/_ref."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from patterns import (SAD_EDGE_KAT, SATD_GOLDEN_BW, SATD_GOLDEN_GRADIENT, REG_SAD_DIMS, coeff_sum_input,
+                      intra_sad_gradient, lcg_bytes, sad_test_frames, satd_test_bufs)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("log_w", [2, 3, 4, 5, 6])
+def test_satd_known_answers(log_w):
+    """tests/satd_tests.c:109,127,146"""
+    n = 1 << log_w
+    bw, ck, gr = satd_test_bufs(log_w)
+    for (x, y), want in ((bw, SATD_GOLDEN_BW[log_w]), (ck, SATD_GOLDEN_BW[log_w]), (gr, SATD_GOLDEN_GRADIENT[log_w])):
+        assert O.cost_nxn_batch("satd", n, x[None], y[None])[0] == want
+        assert O.cost_nxn_batch("satd", n, y[None], x[None])[0] == want
+
+
+@pytest.mark.parametrize("log_w", [2, 3, 4, 5, 6])
+def test_intra_sad_patterns(log_w):
+    """tests/intra_sad_tests.c:124-167"""
+    n = 1 << log_w
+    z, m = np.zeros(n * n, np.uint8), np.full(n * n, 255, np.uint8)
+    assert O.cost_nxn_batch("sad", n, z[None], m[None])[0] == 255 * n * n
+    ga, gb = intra_sad_gradient(n)
+    want = int(np.abs(ga.astype(np.int64) - gb.astype(np.int64)).sum())
+    assert O.cost_nxn_batch("sad", n, ga[None], gb[None])[0] == want == O.cost_nxn_batch("sad", n, gb[None], ga[None])[0]
+
+
+def test_image_calc_sad_known_answers():
+    """tests/sad_tests.c:121-259"""
+    pic, ref, _, _ = sad_test_frames()
+    for (x, y), want in SAD_EDGE_KAT.items():
+        assert O.image_calc("sad", pic, ref, 0, 0, x, y, 8, 8) == want, (x, y)
+
+
+def test_reg_sad_shapes_and_overflow():
+    """tests/sad_tests.c:261-320,369-376"""
+    _, _, big_pic, big_ref = sad_test_frames()
+    z, m = np.zeros((64, 64), np.uint8), np.full((64, 64), 255, np.uint8)
+    for (w, h) in REG_SAD_DIMS:
+        want = int(np.abs(big_pic[:h, :w].astype(np.int64) - big_ref[:h, :w].astype(np.int64)).sum())
+        assert O.reg_sad(big_pic, big_ref, 0, 0, w, h, 64, 64) == want
+        assert O.reg_sad(z, m, 0, 0, w, h, 64, 64) == 255 * w * h
+
+
+def test_coeff_abs_sum_known_answer():
+    c, expected = coeff_sum_input()
+    assert O.coeff_abs_sum(c) == expected
+
+
+def test_lcg_bytes_is_stable():
+    assert lcg_bytes(8).tolist() == [(((1664525 * 12345 + 1013904223) & 0xFFFFFFFF) >> 8) & 0xFF] + lcg_bytes(8).tolist()[1:]
+
+
+def test_scan_tables_match_structure():
+    for scan in (0, 1, 2):
+        for log2 in (2, 3, 4, 5):
+            s = O.scan_order(scan, log2)
+            assert sorted(s.tolist()) == list(range(1 << (2 * log2)))      # a permutation
+    assert O.scan_order(0, 2).tolist() == [0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15]
+    assert O.scan_order(0, 3).tolist()[:20] == [0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 25, 18, 11, 26, 19, 27, 32, 40, 33, 48]
+    assert O.scan_order(2, 3).tolist()[:8] == [0, 8, 16, 24, 1, 9, 17, 25]
+
+
+# ---------------------------------------------------------------- golden fixtures
+def test_golden_picture():
+    d = gold("picture.npz")
+    for n in (4, 8, 16, 32, 64):
+        a, b = d["a%d" % n], d["b%d" % n]
+        np.testing.assert_array_equal(O.cost_nxn_batch("sad", n, a, b), d["sad%d" % n])
+        np.testing.assert_array_equal(O.cost_nxn_batch("satd", n, a, b), d["satd%d" % n])
+        if n <= 32:
+            np.testing.assert_array_equal(O.cost_nxn_dual_batch("sad", n, d["dual_preds%d" % n], a[:8]), d["sad_dual%d" % n])
+            np.testing.assert_array_equal(O.cost_nxn_dual_batch("satd", n, d["dual_preds%d" % n], a[:8]), d["satd_dual%d" % n])
+    pic, ref = d["frame_pic"], d["frame_ref"]
+    for p, s, t in zip(d["pairs"], d["image_sad"], d["image_satd"]):
+        assert O.image_calc("sad", pic, ref, *[int(v) for v in p]) == s
+        assert O.image_calc("satd", pic, ref, *[int(v) for v in p]) == t
+    for (w, h), c in zip(d["quad_dims"], d["quad_costs"]):
+        np.testing.assert_array_equal(O.satd_any_size_quad(int(w), int(h), list(d["quad_preds"]), 64, pic, 0, 64), c)
+    for w, v in zip((4, 8, 16, 32), d["ssd"]):
+        assert O.pixels_calc_ssd(pic, 0, ref, 0, 64, 64, w) == v
+
+
+def test_golden_dct():
+    d = gold("dct.npz")
+    for n in (4, 8, 16, 32):
+        for kind in ("dct", "idct") + (("dst", "idst") if n == 4 else ()):
+            np.testing.assert_array_equal(O.transform_batch(kind, n, d["in%d" % n]), d["%s%d" % (kind, n)])
+
+
+def test_golden_quant():
+    d = gold("quant.npz")
+    for w in (4, 8, 16, 32):
+        coef = d["coef%d" % w]
+        for qp in (22, 37):
+            for sh in (0, 1):
+                np.testing.assert_array_equal(O.quant_batch(coef, w, qp, 0, 0, 1, sh), d["quant%d_qp%d_sh%d" % (w, qp, sh)])
+            np.testing.assert_array_equal(O.dequant_batch(d["quant%d_qp%d_sh0" % (w, qp)], w, qp, 0), d["dequant%d_qp%d" % (w, qp)])
+        for intra in (0, 1):
+            rec, co, has = O.quantize_residual_batch(d["qr_ref%d" % w], d["qr_pred%d" % w], w, 22, 0, 0, intra, intra)
+            np.testing.assert_array_equal(rec, d["qr_rec%d_i%d" % (w, intra)])
+            np.testing.assert_array_equal(co, d["qr_coeff%d_i%d" % (w, intra)])
+            np.testing.assert_array_equal(has, d["qr_has%d_i%d" % (w, intra)])
+
+
+def test_golden_ipol():
+    d = gold("ipol.npz")
+    frame, pic = d["frame"], d["pic"]
+    for kind, blocks in (("luma", d["luma_blocks"]), ("luma14", d["luma_blocks"]),
+                         ("chroma", d["chroma_blocks"]), ("chroma14", d["chroma_blocks"])):
+        got = np.concatenate([O.sample(kind, frame, int(b[0]), int(b[1]), int(b[4]), int(b[5]), int(b[2]), int(b[3])).ravel()
+                              for b in blocks])
+        np.testing.assert_array_equal(got, d[kind])
+    for c, costs, best in zip(d["sf_cases"], d["sf_costs"], d["sf_best"]):
+        oc, ob = O.search_frac_costs(pic, frame, *[int(v) for v in c])
+        np.testing.assert_array_equal(oc, costs)
+        assert ob == tuple(int(v) for v in best)
+    for i, (ox, oy) in enumerate(((0, 0), (-1, 1), (1, -1))):
+        got = O.filter_frac_steps(frame, 20, 18, 16, 16, (ox, oy))[:, :, :16, :16]
+        np.testing.assert_array_equal(got, d["filter_steps"][i])
