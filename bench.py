@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- kernel-level throughput of the block-kernel hot path on MI355X.
+
+Metric (BASELINE.json): Mblocks/s (SAD8 / SATD8 / DCT32) per GPU.
+Workload (BASELINE.json configs[1] + the DCT32 of the headline metric): the
+1080p CTU grid -- per frame 32 400 8x8 luma block pairs for sad_8x8 and for
+satd_8x8 and 1 980 full 32x32 residual blocks for dct_32x32 -- batched over
+FRAMES frames per launch so that every operand array (>= 0.5 GB) is larger than
+the 256 MiB Infinity Cache: the kernels stream from HBM.
+
+A "step" = one pass of the hot path over one batch: one launch each of
+kvz_hip_sad_nxn_batch(8), kvz_hip_satd_nxn_batch(8), kvz_hip_transform_batch(DCT,32)
+through the C ABI, inputs resident in HBM.  `value` = all blocks processed by all
+ranks / wall time (barrier + device sync on both sides, max over ranks).
+
+Multi-GPU: blocks are independent, so each rank owns its own batch (CTU-row
+shards of different frames) and there is no data-path collective: "scaling":
+"weak".  Launch: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BLK8_PER_FRAME = 32400          # (1920/8) * (1080/8)
+BLK32_PER_FRAME = 1980          # (1920/32) * floor(1080/32)
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy ceiling
+BYTES = {"sad_8x8": 132, "satd_8x8": 132, "dct_32x32": 4096}   # SURVEY 8(d) algorithmic bytes per block
+
+
+def cpu_baseline(budget_s=3.0):
+    """The reference's best SIMD strategy (avx2) -- or our scalar port if the compiled
+    reference is absent -- timed on this host's cores on a bounded sample of the same
+    workload: 4 frames (129 600 8x8 pairs = 16.6 MB, 7 920 32x32 blocks = 32 MB in+out),
+    larger than L2 so the CPU also streams.  One harness thread per core."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    frames = 4
+    n8, n32 = BLK8_PER_FRAME * frames, BLK32_PER_FRAME * frames
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    g = np.random.default_rng(12345)
+    rates, kind, strategy = {}, None, None
+    import ref_lib as R
+    if R.available():
+        L = R.lib()
+        kind = "reference"
+        strategy = "avx2" if R.has_strategy("satd_8x8", "avx2") else "generic"
+
+        def run_threads(fn):
+            out = [0.0] * cores
+            def work(i):
+                out[i] = fn(i)
+            ts = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+            [t.start() for t in ts]; [t.join() for t in ts]
+            return out
+
+        bufs = []
+        for i in range(cores):
+            a = R._aligned(g.integers(0, 256, n8 * 64, dtype=np.uint8))
+            b = R._aligned(np.clip(a.astype(np.int16) + g.integers(-8, 9, a.shape), 0, 255).astype(np.uint8))
+            x = R._aligned(g.integers(-255, 256, n32 * 1024).astype(np.int16))
+            y = R._aligned(np.zeros(n32 * 1024, np.int16))
+            bufs.append((a, b, x, y))
+        u8p, i16p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16)
+        for name, t in (("sad_8x8", b"sad_8x8"), ("satd_8x8", b"satd_8x8")):
+            r = run_threads(lambda i: L.ref_bench_cost_nxn(t, strategy.encode(), 8, bufs[i][0].ctypes.data_as(u8p),
+                                                           bufs[i][1].ctypes.data_as(u8p), n8, budget_s, None))
+            rates[name] = (sum(r), r[0])
+        r = run_threads(lambda i: L.ref_bench_transform(b"dct_32x32", strategy.encode(), 32, bufs[i][2].ctypes.data_as(i16p),
+                                                        bufs[i][3].ctypes.data_as(i16p), n32, budget_s))
+        rates["dct_32x32"] = (sum(r), r[0])
+    else:
+        import oracle_lib as O
+        kind, strategy, cores = "port", "oracle (scalar C restatement of generic)", 1
+        a = g.integers(0, 256, (20000, 64), dtype=np.uint8)
+        b = g.integers(0, 256, (20000, 64), dtype=np.uint8)
+        for name, k in (("sad_8x8", "sad"), ("satd_8x8", "satd")):
+            t0 = time.time(); O.cost_nxn_batch(k, 8, a, b); dt = time.time() - t0
+            rates[name] = (20000 / dt, 20000 / dt)
+        x = g.integers(-255, 256, (2000, 1024)).astype(np.int16)
+        t0 = time.time(); O.transform_batch("dct", 32, x); dt = time.time() - t0
+        rates["dct_32x32"] = (2000 / dt, 2000 / dt)
+    # the same block mix as one GPU step: time per frame at the measured per-function rates
+    def mix(idx):
+        t = BLK8_PER_FRAME / rates["sad_8x8"][idx] + BLK8_PER_FRAME / rates["satd_8x8"][idx] + BLK32_PER_FRAME / rates["dct_32x32"][idx]
+        return (2 * BLK8_PER_FRAME + BLK32_PER_FRAME) / t / 1e6
+    return {
+        "value": round(mix(0), 3), "unit": "Mblocks/s", "cores": cores, "kind": kind,
+        "sample": "%s strategy, %d thread(s), each %.0f s per function over 4 frames of the 1080p grid "
+                  "(129600 8x8 pairs, 7920 32x32 blocks; streaming working set); value = same SAD8+SATD8+DCT32 block mix as a GPU step"
+                  % (strategy, cores, budget_s),
+        "per_thread_value_under_load": round(mix(1), 3),
+        "per_function_Mblocks_s": {k: round(v[0] / 1e6, 3) for k, v in rates.items()},
+        "per_function_Mblocks_s_one_thread_under_load": {k: round(v[1] / 1e6, 3) for k, v in rates.items()},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=128, help="1080p frames per batch (per GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: kvazaar_amd has no CPU path")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from kvazaar_amd import _lib
+    L = _lib.init(local_rank)
+
+    F = args.frames
+    n8, n32 = BLK8_PER_FRAME * F, BLK32_PER_FRAME * F
+    gen = torch.Generator(device=dev); gen.manual_seed(12345 + rank)
+    cur = torch.randint(0, 256, (n8, 64), dtype=torch.uint8, device=dev, generator=gen)
+    noise = torch.randint(-8, 9, (n8, 64), dtype=torch.int16, device=dev, generator=gen)
+    ref = (cur.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+    del noise
+    res = torch.randint(-255, 256, (n32, 1024), dtype=torch.int16, device=dev, generator=gen)
+    sad = torch.empty(n8, dtype=torch.int32, device=dev)
+    satd = torch.empty(n8, dtype=torch.int32, device=dev)
+    coef = torch.empty_like(res)
+    torch.cuda.synchronize()
+
+    stream = L.kvz_hip_stream_create()
+    evs = [[L.kvz_hip_event_create() for _ in range(4)] for _ in range(args.steps)]
+
+    def step(ev=None):
+        if ev: L.kvz_hip_event_record(ev[0], stream)
+        _lib.check(L.kvz_hip_sad_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, sad.data_ptr(), stream), "sad_8x8")
+        if ev: L.kvz_hip_event_record(ev[1], stream)
+        _lib.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd.data_ptr(), stream), "satd_8x8")
+        if ev: L.kvz_hip_event_record(ev[2], stream)
+        _lib.check(L.kvz_hip_transform_batch(0, 32, res.data_ptr(), coef.data_ptr(), n32, stream), "dct_32x32")
+        if ev: L.kvz_hip_event_record(ev[3], stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel device time from the HIP events recorded inside the timed region
+    ms = {"sad_8x8": 0.0, "satd_8x8": 0.0, "dct_32x32": 0.0}
+    f = C.c_float()
+    for ev in evs:
+        for i, name in enumerate(("sad_8x8", "satd_8x8", "dct_32x32")):
+            _lib.check(L.kvz_hip_event_elapsed_ms(ev[i], ev[i + 1], C.byref(f)), "event_elapsed")
+            ms[name] += f.value
+    avg_ms = {k: v / args.steps for k, v in ms.items()}
+    blocks = {"sad_8x8": n8, "satd_8x8": n8, "dct_32x32": n32}
+
+    # light integrity property at full size (parity proper lives in tests/): SAD of a block with itself is 0,
+    # SATD >= SAD/.. is not generally true, so check idempotence: a second launch gives identical costs
+    satd2 = torch.empty_like(satd)
+    _lib.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd2.data_ptr(), stream), "satd_8x8")
+    L.kvz_hip_stream_sync(stream)
+    torch.cuda.synchronize()
+    assert bool((satd2 == satd).all()), "non-deterministic satd"
+
+    if rank == 0:
+        total_blocks = (2 * n8 + n32) * world * args.steps
+        kern = {}
+        for name in ms:
+            gbs = BYTES[name] * blocks[name] / (avg_ms[name] * 1e-3) / 1e9
+            kern[name] = {"Mblocks_s": round(blocks[name] / (avg_ms[name] * 1e-3) / 1e6, 1), "avg_launch_ms": round(avg_ms[name], 5),
+                          "blocks_per_launch": blocks[name], "algorithmic_bytes_per_block": BYTES[name],
+                          "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        dom = max(ms, key=lambda k: ms[k])
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from a separate rocprofv3 --pmc pass
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mblocks/s (SAD8/SATD8/DCT32) per GPU",
+            "value": round(total_blocks / dt / 1e6, 1),
+            "unit": "Mblocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1080p CTU grid x %d frames per launch per GPU: sad_8x8 + satd_8x8 on %d 8x8 block pairs, "
+                                   "dct_32x32 on %d int16 residual blocks, via the kvz_hip C ABI (batched 'hip' strategy entries)"
+                                   % (F, n8, n32),
+                       "frames_per_batch": F, "parallelism": "independent batches per GPU, no data-path collective"},
+            "kernels": kern,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

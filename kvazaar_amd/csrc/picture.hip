@@ -11,6 +11,21 @@
 using namespace kvzhip;
 
 typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Streaming (read-once) loads: the nontemporal policy keeps once-read bytes from
+// displacing useful lines; measured +4..10 % HBM read rate on MI355X (tools/bw_probe.hip).
+__device__ __forceinline__ uint4 ld_stream16(const u8 *p)
+{
+  u32x4 v = __builtin_nontemporal_load((const u32x4 *)p);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 ld_stream8(const u8 *p)
+{
+  u32x2 v = __builtin_nontemporal_load((const u32x2 *)p);
+  return make_uint2(v.x, v.y);
+}
 
 __device__ __forceinline__ u32 sad_dword(u32 a, u32 b, u32 acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
 __device__ __forceinline__ u32 sad16(uint4 a, uint4 b)
@@ -45,22 +60,36 @@ __global__ __launch_bounds__(256) void sad_nxn_kernel(const u8 *__restrict__ a, 
 
   for (size_t base = wave * CH; base < total_chunks; base += nwaves * CH) {
     u32 s[U];
+    // wave-uniform: a full tile issues all 2*U loads back to back (no per-load
+    // bounds branch, so nothing forces an early s_waitcnt); only the last,
+    // ragged tile takes the guarded path.
+    const bool full = base + CH <= total_chunks;
+    uint4 x[U], y[U];
+    if (full && !DUAL) {
+      const u8 *pa = a + (base + lane) * 16, *pb = b + (base + lane) * 16;
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = ld_stream16(pa + u * 1024);
+#pragma unroll
+      for (int u = 0; u < U; ++u) y[u] = ld_stream16(pb + u * 1024);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t c = base + (size_t)u * 64 + lane;
+        const size_t cc = c < total_chunks ? c : total_chunks - 1;
+        if (DUAL) {
+          const size_t blk = cc / L, within = cc % L;      // blk = 2*item + k
+          x[u] = ld_stream16(a + (blk >> 1) * item_stride + (blk & 1) * pred_stride + within * 16);
+          y[u] = ld_stream16(b + (blk >> 1) * (size_t)(N * N) + within * 16);
+        } else {
+          x[u] = ld_stream16(a + cc * 16);
+          y[u] = ld_stream16(b + cc * 16);
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t c = base + (size_t)u * 64 + lane;
-      s[u] = 0;
-      if (c < total_chunks) {
-        uint4 x, y;
-        if (DUAL) {
-          const size_t blk = c / L, within = c % L;      // blk = 2*item + k
-          x = *(const uint4 *)(a + (blk >> 1) * item_stride + (blk & 1) * pred_stride + within * 16);
-          y = *(const uint4 *)(b + (blk >> 1) * (size_t)(N * N) + within * 16);
-        } else {
-          x = *(const uint4 *)(a + c * 16);
-          y = *(const uint4 *)(b + c * 16);
-        }
-        s[u] = sad16(x, y);
-      }
+      s[u] = (full || c < total_chunks) ? sad16(x[u], y[u]) : 0u;
     }
     if (L == 1) {                                // N == 4: every chunk is a whole block
 #pragma unroll
@@ -189,40 +218,133 @@ __global__ __launch_bounds__(256) void satd_nxn_kernel(const u8 *__restrict__ a,
   const size_t total = count * SB;
   const size_t total_up = (total + 63) & ~(size_t)63;     // keep whole waves in the loop (DPP)
   for (size_t i = tid; i < total_up; i += nthreads) {
-    u32 v = 0;
     const bool valid = i < total;
-    const size_t blk = i / SB;
-    const int sidx = (int)(i % SB), sy = sidx / W8, sx = sidx % W8;
-    if (valid) {
-      const u8 *pa, *pb;
-      if (DUAL) {
-        pa = a + (blk >> 1) * item_stride + (blk & 1) * pred_stride;
-        pb = b + (blk >> 1) * (size_t)(N * N);
-      } else {
-        pa = a + blk * (size_t)(N * N);
-        pb = b + blk * (size_t)(N * N);
-      }
-      pa += (size_t)(sy * 8) * N + sx * 8;
-      pb += (size_t)(sy * 8) * N + sx * 8;
-      u32 ra[16], rb[16];
-      if (N == 8) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          uint4 t = ((const uint4 *)pa)[k], w = ((const uint4 *)pb)[k];
-          ra[4 * k] = t.x; ra[4 * k + 1] = t.y; ra[4 * k + 2] = t.z; ra[4 * k + 3] = t.w;
-          rb[4 * k] = w.x; rb[4 * k + 1] = w.y; rb[4 * k + 2] = w.z; rb[4 * k + 3] = w.w;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          uint2 t = *(const uint2 *)(pa + (size_t)r * N), w = *(const uint2 *)(pb + (size_t)r * N);
-          ra[2 * r] = t.x; ra[2 * r + 1] = t.y; rb[2 * r] = w.x; rb[2 * r + 1] = w.y;
-        }
-      }
-      v = satd8x8_regs(ra, rb);
+    const size_t ii = valid ? i : total - 1;              // tail lanes re-read the last sub-block (result discarded)
+    const size_t blk = ii / SB;
+    const int sidx = (int)(ii % SB), sy = sidx / W8, sx = sidx % W8;
+    const u8 *pa, *pb;
+    if (DUAL) {
+      pa = a + (blk >> 1) * item_stride + (blk & 1) * pred_stride;
+      pb = b + (blk >> 1) * (size_t)(N * N);
+    } else {
+      pa = a + blk * (size_t)(N * N);
+      pb = b + blk * (size_t)(N * N);
     }
+    pa += (size_t)(sy * 8) * N + sx * 8;
+    pb += (size_t)(sy * 8) * N + sx * 8;
+    u32 ra[16], rb[16];
+    if (N == 8) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint4 t = *(const uint4 *)(pa + 16 * k), w = *(const uint4 *)(pb + 16 * k);
+        ra[4 * k] = t.x; ra[4 * k + 1] = t.y; ra[4 * k + 2] = t.z; ra[4 * k + 3] = t.w;
+        rb[4 * k] = w.x; rb[4 * k + 1] = w.y; rb[4 * k + 2] = w.z; rb[4 * k + 3] = w.w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint2 t = *(const uint2 *)(pa + (size_t)r * N), w = *(const uint2 *)(pb + (size_t)r * N);
+        ra[2 * r] = t.x; ra[2 * r + 1] = t.y; rb[2 * r] = w.x; rb[2 * r + 1] = w.y;
+      }
+    }
+    u32 v = satd8x8_regs(ra, rb);
+    if (!valid) v = 0;
     v = group_sum<SB>(v);
     if (valid && sidx == 0) costs[blk] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// satd_8x8 over contiguous block pairs, the headline kernel: same fully coalesced
+// streaming as sad_nxn_kernel (lane = one 16-byte chunk = rows 2p, 2p+1 of a block,
+// 4 lanes per block, U chunks per array in flight per lane).  The Hadamard runs
+// on packed int16: horizontal stages and the row-pair stage in registers, the
+// two remaining vertical stages across the quad with DPP quad_perm moves.  A lane
+// whose stage bit is set computes (partner - own) instead of (own - partner):
+// the sign of a whole coefficient never matters under the absolute sum.
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ v2s dpp_v2s(v2s v)
+{
+  return as_v2s((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(v), CTRL, 0xF, 0xF, true));
+}
+
+// x, y: the lane's 16-byte chunk of each block (rows 2p and 2p+1).  Returns the
+// lane's share of m = sum max(|a|,|b|); the block's SATD is (sum over the quad + 1) >> 1.
+__device__ __forceinline__ u32 satd8_quad_part(uint4 x, uint4 y, v2s m1, v2s m2)
+{
+  v2s d[2][4];
+  d[0][0] = unpack_lo(x.x) - unpack_lo(y.x); d[0][1] = unpack_hi(x.x) - unpack_hi(y.x);
+  d[0][2] = unpack_lo(x.y) - unpack_lo(y.y); d[0][3] = unpack_hi(x.y) - unpack_hi(y.y);
+  d[1][0] = unpack_lo(x.z) - unpack_lo(y.z); d[1][1] = unpack_hi(x.z) - unpack_hi(y.z);
+  d[1][2] = unpack_lo(x.w) - unpack_lo(y.w); d[1][3] = unpack_hi(x.w) - unpack_hi(y.w);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {          // column bits 2 and 1
+    v2s s0 = d[j][0] + d[j][2], s1 = d[j][1] + d[j][3], e0 = d[j][0] - d[j][2], e1 = d[j][1] - d[j][3];
+    d[j][0] = s0 + s1; d[j][1] = s0 - s1; d[j][2] = e0 + e1; d[j][3] = e0 - e1;
+  }
+  v2s w[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { w[q] = d[0][q] + d[1][q]; w[q + 4] = d[0][q] - d[1][q]; }   // row bit 0
+  u32 m = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v2s t = dpp_v2s<0xB1>(w[i]);         // quad_perm [1,0,3,2]: row bit 1
+    v2s u = w[i] * m1 + t;
+    t = dpp_v2s<0x4E>(u);                // quad_perm [2,3,0,1]: row bit 2
+    u = u * m2 + t;
+    m += absmax_halves(u);               // column bit 0 folded into the absolute sum
+  }
+  return m;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void satd8_kernel(const u8 *__restrict__ a, const u8 *__restrict__ b,
+                                                    u32 *__restrict__ costs, size_t count)
+{
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  const size_t total_chunks = count * 4;
+  constexpr size_t CH = (size_t)64 * U;
+  const short sg1 = (lane & 1) ? (short)-1 : (short)1, sg2 = (lane & 2) ? (short)-1 : (short)1;
+  const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 };
+
+  for (size_t base = wave * CH; base < total_chunks; base += nwaves * CH) {
+    const bool full = base + CH <= total_chunks;      // wave-uniform
+    uint4 x[U], y[U];
+    if (full) {
+      const u8 *pa = a + (base + lane) * 16, *pb = b + (base + lane) * 16;
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = ld_stream16(pa + u * 1024);
+#pragma unroll
+      for (int u = 0; u < U; ++u) y[u] = ld_stream16(pb + u * 1024);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t c = base + (size_t)u * 64 + lane;
+        const size_t cc = c < total_chunks ? c : total_chunks - 1;   // whole quads are in or out: count*4 chunks
+        x[u] = ld_stream16(a + cc * 16);
+        y[u] = ld_stream16(b + cc * 16);
+      }
+    }
+    u32 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      u32 m = satd8_quad_part(x[u], y[u], m1, m2);
+      m += dpp_mov<0xB1>(m);
+      m += dpp_mov<0x4E>(m);
+      r[u] = (m + 1) >> 1;
+    }
+    // lane (g = lane >> 2, p = lane & 3) stores result p of quad g: one coalesced 256-byte store per wave
+    const int g = lane >> 2, p = lane & 3;
+    if (p < U) {
+      u32 v = r[0];
+#pragma unroll
+      for (int i = 1; i < U; ++i) v = (p == i) ? r[i] : v;
+      const size_t blk = (base + (size_t)p * 64) / 4 + g;
+      if (blk < count) costs[blk] = v;
+    }
   }
 }
 
@@ -498,7 +620,10 @@ static int launch_satd(int n, const u8 *a, const u8 *b, size_t count, u32 *costs
   const unsigned threads = 256;
   switch (n) {
     case 4: hipLaunchKernelGGL((satd_4x4_kernel<DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
-    case 8: hipLaunchKernelGGL((satd_nxn_kernel<8, DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    case 8:
+      if (!DUAL) hipLaunchKernelGGL((satd8_kernel<4>), dim3(stream_grid(count * 4, threads * 4)), dim3(threads), 0, st, a, b, costs, count);
+      else hipLaunchKernelGGL((satd_nxn_kernel<8, DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is);
+      break;
     case 16: hipLaunchKernelGGL((satd_nxn_kernel<16, DUAL>), dim3(stream_grid(count * 4, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
     case 32: hipLaunchKernelGGL((satd_nxn_kernel<32, DUAL>), dim3(stream_grid(count * 16, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
     case 64: hipLaunchKernelGGL((satd_nxn_kernel<64, DUAL>), dim3(stream_grid(count * 64, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
