@@ -63,6 +63,11 @@ KVZ_HIP_API int kvz_hip_device_count(void);
 KVZ_HIP_API const char *kvz_hip_last_error(void);
 KVZ_HIP_API const char *kvz_hip_device_name(void);
 
+/* Launch-geometry knobs for tuning runs (tools/tune.py); value < 0 restores the
+ * built-in default.  Keys: "sad_wgs_per_cu", "satd8_wgs_per_cu", "dct32_wgs_per_cu",
+ * "idct32_wgs_per_cu", "dct_wgs_per_cu".  Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID. */
+KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);
+
 /* Thin device-memory helpers so a C host needs no HIP headers. */
 KVZ_HIP_API void *kvz_hip_malloc(size_t bytes);
 KVZ_HIP_API void kvz_hip_free(void *dptr);

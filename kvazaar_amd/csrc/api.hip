@@ -18,6 +18,15 @@ static hipStream_t g_stream = nullptr;
 static char g_err[512] = "";
 static char g_name[256] = "";
 
+struct tune_entry { const char *key; int value; };
+static tune_entry g_tune[] = { { "sad_wgs_per_cu", -1 }, { "satd8_wgs_per_cu", -1 }, { "dct32_wgs_per_cu", -1 },
+                               { "idct32_wgs_per_cu", -1 }, { "dct_wgs_per_cu", -1 } };
+int tuning(const char *key, int dflt)
+{
+  for (auto &e : g_tune) if (!std::strcmp(e.key, key)) return e.value >= 0 ? e.value : dflt;
+  return dflt;
+}
+
 bool ctx_ready() { return g_ready.load(std::memory_order_acquire); }
 hipStream_t ctx_stream(kvz_hip_stream s) { return s ? (hipStream_t)s : g_stream; }
 int num_cus() { return g_num_cus; }
@@ -39,6 +48,13 @@ using namespace kvzhip;
   } while (0)
 
 extern "C" {
+
+int kvz_hip_set_tuning(const char *key, int value)
+{
+  if (!key) return KVZ_HIP_ERR_INVALID;
+  for (auto &e : g_tune) if (!std::strcmp(e.key, key)) { e.value = value; return KVZ_HIP_OK; }
+  return KVZ_HIP_ERR_INVALID;
+}
 
 int kvz_hip_device_count(void)
 {

@@ -11,6 +11,8 @@
 #include "kvz_hip_internal.h"
 #include "transform_core.h"
 
+#include <cstdlib>
+
 using namespace kvzhip;
 
 template <int N, int KIND>
@@ -56,11 +58,20 @@ __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ 
   }
 }
 
+namespace kvzhip { int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipStream_t st); }
+
+// KVZ_HIP_DCT32_VALU=1 selects the VALU/LDS butterfly kernel for 32x32 (A/B comparison only)
+static bool dct32_use_valu()
+{
+  static const bool v = [] { const char *e = getenv("KVZ_HIP_DCT32_VALU"); return e && e[0] == '1'; }();
+  return v;
+}
+
 template <int N, int KIND>
 static int launch_transform(const i16 *in, i16 *out, size_t count, hipStream_t st)
 {
   constexpr int TPB = 256 / N;
-  const unsigned grid = stream_grid(count, TPB, 16);
+  const unsigned grid = stream_grid(count, TPB, (unsigned)tuning("dct_wgs_per_cu", 16));
   hipLaunchKernelGGL((transform_kernel<N, KIND>), dim3(grid), dim3(256), 0, st, in, out, count);
   KVZ_CHECK_LAUNCH("transform_kernel");
   return KVZ_HIP_OK;
@@ -78,7 +89,7 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
         case 4: return launch_transform<4, 0>(in, out, count, st);
         case 8: return launch_transform<8, 0>(in, out, count, st);
         case 16: return launch_transform<16, 0>(in, out, count, st);
-        case 32: return launch_transform<32, 0>(in, out, count, st);
+        case 32: return dct32_use_valu() ? launch_transform<32, 0>(in, out, count, st) : launch_dct32_mfma(false, in, out, count, st);
       }
       break;
     case KVZ_HIP_IDCT:
@@ -86,7 +97,7 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
         case 4: return launch_transform<4, 1>(in, out, count, st);
         case 8: return launch_transform<8, 1>(in, out, count, st);
         case 16: return launch_transform<16, 1>(in, out, count, st);
-        case 32: return launch_transform<32, 1>(in, out, count, st);
+        case 32: return dct32_use_valu() ? launch_transform<32, 1>(in, out, count, st) : launch_dct32_mfma(true, in, out, count, st);
       }
       break;
     case KVZ_HIP_DST:

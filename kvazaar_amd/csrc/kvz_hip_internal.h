@@ -21,6 +21,7 @@ hipStream_t ctx_stream(kvz_hip_stream s);      // NULL -> library default stream
 void set_error(const char *what, hipError_t e);
 void set_error_msg(const char *what);
 int num_cus();
+int tuning(const char *key, int dflt);     // kvz_hip_set_tuning override or dflt
 
 #define KVZ_CHECK_CTX()                         \
   do {                                          \

@@ -1,0 +1,47 @@
+"""Multi-GPU partition of the hot path: blocks are independent, so a
+frame (or a batch of frames) is cut into contiguous CTU-row shards, one per rank,
+and there is no collective on the data path -- costs / coefficients stay on the
+rank that produced them.  The helpers here are pure host logic (no GPU), shared by
+bench.py and the gloo tests."""
+
+CTU = 64   # LCU_WIDTH, src/global.h:137
+
+
+def ctu_rows(frame_height, ctu=CTU):
+    return (frame_height + ctu - 1) // ctu
+
+
+def row_range(n_rows, world, rank):
+    """contiguous [lo, hi) of CTU rows owned by `rank`; the first n_rows % world ranks get one extra row"""
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pixel_rows(frame_height, world, rank, ctu=CTU):
+    lo, hi = row_range(ctu_rows(frame_height, ctu), world, rank)
+    return lo * ctu, min(hi * ctu, frame_height)
+
+
+def halo_rows(frame_height, world, rank, margin, ctu=CTU):
+    """pixel rows of the REFERENCE frame a rank needs for motion search: its own rows +- margin
+    (one CTU row + filter taps + deblock/SAO delay: SURVEY 8e), clipped to the frame"""
+    lo, hi = pixel_rows(frame_height, world, rank, ctu)
+    return max(0, lo - margin), min(frame_height, hi + margin)
+
+
+def blocks_in_rows(frame_width, y_lo, y_hi, n):
+    """number of full n x n blocks whose top-left lies in pixel rows [y_lo, y_hi) on the n-grid"""
+    first = (y_lo + n - 1) // n
+    last = y_hi // n
+    return max(0, last - first) * (frame_width // n)
+
+
+def max_over_ranks(dt, dist=None, device=None):
+    """bench contract: the reported time is the MAX over ranks"""
+    if dist is None or not dist.is_initialized():
+        return dt
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

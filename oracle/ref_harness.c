@@ -308,3 +308,45 @@ double ref_bench_reg_sad(const char *name, const kvz_pixel *a, const kvz_pixel *
   if (checksum) *checksum = acc;
   return (double)done / (t1 - t0);
 }
+
+/* ------------------------------------------------------------------------
+ * Integration check of the drop-in boundary: load libkvzhip.so and let it
+ * register its "hip" strategies into THIS process's reference registry through
+ * the reference's own kvz_strategyselector_register -- exactly what the patched
+ * strategies-*.c of INTEGRATION.md do.  The accessors below are the glue a
+ * Kvazaar maintainer compiles inside the encoder (they need encoderstate.h).
+ * ------------------------------------------------------------------------ */
+#include <dlfcn.h>
+#include "../include/kvz_hip.h"
+
+static int acc_qp(const void *s) { return ((const encoder_state_t *)s)->qp; }
+static int acc_slice_is_intra(const void *s) { return ((const encoder_state_t *)s)->frame->slicetype == KVZ_SLICE_I; }
+static int acc_signhide(const void *s) { return ((const encoder_state_t *)s)->encoder_control->cfg.signhide_enable; }
+static int acc_sl_enable(const void *s) { return ((const encoder_state_t *)s)->encoder_control->scaling_list.enable; }
+static const int32_t *acc_quant_coeff(const void *s, int log2_tr, int list, int rem)
+{ return ((const encoder_state_t *)s)->encoder_control->scaling_list.quant_coeff[log2_tr - 2][list][rem]; }
+static const int32_t *acc_dequant_coeff(const void *s, int log2_tr, int list, int rem)
+{ return ((const encoder_state_t *)s)->encoder_control->scaling_list.de_quant_coeff[log2_tr - 2][list][rem]; }
+static int acc_rdoq(const void *s) { return ((const encoder_state_t *)s)->encoder_control->cfg.rdoq_enable; }
+static int acc_cu_is_intra(const void *cu) { return ((const cu_info_t *)cu)->type == CU_INTRA; }
+
+/* returns the number of strategies the hip library registered, or -1 */
+int ref_register_hip(const char *lib_path)
+{
+  void *h = dlopen(lib_path, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { fprintf(stderr, "dlopen %s: %s\n", lib_path, dlerror()); return -1; }
+  void (*set_reg)(kvz_hip_register_fn) = (void (*)(kvz_hip_register_fn))dlsym(h, "kvz_hip_set_registrar");
+  void (*set_acc)(const kvz_hip_state_accessors *) = (void (*)(const kvz_hip_state_accessors *))dlsym(h, "kvz_hip_set_state_accessors");
+  int (*reg_pic)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_picture_hip");
+  int (*reg_dct)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_dct_hip");
+  int (*reg_quant)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_quant_hip");
+  int (*reg_ipol)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_ipol_hip");
+  if (!set_reg || !set_acc || !reg_pic || !reg_dct || !reg_quant || !reg_ipol) return -1;
+  static const kvz_hip_state_accessors acc = { acc_qp, acc_slice_is_intra, acc_signhide, acc_sl_enable,
+                                               acc_quant_coeff, acc_dequant_coeff, acc_rdoq, acc_cu_is_intra };
+  set_reg(kvz_strategyselector_register);
+  set_acc(&acc);
+  unsigned before = g_list.count;
+  if (!reg_pic(&g_list, 8) || !reg_dct(&g_list, 8) || !reg_quant(&g_list, 8) || !reg_ipol(&g_list, 8)) return -1;
+  return (int)(g_list.count - before);
+}

@@ -1,0 +1,160 @@
+"""GPU: the drop-in boundary.  libkvzhip.so registers its "hip" strategies into the
+COMPILED REFERENCE's own registry (kvz_strategyselector_register, via the glue of
+oracle/ref_harness.c == INTEGRATION.md), and the reference's callers / the
+reference's unit-test vectors are run against them by strategy name -- the way
+tests/test_strategies.c:29-52 iterates every registered implementation.
+Needs the prebuilt oracle/_ref/libkvzref.so (travels with gpurun)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_lib as R
+from patterns import (SAD_EDGE_KAT, SATD_GOLDEN_BW, SATD_GOLDEN_GRADIENT, REG_SAD_DIMS, coeff_sum_input,
+                      dct_test_input, intra_sad_gradient, rng, sad_test_frames, satd_test_bufs)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    L = R.lib()
+    L.ref_register_hip.restype = C.c_int
+    L.ref_register_hip.argtypes = [C.c_char_p]
+    n = L.ref_register_hip(os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so").encode())
+    assert n > 0, "hip strategies failed to register"
+    return n
+
+
+def test_registration_and_selection(hip):
+    regs = [(t, n, p) for (t, n, p) in R.strategies() if n == "hip"]
+    types = {t for (t, _, _) in regs}
+    # every picture cost function, every transform, the quant group and the sample filters
+    for t in ["reg_sad", "satd_any_size", "satd_any_size_quad", "pixels_calc_ssd", "coeff_abs_sum", "quant", "dequant",
+              "quantize_residual", "sample_quarterpel_luma", "sample_octpel_chroma", "sample_14bit_quarterpel_luma",
+              "sample_14bit_octpel_chroma", "fast_forward_dst_4x4", "fast_inverse_dst_4x4"] + \
+             ["%s_%dx%d" % (k, n, n) for k in ("sad", "satd", "dct", "idct") for n in (4, 8, 16, 32)] + \
+             ["sad_64x64", "satd_64x64"] + ["%s_%dx%d_dual" % (k, n, n) for k in ("sad", "satd") for n in (4, 8, 16, 32, 64)]:
+        assert t in types, t
+    assert all(p == 50 for (_, _, p) in regs)
+    assert hip == len(regs)
+    # the selector's rule (highest priority wins, strategyselector.c:258-302) now picks hip over avx2 (40)
+    L = R.lib()
+    for t in ("sad_8x8", "satd_8x8", "dct_32x32", "reg_sad"):
+        assert L.ref_strategy(t.encode(), b"best") == L.ref_strategy(t.encode(), b"hip")
+
+
+@pytest.mark.parametrize("log_w", [2, 3, 4, 5, 6])
+def test_satd_and_sad_reference_unit_vectors(hip, log_w):
+    n = 1 << log_w
+    bw, ck, gr = satd_test_bufs(log_w)
+    for (x, y), want in ((bw, SATD_GOLDEN_BW[log_w]), (ck, SATD_GOLDEN_BW[log_w]), (gr, SATD_GOLDEN_GRADIENT[log_w])):
+        assert R.cost_nxn_batch("satd", n, x[None], y[None], "hip")[0] == want
+        assert R.cost_nxn_batch("satd", n, y[None], x[None], "hip")[0] == want
+    z, m = np.zeros(n * n, np.uint8), np.full(n * n, 255, np.uint8)
+    assert R.cost_nxn_batch("sad", n, z[None], m[None], "hip")[0] == 255 * n * n
+    ga, gb = intra_sad_gradient(n)
+    assert R.cost_nxn_batch("sad", n, ga[None], gb[None], "hip")[0] == int(np.abs(ga.astype(int) - gb.astype(int)).sum())
+
+
+def test_image_calc_sad_through_reference_caller(hip):
+    """kvz_image_calc_sad (image.c:455) with kvz_reg_sad = hip: tests/sad_tests.c:121-259 closed forms"""
+    pic, ref, big_pic, big_ref = sad_test_frames()
+    for (x, y), want in SAD_EDGE_KAT.items():
+        assert R.image_calc("sad", pic, ref, 0, 0, x, y, 8, 8, "hip") == want, (x, y)
+    for (w, h) in REG_SAD_DIMS:
+        want = int(np.abs(big_pic[:h, :w].astype(int) - big_ref[:h, :w].astype(int)).sum())
+        assert R.reg_sad(big_pic, big_ref, 0, 0, w, h, 64, 64, "hip") == want
+
+
+def test_picture_group_vs_generic(hip):
+    g = rng(5)
+    for n in (4, 8, 16, 32):
+        orig = g.integers(0, 256, (3, n * n), dtype=np.uint8)
+        preds = g.integers(0, 256, (3, 2048), dtype=np.uint8)
+        for kind in ("sad", "satd"):
+            np.testing.assert_array_equal(R.cost_nxn_dual_batch(kind, n, preds, orig, "hip"),
+                                          R.cost_nxn_dual_batch(kind, n, preds, orig, "generic"))
+    a = g.integers(0, 256, 80 * 80, dtype=np.uint8)
+    b = g.integers(0, 256, 100 * 80, dtype=np.uint8)
+    for (w, h) in ((8, 8), (16, 16), (12, 8), (8, 12), (4, 4), (64, 64), (24, 16)):
+        assert R.satd_any_size(w, h, a, 3, 80, b, 7, 100, "hip") == R.satd_any_size(w, h, a, 3, 80, b, 7, 100, "generic")
+    preds = [g.integers(0, 256, 64 * 72, dtype=np.uint8) for _ in range(4)]
+    for (w, h) in ((8, 8), (16, 16), (64, 64), (12, 16), (16, 12), (4, 8)):
+        np.testing.assert_array_equal(R.satd_any_size_quad(w, h, preds, 64, b, 11, 100, "hip"),
+                                      R.satd_any_size_quad(w, h, preds, 64, b, 11, 100, "generic"))
+    for w in (4, 8, 16, 32, 64):
+        assert R.pixels_calc_ssd(a, 2, b, 5, 80, 100, w, "hip") == R.pixels_calc_ssd(a, 2, b, 5, 80, 100, w, "generic")
+    assert R.image_calc("satd", a.reshape(80, 80), b.reshape(80, 100), 8, 8, -3, 70, 16, 16, "hip") == \
+        O.image_calc("satd", a.reshape(80, 80), b.reshape(80, 100), 8, 8, -3, 70, 16, 16)
+
+
+def test_dct_group_reference_unit_vectors(hip):
+    """tests/dct_tests.c: every registered dct/idct implementation must equal generic on the gradient input"""
+    src = dct_test_input()
+    g = rng(9)
+    for n in (4, 8, 16, 32):
+        x = np.concatenate([src[:n * n][None], g.integers(-32768, 32768, (2, n * n)).astype(np.int16)])
+        for kind in ("dct", "idct") + (("dst", "idst") if n == 4 else ()):
+            np.testing.assert_array_equal(R.transform_batch(kind, n, x, "hip"), R.transform_batch(kind, n, x, "generic"))
+
+
+def test_quant_group_through_encoder_state(hip):
+    """quant / dequant / quantize_residual receive the reference's encoder_state_t and read it through the
+    accessor glue; flat and default scaling lists; coeff_abs_sum KAT (tests/coeff_sum_tests.c)"""
+    c, expected = coeff_sum_input()
+    assert R.coeff_abs_sum(c, "hip") == expected
+    g = rng(31)
+    for w in (4, 8, 16, 32):
+        coef = g.integers(-2500, 2501, (3, w * w)).astype(np.int16)
+        for sl in (0, 1):
+            for sh in (0, 1):
+                q_h = R.quant_batch(coef, w, 27, 0, 0, 1, sh, 1, sl, "hip")
+                q_g = R.quant_batch(coef, w, 27, 0, 0, 1, sh, 1, sl, "generic")
+                np.testing.assert_array_equal(q_h, q_g, err_msg="quant w=%d sl=%d sh=%d" % (w, sl, sh))
+            np.testing.assert_array_equal(R.dequant_batch(q_g, w, 27, 0, 1, sl, "hip"), R.dequant_batch(q_g, w, 27, 0, 1, sl, "generic"))
+        ref_in = g.integers(0, 256, (3, w * w), dtype=np.uint8)
+        pred = np.clip(ref_in.astype(int) + g.integers(-30, 31, ref_in.shape), 0, 255).astype(np.uint8)
+        for intra in (0, 1):
+            h = R.quantize_residual_batch(ref_in, pred, w, 24, 0, 0, intra, intra, 0, 0, "hip")
+            r = R.quantize_residual_batch(ref_in, pred, w, 24, 0, 0, intra, intra, 0, 0, "generic")
+            for a, b in zip(h, r):
+                np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["luma", "luma14", "chroma", "chroma14"])
+def test_ipol_sample_filters(hip, kind):
+    g = rng(60)
+    frame = g.integers(0, 256, (96, 96), dtype=np.uint8)
+    luma = kind.startswith("luma")
+    for (w, h) in (((8, 8), (16, 16), (64, 64)) if luma else ((4, 4), (8, 8), (32, 32))):
+        for (fx, fy) in ((0, 0), (1, 2), (3, 3)) if luma else ((0, 0), (3, 5), (7, 1)):
+            np.testing.assert_array_equal(R.sample(kind, frame, 12, 10, w, h, fx, fy, "hip"),
+                                          R.sample(kind, frame, 12, 10, w, h, fx, fy, "generic"))
+
+
+def test_concurrent_calls_from_worker_threads(hip):
+    """the strategy pointers are called concurrently from all threadqueue workers (encoderstate.c:781):
+    per-thread streams + staging, no shared state"""
+    import threading
+    g = rng(77)
+    a = g.integers(0, 256, (64, 64), dtype=np.uint8)
+    b = g.integers(0, 256, (64, 64), dtype=np.uint8)
+    want = O.cost_nxn_batch("satd", 8, a, b)
+    errs = []
+
+    def work():
+        try:
+            for _ in range(3):
+                got = R.cost_nxn_batch("satd", 8, a, b, "hip")
+                if not (got == want).all():
+                    errs.append("mismatch")
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs

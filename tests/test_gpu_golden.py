@@ -1,0 +1,76 @@
+"""GPU: the HIP kernels against the committed golden fixtures (outputs of the compiled
+reference's generic strategy, oracle/gen_golden.py) -- independent of the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from kvazaar_amd import api as a, _lib
+    _lib.init(0)
+    return a
+
+
+def test_golden_picture(api):
+    d = gold("picture.npz")
+    for n in (4, 8, 16, 32, 64):
+        a, b = d["a%d" % n], d["b%d" % n]
+        np.testing.assert_array_equal(api.cost_nxn_batch("sad", n, a, b), d["sad%d" % n])
+        np.testing.assert_array_equal(api.cost_nxn_batch("satd", n, a, b), d["satd%d" % n])
+        if n <= 32:
+            np.testing.assert_array_equal(api.cost_nxn_dual_batch("sad", n, d["dual_preds%d" % n], a[:8]), d["sad_dual%d" % n])
+            np.testing.assert_array_equal(api.cost_nxn_dual_batch("satd", n, d["dual_preds%d" % n], a[:8]), d["satd_dual%d" % n])
+    pic, ref = d["frame_pic"], d["frame_ref"]
+    np.testing.assert_array_equal(api.image_calc_sad_batch(pic, ref, d["pairs"]), d["image_sad"])
+    np.testing.assert_array_equal(api.image_calc_satd_batch(pic, ref, d["pairs"]), d["image_satd"])
+    dims = d["quad_dims"]
+    preds = np.concatenate([d["quad_preds"]] * len(dims))
+    got = api.satd_any_size_quad_batch(preds, pic, [(0, 0, 0, 0, int(w), int(h)) for (w, h) in dims])
+    np.testing.assert_array_equal(got, d["quad_costs"])
+    got = api.pixels_calc_ssd_batch(pic, ref, [(0, 0, 0, 0, w, w) for w in (4, 8, 16, 32)])
+    np.testing.assert_array_equal(got, d["ssd"])
+
+
+def test_golden_dct(api):
+    d = gold("dct.npz")
+    for n in (4, 8, 16, 32):
+        for kind in ("dct", "idct") + (("dst", "idst") if n == 4 else ()):
+            np.testing.assert_array_equal(api.transform_batch(kind, n, d["in%d" % n]), d["%s%d" % (kind, n)])
+
+
+def test_golden_quant(api):
+    d = gold("quant.npz")
+    for w in (4, 8, 16, 32):
+        coef = d["coef%d" % w]
+        for qp in (22, 37):
+            for sh in (0, 1):
+                np.testing.assert_array_equal(api.quant_batch(coef, w, qp, 0, 0, 1, sh), d["quant%d_qp%d_sh%d" % (w, qp, sh)])
+            np.testing.assert_array_equal(api.dequant_batch(d["quant%d_qp%d_sh0" % (w, qp)], w, qp, 0), d["dequant%d_qp%d" % (w, qp)])
+        for intra in (0, 1):
+            rec, co, has = api.quantize_residual_batch(d["qr_ref%d" % w], d["qr_pred%d" % w], w, 22, 0, 0, intra, intra)
+            np.testing.assert_array_equal(rec, d["qr_rec%d_i%d" % (w, intra)])
+            np.testing.assert_array_equal(co, d["qr_coeff%d_i%d" % (w, intra)])
+            np.testing.assert_array_equal(has, d["qr_has%d_i%d" % (w, intra)])
+
+
+def test_golden_ipol(api):
+    d = gold("ipol.npz")
+    frame, pic = d["frame"], d["pic"]
+    for kind, blocks in (("luma", d["luma_blocks"]), ("luma14", d["luma_blocks"]),
+                         ("chroma", d["chroma_blocks"]), ("chroma14", d["chroma_blocks"])):
+        got = np.concatenate([o.ravel() for o in api.sample_batch(kind, frame, blocks)])
+        np.testing.assert_array_equal(got, d[kind])
+    cases = d["sf_cases"]
+    pairs = [(int(x), int(y), int(x + mvx), int(y + mvy), int(w), int(h)) for (x, y, w, h, mvx, mvy) in cases]
+    costs, best = api.search_frac_batch(pic, frame, pairs)
+    np.testing.assert_array_equal(costs, d["sf_costs"])
+    np.testing.assert_array_equal(best, d["sf_best"])

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Per-kernel throughput of every batched entry of the C ABI (HIP-event timed, inputs
+resident in HBM, working sets larger than the 256 MiB Infinity Cache where the kernel
+streams).  Development tool; bench.py is the contract benchmark.
+
+  python tools/bench_all.py                       # table of all kernels
+  python tools/bench_all.py --only dct --tune dct32_wgs_per_cu=3,4,5,6,8   # interleaved A/B in one process
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+from kvazaar_amd import _lib  # noqa: E402
+from kvazaar_amd._lib import QuantParams  # noqa: E402
+
+
+def timed(L, stream, fn, iters=20, warm=3):
+    e0, e1 = L.kvz_hip_event_create(), L.kvz_hip_event_create()
+    for _ in range(warm):
+        fn()
+    L.kvz_hip_event_record(e0, stream)
+    for _ in range(iters):
+        fn()
+    L.kvz_hip_event_record(e1, stream)
+    ms = C.c_float()
+    _lib.check(L.kvz_hip_event_elapsed_ms(e0, e1, C.byref(ms)), "elapsed")
+    L.kvz_hip_event_destroy(e0); L.kvz_hip_event_destroy(e1)
+    return ms.value / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--tune", default="", help="key=v1,v2,... (interleaved rounds)")
+    ap.add_argument("--mb", type=int, default=512, help="bytes per operand array (MiB)")
+    ap.add_argument("--rounds", type=int, default=3)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    L = _lib.init(0)
+    st = L.kvz_hip_stream_create()
+    nbytes = args.mb << 20
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    a8 = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev, generator=g)
+    b8 = (a8.to(torch.int16) + torch.randint(-8, 9, (nbytes,), dtype=torch.int16, device=dev, generator=g)).clamp_(0, 255).to(torch.uint8)
+    r16 = torch.randint(-255, 256, (nbytes // 2,), dtype=torch.int16, device=dev, generator=g)
+    o16 = torch.empty_like(r16)
+    o8 = torch.empty_like(a8)
+    o32 = torch.empty(nbytes // 16, dtype=torch.int32, device=dev)
+    has = torch.empty(nbytes // 16, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    cases = []   # (name, blocks, algorithmic bytes per block, fn)
+    for n in (4, 8, 16, 32, 64):
+        cnt = nbytes // (n * n)
+        cases.append(("sad_%dx%d" % (n, n), cnt, 2 * n * n + 4,
+                      lambda n=n, cnt=cnt: L.kvz_hip_sad_nxn_batch(n, a8.data_ptr(), b8.data_ptr(), cnt, o32.data_ptr(), st)))
+        cases.append(("satd_%dx%d" % (n, n), cnt, 2 * n * n + 4,
+                      lambda n=n, cnt=cnt: L.kvz_hip_satd_nxn_batch(n, a8.data_ptr(), b8.data_ptr(), cnt, o32.data_ptr(), st)))
+    for n in (4, 8, 16, 32):
+        cnt = (nbytes // 2) // (n * n)
+        for kind, kid in (("dct", 0), ("idct", 1)):
+            cases.append(("%s_%dx%d" % (kind, n, n), cnt, 4 * n * n,
+                          lambda n=n, cnt=cnt, kid=kid: L.kvz_hip_transform_batch(kid, n, r16.data_ptr(), o16.data_ptr(), cnt, st)))
+    qp = QuantParams(); qp.qp = 27
+    for n in (4, 8, 16, 32):
+        cnt = (nbytes // 2) // (n * n)
+        cases.append(("quant_%dx%d" % (n, n), cnt, 4 * n * n,
+                      lambda n=n, cnt=cnt: L.kvz_hip_quant_batch(C.byref(qp), r16.data_ptr(), o16.data_ptr(), n, 0, 0, cnt, st)))
+        cases.append(("dequant_%dx%d" % (n, n), cnt, 4 * n * n,
+                      lambda n=n, cnt=cnt: L.kvz_hip_dequant_batch(C.byref(qp), r16.data_ptr(), o16.data_ptr(), n, 0, cnt, st)))
+        cnt2 = (nbytes // 4) // (n * n)
+        cases.append(("quantize_residual_%dx%d" % (n, n), cnt2, 5 * n * n,
+                      lambda n=n, cnt2=cnt2: L.kvz_hip_quantize_residual_batch(C.byref(qp), 0, n, 0, 0, 0, a8.data_ptr(), b8.data_ptr(),
+                                                                              o8.data_ptr(), o16.data_ptr(), has.data_ptr(), cnt2, st)))
+
+    tune_key, tune_vals = None, [None]
+    if args.tune:
+        tune_key, vals = args.tune.split("=")
+        tune_vals = [int(v) for v in vals.split(",")]
+    print("%-26s %10s %12s %10s %8s" % ("kernel", "tune", "Mblocks/s", "GB/s", "ms"))
+    for name, blocks, bpb, fn in cases:
+        if args.only and args.only not in name:
+            continue
+        best = {}
+        for _ in range(args.rounds):
+            for v in tune_vals:
+                if tune_key:
+                    _lib.check(L.kvz_hip_set_tuning(tune_key.encode(), v), "set_tuning")
+                ms = timed(L, st, lambda: _lib.check(fn(), name))
+                best[v] = min(best.get(v, 1e9), ms)
+        for v in tune_vals:
+            ms = best[v]
+            print("%-26s %10s %12.1f %10.1f %8.4f" % (name, "-" if v is None else v, blocks / ms / 1e3, blocks * bpb / ms / 1e6, ms))
+    if tune_key:
+        L.kvz_hip_set_tuning(tune_key.encode(), -1)
+
+
+if __name__ == "__main__":
+    main()
