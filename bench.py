@@ -44,7 +44,7 @@ def cpu_baseline(budget_s=3.0):
     frames = 4
     n8, n32 = BLK8_PER_FRAME * frames, BLK32_PER_FRAME * frames
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = min(16, len(os.sched_getaffinity(0)))   # the CPU share of a 1-GPU box is 16 threads
     except AttributeError:
         cores = os.cpu_count() or 1
     g = np.random.default_rng(12345)
