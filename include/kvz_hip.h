@@ -256,6 +256,14 @@ typedef struct {
   int (*rdoq_enable)(const void *state);
   /* cu_info_t fields used by quantize_residual (quant-generic.c:197-225) */
   int (*cu_is_intra)(const void *cur_cu);
+  /* optional (may be NULL): planes of hi_prec_buf_t (image.h:38-46) and of lcu_t.rec (cu.h:287-325)
+   * for inter_recon_bipred; without them that one function stays on the CPU strategy */
+  const int16_t *(*hi_prec_y)(const void *hi_prec_buf);
+  const int16_t *(*hi_prec_u)(const void *hi_prec_buf);
+  const int16_t *(*hi_prec_v)(const void *hi_prec_buf);
+  kvz_hip_pixel *(*lcu_rec_y)(void *lcu);
+  kvz_hip_pixel *(*lcu_rec_u)(void *lcu);
+  kvz_hip_pixel *(*lcu_rec_v)(void *lcu);
 } kvz_hip_state_accessors;
 KVZ_HIP_API void kvz_hip_set_state_accessors(const kvz_hip_state_accessors *acc);
 

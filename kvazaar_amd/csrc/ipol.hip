@@ -275,6 +275,112 @@ __global__ __launch_bounds__(256) void search_frac_kernel(const u8 *__restrict__
   }
 }
 
+// ---------------------------------------------------------------------------
+// One reference filter step (ipol_blocks_func, strategies-ipol.h:36-38) for the
+// per-call strategy shim: produces exactly what the generic step writes -- the
+// four filtered blocks and the horizontal planes / first-column arrays the
+// following steps read from the caller's scratch (ipol-generic.c:192-658).
+// `win` is the window the reference reads around `src`: rows -3 .. h+4,
+// cols -3 .. w+5 (stride w + 9), i.e. P rows -4 .. h+3, P cols -4 .. w+4.
+// Planes are emitted compactly: hor_out[p][(h+8) * w], cols_out[p][h+8].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frac_step_kernel(const u8 *__restrict__ win, int w, int h, int step, int fme_level,
+                                                        int hx, int hy, u8 *__restrict__ filtered /*[4][h*w]*/,
+                                                        i16 *__restrict__ hor_out /*[2][(h+8)*w]*/, i16 *__restrict__ cols_out /*[2][h+8]*/)
+{
+  __shared__ u8 s_p[72 * 76];
+  __shared__ i16 s_h[2][72 * FR_HS];
+  const int tid = threadIdx.x, ph = h + 8, pw = w + 9, PS = 76;
+  for (int i = tid; i < ph * pw; i += 256) { const int y = i / pw, x = i - y * pw; s_p[y * PS + x] = win[i]; }
+  __syncthreads();
+  // H plane of filter f over rows -4 .. h+3 (index y), cols -1 .. w-1 (index x = c + 1)
+  auto hor_plane = [&](int f, i16 *dst) {
+    const signed char *fl = c_luma_filter[f];
+    for (int i = tid; i < ph * (w + 1); i += 256) {
+      const int y = i / (w + 1), x = i - y * (w + 1);
+      int acc = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc += fl[t] * (int)s_p[y * PS + x + t];
+      dst[y * FR_HS + x] = (i16)acc;
+    }
+  };
+  auto emit_plane = [&](const i16 *pl, int slot, int first_y) {        // hor_intermediate / hor_first_cols contents
+    for (int i = tid; i < ph * (w + 1); i += 256) {
+      const int y = i / (w + 1), x = i - y * (w + 1);
+      if (y < first_y) continue;
+      if (x == 0) cols_out[slot * ph + y] = pl[y * FR_HS];
+      else hor_out[(size_t)slot * ph * w + y * w + (x - 1)] = pl[y * FR_HS + x];
+    }
+  };
+  auto filter_cand = [&](int fy, int ry, int cx, const i16 *pl, u8 *dst) {
+    const signed char *vf = c_luma_filter[fy];
+    for (int i = tid; i < w * h; i += 256) {
+      const int y = i / w, x = i - y * w, r = y + ry, cc = x + cx;
+      int acc = 0;
+      if (!pl) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += vf[j] * 64 * (int)s_p[(r + 1 + j) * PS + cc + 4];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += vf[j] * (int)pl[(r + 1 + j) * FR_HS + cc + 1];
+      }
+      dst[y * w + x] = round_clip16((i16)(acc >> 6));
+    }
+  };
+  u8 *f0 = filtered, *f1 = filtered + w * h, *f2 = filtered + 2 * w * h, *f3 = filtered + 3 * w * h;
+  if (step < 2) {
+    hor_plane(2, s_h[0]);
+    __syncthreads();
+    if (step == 0) {
+      // hor_intermediate[0] / hor_first_cols[0] hold the fir0 plane = 64 * P (ipol-generic.c:226-241)
+      for (int i = tid; i < ph * (w + 1); i += 256) {
+        const int y = i / (w + 1), x = i - y * (w + 1);
+        const i16 v = (i16)(64 * (int)s_p[y * PS + x + 3]);
+        if (x == 0) cols_out[y] = v; else hor_out[y * w + (x - 1)] = v;
+      }
+      emit_plane(s_h[0], 1, fme_level > 1 ? 0 : 1);                    // hor_intermediate[1] / hor_first_cols[2]
+      filter_cand(0, 0, -1, s_h[0], f0); filter_cand(0, 0, 0, s_h[0], f1);
+      filter_cand(2, -1, 0, nullptr, f2); filter_cand(2, 0, 0, nullptr, f3);
+    } else {
+      filter_cand(2, -1, -1, s_h[0], f0); filter_cand(2, -1, 0, s_h[0], f1);
+      filter_cand(2, 0, -1, s_h[0], f2); filter_cand(2, 0, 0, s_h[0], f3);
+    }
+  } else {
+    const int bx = 2 * hx, by = 2 * hy;
+    hor_plane((bx - 1) & 3, s_h[0]);
+    hor_plane((bx + 1) & 3, s_h[1]);
+    __syncthreads();
+    if (step == 2) {
+      emit_plane(s_h[0], 0, 0);                                        // hor_intermediate[3] / hor_first_cols[1]
+      emit_plane(s_h[1], 1, 0);                                        // hor_intermediate[4] / hor_first_cols[3]
+      filter_cand(by & 3, by >> 2, (bx - 1) >> 2, s_h[0], f0);
+      filter_cand(by & 3, by >> 2, (bx + 1) >> 2, s_h[1], f1);
+      __syncthreads();
+      // top / bottom use the half-pel column plane: fx = bx & 3 (2 -> recompute H_2, 0 -> pixels)
+      if (bx & 3) { hor_plane(2, s_h[0]); __syncthreads(); }
+      const i16 *hp = (bx & 3) ? s_h[0] : nullptr;
+      filter_cand((by - 1) & 3, (by - 1) >> 2, bx >> 2, hp, f2);
+      filter_cand((by + 1) & 3, (by + 1) >> 2, bx >> 2, hp, f3);
+    } else {
+      filter_cand((by - 1) & 3, (by - 1) >> 2, (bx - 1) >> 2, s_h[0], f0);
+      filter_cand((by - 1) & 3, (by - 1) >> 2, (bx + 1) >> 2, s_h[1], f1);
+      filter_cand((by + 1) & 3, (by + 1) >> 2, (bx - 1) >> 2, s_h[0], f2);
+      filter_cand((by + 1) & 3, (by + 1) >> 2, (bx + 1) >> 2, s_h[1], f3);
+    }
+  }
+}
+
+namespace kvzhip {
+int launch_frac_step(const u8 *win, int w, int h, int step, int fme_level, int hx, int hy,
+                     u8 *filtered, i16 *hor_out, i16 *cols_out, hipStream_t st)
+{
+  if (w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7) || step < 0 || step > 3) return KVZ_HIP_ERR_INVALID;
+  hipLaunchKernelGGL(frac_step_kernel, dim3(1), dim3(256), 0, st, win, w, h, step, fme_level, hx, hy, filtered, hor_out, cols_out);
+  KVZ_CHECK_LAUNCH("frac_step_kernel");
+  return KVZ_HIP_OK;
+}
+}  // namespace kvzhip
+
 extern "C" {
 
 static int sample_launch(bool luma, const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,

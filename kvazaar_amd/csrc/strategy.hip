@@ -24,6 +24,11 @@ using namespace kvzhip;
 extern "C" int kvz_strategyselector_register(void *opaque, const char *type, const char *strategy_name, int priority, void *fptr)
     __attribute__((weak, visibility("default")));
 
+namespace kvzhip {
+int launch_frac_step(const u8 *win, int w, int h, int step, int fme_level, int hx, int hy,
+                     u8 *filtered, i16 *hor_out, i16 *cols_out, hipStream_t st);
+}
+
 namespace {
 
 kvz_hip_register_fn g_registrar = nullptr;
@@ -337,6 +342,73 @@ void hip_sample(const void *encoder, kvz_hip_pixel *src, int16_t src_stride, int
     std::memcpy((u8 *)dst + (size_t)y * dst_stride * esz, c.h + oo + (size_t)y * width * esz, (size_t)width * esz);
 }
 
+// ipol_blocks_func (strategies-ipol.h:36-38): one of the four frac-search filter steps.  The caller owns
+// `filtered`, `hor_intermediate`, `hor_first_cols`; every element the generic step defines is written.
+template <int STEP>
+void hip_filter_step(const void *encoder, kvz_hip_pixel *src, int16_t src_stride, int width, int height,
+                     kvz_hip_pixel filtered[4][64 * 64], int16_t hor_intermediate[5][72 * 64], int8_t fme_level,
+                     int16_t hor_first_cols[5][72], int8_t hpel_off_x, int8_t hpel_off_y)
+{
+  (void)encoder;
+  const int w = width, h = height, ph = h + 8, pw = w + 9;
+  call_ctx &c = tls(); stage s(c);
+  size_t ow = s.take((size_t)pw * ph), in_end = s.off;
+  size_t of = s.take((size_t)4 * w * h), oh = s.take((size_t)2 * ph * w * 2), oc = s.take((size_t)2 * ph * 2), out_end = s.off;
+  pack_rows(c.h + ow, src - (ptrdiff_t)3 * src_stride - 3, pw, ph, (size_t)src_stride);
+  s.h2d(0, in_end);
+  MUST(launch_frac_step(c.d + ow, w, h, STEP, fme_level, hpel_off_x, hpel_off_y, c.d + of, (i16 *)(c.d + oh), (i16 *)(c.d + oc), c.st));
+  s.d2h(of, out_end - of); s.sync();
+  for (int k = 0; k < 4; ++k)
+    for (int y = 0; y < h; ++y) std::memcpy(&filtered[k][y * 64], c.h + of + ((size_t)k * h + y) * w, (size_t)w);
+  if (STEP == 0 || STEP == 2) {
+    // step 0 fills hor_intermediate[0],[1] and hor_first_cols[0],[2]; step 2 fills [3],[4] and [1],[3]
+    const int hslot[2] = { STEP == 0 ? 0 : 3, STEP == 0 ? 1 : 4 }, cslot[2] = { STEP == 0 ? 0 : 1, STEP == 0 ? 2 : 3 };
+    const i16 *hsrc = (const i16 *)(c.h + oh), *csrc = (const i16 *)(c.h + oc);
+    for (int p = 0; p < 2; ++p) {
+      const int first_y = (STEP == 0 && p == 1 && fme_level <= 1) ? 1 : 0;
+      for (int y = first_y; y < ph; ++y) {
+        std::memcpy(&hor_intermediate[hslot[p]][y * 64], hsrc + ((size_t)p * ph + y) * w, (size_t)w * 2);
+        hor_first_cols[cslot[p]][y] = csrc[p * ph + y];
+      }
+    }
+  }
+}
+
+// inter_recon_bipred_func (strategies-picture.h:117-130, picture-generic.c:538-588): the lcu_t / hi_prec_buf_t
+// planes are reached through the accessor glue; luma w x h at (xpos, ypos) & 63 and chroma w/2 x h/2.
+void hip_inter_recon_bipred(const int hi_prec_luma_rec0, const int hi_prec_luma_rec1, const int hi_prec_chroma_rec0,
+                            const int hi_prec_chroma_rec1, int height, int width, int ypos, int xpos,
+                            const void *hp0, const void *hp1, void *lcu, kvz_hip_pixel *temp_lcu_y,
+                            kvz_hip_pixel *temp_lcu_u, kvz_hip_pixel *temp_lcu_v)
+{
+  struct plane { int hi0, hi1; const int16_t *h0, *h1; const u8 *t0; u8 *rec; int w, h, x, y, stride; };
+  const plane pl[3] = {
+    { hi_prec_luma_rec0, hi_prec_luma_rec1, g_acc.hi_prec_y(hp0), g_acc.hi_prec_y(hp1), temp_lcu_y, g_acc.lcu_rec_y(lcu), width, height, xpos & 63, ypos & 63, 64 },
+    { hi_prec_chroma_rec0, hi_prec_chroma_rec1, g_acc.hi_prec_u(hp0), g_acc.hi_prec_u(hp1), temp_lcu_u, g_acc.lcu_rec_u(lcu), width >> 1, height >> 1, (xpos >> 1) & 31, (ypos >> 1) & 31, 32 },
+    { hi_prec_chroma_rec0, hi_prec_chroma_rec1, g_acc.hi_prec_v(hp0), g_acc.hi_prec_v(hp1), temp_lcu_v, g_acc.lcu_rec_v(lcu), width >> 1, height >> 1, (xpos >> 1) & 31, (ypos >> 1) & 31, 32 } };
+  for (const plane &p : pl) {
+    if (p.w <= 0 || p.h <= 0) continue;
+    call_ctx &c = tls(); stage s(c);
+    const size_t n = (size_t)p.w * p.h;
+    size_t o0 = s.take(n * 2), o1 = s.take(n * 2), in_end = s.off, od = s.take(n);
+    // the reference wraps coordinates inside the LCU: (pos + t) & (LCU_WIDTH - 1)
+    for (int y = 0; y < p.h; ++y)
+      for (int x = 0; x < p.w; ++x) {
+        const int yy = (p.y + y) & (p.stride - 1), xx = (p.x + x) & (p.stride - 1), i = yy * p.stride + xx;
+        if (p.hi0) ((int16_t *)(c.h + o0))[y * p.w + x] = p.h0[i]; else (c.h + o0)[y * p.w + x] = p.t0[i];
+        if (p.hi1) ((int16_t *)(c.h + o1))[y * p.w + x] = p.h1[i]; else (c.h + o1)[y * p.w + x] = p.rec[i];
+      }
+    s.h2d(0, in_end);
+    MUST(kvz_hip_bipred_blend_batch(p.w, p.h, p.hi0, c.d + o0, p.hi1, c.d + o1, c.d + od, 1, c.st));
+    s.d2h(od, n); s.sync();
+    for (int y = 0; y < p.h; ++y)
+      for (int x = 0; x < p.w; ++x) {
+        const int yy = (p.y + y) & (p.stride - 1), xx = (p.x + x) & (p.stride - 1);
+        p.rec[yy * p.stride + xx] = (c.h + od)[y * p.w + x];
+      }
+  }
+}
+
 int reg(void *opaque, const char *type, void *fptr)
 {
   kvz_hip_register_fn f = g_registrar ? g_registrar : (kvz_hip_register_fn)kvz_strategyselector_register;
@@ -362,10 +434,9 @@ void kvz_hip_set_state_accessors(const kvz_hip_state_accessors *acc)
   else g_have_acc = false;
 }
 
-// STRATEGIES_PICTURE_EXPORTS, strategies-picture.h:174-199.  inter_recon_bipred is
-// not registered: its lcu_t / hi_prec_buf_t arguments are encoder structs and the
-// function is only reached with --bipred (off at every preset up to medium); the
-// batched blend kvz_hip_bipred_blend_batch covers the arithmetic.
+// STRATEGIES_PICTURE_EXPORTS, strategies-picture.h:174-199.  inter_recon_bipred takes
+// lcu_t / hi_prec_buf_t encoder structs, so it registers only when the host glue
+// supplied the plane accessors.
 int kvz_strategy_register_picture_hip(void *opaque, uint8_t bitdepth)
 {
   if (!hook_ready(bitdepth)) return 0;
@@ -394,6 +465,8 @@ int kvz_strategy_register_picture_hip(void *opaque, uint8_t bitdepth)
   ok &= reg(opaque, "satd_64x64_dual", (void *)&hip_cost_nxn_dual<64, true>);
   ok &= reg(opaque, "satd_any_size_quad", (void *)&hip_satd_any_size_quad);
   ok &= reg(opaque, "pixels_calc_ssd", (void *)&hip_pixels_calc_ssd);
+  if (g_have_acc && g_acc.hi_prec_y && g_acc.hi_prec_u && g_acc.hi_prec_v && g_acc.lcu_rec_y && g_acc.lcu_rec_u && g_acc.lcu_rec_v)
+    ok &= reg(opaque, "inter_recon_bipred", (void *)&hip_inter_recon_bipred);
   return ok;
 }
 
@@ -431,10 +504,10 @@ int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth)
   return ok;
 }
 
-// STRATEGIES_IPOL_EXPORTS, strategies-ipol.h:65-74: the four sample filters.  The
-// filter_{hpel,qpel}_blocks_* steps are stateful across calls through caller-owned
-// scratch and are offloaded as one fused search (kvz_hip_search_frac_batch)
-// instead of four per-call shims; get_extended_block is host-side pointer logic.
+// STRATEGIES_IPOL_EXPORTS, strategies-ipol.h:65-74: the four sample filters and the four
+// frac-search filter steps (each writes the caller's scratch exactly like generic; the
+// throughput form is the fused kvz_hip_search_frac_batch).  get_extended_block is host
+// pointer/malloc logic (it returns host memory the caller frees) and stays on the CPU.
 int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
 {
   if (!hook_ready(bitdepth)) return 0;
@@ -443,6 +516,10 @@ int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
   ok &= reg(opaque, "sample_octpel_chroma", (void *)&hip_sample<false, false>);
   ok &= reg(opaque, "sample_14bit_quarterpel_luma", (void *)&hip_sample<true, true>);
   ok &= reg(opaque, "sample_14bit_octpel_chroma", (void *)&hip_sample<false, true>);
+  ok &= reg(opaque, "filter_hpel_blocks_hor_ver_luma", (void *)&hip_filter_step<0>);
+  ok &= reg(opaque, "filter_hpel_blocks_diag_luma", (void *)&hip_filter_step<1>);
+  ok &= reg(opaque, "filter_qpel_blocks_hor_ver_luma", (void *)&hip_filter_step<2>);
+  ok &= reg(opaque, "filter_qpel_blocks_diag_luma", (void *)&hip_filter_step<3>);
   return ok;
 }
 

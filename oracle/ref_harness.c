@@ -329,6 +329,12 @@ static const int32_t *acc_dequant_coeff(const void *s, int log2_tr, int list, in
 { return ((const encoder_state_t *)s)->encoder_control->scaling_list.de_quant_coeff[log2_tr - 2][list][rem]; }
 static int acc_rdoq(const void *s) { return ((const encoder_state_t *)s)->encoder_control->cfg.rdoq_enable; }
 static int acc_cu_is_intra(const void *cu) { return ((const cu_info_t *)cu)->type == CU_INTRA; }
+static const int16_t *acc_hp_y(const void *b) { return ((const hi_prec_buf_t *)b)->y; }
+static const int16_t *acc_hp_u(const void *b) { return ((const hi_prec_buf_t *)b)->u; }
+static const int16_t *acc_hp_v(const void *b) { return ((const hi_prec_buf_t *)b)->v; }
+static kvz_pixel *acc_rec_y(void *l) { return ((lcu_t *)l)->rec.y; }
+static kvz_pixel *acc_rec_u(void *l) { return ((lcu_t *)l)->rec.u; }
+static kvz_pixel *acc_rec_v(void *l) { return ((lcu_t *)l)->rec.v; }
 
 /* returns the number of strategies the hip library registered, or -1 */
 int ref_register_hip(const char *lib_path)
@@ -343,10 +349,28 @@ int ref_register_hip(const char *lib_path)
   int (*reg_ipol)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_ipol_hip");
   if (!set_reg || !set_acc || !reg_pic || !reg_dct || !reg_quant || !reg_ipol) return -1;
   static const kvz_hip_state_accessors acc = { acc_qp, acc_slice_is_intra, acc_signhide, acc_sl_enable,
-                                               acc_quant_coeff, acc_dequant_coeff, acc_rdoq, acc_cu_is_intra };
+                                               acc_quant_coeff, acc_dequant_coeff, acc_rdoq, acc_cu_is_intra,
+                                               acc_hp_y, acc_hp_u, acc_hp_v, acc_rec_y, acc_rec_u, acc_rec_v };
   set_reg(kvz_strategyselector_register);
   set_acc(&acc);
   unsigned before = g_list.count;
   if (!reg_pic(&g_list, 8) || !reg_dct(&g_list, 8) || !reg_quant(&g_list, 8) || !reg_ipol(&g_list, 8)) return -1;
   return (int)(g_list.count - before);
+}
+
+/* inter_recon_bipred (strategies-picture.h:117-130) of the named strategy on flat planes:
+ * hp0/hp1 = 14-bit buffers (y 64x64, u/v 32x32), rec = lcu->rec planes (in/out), tmp = temp_lcu planes */
+void ref_bipred(const char *name, int hi_l0, int hi_l1, int hi_c0, int hi_c1, int height, int width, int ypos, int xpos,
+                int16_t *hp0_y, int16_t *hp0_u, int16_t *hp0_v, int16_t *hp1_y, int16_t *hp1_u, int16_t *hp1_v,
+                kvz_pixel *rec_y, kvz_pixel *rec_u, kvz_pixel *rec_v, kvz_pixel *tmp_y, kvz_pixel *tmp_u, kvz_pixel *tmp_v)
+{
+  lcu_t *lcu = calloc(1, sizeof(lcu_t));
+  hi_prec_buf_t b0, b1;
+  memset(&b0, 0, sizeof(b0)); memset(&b1, 0, sizeof(b1));
+  b0.y = hp0_y; b0.u = hp0_u; b0.v = hp0_v; b1.y = hp1_y; b1.u = hp1_u; b1.v = hp1_v;
+  memcpy(lcu->rec.y, rec_y, 64 * 64); memcpy(lcu->rec.u, rec_u, 32 * 32); memcpy(lcu->rec.v, rec_v, 32 * 32);
+  ((inter_recon_bipred_func *)ref_strategy("inter_recon_bipred", name))(hi_l0, hi_l1, hi_c0, hi_c1, height, width, ypos, xpos,
+                                                                         &b0, &b1, lcu, tmp_y, tmp_u, tmp_v);
+  memcpy(rec_y, lcu->rec.y, 64 * 64); memcpy(rec_u, lcu->rec.u, 32 * 32); memcpy(rec_v, lcu->rec.v, 32 * 32);
+  free(lcu);
 }

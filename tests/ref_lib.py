@@ -72,6 +72,8 @@ def lib():
         L.ref_filter_step.restype = None
         L.ref_filter_step.argtypes = [S, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, u8p, i16p, i16p,
                                       C.c_int, C.c_int, C.c_int]
+        L.ref_bipred.restype = None
+        L.ref_bipred.argtypes = [S] + [C.c_int] * 8 + [i16p] * 6 + [u8p] * 6
         L.ref_bench_cost_nxn.restype = C.c_double
         L.ref_bench_cost_nxn.argtypes = [S, S, C.c_int, u8p, u8p, C.c_size_t, C.c_double, u32p]
         L.ref_bench_transform.restype = C.c_double
@@ -260,3 +262,15 @@ def search_frac_costs(pic, ref, x, y, w, h, mvx, mvy, name="generic"):
     lib().ref_search_frac_costs(name.encode(), _p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],
                                 x, y, w, h, mvx, mvy, _p(costs, u32p), best)
     return costs, (best[0], best[1])
+
+
+def bipred(hi, height, width, ypos, xpos, hp0, hp1, rec, tmp, name="generic"):
+    """hi = (luma0, luma1, chroma0, chroma1); hp0/hp1 = (y[4096], u[1024], v[1024]) int16;
+    rec/tmp = (y, u, v) uint8.  Returns the updated rec planes."""
+    h0 = [np.ascontiguousarray(a, dtype=np.int16).copy() for a in hp0]
+    h1 = [np.ascontiguousarray(a, dtype=np.int16).copy() for a in hp1]
+    r = [np.ascontiguousarray(a, dtype=np.uint8).copy() for a in rec]
+    t = [np.ascontiguousarray(a, dtype=np.uint8).copy() for a in tmp]
+    lib().ref_bipred(name.encode(), *[int(v) for v in hi], height, width, ypos, xpos,
+                     *[_p(a, i16p) for a in h0 + h1], *[_p(a, u8p) for a in r + t])
+    return r

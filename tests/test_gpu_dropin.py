@@ -36,7 +36,9 @@ def test_registration_and_selection(hip):
     # every picture cost function, every transform, the quant group and the sample filters
     for t in ["reg_sad", "satd_any_size", "satd_any_size_quad", "pixels_calc_ssd", "coeff_abs_sum", "quant", "dequant",
               "quantize_residual", "sample_quarterpel_luma", "sample_octpel_chroma", "sample_14bit_quarterpel_luma",
-              "sample_14bit_octpel_chroma", "fast_forward_dst_4x4", "fast_inverse_dst_4x4"] + \
+              "sample_14bit_octpel_chroma", "fast_forward_dst_4x4", "fast_inverse_dst_4x4", "inter_recon_bipred",
+              "filter_hpel_blocks_hor_ver_luma", "filter_hpel_blocks_diag_luma", "filter_qpel_blocks_hor_ver_luma",
+              "filter_qpel_blocks_diag_luma"] + \
              ["%s_%dx%d" % (k, n, n) for k in ("sad", "satd", "dct", "idct") for n in (4, 8, 16, 32)] + \
              ["sad_64x64", "satd_64x64"] + ["%s_%dx%d_dual" % (k, n, n) for k in ("sad", "satd") for n in (4, 8, 16, 32, 64)]:
         assert t in types, t
@@ -158,3 +160,32 @@ def test_concurrent_calls_from_worker_threads(hip):
     ts = [threading.Thread(target=work) for _ in range(4)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert not errs, errs
+
+
+@pytest.mark.parametrize("pattern", ["random", "extreme"])
+def test_frac_filter_steps_write_the_callers_scratch_like_generic(hip, pattern):
+    """the four ipol_blocks_func steps: filtered blocks AND the state the next steps read; steps may be
+    mixed between strategies, so run hip steps and generic steps on the same arrays' contents"""
+    g = rng(70)
+    frame = g.integers(0, 256, (96, 96), dtype=np.uint8)
+    if pattern == "extreme":
+        frame = np.where(g.integers(0, 2, (96, 96)) > 0, 255, 0).astype(np.uint8)
+    for (w, h) in ((8, 8), (16, 16), (64, 64), (16, 8)):
+        for off in ((0, 0), (-1, 1), (1, -1), (1, 1), (-1, -1), (0, 1)):
+            hipr = R.filter_frac_steps(frame, 10, 9, w, h, off, 4, "hip")
+            gen = R.filter_frac_steps(frame, 10, 9, w, h, off, 4, "generic")
+            np.testing.assert_array_equal(hipr[:, :, :h, :w], gen[:, :, :h, :w], err_msg="%dx%d off=%s" % (w, h, off))
+
+
+def test_inter_recon_bipred(hip):
+    g = rng(13)
+    for (w, h, x, y) in ((16, 16, 0, 0), (8, 8, 24, 40), (64, 64, 0, 0), (32, 16, 96, 72)):
+        for hi in ((1, 1, 1, 1), (0, 0, 0, 0), (1, 0, 0, 1), (0, 1, 1, 0)):
+            hp0 = [g.integers(-2000, 18000, n).astype(np.int16) for n in (4096, 1024, 1024)]
+            hp1 = [g.integers(-2000, 18000, n).astype(np.int16) for n in (4096, 1024, 1024)]
+            rec = [g.integers(0, 256, n, dtype=np.uint8) for n in (4096, 1024, 1024)]
+            tmp = [g.integers(0, 256, n, dtype=np.uint8) for n in (4096, 1024, 1024)]
+            a = R.bipred(hi, h, w, y, x, hp0, hp1, rec, tmp, "hip")
+            b = R.bipred(hi, h, w, y, x, hp0, hp1, rec, tmp, "generic")
+            for p, q in zip(a, b):
+                np.testing.assert_array_equal(p, q)
