@@ -29,91 +29,9 @@
 // one; kappa(h, e) below is the accumulator's row map, natural order 16h+e is
 // used where the operand comes from memory.  (Lane maps verified with exact
 // integer data on MI355X: tools/mfma_probe.hip.)
-#include "kvz_hip_internal.h"
-#include "transform_core.h"
+#include "dct32_mfma_core.h"
 
 using namespace kvzhip;
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-
-struct m32_table {
-  signed char v[32 * 32];
-  constexpr m32_table() : v()
-  {
-    for (int k = 0; k < 32; ++k)
-      for (int n = 0; n < 32; ++n) v[k * 32 + n] = (signed char)dct_coef(32, k, n);
-  }
-};
-__constant__ m32_table c_m32 = m32_table();
-
-// accumulator row of register g in lane half h: rows (g&3) + 8*(g>>2) + 4h
-__device__ __forceinline__ int kappa(int h, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
-
-union op16 { i32x4 v; signed char b[16]; u32 w[4]; };
-
-// byte planes of 16 int16 held as 8 dwords (element pairs): hi = X >> 8, lo' = (X & 255) - 128
-__device__ __forceinline__ void planes_from_rows(const u32 (&d)[8], op16 &hi, op16 &lo)
-{
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    lo.w[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x06040200u) ^ 0x80808080u;
-    hi.w[q] = __builtin_amdgcn_perm(d[2 * q + 1], d[2 * q], 0x07050301u);
-  }
-}
-// byte planes of 16 values held one per register (low 16 bits significant)
-__device__ __forceinline__ void planes_from_regs(const int (&t)[16], op16 &hi, op16 &lo, u32 lo_xor)
-{
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const u32 p01 = __builtin_amdgcn_perm((u32)t[4 * q + 1], (u32)t[4 * q], 0x05010400u);       // l0 l1 h0 h1
-    const u32 p23 = __builtin_amdgcn_perm((u32)t[4 * q + 3], (u32)t[4 * q + 2], 0x05010400u);   // l2 l3 h2 h3
-    lo.w[q] = __builtin_amdgcn_perm(p23, p01, 0x05040100u) ^ lo_xor;
-    hi.w[q] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
-  }
-}
-
-__device__ __forceinline__ i32x16 mfma_i8(const op16 &a, const op16 &b, i32x16 c)
-{
-  return __builtin_amdgcn_mfma_i32_32x32x32_i8(a.v, b.v, c, 0, 0, 0);
-}
-
-// 16-byte slot of logical chunk c (row j = c >> 2, quarter c & 3) inside the wave's 2 KiB LDS tile
-__device__ __forceinline__ int slot_of(int c) { const int j = c >> 2; return (c & ~3) | ((c & 3) ^ ((j >> 2) & 3)); }
-
-__device__ __forceinline__ void load_chunks(const i16 *blk, int lane, u32x4v (&c)[2])
-{
-  c[0] = __builtin_nontemporal_load((const u32x4v *)blk + lane);
-  c[1] = __builtin_nontemporal_load((const u32x4v *)blk + 64 + lane);
-}
-
-// linear chunks (lane l holds chunks l and 64 + l) -> lane (r, h) holds row r, columns 16h .. 16h+15
-__device__ __forceinline__ void chunks_to_rows(u8 *tile, int lane, int r, int h, const u32x4v (&c)[2], u32 (&d)[8])
-{
-  *(u32x4v *)(tile + slot_of(lane) * 16) = c[0];
-  *(u32x4v *)(tile + slot_of(64 + lane) * 16) = c[1];
-  const u32x4v a = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h) * 16);
-  const u32x4v b = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h + 1) * 16);
-  d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
-}
-
-// lane (r, h) holds out[r][kappa(h, g)], g = 0..15 (four runs of four consecutive int16)
-// -> linear chunks, stored with two coalesced 16-byte stores per lane
-__device__ __forceinline__ void rows_to_chunks_store(u8 *tile, int lane, int r, int h, const int (&o)[16], i16 *blk)
-{
-#pragma unroll
-  for (int gg = 0; gg < 4; ++gg) {
-    uint2 v;
-    v.x = __builtin_amdgcn_perm((u32)o[4 * gg + 1], (u32)o[4 * gg], 0x05040100u);
-    v.y = __builtin_amdgcn_perm((u32)o[4 * gg + 3], (u32)o[4 * gg + 2], 0x05040100u);
-    *(uint2 *)(tile + slot_of(4 * r + gg) * 16 + 8 * h) = v;     // columns 8gg + 4h .. +3 of row r
-  }
-  const u32x4v a = *(const u32x4v *)(tile + slot_of(lane) * 16);
-  const u32x4v b = *(const u32x4v *)(tile + slot_of(64 + lane) * 16);
-  *((u32x4v *)blk + lane) = a;
-  *((u32x4v *)blk + 64 + lane) = b;
-}
 
 template <bool INVERSE>
 __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
@@ -122,7 +40,6 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const signed char *M = c_m32.v;
-  const i32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 
   // constant operands (built once per wave)
   op16 t_nat, t_kap, t_col, t_id;
@@ -142,12 +59,7 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
   // (lane half, register): a 2 x 16 table in LDS, read back as broadcasts, instead of 16 live registers
   __shared__ __attribute__((aligned(16))) int s_c2[2][16];
   if (INVERSE) {
-    if (threadIdx.x < 32) {
-      const int row = kappa(threadIdx.x >> 4, threadIdx.x & 15);
-      int cs = 0;
-      for (int n = 0; n < 32; ++n) cs += M[n * 32 + row];
-      s_c2[threadIdx.x >> 4][threadIdx.x & 15] = 128 * cs + (1 << 11);
-    }
+    fill_inv_c2(s_c2);
     __syncthreads();
   }
 
@@ -163,43 +75,8 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
     op16 hi, lo;
     planes_from_rows(d, hi, lo);
     int o[16];
-    if (!INVERSE) {
-      // pass 1: T' = S * M^T  (A = S rows, B[n][k] = M[k][n]); D[j][k]: row j = kappa(h,g), col k = r
-      const i32x16 ah = mfma_i8(hi, t_nat, zero), al = mfma_i8(lo, t_nat, zero);
-      const int c1 = 128 * rowsum + (1 << 3);
-      int tt[16];
-#pragma unroll
-      for (int g = 0; g < 16; ++g) tt[g] = ((ah[g] << 8) + al[g] + c1) >> 4;       // low 16 bits = (short) wrap
-      // pass 2: D[k][x] = sum_j T'[j][k] * M[x][j] = out[x][k]  (A = T'^T from the accumulator, B[j][x] = M[x][j])
-      op16 h2, l2;
-      planes_from_regs(tt, h2, l2, 0x80808080u);
-      const i32x16 bh = mfma_i8(h2, t_kap, zero), bl = mfma_i8(l2, t_kap, zero);
-      const int c2 = 128 * rowsum + (1 << 10);
-#pragma unroll
-      for (int g = 0; g < 16; ++g) o[g] = ((bh[g] << 8) + bl[g] + c2) >> 11;
-    } else {
-      // transpose through the matrix core: D = in * I puts column r of `in` on lane r (rows kappa(h,g) in registers)
-      const i32x16 xh = mfma_i8(hi, t_id, zero), xl = mfma_i8(lo, t_id, zero);
-      int th[16], tl[16];
-#pragma unroll
-      for (int g = 0; g < 16; ++g) { th[g] = xh[g]; tl[g] = xl[g]; }
-      op16 ph, pl, dummy;
-      // the planes are already split: pack the low bytes of each
-      planes_from_regs(th, dummy, ph, 0u);
-      planes_from_regs(tl, dummy, pl, 0u);
-      // pass 1: U^T = in^T * M  (A = in^T, B[k2][j'] = M[k2][j']); D[k][j']: row k = kappa(h,g), col j' = r
-      const i32x16 ah = mfma_i8(ph, t_col, zero), al = mfma_i8(pl, t_col, zero);
-      const int c1 = 128 * colsum + (1 << 6);
-      int uu[16];
-#pragma unroll
-      for (int g = 0; g < 16; ++g) uu[g] = clip16(((ah[g] << 8) + al[g] + c1) >> 7);
-      // pass 2: D[i'][j'] = sum_k M[k][i'] * U[j'][k] = out[j'][i']  (A[i'][k] = M[k][i'], B = U^T from the accumulator)
-      op16 h2, l2;
-      planes_from_regs(uu, h2, l2, 0x80808080u);
-      const i32x16 bh = mfma_i8(t_col, h2, zero), bl = mfma_i8(t_col, l2, zero);
-#pragma unroll
-      for (int g = 0; g < 16; ++g) o[g] = clip16(((bh[g] << 8) + bl[g] + s_c2[h][g]) >> 12);
-    }
+    if (!INVERSE) fwd32_core(hi, lo, t_nat, t_kap, rowsum, o);
+    else inv32_core(hi, lo, t_id, t_col, colsum, s_c2[h], o);
     rows_to_chunks_store(tile, lane, r, h, o, out + t * 1024);
     cur[0] = nx1[0]; cur[1] = nx1[1]; nx1[0] = nx2[0]; nx1[1] = nx2[1];
   }

@@ -338,6 +338,12 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
   }
 }
 
+namespace kvzhip {
+int launch_quantize_residual32_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
+                                    int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
+                                    int dq_scale, const int32_t *dqtable, hipStream_t st);
+}
+
 extern "C" {
 
 int kvz_hip_quant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *coef, kvz_hip_coeff *q_coef,
@@ -397,6 +403,10 @@ int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_int
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
+  if (width == 32 && !use_trskip && !k.signhide &&
+      ((((uintptr_t)ref_in | (uintptr_t)pred_in | (uintptr_t)rec_out | (uintptr_t)coeff_out) & 15) == 0))
+    return launch_quantize_residual32_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
+                                           k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, st);
 #define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, 16)), dim3(256), 0, st, \
                                           ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, scan_order, k)
   switch (width) {
