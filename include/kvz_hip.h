@@ -148,6 +148,29 @@ KVZ_HIP_API int kvz_hip_satd_any_size_quad_batch(const kvz_hip_pixel *preds, uin
                                                  const kvz_hip_pixel *orig, uint32_t orig_stride,
                                                  const kvz_hip_block_pair *pairs, size_t count,
                                                  uint32_t *costs, kvz_hip_stream s);
+/* Batched integer motion-estimation costs, one CTU per workgroup: what check_mv_cost
+ * (search_inter.c:195-232) computes one candidate at a time through
+ * kvz_image_calc_sad (image.c:455-486), for every candidate of a pattern and every
+ * square PU size of the CTU in one launch.  For CTU i (64x64 at (x, y) in `pic`),
+ * search centre (mvx, mvy) in full pels, and candidate m = centre + mv_offsets[m]:
+ *   costs[(i*n_mv + m)*85 + k] = kvz_image_calc_sad(pic, ref, bx, by, bx + mv, by + mv, bw, bw)
+ * with k = 0: the 64x64 PU; 1..4: the 32x32 PUs, 5..20: 16x16, 21..84: 8x8, each
+ * group in raster order inside the CTU.  The reference block may leave the frame
+ * (edge replicated).  PUs not entirely inside `pic` (ragged last CTU row/column)
+ * get 0xFFFFFFFF.  The CTU's source block and its search window are fetched from
+ * HBM once and stay in LDS; larger PUs are sums of the 8x8 SADs.
+ * |mv_offsets| <= 64 in each component. */
+typedef struct {
+  int32_t x, y;            /* CTU top-left in the picture (multiples of 8) */
+  int32_t mvx, mvy;        /* search centre, full-pel */
+} kvz_hip_ctu_search;
+#define KVZ_HIP_CTU_PUS 85
+KVZ_HIP_API int kvz_hip_ctu_sad_grid_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
+                                           const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                           const kvz_hip_ctu_search *ctus, size_t count,
+                                           const int16_t *mv_offsets /* device, [n_mv][2] = (dx, dy) */, int n_mv,
+                                           uint32_t *costs /* [count][n_mv][85] */, kvz_hip_stream s);
+
 /* inter_recon_bipred_func's blend (picture-generic.c:538-588) for `count` planes
  * of w x h samples laid out contiguously (stride w): each source is either 14-bit
  * int16 samples (hi_prec != 0) or pixels. */

@@ -68,6 +68,7 @@ SIGNATURES = {
     "kvz_hip_image_calc_satd_batch": (_I, [_P, _U, _P, _U, _I, _I, _P, _SZ, _P, _P]),
     "kvz_hip_pixels_calc_ssd_batch": (_I, [_P, _U, _P, _U, _P, _SZ, _P, _P]),
     "kvz_hip_satd_any_size_quad_batch": (_I, [_P, _U, _SZ, _P, _U, _P, _SZ, _P, _P]),
+    "kvz_hip_ctu_sad_grid_batch": (_I, [_P, _U, _I, _I, _P, _U, _I, _I, _P, _SZ, _P, _I, _P, _P]),
     "kvz_hip_bipred_blend_batch": (_I, [_I, _I, _I, _P, _I, _P, _P, _SZ, _P]),
     "kvz_hip_transform_batch": (_I, [_I, _I, _P, _P, _SZ, _P]),
     "kvz_hip_quant_batch": (_I, [C.POINTER(QuantParams), _P, _P, _I, _I, _I, _SZ, _P]),

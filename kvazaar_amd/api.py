@@ -145,6 +145,21 @@ def bipred_blend_batch(w, h, hi0, s0, hi1, s1):
     return o.to_numpy(np.uint8, (count, h, w))
 
 
+def ctu_sad_grid_batch(pic, ref, ctus, mv_offsets):
+    """ctus: (x, y, mvx, mvy) rows; mv_offsets: (dx, dy) rows -> uint32 [n_ctu, n_mv, 85]"""
+    L = _lib.init()
+    pic = np.ascontiguousarray(pic, dtype=np.uint8)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    c = np.ascontiguousarray(np.asarray(ctus, dtype=np.int32).reshape(-1, 4))
+    mv = np.ascontiguousarray(np.asarray(mv_offsets, dtype=np.int16).reshape(-1, 2))
+    n, k = c.shape[0], mv.shape[0]
+    a, b, dc, dm, o = (DeviceBuffer.from_numpy(pic), DeviceBuffer.from_numpy(ref), DeviceBuffer.from_numpy(c),
+                       DeviceBuffer.from_numpy(mv), DeviceBuffer(4 * 85 * n * k))
+    check(L.kvz_hip_ctu_sad_grid_batch(a.ptr, pic.shape[1], pic.shape[1], pic.shape[0], b.ptr, ref.shape[1], ref.shape[1],
+                                       ref.shape[0], dc.ptr, n, dm.ptr, k, o.ptr, None), "ctu_sad_grid batch")
+    return o.to_numpy(np.uint32, (n, k, 85))
+
+
 # ------------------------------------------------------------------ dct
 def transform_batch(kind, n, blocks):
     L = _lib.init()

@@ -806,3 +806,30 @@ void orc_search_frac_costs(const orc_pixel *pic, int pic_stride,
   }
   free(st); free(filtered); free(ext);
 }
+
+/* Batched ME costs of one CTU: the values check_mv_cost (search_inter.c:195-232) obtains
+ * one by one from kvz_image_calc_sad (image.c:455-486), for every candidate offset and
+ * each of the 85 square PUs (64x64, 4 x 32x32, 16 x 16x16, 64 x 8x8; raster order per
+ * size).  PUs not entirely inside the picture get 0xFFFFFFFF. */
+void orc_ctu_sad_grid(const orc_pixel *pic, int pic_stride, int pic_w, int pic_h,
+                      const orc_pixel *ref, int ref_stride, int ref_w, int ref_h,
+                      int ctu_x, int ctu_y, int mvx, int mvy,
+                      const int16_t *mv_offsets, int n_mv, uint32_t *costs)
+{
+  static const int sizes[4] = { 64, 32, 16, 8 }, first[4] = { 0, 1, 5, 21 };
+  for (int m = 0; m < n_mv; ++m) {
+    const int dx = mv_offsets[2 * m], dy = mv_offsets[2 * m + 1];
+    uint32_t *o = costs + (size_t)m * 85;
+    for (int l = 0; l < 4; ++l) {
+      const int n = sizes[l], per = 64 / n;
+      for (int j = 0; j < per; ++j)
+        for (int i = 0; i < per; ++i) {
+          const int bx = ctu_x + i * n, by = ctu_y + j * n;
+          uint32_t v = 0xffffffffu;
+          if (dx >= -64 && dx <= 64 && dy >= -64 && dy <= 64 && bx + n <= pic_w && by + n <= pic_h)
+            v = orc_image_calc_sad(pic, pic_stride, ref, ref_stride, ref_w, ref_h, bx, by, bx + mvx + dx, by + mvy + dy, n, n);
+          o[first[l] + j * per + i] = v;
+        }
+    }
+  }
+}

@@ -75,6 +75,12 @@ unsigned orc_image_calc_satd(const orc_pixel *pic, int pic_stride,
                              const orc_pixel *ref, int ref_stride, int ref_w, int ref_h,
                              int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh);
 
+/* batched ME costs of one CTU (check_mv_cost, search_inter.c:195-232, over image.c:455-486) */
+void orc_ctu_sad_grid(const orc_pixel *pic, int pic_stride, int pic_w, int pic_h,
+                      const orc_pixel *ref, int ref_stride, int ref_w, int ref_h,
+                      int ctu_x, int ctu_y, int mvx, int mvy,
+                      const int16_t *mv_offsets, int n_mv, uint32_t *costs /* [n_mv][85] */);
+
 /* ---- dct group (strategies/generic/dct-generic.c) ---- */
 enum orc_tr_kind { ORC_DCT = 0, ORC_IDCT = 1, ORC_DST = 2, ORC_IDST = 3 };
 /* n in {4,8,16,32}; DST only for n==4.  :567-617 */

@@ -54,6 +54,8 @@ def lib():
         for f in ("orc_image_calc_sad", "orc_image_calc_satd"):
             getattr(L, f).restype = C.c_uint
             getattr(L, f).argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int] + [C.c_int] * 6
+        L.orc_ctu_sad_grid.restype = None
+        L.orc_ctu_sad_grid.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int] + [C.c_int] * 4 + [i16p, C.c_int, u32p]
         L.orc_transform.restype = None
         L.orc_transform.argtypes = [C.c_int, C.c_int, i16p, i16p]
         L.orc_dct_matrix.restype = i16p
@@ -284,3 +286,16 @@ def search_frac_costs(pic, ref, x, y, w, h, mvx, mvy):
     lib().orc_search_frac_costs(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],
                                 x, y, w, h, mvx, mvy, _p(costs, u32p), best)
     return costs, (best[0], best[1])
+
+
+def ctu_sad_grid(pic, ref, ctus, mv_offsets):
+    """ctus: (x, y, mvx, mvy) rows; mv_offsets: (dx, dy) rows -> uint32 [n_ctu, n_mv, 85]"""
+    pic, ref = _u8(pic), _u8(ref)
+    mv = np.ascontiguousarray(mv_offsets, dtype=np.int16).reshape(-1, 2)
+    ctus = np.asarray(ctus, dtype=np.int32).reshape(-1, 4)
+    out = np.zeros((ctus.shape[0], mv.shape[0], 85), dtype=np.uint32)
+    for i, (x, y, mvx, mvy) in enumerate(ctus):
+        lib().orc_ctu_sad_grid(_p(pic, u8p), pic.shape[1], pic.shape[1], pic.shape[0], _p(ref, u8p), ref.shape[1],
+                               ref.shape[1], ref.shape[0], int(x), int(y), int(mvx), int(mvy), _p(mv, i16p), mv.shape[0],
+                               _p(out[i], u32p))
+    return out

@@ -344,3 +344,27 @@ def test_search_frac_extreme_pixels(api):
         oc, ob = O.search_frac_costs(pic, ref, p[0], p[1], 16, 16, p[2] - p[0], p[3] - p[1])
         np.testing.assert_array_equal(costs[i], oc)
         assert tuple(best[i]) == ob
+
+
+# ------------------------------------------------------------------ batched ME
+def test_ctu_sad_grid(api):
+    """one CTU per workgroup: all candidates x all 85 square PUs == kvz_image_calc_sad per (PU, candidate)"""
+    g = rng(90)
+    H, W = 200, 264                       # ragged: last CTU row 8 px high, last CTU column 8 px wide
+    ref = g.integers(0, 256, (H, W), dtype=np.uint8)
+    pic = np.clip(np.roll(ref, (2, -3), axis=(0, 1)).astype(np.int32) + g.integers(-5, 6, (H, W)), 0, 255).astype(np.uint8)
+    ctus = [(x, y, mvx, mvy) for y in range(0, H, 64) for x in range(0, W, 64)
+            for (mvx, mvy) in ((0, 0), (3, -2), (-70, 5), (40, 150))]
+    grid = [(dx, dy) for dy in (-6, -3, 0, 3, 6) for dx in (-6, -3, 0, 3, 6)]           # speed_tests.c:205-236
+    hexbs = [(0, 0), (-2, 0), (-1, -2), (1, -2), (2, 0), (1, 2), (-1, 2), (1, 0), (0, 1), (-1, 0), (0, -1)]
+    wide = [(-64, -64), (64, 64), (17, -33), (-1, 1), (65, 0), (0, -100)]                # incl. two out-of-range offsets
+    for offs in (grid, hexbs, wide):
+        got = api.ctu_sad_grid_batch(pic, ref, ctus, offs)
+        want = O.ctu_sad_grid(pic, ref, ctus, offs)
+        np.testing.assert_array_equal(got, want)
+    # hierarchy: a 16x16 cost equals the sum of its four 8x8 costs where all are valid
+    c = api.ctu_sad_grid_batch(pic, ref, [(0, 0, 1, 1)], grid)[0]
+    s8 = c[:, 21:].reshape(-1, 8, 8).astype(np.int64)
+    s16 = s8.reshape(-1, 4, 2, 4, 2).sum(axis=(2, 4)).reshape(-1, 16)
+    np.testing.assert_array_equal(c[:, 5:21], s16)
+    assert (c[:, 0] == s8.sum(axis=(1, 2))).all()

@@ -78,6 +78,25 @@ def main():
                       lambda n=n, cnt2=cnt2: L.kvz_hip_quantize_residual_batch(C.byref(qp), 0, n, 0, 0, 0, a8.data_ptr(), b8.data_ptr(),
                                                                               o8.data_ptr(), o16.data_ptr(), has.data_ptr(), cnt2, st)))
 
+    # batched ME: 1080p CTU grid x frames, the speed_tests.c +-6 grid (25 candidates) -> 85 PU costs each
+    import numpy as np
+    W, H, F = 1920, 1080, 16
+    picf = torch.randint(0, 256, (F * H, W), dtype=torch.uint8, device=dev, generator=g)
+    reff = torch.roll(picf, shifts=(1, 2), dims=(0, 1)).contiguous()
+    ctu_list = np.array([(x, f * H + y, 0, 0) for f in range(F) for y in range(0, H - 63, 64) for x in range(0, W, 64)], dtype=np.int32)
+    ctus_d = torch.from_numpy(ctu_list).to(dev)
+    for label, offs in (("grid25", [(dx, dy) for dy in (-6, -3, 0, 3, 6) for dx in (-6, -3, 0, 3, 6)]),
+                        ("full8", [(dx, dy) for dy in range(-8, 9) for dx in range(-8, 9)])):
+        mv_d = torch.tensor(offs, dtype=torch.int16, device=dev)
+        out_d = torch.empty((len(ctu_list), len(offs), 85), dtype=torch.int32, device=dev)
+        n_sad8 = len(ctu_list) * len(offs) * 64
+        # bytes per 8x8-candidate: the HBM traffic of this kernel divided by the 8x8 SADs it produces
+        bpb = (len(ctu_list) * (4096 + (64 + 16) ** 2) + out_d.numel() * 4) / n_sad8
+        cases.append(("ctu_sad_%s(8x8 cands)" % label, n_sad8, bpb,
+                      lambda mv_d=mv_d, out_d=out_d, offs=offs: L.kvz_hip_ctu_sad_grid_batch(
+                          picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, ctus_d.data_ptr(), len(ctu_list),
+                          mv_d.data_ptr(), len(offs), out_d.data_ptr(), st)))
+
     tune_key, tune_vals = None, [None]
     if args.tune:
         tune_key, vals = args.tune.split("=")
