@@ -119,14 +119,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: kvazaar_amd has no CPU path")
+    # rehearsal knobs for a 1-GPU box (never set by the driver): ranks share device 0 and rendezvous over gloo,
+    # because RCCL refuses two ranks on one device
+    backend = os.environ.get("KVZ_BENCH_BACKEND", "nccl")
+    if os.environ.get("KVZ_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from kvazaar_amd import _lib
     L = _lib.init(local_rank)
@@ -169,7 +178,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -348,6 +348,141 @@ __global__ __launch_bounds__(256) void satd8_kernel(const u8 *__restrict__ a, co
   }
 }
 
+// ---------------------------------------------------------------------------
+// satd_16x16 with the same streaming scheme: lane = one 16-byte chunk = one row
+// of a 16x16 block (16 lanes per block) = one row of its left and of its right
+// 8x8 sub-block.  Horizontal stages in registers; the three vertical stages cross
+// 8 lanes: quad_perm for row bits 0/1, a row_shl:4 / row_shr:4 pair (bank-masked)
+// for row bit 2.  Per-sub-block rounding (sum+2)>>2 is applied before the four
+// sub-blocks are added (strategies-picture.h:40-56).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ v2s dpp_xor4_v2s(v2s v)
+{
+  int t = __builtin_amdgcn_update_dpp(0, (int)as_u32(v), 0x104, 0xF, 0x5, false);      // row_shl:4 into banks 0, 2
+  t = __builtin_amdgcn_update_dpp(t, (int)as_u32(v), 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1, 3
+  return as_v2s((u32)t);
+}
+__device__ __forceinline__ u32 dpp_xor4_u32(u32 v)
+{
+  int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
+  t = __builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+  return (u32)t;
+}
+
+// x, y: row `lane & 15` of the block in each array.  Returns the block's SATD in every lane of its 16-lane row.
+__device__ __forceinline__ u32 satd16_row_part(uint4 x, uint4 y, v2s m1, v2s m2, v2s m4)
+{
+  v2s d[8];
+  d[0] = unpack_lo(x.x) - unpack_lo(y.x); d[1] = unpack_hi(x.x) - unpack_hi(y.x);
+  d[2] = unpack_lo(x.y) - unpack_lo(y.y); d[3] = unpack_hi(x.y) - unpack_hi(y.y);
+  d[4] = unpack_lo(x.z) - unpack_lo(y.z); d[5] = unpack_hi(x.z) - unpack_hi(y.z);
+  d[6] = unpack_lo(x.w) - unpack_lo(y.w); d[7] = unpack_hi(x.w) - unpack_hi(y.w);
+  u32 m[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {          // left / right 8x8 sub-block
+    v2s *e = d + 4 * s;
+    v2s s0 = e[0] + e[2], s1 = e[1] + e[3], f0 = e[0] - e[2], f1 = e[1] - e[3];     // column bits 2, 1
+    v2s w[4] = { s0 + s1, s0 - s1, f0 + f1, f0 - f1 };
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v2s t = dpp_v2s<0xB1>(w[i]);       // row bit 0
+      v2s u = w[i] * m1 + t;
+      t = dpp_v2s<0x4E>(u);              // row bit 1
+      u = u * m2 + t;
+      t = dpp_xor4_v2s(u);               // row bit 2
+      u = u * m4 + t;
+      acc += absmax_halves(u);           // column bit 0 folded
+    }
+    // sum over the 8 rows of the sub-block, then its rounding
+    acc += dpp_mov<0xB1>(acc);
+    acc += dpp_mov<0x4E>(acc);
+    acc += dpp_xor4_u32(acc);
+    m[s] = (acc + 1) >> 1;
+  }
+  u32 r = m[0] + m[1];                   // top (lanes 0-7) or bottom (lanes 8-15) pair of sub-blocks
+  r += dpp_mov<0x128>(r);                // row_ror:8 -> the other pair
+  return r;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void satd16_kernel(const u8 *__restrict__ a, const u8 *__restrict__ b,
+                                                     u32 *__restrict__ costs, size_t count)
+{
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  const size_t total_chunks = count * 16;
+  constexpr size_t CH = (size_t)64 * U;
+  const short sg1 = (lane & 1) ? (short)-1 : (short)1, sg2 = (lane & 2) ? (short)-1 : (short)1, sg4 = (lane & 4) ? (short)-1 : (short)1;
+  const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 }, m4 = { sg4, sg4 };
+
+  for (size_t base = wave * CH; base < total_chunks; base += nwaves * CH) {
+    const bool full = base + CH <= total_chunks;
+    uint4 x[U], y[U];
+    if (full) {
+      const u8 *pa = a + (base + lane) * 16, *pb = b + (base + lane) * 16;
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = ld_stream16(pa + u * 1024);
+#pragma unroll
+      for (int u = 0; u < U; ++u) y[u] = ld_stream16(pb + u * 1024);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t c = base + (size_t)u * 64 + lane;
+        const size_t cc = c < total_chunks ? c : total_chunks - 1;
+        x[u] = ld_stream16(a + cc * 16);
+        y[u] = ld_stream16(b + cc * 16);
+      }
+    }
+    u32 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = satd16_row_part(x[u], y[u], m1, m2, m4);
+    const int g = lane >> 4, p = lane & 15;          // 4 blocks per wave-load
+    if (p < U) {
+      u32 v = r[0];
+#pragma unroll
+      for (int i = 1; i < U; ++i) v = (p == i) ? r[i] : v;
+      const size_t blk = (base + (size_t)p * 64) / 16 + g;
+      if (blk < count) costs[blk] = v;
+    }
+  }
+}
+
+// satd_4x4 streaming: lane = one block pair per load, U loads per array in flight
+template <int U>
+__global__ __launch_bounds__(256) void satd4_kernel(const u8 *__restrict__ a, const u8 *__restrict__ b,
+                                                    u32 *__restrict__ costs, size_t count)
+{
+  const int lane = threadIdx.x & 63;
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  constexpr size_t CH = (size_t)64 * U;
+  for (size_t base = wave * CH; base < count; base += nwaves * CH) {
+    const bool full = base + CH <= count;
+    uint4 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = base + (size_t)u * 64 + lane;
+      const size_t cc = (full || c < count) ? c : count - 1;
+      x[u] = ld_stream16(a + cc * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = base + (size_t)u * 64 + lane;
+      const size_t cc = (full || c < count) ? c : count - 1;
+      y[u] = ld_stream16(b + cc * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t c = base + (size_t)u * 64 + lane;
+      u32 ra[4] = { x[u].x, x[u].y, x[u].z, x[u].w }, rb[4] = { y[u].x, y[u].y, y[u].z, y[u].w };
+      const u32 v = satd4x4_regs(ra, rb);
+      if (full || c < count) costs[c] = v;
+    }
+  }
+}
+
 // satd_4x4 / satd_4x4_dual: lane = one 16-byte block pair
 template <bool DUAL>
 __global__ __launch_bounds__(256) void satd_4x4_kernel(const u8 *__restrict__ a, const u8 *__restrict__ b,
@@ -619,12 +754,18 @@ static int launch_satd(int n, const u8 *a, const u8 *b, size_t count, u32 *costs
 {
   const unsigned threads = 256;
   switch (n) {
-    case 4: hipLaunchKernelGGL((satd_4x4_kernel<DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    case 4:
+      if (!DUAL) hipLaunchKernelGGL((satd4_kernel<4>), dim3(stream_grid(count, threads * 4)), dim3(threads), 0, st, a, b, costs, count);
+      else hipLaunchKernelGGL((satd_4x4_kernel<DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is);
+      break;
     case 8:
       if (!DUAL) hipLaunchKernelGGL((satd8_kernel<4>), dim3(stream_grid(count * 4, threads * 4, (unsigned)tuning("satd8_wgs_per_cu", 8))), dim3(threads), 0, st, a, b, costs, count);
       else hipLaunchKernelGGL((satd_nxn_kernel<8, DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is);
       break;
-    case 16: hipLaunchKernelGGL((satd_nxn_kernel<16, DUAL>), dim3(stream_grid(count * 4, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
+    case 16:
+      if (!DUAL) hipLaunchKernelGGL((satd16_kernel<4>), dim3(stream_grid(count * 16, threads * 4)), dim3(threads), 0, st, a, b, costs, count);
+      else hipLaunchKernelGGL((satd_nxn_kernel<16, DUAL>), dim3(stream_grid(count * 4, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is);
+      break;
     case 32: hipLaunchKernelGGL((satd_nxn_kernel<32, DUAL>), dim3(stream_grid(count * 16, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
     case 64: hipLaunchKernelGGL((satd_nxn_kernel<64, DUAL>), dim3(stream_grid(count * 64, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
     default: return KVZ_HIP_ERR_INVALID;
