@@ -260,21 +260,38 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
   __shared__ __attribute__((aligned(16))) i16 sq[TPB * N * N];      // quantized coefficients (row-major, unpadded)
   __shared__ int s_has[TPB];
 
+  __shared__ __attribute__((aligned(16))) u8 sp[TPB * N * N];       // prediction, overwritten in place by the reconstruction
+
   const int tid = threadIdx.x, tu = tid / N, row = tid % N;
   const size_t ngroups = (count + TPB - 1) / TPB;
   i16 *a = sa + tu * N * LD, *b = sb + tu * N * LD, *q = sq + tu * N * N;
+  u8 *pp = sp + tu * N * N + row * N;
+  constexpr int PCH = TPB * N * N / 16;              // 16-pixel chunks per group (64 .. 512)
 
   for (size_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-    const size_t blk = g * TPB + tu;
+    const size_t first = g * TPB;
+    const size_t blk = first + tu;
     const bool valid = blk < count;
-    const size_t base = (valid ? blk : 0) * (size_t)(N * N) + (size_t)row * N;
-    int pred[N];
-    // residual row (ref - pred) as int16
+    // stage in: coalesced 16-byte loads of ref and pred; residual (ref - pred) as int16 into `a`, pred kept in LDS
 #pragma unroll
-    for (int x = 0; x < N; ++x) {
-      const int r = ref_in[base + x], p = pred_in[base + x];
-      pred[x] = p;
-      a[row * LD + x] = (i16)(r - p);
+    for (int c = tid; c < PCH; c += 256) {
+      const int e = c * 16, t = e / (N * N), w = e % (N * N);
+      uint4 rv = make_uint4(0, 0, 0, 0), pv = rv;
+      if (first + t < count) {
+        rv = *(const uint4 *)(ref_in + first * (size_t)(N * N) + e);
+        pv = *(const uint4 *)(pred_in + first * (size_t)(N * N) + e);
+      }
+      *(uint4 *)(sp + e) = pv;
+      const u32 rr[4] = { rv.x, rv.y, rv.z, rv.w }, pq[4] = { pv.x, pv.y, pv.z, pv.w };
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {                  // 8 residuals = one 16-byte LDS store
+        union { uint4 v; i16 s[8]; } o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          o.s[i] = (i16)((int)((rr[2 * j + (i >> 2)] >> (8 * (i & 3))) & 255u) - (int)((pq[2 * j + (i >> 2)] >> (8 * (i & 3))) & 255u));
+        const int ww = w + 8 * j;
+        *(uint4 *)(sa + t * N * LD + (ww / N) * LD + (ww % N)) = o.v;
+      }
     }
     if (row == 0) s_has[tu] = 0;
     __syncthreads();
@@ -321,18 +338,25 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
       transform_2d_lds<N, TRK + 1, LD>(a, b, row);
     }
     __syncthreads();
-    if (valid) {
+    if (has) {                                       // reconstruction over the prediction, in place
 #pragma unroll
       for (int x = 0; x < N; ++x) {
-        int out = pred[x];
-        if (has) {
-          const i16 val = (i16)((int)a[row * LD + x] + pred[x]);
-          out = val < 0 ? 0 : (val > 255 ? 255 : val);
-        }
-        rec_out[base + x] = (u8)out;
-        coeff_out[base + x] = q[row * N + x];
+        const i16 val = (i16)((int)a[row * LD + x] + (int)pp[x]);
+        pp[x] = (u8)(val < 0 ? 0 : (val > 255 ? 255 : val));
       }
-      if (row == 0) has_coeffs[blk] = has;
+    }
+    if (valid && row == 0) has_coeffs[blk] = has;
+    __syncthreads();
+    // stage out: coalesced 16-byte stores of the reconstruction and of the quantized coefficients
+#pragma unroll
+    for (int c = tid; c < PCH; c += 256) {
+      const int e = c * 16, t = e / (N * N);
+      if (first + t < count) *(uint4 *)(rec_out + first * (size_t)(N * N) + e) = *(const uint4 *)(sp + e);
+    }
+#pragma unroll
+    for (int c = tid; c < 2 * PCH; c += 256) {
+      const int e = c * 8, t = e / (N * N);
+      if (first + t < count) *(uint4 *)(coeff_out + first * (size_t)(N * N) + e) = *(const uint4 *)(sq + e);
     }
     __syncthreads();
   }
@@ -400,11 +424,11 @@ int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_int
   const int tq = color == 0 ? 0 : 2, tdq = color == 0 ? 0 : (color == 1 ? 2 : 3);
   if (!p || !ref_in || !pred_in || !rec_out || !coeff_out || !has_coeffs || color < 0 || color > 2 ||
       scan_order < 0 || scan_order > 2 || !make_consts(p, width, tq, tdq, &k)) return KVZ_HIP_ERR_INVALID;
+  if ((((uintptr_t)ref_in | (uintptr_t)pred_in | (uintptr_t)rec_out | (uintptr_t)coeff_out) & 15) != 0) return KVZ_HIP_ERR_INVALID;
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
-  if (width == 32 && !use_trskip && !k.signhide &&
-      ((((uintptr_t)ref_in | (uintptr_t)pred_in | (uintptr_t)rec_out | (uintptr_t)coeff_out) & 15) == 0))
+  if (width == 32 && !use_trskip && !k.signhide)
     return launch_quantize_residual32_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
                                            k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, st);
 #define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, 16)), dim3(256), 0, st, \
