@@ -128,93 +128,98 @@ __device__ __forceinline__ u32 satd8x8_lds(const u8 *a, int sa, const u8 *b, int
   return (m + 1) >> 1;
 }
 
-#define FR_PS 72                 /* P window row stride: cols -4 .. w+3 (<= 72) */
-#define FR_HS 65                 /* H plane row stride: cols -1 .. w-1 (<= 65) */
+#define FR_HS 65                 /* H plane row stride of the per-call filter step kernel */
 
 struct frac_cand { int fx, fy, ry, cx; };
 // square[] of search_inter.c:972-976
 __constant__ signed char c_sq_x[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 };
 __constant__ signed char c_sq_y[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
 
-__global__ __launch_bounds__(256) void search_frac_kernel(const u8 *__restrict__ pic, u32 pic_stride, refplane_t ref,
-                                                          const kvz_hip_block_pair *__restrict__ pairs,
-                                                          u32 *__restrict__ costs, i32 *__restrict__ best)
+// LDS geometry of one block's working set.  BIG: blocks up to 64x64, the whole 256-thread workgroup
+// cooperates (barriers).  SMALL: blocks up to 16x16, ONE WAVE per block, four blocks per workgroup,
+// wave-private LDS slices and no barrier (DS operations of a wave execute in order).
+template <int MAXW>
+struct frac_geom {
+  static constexpr int PS = MAXW + 8;                 // P window stride: cols -4 .. w+3
+  static constexpr int PR = MAXW + 8;                 // P rows -4 .. h+3
+  static constexpr int HS = MAXW + 1;                 // H plane stride: cols -1 .. w-1
+  static constexpr int CS = MAXW;                     // cur / candidate stride
+  static constexpr int P_BYTES = PS * PR, CUR_BYTES = CS * MAXW, H_ELEMS = PR * HS, CAND_BYTES = CS * MAXW;
+  static constexpr int TOTAL = ((P_BYTES + CUR_BYTES + 4 * CAND_BYTES + 15) & ~15) + 3 * H_ELEMS * 2 + 32;
+};
+
+template <int MAXW, int T, bool WAVE>
+__device__ __forceinline__ void search_frac_core(int tid, u8 *lds, const u8 *__restrict__ pic, u32 pic_stride, const refplane_t &ref,
+                                                 const kvz_hip_block_pair &d, u32 *__restrict__ out, i32 *__restrict__ best)
 {
-  __shared__ u8 s_p[72 * FR_PS];          // P rows -4 .. h+3
-  __shared__ u8 s_cur[64 * 64];
-  __shared__ i16 s_h[3][72 * FR_HS];      // H planes: [0] fx = 2, [1] left qpel filter, [2] right qpel filter
-  __shared__ u8 s_cand[4][64 * 64];
-  __shared__ u32 s_cost[4];
-  __shared__ int s_sel[2];
+  typedef frac_geom<MAXW> G;
+  u8 *s_p = lds, *s_cur = s_p + G::P_BYTES, *s_cand = s_cur + G::CUR_BYTES;
+  i16 *s_h = (i16 *)(lds + ((G::P_BYTES + G::CUR_BYTES + 4 * G::CAND_BYTES + 15) & ~15));
+  u32 *s_cost = (u32 *)(s_h + 3 * G::H_ELEMS);
+  int *s_sel = (int *)(s_cost + 4);
+  auto sync = [&]() { if (!WAVE) __syncthreads(); };
 
-  const kvz_hip_block_pair d = pairs[blockIdx.x];
-  const int w = d.width, h = d.height, tid = threadIdx.x;
+  const int w = d.width, h = d.height;
   const int pw = w + 8, ph = h + 8;
-  if (w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7)) {      // unsupported shape: flag it, touch nothing
-    if (tid < 17) costs[(size_t)blockIdx.x * 17 + tid] = 0xffffffffu;
-    if (tid < 2) best[(size_t)blockIdx.x * 2 + tid] = -1;
-    return;
-  }
-
-  for (int i = tid; i < pw * ph; i += 256) {
+  for (int i = tid; i < pw * ph; i += T) {
     const int y = i / pw, x = i - y * pw;
-    s_p[y * FR_PS + x] = ref_px(ref, d.x2 - 4 + x, d.y2 - 4 + y);
+    s_p[y * G::PS + x] = ref_px(ref, d.x2 - 4 + x, d.y2 - 4 + y);
   }
-  for (int i = tid; i < w * h; i += 256) {
+  for (int i = tid; i < w * h; i += T) {
     const int y = i / w, x = i - y * w;
-    s_cur[y * 64 + x] = pic[(size_t)(d.y1 + y) * pic_stride + d.x1 + x];
+    s_cur[y * G::CS + x] = pic[(size_t)(d.y1 + y) * pic_stride + d.x1 + x];
   }
-  __syncthreads();
+  sync();
 
   // H plane for filter f: rows r = -4 .. h+3 (index r+4), cols c = -1 .. w-1 (index c+1)
   auto hor_plane = [&](int f, i16 *dst) {
     const signed char *fl = c_luma_filter[f];
-    for (int i = tid; i < ph * (w + 1); i += 256) {
+    for (int i = tid; i < ph * (w + 1); i += T) {
       const int y = i / (w + 1), x = i - y * (w + 1);     // c = x - 1 -> P cols c-3 .. c+4 -> window index x .. x+7
       int acc = 0;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc += fl[t] * (int)s_p[y * FR_PS + x + t];
-      dst[y * FR_HS + x] = (i16)acc;
+      for (int t = 0; t < 8; ++t) acc += fl[t] * (int)s_p[y * G::PS + x + t];
+      dst[y * G::HS + x] = (i16)acc;
     }
   };
-  // candidate k of a step: S(fx, fy; y + ry, x + cx) for the whole block
+  // candidate: S(fx, fy; y + ry, x + cx) for the whole block
   auto filter_cand = [&](const frac_cand &c, int plane, u8 *dst) {
     const signed char *vf = c_luma_filter[c.fy];
-    for (int i = tid; i < w * h; i += 256) {
+    for (int i = tid; i < w * h; i += T) {
       const int y = i / w, x = i - y * w;
       const int r = y + c.ry, cc = x + c.cx;              // H row index of (r-3+j) is r+1+j, col index cc+1
       int acc = 0;
       if (plane < 0) {                                    // fx == 0: H_0 = 64 * P
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += vf[j] * 64 * (int)s_p[(r + 1 + j) * FR_PS + cc + 4];
+        for (int j = 0; j < 8; ++j) acc += vf[j] * 64 * (int)s_p[(r + 1 + j) * G::PS + cc + 4];
       } else {
+        const i16 *pl = s_h + plane * G::H_ELEMS;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += vf[j] * (int)s_h[plane][(r + 1 + j) * FR_HS + cc + 1];
+        for (int j = 0; j < 8; ++j) acc += vf[j] * (int)pl[(r + 1 + j) * G::HS + cc + 1];
       }
-      dst[y * 64 + x] = round_clip16((i16)(acc >> 6));
+      dst[y * G::CS + x] = round_clip16((i16)(acc >> 6));
     }
   };
   // SATD of candidates 0..ncand-1 against s_cur -> s_cost
   auto score = [&](int ncand, const u8 *cand0, int cand_stride, int cand_pitch) {
     if (tid < 4) s_cost[tid] = 0;
-    __syncthreads();
+    sync();
     const int w8 = w >> 3, n8 = w8 * (h >> 3);
-    for (int i = tid; i < ncand * n8; i += 256) {
+    for (int i = tid; i < ncand * n8; i += T) {
       const int k = i / n8, sb = i - k * n8, by = sb / w8, bx = sb - by * w8;
-      const u32 v = satd8x8_lds(s_cur + by * 8 * 64 + bx * 8, 64, cand0 + (size_t)k * cand_pitch + by * 8 * cand_stride + bx * 8, cand_stride);
+      const u32 v = satd8x8_lds(s_cur + by * 8 * G::CS + bx * 8, G::CS, cand0 + (size_t)k * cand_pitch + by * 8 * cand_stride + bx * 8, cand_stride);
       atomicAdd(&s_cost[k], v);
     }
-    __syncthreads();
+    sync();
   };
 
-  u32 *out = costs + (size_t)blockIdx.x * 17;
   // integer position: candidate = P[y][x]
-  score(1, s_p + 4 * FR_PS + 4, FR_PS, 0);
+  score(1, s_p + 4 * G::PS + 4, G::PS, 0);
   u32 best_cost = s_cost[0];
   if (tid == 0) out[0] = best_cost;
 
-  hor_plane(2, s_h[0]);
-  __syncthreads();
+  hor_plane(2, s_h);
+  sync();
 
   int best_index = 0;
   for (int step = 0; step < 4; ++step) {
@@ -231,13 +236,16 @@ __global__ __launch_bounds__(256) void search_frac_kernel(const u8 *__restrict__
     } else {
       const int hx = s_sel[0], hy = s_sel[1];              // best half-pel offset in {-1,0,1}^2
       const int bx = 2 * hx, by = 2 * hy;
-      const int hp = (bx & 3) ? 0 : -1;                    // plane of the half-pel column itself: fx 2 -> s_h[0], fx 0 -> P
+      const int hp = (bx & 3) ? 0 : -1;                    // plane of the half-pel column itself: fx 2 -> plane 0, fx 0 -> P
       if (step == 2) {
         c[0] = { (bx - 1) & 3, by & 3, by >> 2, (bx - 1) >> 2 };
         c[1] = { (bx + 1) & 3, by & 3, by >> 2, (bx + 1) >> 2 };
         c[2] = { bx & 3, (by - 1) & 3, (by - 1) >> 2, bx >> 2 };
         c[3] = { bx & 3, (by + 1) & 3, (by + 1) >> 2, bx >> 2 };
         plane[0] = 1; plane[1] = 2; plane[2] = hp; plane[3] = hp;
+        hor_plane((bx - 1) & 3, s_h + G::H_ELEMS);
+        hor_plane((bx + 1) & 3, s_h + 2 * G::H_ELEMS);
+        sync();
       } else {
         c[0] = { (bx - 1) & 3, (by - 1) & 3, (by - 1) >> 2, (bx - 1) >> 2 };
         c[1] = { (bx + 1) & 3, (by - 1) & 3, (by - 1) >> 2, (bx + 1) >> 2 };
@@ -245,16 +253,11 @@ __global__ __launch_bounds__(256) void search_frac_kernel(const u8 *__restrict__
         c[3] = { (bx + 1) & 3, (by + 1) & 3, (by + 1) >> 2, (bx + 1) >> 2 };
         plane[0] = 1; plane[1] = 2; plane[2] = 1; plane[3] = 2;
       }
-      if (step == 2) {
-        hor_plane((bx - 1) & 3, s_h[1]);
-        hor_plane((bx + 1) & 3, s_h[2]);
-        __syncthreads();
-      }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) filter_cand(c[k], plane[k], s_cand[k]);
-    __syncthreads();
-    score(4, s_cand[0], 64, 64 * 64);
+    for (int k = 0; k < 4; ++k) filter_cand(c[k], plane[k], s_cand + k * G::CAND_BYTES);
+    sync();
+    score(4, s_cand, G::CS, G::CAND_BYTES);
     // decision: same order and strict '<' as search_inter.c:1096-1102
     const int i0 = (step & 1) ? 5 : 1;
 #pragma unroll
@@ -264,15 +267,47 @@ __global__ __launch_bounds__(256) void search_frac_kernel(const u8 *__restrict__
       if (cj < best_cost) { best_cost = cj; best_index = i0 + j; }
     }
     if (step == 1 || step == 3) {
-      if (tid == 0) best[(size_t)blockIdx.x * 2 + (step == 3)] = best_index;
+      if (tid == 0) best[step == 3] = best_index;
       if (step == 1) {
-        __syncthreads();
+        sync();
         if (tid == 0) { s_sel[0] = c_sq_x[best_index]; s_sel[1] = c_sq_y[best_index]; }
         best_index = 0;
       }
     }
-    __syncthreads();
+    sync();
   }
+}
+
+__device__ __forceinline__ bool frac_shape_ok(int w, int h) { return !(w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7)); }
+
+// blocks larger than 16x16 (and malformed descriptors, which are flagged): one workgroup per descriptor
+__global__ __launch_bounds__(256) void search_frac_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, refplane_t ref,
+                                                              const kvz_hip_block_pair *__restrict__ pairs,
+                                                              u32 *__restrict__ costs, i32 *__restrict__ best)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
+  const kvz_hip_block_pair d = pairs[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (!frac_shape_ok(d.width, d.height)) {            // unsupported shape: flag it, touch nothing else
+    if (tid < 17) costs[(size_t)blockIdx.x * 17 + tid] = 0xffffffffu;
+    if (tid < 2) best[(size_t)blockIdx.x * 2 + tid] = -1;
+    return;
+  }
+  if (d.width <= 16 && d.height <= 16) return;        // handled by search_frac_small_kernel
+  search_frac_core<64, 256, false>(tid, lds, pic, pic_stride, ref, d, costs + (size_t)blockIdx.x * 17, best + (size_t)blockIdx.x * 2);
+}
+
+// blocks up to 16x16: one wave per descriptor, four descriptors per workgroup, no barrier
+__global__ __launch_bounds__(256) void search_frac_small_kernel(const u8 *__restrict__ pic, u32 pic_stride, refplane_t ref,
+                                                                const kvz_hip_block_pair *__restrict__ pairs, size_t count,
+                                                                u32 *__restrict__ costs, i32 *__restrict__ best)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[4][(frac_geom<16>::TOTAL + 15) & ~15];
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= count) return;
+  const kvz_hip_block_pair d = pairs[i];
+  if (!frac_shape_ok(d.width, d.height) || d.width > 16 || d.height > 16) return;
+  search_frac_core<16, 64, true>(threadIdx.x & 63, lds[threadIdx.x >> 6], pic, pic_stride, ref, d, costs + i * 17, best + i * 2);
 }
 
 // ---------------------------------------------------------------------------
@@ -428,8 +463,11 @@ int kvz_hip_search_frac_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, con
   if (count == 0) return KVZ_HIP_OK;
   if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
   refplane_t r = { ref, ref_stride, ref_w, ref_h };
-  hipLaunchKernelGGL(search_frac_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), pic, pic_stride, r, pairs, costs, best);
-  KVZ_CHECK_LAUNCH("search_frac_kernel");
+  // two passes over the same descriptor list: each kernel takes the size class it is built for and skips the rest
+  hipLaunchKernelGGL(search_frac_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, ctx_stream(s), pic, pic_stride, r, pairs, count, costs, best);
+  KVZ_CHECK_LAUNCH("search_frac_small_kernel");
+  hipLaunchKernelGGL(search_frac_big_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), pic, pic_stride, r, pairs, costs, best);
+  KVZ_CHECK_LAUNCH("search_frac_big_kernel");
   return KVZ_HIP_OK;
 }
 

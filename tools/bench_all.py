@@ -97,6 +97,36 @@ def main():
                           picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, ctus_d.data_ptr(), len(ctu_list),
                           mv_d.data_ptr(), len(offs), out_d.data_ptr(), st)))
 
+    # frame-level kernels on one 1080p frame pair x F frames: every 8x8 / 16x16 / 64x64 block with a small MV
+    rs = np.random.default_rng(3)
+    for n in (8, 16, 64):
+        prs = np.array([(x, f * H + y, min(max(x + int(dx), 0), W - n), f * H + min(max(y + int(dy), 0), H - n), n, n)
+                        for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)
+                        for (dx, dy) in [rs.integers(-6, 7, 2)]], dtype=np.int32)
+        prs_d = torch.from_numpy(prs).to(dev)
+        outp = torch.empty(len(prs), dtype=torch.int32, device=dev)
+        cases.append(("reg_sad_frame_%dx%d" % (n, n), len(prs), 2 * n * n + 4 + 24,
+                      lambda prs_d=prs_d, outp=outp, k=len(prs): L.kvz_hip_reg_sad_batch(picf.data_ptr(), W, reff.data_ptr(), W, prs_d.data_ptr(), k, outp.data_ptr(), st)))
+        cases.append(("image_satd_frame_%dx%d" % (n, n), len(prs), 2 * n * n + 4 + 24,
+                      lambda prs_d=prs_d, outp=outp, k=len(prs): L.kvz_hip_image_calc_satd_batch(picf.data_ptr(), W, reff.data_ptr(), W, W, F * H, prs_d.data_ptr(), k, outp.data_ptr(), st)))
+    # ipol: quarter-pel luma samples and the fused fractional search, all blocks of 4 frames
+    for n in (8, 16, 64):
+        blks = np.array([(x, f * H + y, int(fx), int(fy), n, n) for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)
+                         for (fx, fy) in [rs.integers(0, 4, 2)]], dtype=np.int32)
+        blks_d = torch.from_numpy(blks).to(dev)
+        offs_d = torch.arange(len(blks), dtype=torch.int64, device=dev) * (n * n)
+        dst = torch.empty(len(blks) * n * n, dtype=torch.uint8, device=dev)
+        cases.append(("sample_luma_%dx%d" % (n, n), len(blks), (n + 7) * (n + 7) + n * n,
+                      lambda blks_d=blks_d, offs_d=offs_d, dst=dst, k=len(blks): L.kvz_hip_sample_luma_batch(
+                          reff.data_ptr(), W, W, F * H, blks_d.data_ptr(), offs_d.data_ptr(), k, 0, dst.data_ptr(), st)))
+        prs = np.array([(x, f * H + y, x + 1, f * H + y + 1, n, n) for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)], dtype=np.int32)
+        prs_d = torch.from_numpy(prs).to(dev)
+        co = torch.empty(len(prs) * 17, dtype=torch.int32, device=dev)
+        be = torch.empty(len(prs) * 2, dtype=torch.int32, device=dev)
+        cases.append(("search_frac_%dx%d" % (n, n), len(prs), (n + 8) * (n + 8) + n * n + 76,
+                      lambda prs_d=prs_d, co=co, be=be, k=len(prs): L.kvz_hip_search_frac_batch(
+                          picf.data_ptr(), W, reff.data_ptr(), W, W, F * H, prs_d.data_ptr(), k, co.data_ptr(), be.data_ptr(), st)))
+
     tune_key, tune_vals = None, [None]
     if args.tune:
         tune_key, vals = args.tune.split("=")
