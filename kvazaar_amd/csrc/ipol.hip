@@ -34,36 +34,67 @@ __device__ __forceinline__ u8 round_clip16(i16 sample) { return fast_clip16((i16
 // int16, vertical pass >> 6, then (+32) >> 6 and the 32-bit clip (or the raw
 // 14-bit sample).  Always both passes, like the reference.
 // ---------------------------------------------------------------------------
-template <int TAPS, bool OUT14>
-__global__ __launch_bounds__(256) void sample_kernel(refplane_t ref, const kvz_hip_ipol_block *__restrict__ blocks,
-                                                     const unsigned long long *__restrict__ out_offsets, void *__restrict__ dst)
+template <int TAPS, bool OUT14, int MAXW, int T, bool WAVE>
+__device__ __forceinline__ void sample_core(int tid, u8 *s_win, i16 *s_hor, const refplane_t &ref, const kvz_hip_ipol_block &b,
+                                            size_t o, void *__restrict__ dst)
 {
-  constexpr int MAXW = TAPS == 8 ? 64 : 32;
   constexpr int OFF = TAPS / 2 - 1;                 // 3 luma, 1 chroma
-  __shared__ u8 s_win[(MAXW + TAPS - 1) * (MAXW + TAPS)];
-  __shared__ i16 s_hor[(MAXW + TAPS - 1) * MAXW];
-  const kvz_hip_ipol_block b = blocks[blockIdx.x];
+  constexpr int WS = MAXW + TAPS;
   const int w = b.width, h = b.height;
-  if (w < 1 || h < 1 || w > MAXW || h > MAXW) return;             // unsupported shape: nothing written
-  const int ww = w + TAPS - 1, wh = h + TAPS - 1, ws = MAXW + TAPS;
+  const int ww = w + TAPS - 1, wh = h + TAPS - 1;
   const signed char *hf = TAPS == 8 ? c_luma_filter[b.mv_frac_x & 3] : c_chroma_filter[b.mv_frac_x & 7];
   const signed char *vf = TAPS == 8 ? c_luma_filter[b.mv_frac_y & 3] : c_chroma_filter[b.mv_frac_y & 7];
-
-  for (int i = threadIdx.x; i < ww * wh; i += blockDim.x) {
-    const int y = i / ww, x = i - y * ww;
-    s_win[y * ws + x] = ref_px(ref, b.x - OFF + x, b.y - OFF + y);
+  {
+    // window rows as (unaligned) dwords when the dword-rounded window lies inside the frame,
+    // else byte by byte with edge replication (kvz_get_extended_block, ipol-generic.c:731-784)
+    const int x0 = b.x - OFF, y0 = b.y - OFF, wq = (ww + 3) >> 2;
+    if (x0 >= 0 && y0 >= 0 && x0 + 4 * wq <= ref.w && y0 + wh <= ref.h) {
+      for (int i = tid; i < wq * wh; i += T) {
+        const int y = i / wq, q = i - y * wq;
+        u32 v;
+        __builtin_memcpy(&v, ref.p + (size_t)(y0 + y) * ref.stride + x0 + 4 * q, 4);
+        *(u32 *)(s_win + y * WS + 4 * q) = v;
+      }
+    } else {
+      for (int i = tid; i < ww * wh; i += T) {
+        const int y = i / ww, x = i - y * ww;
+        s_win[y * WS + x] = ref_px(ref, x0 + x, y0 + y);
+      }
+    }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < w * wh; i += blockDim.x) {
+  if (!WAVE) __syncthreads();
+  for (int i = tid; i < w * wh; i += T) {
     const int y = i / w, x = i - y * w;
     int acc = 0;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) acc += hf[t] * (int)s_win[y * ws + x + t];
+    for (int t = 0; t < TAPS; ++t) acc += hf[t] * (int)s_win[y * WS + x + t];
     s_hor[y * MAXW + x] = (i16)acc;
   }
-  __syncthreads();
-  const size_t o = (size_t)out_offsets[blockIdx.x];
-  for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+  if (!WAVE) __syncthreads();
+  if ((w & 3) == 0) {                               // four outputs per lane, one 4- or 8-byte store
+    const int w4 = w >> 2;
+    for (int i = tid; i < w4 * h; i += T) {
+      const int y = i / w4, x = (i - y * w4) << 2;
+      int v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int acc = 0;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc += vf[t] * (int)s_hor[(y + t) * MAXW + x + k];
+        v[k] = acc >> 6;
+      }
+      if (OUT14) {
+        const uint2 pk = make_uint2((u32)(v[0] & 0xffff) | ((u32)v[1] << 16), (u32)(v[2] & 0xffff) | ((u32)v[3] << 16));
+        __builtin_memcpy((i16 *)dst + o + (size_t)y * w + x, &pk, 8);
+      } else {
+        const u32 pk = (u32)fast_clip32((v[0] + 32) >> 6) | ((u32)fast_clip32((v[1] + 32) >> 6) << 8) |
+                       ((u32)fast_clip32((v[2] + 32) >> 6) << 16) | ((u32)fast_clip32((v[3] + 32) >> 6) << 24);
+        __builtin_memcpy((u8 *)dst + o + (size_t)y * w + x, &pk, 4);
+      }
+    }
+    return;
+  }
+  for (int i = tid; i < w * h; i += T) {
     const int y = i / w, x = i - y * w;
     int acc = 0;
 #pragma unroll
@@ -72,6 +103,35 @@ __global__ __launch_bounds__(256) void sample_kernel(refplane_t ref, const kvz_h
     if (OUT14) ((i16 *)dst)[o + i] = (i16)acc;
     else ((u8 *)dst)[o + i] = fast_clip32((acc + 32) >> 6);
   }
+}
+
+// blocks wider or taller than 16: one workgroup per block
+template <int TAPS, bool OUT14>
+__global__ __launch_bounds__(256) void sample_big_kernel(refplane_t ref, const kvz_hip_ipol_block *__restrict__ blocks,
+                                                         const unsigned long long *__restrict__ out_offsets, void *__restrict__ dst)
+{
+  constexpr int MAXW = TAPS == 8 ? 64 : 32;
+  __shared__ u8 s_win[(MAXW + TAPS - 1) * (MAXW + TAPS)];
+  __shared__ i16 s_hor[(MAXW + TAPS - 1) * MAXW];
+  const kvz_hip_ipol_block b = blocks[blockIdx.x];
+  if (b.width < 1 || b.height < 1 || b.width > MAXW || b.height > MAXW) return;     // unsupported shape: nothing written
+  if (b.width <= 16 && b.height <= 16) return;                                      // sample_small_kernel's
+  sample_core<TAPS, OUT14, MAXW, 256, false>(threadIdx.x, s_win, s_hor, ref, b, (size_t)out_offsets[blockIdx.x], dst);
+}
+
+// blocks up to 16x16: one wave per block, four blocks per workgroup, wave-private LDS, no barrier
+template <int TAPS, bool OUT14>
+__global__ __launch_bounds__(256) void sample_small_kernel(refplane_t ref, const kvz_hip_ipol_block *__restrict__ blocks, size_t count,
+                                                           const unsigned long long *__restrict__ out_offsets, void *__restrict__ dst)
+{
+  __shared__ u8 s_win[4][(16 + TAPS - 1) * (16 + TAPS)];
+  __shared__ i16 s_hor[4][(16 + TAPS - 1) * 16];
+  const int wv = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 4 + wv;
+  if (i >= count) return;
+  const kvz_hip_ipol_block b = blocks[i];
+  if (b.width < 1 || b.height < 1 || b.width > 16 || b.height > 16) return;
+  sample_core<TAPS, OUT14, 16, 64, true>(threadIdx.x & 63, s_win[wv], s_hor[wv], ref, b, (size_t)out_offsets[i], dst);
 }
 
 // ---------------------------------------------------------------------------
@@ -429,13 +489,15 @@ static int sample_launch(bool luma, const kvz_hip_pixel *ref, uint32_t ref_strid
   refplane_t r = { ref, ref_stride, ref_w, ref_h };
   hipStream_t st = ctx_stream(s);
   const unsigned long long *oo = (const unsigned long long *)out_offsets;
-  if (luma) {
-    if (out_14bit) hipLaunchKernelGGL((sample_kernel<8, true>), dim3((unsigned)count), dim3(256), 0, st, r, blocks, oo, dst);
-    else hipLaunchKernelGGL((sample_kernel<8, false>), dim3((unsigned)count), dim3(256), 0, st, r, blocks, oo, dst);
-  } else {
-    if (out_14bit) hipLaunchKernelGGL((sample_kernel<4, true>), dim3((unsigned)count), dim3(256), 0, st, r, blocks, oo, dst);
-    else hipLaunchKernelGGL((sample_kernel<4, false>), dim3((unsigned)count), dim3(256), 0, st, r, blocks, oo, dst);
-  }
+  const unsigned gs = (unsigned)((count + 3) / 4), gb = (unsigned)count;
+#define KVZ_SAMPLE(TAPS, O14)                                                                                        \
+  do {                                                                                                               \
+    hipLaunchKernelGGL((sample_small_kernel<TAPS, O14>), dim3(gs), dim3(256), 0, st, r, blocks, count, oo, dst);     \
+    hipLaunchKernelGGL((sample_big_kernel<TAPS, O14>), dim3(gb), dim3(256), 0, st, r, blocks, oo, dst);              \
+  } while (0)
+  if (luma) { if (out_14bit) KVZ_SAMPLE(8, true); else KVZ_SAMPLE(8, false); }
+  else { if (out_14bit) KVZ_SAMPLE(4, true); else KVZ_SAMPLE(4, false); }
+#undef KVZ_SAMPLE
   KVZ_CHECK_LAUNCH("sample_kernel");
   return KVZ_HIP_OK;
 }
