@@ -368,3 +368,17 @@ def test_ctu_sad_grid(api):
     s16 = s8.reshape(-1, 4, 2, 4, 2).sum(axis=(2, 4)).reshape(-1, 16)
     np.testing.assert_array_equal(c[:, 5:21], s16)
     assert (c[:, 0] == s8.sum(axis=(1, 2))).all()
+
+
+def test_transform_alternate_kernels(api):
+    """the non-default variants stay bit-exact: MFMA inverse 16x16 (default: butterflies)"""
+    from kvazaar_amd import _lib
+    L = _lib.load()
+    g = rng(21)
+    x = g.integers(-32768, 32768, (131, 256)).astype(np.int16)
+    try:
+        _lib.check(L.kvz_hip_set_tuning(b"idct16_use_mfma", 1), "set_tuning")
+        np.testing.assert_array_equal(api.transform_batch("idct", 16, x), O.transform_batch("idct", 16, x))
+    finally:
+        L.kvz_hip_set_tuning(b"idct16_use_mfma", -1)
+    assert L.kvz_hip_set_tuning(b"no_such_key", 1) != 0
