@@ -67,8 +67,10 @@ __device__ __forceinline__ void chunks_to_rows(u8 *tile, int lane, int r, int h,
 {
   *(u32x4v *)(tile + slot_of(lane) * 16) = c[0];
   *(u32x4v *)(tile + slot_of(64 + lane) * 16) = c[1];
+  wave_lds_fence();
   const u32x4v a = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h) * 16);
   const u32x4v b = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h + 1) * 16);
+  wave_lds_fence();
   d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
 }
 
@@ -83,8 +85,10 @@ __device__ __forceinline__ void rows_to_chunks_store(u8 *tile, int lane, int r, 
     v.y = __builtin_amdgcn_perm((u32)o[4 * gg + 3], (u32)o[4 * gg + 2], 0x05040100u);
     *(uint2 *)(tile + slot_of(4 * r + gg) * 16 + 8 * h) = v;     // columns 8gg + 4h .. +3 of row r
   }
+  wave_lds_fence();
   const u32x4v a = *(const u32x4v *)(tile + slot_of(lane) * 16);
   const u32x4v b = *(const u32x4v *)(tile + slot_of(64 + lane) * 16);
+  wave_lds_fence();               // the tile is rewritten by the next block only after these reads
   *((u32x4v *)blk + lane) = a;
   *((u32x4v *)blk + 64 + lane) = b;
 }

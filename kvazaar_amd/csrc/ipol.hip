@@ -62,7 +62,7 @@ __device__ __forceinline__ void sample_core(int tid, u8 *s_win, i16 *s_hor, cons
       }
     }
   }
-  if (!WAVE) __syncthreads();
+  if (WAVE) wave_lds_fence(); else __syncthreads();
   for (int i = tid; i < w * wh; i += T) {
     const int y = i / w, x = i - y * w;
     int acc = 0;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void sample_core(int tid, u8 *s_win, i16 *s_hor, cons
     for (int t = 0; t < TAPS; ++t) acc += hf[t] * (int)s_win[y * WS + x + t];
     s_hor[y * MAXW + x] = (i16)acc;
   }
-  if (!WAVE) __syncthreads();
+  if (WAVE) wave_lds_fence(); else __syncthreads();
   if ((w & 3) == 0) {                               // four outputs per lane, one 4- or 8-byte store
     const int w4 = w >> 2;
     for (int i = tid; i < w4 * h; i += T) {
@@ -217,7 +217,7 @@ __device__ __forceinline__ void search_frac_core(int tid, u8 *lds, const u8 *__r
   i16 *s_h = (i16 *)(lds + ((G::P_BYTES + G::CUR_BYTES + 4 * G::CAND_BYTES + 15) & ~15));
   u32 *s_cost = (u32 *)(s_h + 3 * G::H_ELEMS);
   int *s_sel = (int *)(s_cost + 4);
-  auto sync = [&]() { if (!WAVE) __syncthreads(); };
+  auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
 
   const int w = d.width, h = d.height;
   const int pw = w + 8, ph = h + 8;

@@ -73,6 +73,16 @@ __device__ __forceinline__ u32 group_sum(u32 v)
   return v;
 }
 
+// Ordering point between two phases of ONE wave that exchange data through its private LDS slice.
+// The hardware executes a wave's DS operations in order, so no s_barrier is needed; this only stops
+// the compiler from moving LDS accesses across the phase boundary.
+__device__ __forceinline__ void wave_lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // kvz_fast_clip_16bit_to_pixel (picture-generic.c:30-48): int16 argument,
