@@ -264,6 +264,9 @@ typedef int (*kvz_hip_register_fn)(void *opaque, const char *type, const char *s
  * (resolved at load time from the host encoder).  A host that links the
  * selector with hidden visibility passes it explicitly. */
 KVZ_HIP_API void kvz_hip_set_registrar(kvz_hip_register_fn fn);
+/* Number of per-call strategy invocations that launched GPU work since load (all threads):
+ * lets a host or test confirm the "hip" pointers are the ones its encoder is calling. */
+KVZ_HIP_API unsigned long long kvz_hip_dropin_calls(void);
 
 /* Accessors for the opaque encoder_state_t the quant strategies receive
  * (encoderstate.h; quant-generic.c:40-50).  Supplied by the few lines of glue

@@ -79,6 +79,7 @@ SIGNATURES = {
     "kvz_hip_sample_chroma_batch": (_I, [_P, _U, _I, _I, _P, _P, _SZ, _I, _P, _P]),
     "kvz_hip_search_frac_batch": (_I, [_P, _U, _P, _U, _I, _I, _P, _SZ, _P, _P, _P]),
     "kvz_hip_set_registrar": (None, [_P]),
+    "kvz_hip_dropin_calls": (C.c_ulonglong, []),
     "kvz_hip_set_state_accessors": (None, [_P]),
     "kvz_strategy_register_picture_hip": (_I, [_P, C.c_uint8]),
     "kvz_strategy_register_dct_hip": (_I, [_P, C.c_uint8]),

@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 
 using namespace kvzhip;
@@ -79,11 +80,13 @@ void die(const char *what, int rc)
 
 inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-// bump allocator over the staging buffer
+std::atomic<unsigned long long> g_dropin_calls{0};
+
+// bump allocator over the staging buffer; one per strategy call that reaches the GPU
 struct stage {
   call_ctx &c;
   size_t off = 0;
-  explicit stage(call_ctx &cc) : c(cc) {}
+  explicit stage(call_ctx &cc) : c(cc) { g_dropin_calls.fetch_add(1, std::memory_order_relaxed); }
   size_t take(size_t bytes)
   {
     size_t o = off;
@@ -381,11 +384,12 @@ void hip_inter_recon_bipred(const int hi_prec_luma_rec0, const int hi_prec_luma_
                             const void *hp0, const void *hp1, void *lcu, kvz_hip_pixel *temp_lcu_y,
                             kvz_hip_pixel *temp_lcu_u, kvz_hip_pixel *temp_lcu_v)
 {
+  // the caller allocates a hi_prec_buf_t only for a fractional MV (inter.c:455-458): hp0 / hp1 may be NULL
   struct plane { int hi0, hi1; const int16_t *h0, *h1; const u8 *t0; u8 *rec; int w, h, x, y, stride; };
   const plane pl[3] = {
-    { hi_prec_luma_rec0, hi_prec_luma_rec1, g_acc.hi_prec_y(hp0), g_acc.hi_prec_y(hp1), temp_lcu_y, g_acc.lcu_rec_y(lcu), width, height, xpos & 63, ypos & 63, 64 },
-    { hi_prec_chroma_rec0, hi_prec_chroma_rec1, g_acc.hi_prec_u(hp0), g_acc.hi_prec_u(hp1), temp_lcu_u, g_acc.lcu_rec_u(lcu), width >> 1, height >> 1, (xpos >> 1) & 31, (ypos >> 1) & 31, 32 },
-    { hi_prec_chroma_rec0, hi_prec_chroma_rec1, g_acc.hi_prec_v(hp0), g_acc.hi_prec_v(hp1), temp_lcu_v, g_acc.lcu_rec_v(lcu), width >> 1, height >> 1, (xpos >> 1) & 31, (ypos >> 1) & 31, 32 } };
+    { hi_prec_luma_rec0, hi_prec_luma_rec1, (hp0 ? g_acc.hi_prec_y(hp0) : nullptr), (hp1 ? g_acc.hi_prec_y(hp1) : nullptr), temp_lcu_y, g_acc.lcu_rec_y(lcu), width, height, xpos & 63, ypos & 63, 64 },
+    { hi_prec_chroma_rec0, hi_prec_chroma_rec1, (hp0 ? g_acc.hi_prec_u(hp0) : nullptr), (hp1 ? g_acc.hi_prec_u(hp1) : nullptr), temp_lcu_u, g_acc.lcu_rec_u(lcu), width >> 1, height >> 1, (xpos >> 1) & 31, (ypos >> 1) & 31, 32 },
+    { hi_prec_chroma_rec0, hi_prec_chroma_rec1, (hp0 ? g_acc.hi_prec_v(hp0) : nullptr), (hp1 ? g_acc.hi_prec_v(hp1) : nullptr), temp_lcu_v, g_acc.lcu_rec_v(lcu), width >> 1, height >> 1, (xpos >> 1) & 31, (ypos >> 1) & 31, 32 } };
   for (const plane &p : pl) {
     if (p.w <= 0 || p.h <= 0) continue;
     call_ctx &c = tls(); stage s(c);
@@ -427,6 +431,8 @@ bool hook_ready(uint8_t bitdepth)
 extern "C" {
 
 void kvz_hip_set_registrar(kvz_hip_register_fn fn) { g_registrar = fn; }
+
+unsigned long long kvz_hip_dropin_calls(void) { return g_dropin_calls.load(std::memory_order_relaxed); }
 
 void kvz_hip_set_state_accessors(const kvz_hip_state_accessors *acc)
 {

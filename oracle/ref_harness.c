@@ -370,7 +370,88 @@ void ref_bipred(const char *name, int hi_l0, int hi_l1, int hi_c0, int hi_c1, in
   b0.y = hp0_y; b0.u = hp0_u; b0.v = hp0_v; b1.y = hp1_y; b1.u = hp1_u; b1.v = hp1_v;
   memcpy(lcu->rec.y, rec_y, 64 * 64); memcpy(lcu->rec.u, rec_u, 32 * 32); memcpy(lcu->rec.v, rec_v, 32 * 32);
   ((inter_recon_bipred_func *)ref_strategy("inter_recon_bipred", name))(hi_l0, hi_l1, hi_c0, hi_c1, height, width, ypos, xpos,
-                                                                         &b0, &b1, lcu, tmp_y, tmp_u, tmp_v);
+                                                                         /* as inter.c:455-458: no buffer without a fractional MV */
+                                                                         (hi_l0 || hi_c0) ? &b0 : NULL, (hi_l1 || hi_c1) ? &b1 : NULL,
+                                                                         lcu, tmp_y, tmp_u, tmp_v);
   memcpy(rec_y, lcu->rec.y, 64 * 64); memcpy(rec_u, lcu->rec.u, 32 * 32); memcpy(rec_v, lcu->rec.v, 32 * 32);
   free(lcu);
+}
+
+/* ------------------------------------------------------------------------
+ * End-to-end check of the drop-in: run the REFERENCE ENCODER (kvz_api,
+ * kvazaar.c:378-395) on raw 4:2:0 frames.  With strategy_name != NULL every
+ * strategy type that `strategy_name` registered in the harness list is installed
+ * into the encoder's global function pointers after encoder_open -- exactly the
+ * table kvz_strategyselector_init fills (strategyselector.h:99-108), i.e. what the
+ * selector does itself once the hooks of INTEGRATION.md are compiled in.
+ * opts: "name=value,name=value" for kvz_config_parse.  Returns the bitstream
+ * length (bytes copied to out, at most cap) or -1.
+ * ------------------------------------------------------------------------ */
+#include "kvazaar.h"
+
+static long append_chunks(const kvz_api *api, kvz_data_chunk *chunks, uint8_t *out, long pos, long cap)
+{
+  for (kvz_data_chunk *c = chunks; c; c = c->next) {
+    if (pos + (long)c->len <= cap) memcpy(out + pos, c->data, c->len);
+    pos += c->len;
+  }
+  if (chunks) api->chunk_free(chunks);
+  return pos;
+}
+
+long ref_encode(const uint8_t *yuv, int w, int h, int nframes, const char *opts, const char *strategy_name,
+                uint8_t *out, long cap, int *installed_out)
+{
+  const kvz_api *api = kvz_api_get(8);
+  if (!api) return -1;
+  kvz_config *cfg = api->config_alloc();
+  api->config_init(cfg);
+  char num[32];
+  snprintf(num, sizeof(num), "%d", w); api->config_parse(cfg, "width", num);
+  snprintf(num, sizeof(num), "%d", h); api->config_parse(cfg, "height", num);
+  char *dup = strdup(opts ? opts : "");
+  for (char *tok = strtok(dup, ","); tok; tok = strtok(NULL, ",")) {
+    char *eq = strchr(tok, '=');
+    const char *val = "true";
+    if (eq) { *eq = 0; val = eq + 1; }
+    if (!api->config_parse(cfg, tok, val)) { fprintf(stderr, "ref_encode: bad option %s=%s\n", tok, val); free(dup); return -1; }
+  }
+  free(dup);
+  kvz_encoder *enc = api->encoder_open(cfg);
+  if (!enc) return -1;
+  int installed = 0;
+  if (strategy_name) {
+    for (const strategy_to_select_t *s = strategies_to_select; s->fptr; ++s) {
+      void *f = NULL;
+      for (unsigned i = 0; i < g_list.count; ++i)
+        if (!strcmp(g_list.strategies[i].type, s->strategy_type) && !strcmp(g_list.strategies[i].strategy_name, strategy_name))
+          f = g_list.strategies[i].fptr;
+      if (f) { *s->fptr = f; ++installed; }
+    }
+  }
+  if (installed_out) *installed_out = installed;
+  long pos = 0;
+  const size_t fsz = (size_t)w * h * 3 / 2;
+  int fed = 0, done = 0;
+  while (!done) {
+    kvz_picture *pic = NULL;
+    if (fed < nframes) {
+      pic = api->picture_alloc(w, h);
+      const uint8_t *f = yuv + fsz * fed;
+      for (int y = 0; y < h; ++y) memcpy(pic->y + (size_t)y * pic->stride, f + (size_t)y * w, w);
+      for (int y = 0; y < h / 2; ++y) {
+        memcpy(pic->u + (size_t)y * (pic->stride / 2), f + (size_t)w * h + (size_t)y * (w / 2), w / 2);
+        memcpy(pic->v + (size_t)y * (pic->stride / 2), f + (size_t)w * h * 5 / 4 + (size_t)y * (w / 2), w / 2);
+      }
+      ++fed;
+    }
+    kvz_data_chunk *chunks = NULL; uint32_t len = 0; kvz_picture *rec = NULL, *src = NULL; kvz_frame_info info;
+    if (!api->encoder_encode(enc, pic, &chunks, &len, &rec, &src, &info)) { api->picture_free(pic); pos = -1; break; }
+    if (!chunks && !pic) done = 1;
+    pos = append_chunks(api, chunks, out, pos, cap);
+    api->picture_free(pic); api->picture_free(rec); api->picture_free(src);
+  }
+  api->encoder_close(enc);
+  api->config_destroy(cfg);
+  return pos;
 }

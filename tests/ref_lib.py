@@ -274,3 +274,38 @@ def bipred(hi, height, width, ypos, xpos, hp0, hp1, rec, tmp, name="generic"):
     lib().ref_bipred(name.encode(), *[int(v) for v in hi], height, width, ypos, xpos,
                      *[_p(a, i16p) for a in h0 + h1], *[_p(a, u8p) for a in r + t])
     return r
+
+
+def synthetic_sequence(w, h, n, seed=5):
+    """n 4:2:0 frames (n, h*3/2, w) with half-pel global motion over a band-limited texture plus noise, so that
+    intra, integer ME, fractional ME, residual coding and skip all occur."""
+    g = np.random.default_rng(seed)
+    big = g.integers(0, 256, (2 * h + 64, 2 * w + 64)).astype(np.float64)
+    for _ in range(3):
+        big = (big + np.roll(big, 1, 0) + np.roll(big, 1, 1) + np.roll(big, (1, 1), (0, 1))) / 4
+    big = np.clip((big - big.mean()) * 6 + 128, 0, 255)
+    frames = np.zeros((n, h * 3 // 2, w), dtype=np.uint8)
+    for i in range(n):
+        oy, ox = 3 * i, 5 * i
+        y = big[oy:oy + 2 * h:2, ox:ox + 2 * w:2] + g.normal(0, 1.5, (h, w))
+        frames[i, :h] = np.clip(y, 0, 255).astype(np.uint8)
+        c = big[oy:oy + 2 * h:4, ox:ox + 2 * w:4]
+        frames[i, h:h + h // 4] = np.clip(c * 0.5 + 64, 0, 255).astype(np.uint8).reshape(h // 4, w)
+        frames[i, h + h // 4:] = np.clip(255 - c * 0.5, 0, 255).astype(np.uint8).reshape(h // 4, w)
+    return frames
+
+
+def encode(frames, w, h, opts, strategy=None, cap=1 << 22):
+    """Run the reference encoder (kvz_api) over the frames; strategy=None keeps the selector's own choice,
+    otherwise every type registered under that name is installed.  Returns (bitstream bytes, n installed)."""
+    L = lib()
+    L.ref_encode.restype = C.c_long
+    L.ref_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_long,
+                             C.POINTER(C.c_int)]
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    out = np.zeros(cap, dtype=np.uint8)
+    inst = C.c_int(0)
+    n = L.ref_encode(frames.ctypes.data, w, h, frames.shape[0], opts.encode(), strategy.encode() if strategy else None,
+                     out.ctypes.data, cap, C.byref(inst))
+    assert 0 < n <= cap, "ref_encode failed (%d)" % n
+    return out[:n].tobytes(), inst.value

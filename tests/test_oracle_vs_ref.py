@@ -252,3 +252,12 @@ def test_avx2_agrees_where_survey_says_so():
         np.testing.assert_array_equal(R.transform_batch("dct", n, res, "avx2"), O.transform_batch("dct", n, res))
         full = g.integers(-32768, 32768, (8, n * n)).astype(np.int16)
         np.testing.assert_array_equal(R.transform_batch("idct", n, full, "avx2"), O.transform_batch("idct", n, full))
+
+
+def test_reference_encoder_harness_generic_equals_selected():
+    """the end-to-end harness used by tests/test_gpu_dropin.py: installing the "generic" strategies into the reference
+    encoder's table gives the same bitstream as the selector's own (avx2) choice -- the property the reference relies on"""
+    frames = R.synthetic_sequence(128, 64, 3)
+    a, n_inst = R.encode(frames, 128, 64, "preset=medium,rdoq=0,qp=30,threads=0", "generic")
+    b, _ = R.encode(frames, 128, 64, "preset=medium,rdoq=0,qp=30,threads=0", None)
+    assert n_inst >= 40 and len(a) > 200 and a == b
