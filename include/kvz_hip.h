@@ -256,6 +256,43 @@ KVZ_HIP_API int kvz_hip_search_frac_batch(const kvz_hip_pixel *pic, uint32_t pic
                                           uint32_t *costs, int32_t *best, kvz_hip_stream s);
 
 /* ------------------------------------------------------------------ */
+/* (2) batched entries -- intra group (strategies/strategies-intra.h)  */
+/*     SURVEY.md section 8(f) row 2                                    */
+/* ------------------------------------------------------------------ */
+/* kvz_intra_ref (intra.h:35-38): reference pixels of one PU, entry 0 of both
+ * arrays = the top-left corner, entries 1..2N the left / top neighbours. */
+typedef struct {
+  kvz_hip_pixel left[2 * 32 + 1];
+  kvz_hip_pixel top[2 * 32 + 1];
+} kvz_hip_intra_ref;
+
+#define KVZ_HIP_INTRA_LUMA 1             /* color == COLOR_Y */
+#define KVZ_HIP_INTRA_FILTER_BOUNDARY 2  /* kvz_intra_predict's filter_boundary */
+#define KVZ_HIP_INTRA_RAW 4              /* the bare strategies kvz_angular_pred / kvz_intra_pred_planar
+                                            (intra-generic.c:37-189) on the given references: no smoothing
+                                            decision, no DC / boundary filters */
+
+/* kvz_intra_predict (intra.c:281-331) for every PU x every listed mode:
+ * reference smoothing (intra.c:164-192) chosen per mode and size, planar,
+ * DC with its edge filter (intra.c:217-278), angular modes 2..34 with the
+ * boundary post-process of modes 10 / 26 (intra.c:195-208).  modes is a HOST
+ * array of num_modes (1..35) mode numbers; prediction (i, k) is written as
+ * N*N contiguous pixels at dst + (i * num_modes + k) * N * N. */
+KVZ_HIP_API int kvz_hip_intra_predict_batch(int log2_width, int flags, const kvz_hip_intra_ref *refs, size_t count,
+                                            const int8_t *modes, int num_modes, kvz_hip_pixel *dst, kvz_hip_stream s);
+
+/* The cost loop of search_intra_rough (search_intra.c:404-520) for all 35
+ * modes at once: satd_costs[35*i + m] = satd_NxN(kvz_intra_predict(mode m), orig_i)
+ * (luma), orig = count contiguous N x N blocks.  sad_costs (NULL, or same shape)
+ * receives sad_NxN for the 4x4 transform-skip test of get_cost
+ * (search_intra.c:99-126).  The host walks the table in the reference's order
+ * and adds the mode-bit cost, so decisions are identical; predictions never
+ * leave the CU. */
+KVZ_HIP_API int kvz_hip_intra_rough_batch(int log2_width, int flags, const kvz_hip_intra_ref *refs,
+                                          const kvz_hip_pixel *orig, size_t count,
+                                          uint32_t *satd_costs, uint32_t *sad_costs, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
 /* (1) strategy registration -- the drop-in boundary                   */
 /* ------------------------------------------------------------------ */
 /* kvz_strategyselector_register (strategyselector.h:87, strategyselector.c:216-256) */
@@ -304,6 +341,7 @@ KVZ_HIP_API int kvz_strategy_register_picture_hip(void *opaque, uint8_t bitdepth
 KVZ_HIP_API int kvz_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);
 KVZ_HIP_API int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);
 KVZ_HIP_API int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);
+KVZ_HIP_API int kvz_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);   /* strategies-intra.h:52-55 */
 
 #ifdef __cplusplus
 }

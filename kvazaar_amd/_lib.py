@@ -78,6 +78,8 @@ SIGNATURES = {
     "kvz_hip_sample_luma_batch": (_I, [_P, _U, _I, _I, _P, _P, _SZ, _I, _P, _P]),
     "kvz_hip_sample_chroma_batch": (_I, [_P, _U, _I, _I, _P, _P, _SZ, _I, _P, _P]),
     "kvz_hip_search_frac_batch": (_I, [_P, _U, _P, _U, _I, _I, _P, _SZ, _P, _P, _P]),
+    "kvz_hip_intra_predict_batch": (_I, [_I, _I, _P, _SZ, _P, _I, _P, _P]),
+    "kvz_hip_intra_rough_batch": (_I, [_I, _I, _P, _P, _SZ, _P, _P, _P]),
     "kvz_hip_set_registrar": (None, [_P]),
     "kvz_hip_dropin_calls": (C.c_ulonglong, []),
     "kvz_hip_set_state_accessors": (None, [_P]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "kvz_strategy_register_dct_hip": (_I, [_P, C.c_uint8]),
     "kvz_strategy_register_quant_hip": (_I, [_P, C.c_uint8]),
     "kvz_strategy_register_ipol_hip": (_I, [_P, C.c_uint8]),
+    "kvz_strategy_register_intra_hip": (_I, [_P, C.c_uint8]),
 }
 
 

@@ -263,3 +263,34 @@ def search_frac_batch(pic, ref, pairs):
     check(L.kvz_hip_search_frac_batch(a.ptr, pic.shape[1], b.ptr, ref.shape[1], ref.shape[1], ref.shape[0], d.ptr,
                                       count, co.ptr, be.ptr, None), "search_frac batch")
     return co.to_numpy(np.uint32, (count, 17)), be.to_numpy(np.int32, (count, 2))
+
+
+# ---- intra group ----
+INTRA_LUMA, INTRA_FILTER_BOUNDARY, INTRA_RAW = 1, 2, 4
+
+
+def intra_predict_batch(refs, log2_width, modes, flags=INTRA_LUMA | INTRA_FILTER_BOUNDARY):
+    """refs: (count, 130) uint8 = kvz_intra_ref {left[65], top[65]}.  kvz_intra_predict for every PU x every mode of
+    `modes`; returns uint8 [count, len(modes), N*N]."""
+    L = _lib.init()
+    refs = np.ascontiguousarray(refs, dtype=np.uint8).reshape(-1, 130)
+    count, n = refs.shape[0], 1 << log2_width
+    m = np.ascontiguousarray(modes, dtype=np.int8)
+    r = DeviceBuffer.from_numpy(refs)
+    out = DeviceBuffer(max(1, count * len(m) * n * n))
+    check(L.kvz_hip_intra_predict_batch(log2_width, flags, r.ptr, count, m.ctypes.data, len(m), out.ptr, None), "intra_predict batch")
+    return out.to_numpy(np.uint8, (count, len(m), n * n))
+
+
+def intra_rough_batch(refs, log2_width, orig, flags=INTRA_LUMA | INTRA_FILTER_BOUNDARY, with_sad=False):
+    """All 35 mode costs of search_intra_rough per PU: returns satd uint32 [count, 35] (and sad if with_sad)."""
+    L = _lib.init()
+    refs = np.ascontiguousarray(refs, dtype=np.uint8).reshape(-1, 130)
+    count, n = refs.shape[0], 1 << log2_width
+    orig = np.ascontiguousarray(orig, dtype=np.uint8).reshape(count, n * n)
+    r, o = DeviceBuffer.from_numpy(refs), DeviceBuffer.from_numpy(orig)
+    satd = DeviceBuffer(max(1, 4 * 35 * count))
+    sad = DeviceBuffer(max(1, 4 * 35 * count)) if with_sad else None
+    check(L.kvz_hip_intra_rough_batch(log2_width, flags, r.ptr, o.ptr, count, satd.ptr, sad.ptr if sad else None, None), "intra_rough batch")
+    a = satd.to_numpy(np.uint32, (count, 35))
+    return (a, sad.to_numpy(np.uint32, (count, 35))) if with_sad else a

@@ -1,0 +1,434 @@
+// intra.hip -- intra prediction (angular / planar / DC) and the fused rough mode search.
+//
+// Reference: src/strategies/generic/intra-generic.c:37-189 (angular_pred, intra_pred_planar),
+// src/intra.c:164-331 (reference smoothing, DC, edge filters, kvz_intra_predict) and the
+// cost loop of search_intra_rough, src/search_intra.c:404-520.  SURVEY.md section 8(f) row 2.
+//
+// Two kernels:
+//   intra_predict_kernel   one wave per (PU, mode): writes the N x N prediction (the drop-in
+//                          strategies and kvz_intra_predict for a list of modes).
+//   intra_rough_kernel     all 35 modes of a PU against its original block, SATD (and SAD) per
+//                          mode, predictions never leave the registers.  Unlike the streaming
+//                          kernels this one is VALU bound: ~240 B of HBM traffic per 8x8 PU
+//                          against 35 predictions + 35 Hadamard transforms.
+//
+// Angular modes are evaluated in the reference's "vertical" orientation (rows advance along the
+// prediction direction) from an extended main reference e[-N .. 2N] held in LDS; horizontal
+// modes are the transpose, and because SATD / SAD are invariant under transposing both blocks
+// the rough kernel compares them against the transposed original instead of flipping.
+#include "kvz_hip_internal.h"
+#include "satd_regs.h"
+
+using namespace kvzhip;
+
+namespace {
+
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+
+constexpr int RS = 68;   // bytes per staged reference array: entries 0 .. 2N (<= 64), zero padded
+
+// intra-generic.c:46-47
+__constant__ int c_ang_disp[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+__constant__ int c_ang_inv[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+
+struct ang_t { int vertical, disp, inv; };
+__device__ __forceinline__ ang_t ang_of(int mode)
+{
+  ang_t a;
+  a.vertical = mode >= 18;
+  const int md = a.vertical ? mode - 26 : 10 - mode;
+  const int amd = md < 0 ? -md : md;
+  a.disp = md < 0 ? -c_ang_disp[amd] : c_ang_disp[amd];
+  a.inv = c_ang_inv[amd];
+  return a;
+}
+
+// intra.c:289-306: which reference kvz_intra_predict hands to the predictor
+__device__ __forceinline__ bool use_filtered(int mode, int log2_width, int flags)
+{
+  if ((flags & KVZ_HIP_INTRA_RAW) || !(flags & KVZ_HIP_INTRA_LUMA) || mode == 1 || log2_width == 2) return false;
+  if (mode == 0) return true;
+  const int dv = mode > 26 ? mode - 26 : 26 - mode, dh = mode > 10 ? mode - 10 : 10 - mode;
+  const int thres = log2_width == 3 ? 7 : (log2_width == 4 ? 1 : 0);
+  return (dv < dh ? dv : dh) > thres;
+}
+// intra.c:314-329: DC edge filter / boundary post-process apply to luma blocks narrower than 32
+__device__ __forceinline__ bool luma_edge_filters(int log2_width, int flags)
+{
+  return !(flags & KVZ_HIP_INTRA_RAW) && (flags & KVZ_HIP_INTRA_LUMA) && log2_width < 5;
+}
+
+// Stage the reference pixels of `npu` PUs: s_ref[p][0] = left, [1] = top (unfiltered, entry 0 = corner),
+// [2], [3] = smoothed left / top (intra.c:164-192).  Entries beyond 2N are zero.  Ends with a barrier.
+template <int N>
+__device__ __forceinline__ void stage_refs(u8 (*s_ref)[4][RS], int npu, const kvz_hip_intra_ref *refs, size_t pu0, size_t count,
+                                           int tid, int nthreads)
+{
+  u32 *z = (u32 *)s_ref;
+  for (int i = tid; i < npu * 4 * RS / 4; i += nthreads) z[i] = 0u;
+  __syncthreads();
+  const u8 *g = (const u8 *)(refs + pu0);
+  const size_t left = count - pu0;
+  const int avail = (int)(left < (size_t)npu ? left : (size_t)npu) * 130;
+  for (int i = tid; i < avail; i += nthreads) {
+    const int p = i / 130, o = i - p * 130, a = o >= 65, k = o - 65 * a;
+    if (k <= 2 * N) s_ref[p][a][k] = g[i];
+  }
+  __syncthreads();
+  constexpr int RW = 2 * N + 1;
+  for (int i = tid; i < npu * 2 * RW; i += nthreads) {
+    const int p = i / (2 * RW), r = i - p * 2 * RW, a = r >= RW, k = r - RW * a;
+    const u8 *src = s_ref[p][a];
+    int v;
+    if (k == 0) v = (s_ref[p][0][1] + 2 * s_ref[p][0][0] + s_ref[p][1][1] + 2) >> 2;
+    else if (k == 2 * N) v = src[k];
+    else v = (src[k - 1] + 2 * src[k] + src[k + 1] + 2) >> 2;
+    s_ref[p][2 + a][k] = (u8)v;
+  }
+  __syncthreads();
+}
+
+// Extended main reference of one PU for an angular mode: e[k], k = idx + N, idx = -N .. 2N+1.
+// idx >= -1: main[idx + 1]; below: the side reference projected with the inverse angle
+// (intra-generic.c:78-93).  Entries the mode never reads are still filled (index clamped).
+template <int N>
+__device__ __forceinline__ u8 ext_entry(const u8 (*ref)[RS], bool fil, const ang_t &a, int idx)
+{
+  const u8 *mainr = ref[2 * fil + (a.vertical ? 1 : 0)];
+  const u8 *side = ref[2 * fil + (a.vertical ? 0 : 1)];
+  if (idx >= -1) return mainr[idx + 1];
+  int si = (128 + (-idx - 1) * a.inv) >> 8;
+  if (si > 2 * N) si = 2 * N;
+  return side[si];
+}
+
+__device__ __forceinline__ int dc_value(const u8 (*ref)[RS], int n, int log2_width)
+{
+  int sum = n;
+  for (int i = 1; i <= n; ++i) sum += ref[0][i] + ref[1][i];
+  return sum >> (log2_width + 1);
+}
+
+// one pixel of the DC prediction (intra.c:217-278)
+__device__ __forceinline__ int dc_px(const u8 (*ref)[RS], int dc, bool edge, int x, int y)
+{
+  if (!edge || (x > 0 && y > 0)) return dc;
+  if (x == 0 && y == 0) return (ref[0][1] + 2 * dc + ref[1][1] + 2) >> 2;
+  if (y == 0) return (ref[1][x + 1] + 3 * dc + 2) >> 2;
+  return (ref[0][y + 1] + 3 * dc + 2) >> 2;
+}
+
+// one pixel of the planar prediction (intra-generic.c:155-189, closed form :167-175)
+__device__ __forceinline__ int planar_px(const u8 *left, const u8 *top, int n, int log2_width, int x, int y)
+{
+  const int hor = (n - 1 - x) * left[y + 1] + (x + 1) * top[n + 1];
+  const int ver = (n - 1 - y) * top[x + 1] + (y + 1) * left[n + 1];
+  return (hor + ver + n) >> (log2_width + 1);
+}
+
+// one pixel of an angular prediction in the vertical orientation: row r, column c; e = &ext[N]
+__device__ __forceinline__ int ang_px(const u8 *e, int disp, int r, int c)
+{
+  const int pos = (r + 1) * disp, di = pos >> 5, f = pos & 31;
+  return ((32 - f) * e[c + di] + f * e[c + di + 1] + 16) >> 5;
+}
+
+// intra_post_process_angular (intra.c:195-208) on column 0 of row r (vertical orientation)
+__device__ __forceinline__ int post_px(int v, const u8 *side, int r)
+{
+  return clampi(v + (((int)side[r + 1] - (int)side[0]) >> 1), 0, 255);
+}
+
+struct mode_list { signed char m[36]; };
+
+// --------------------------------------------------------------------------------------------
+// predictions to memory: one wave per (PU, mode slot)
+// --------------------------------------------------------------------------------------------
+template <int LOG2>
+__global__ __launch_bounds__(256) void intra_predict_kernel(const kvz_hip_intra_ref *__restrict__ refs, size_t count, mode_list modes,
+                                                           int num_modes, int flags, u8 *__restrict__ dst)
+{
+  constexpr int N = 1 << LOG2, ES = 3 * N + 4;
+  __shared__ __align__(16) u8 s_ref[4][4][RS];
+  __shared__ __align__(16) u8 s_ext[4][ES];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t items = count * (size_t)num_modes;
+  for (size_t base = (size_t)blockIdx.x * 4; base < items; base += (size_t)gridDim.x * 4) {
+    // the four waves of the workgroup take four consecutive items; stage their PUs' references
+    __syncthreads();
+    {
+      u32 *z = (u32 *)s_ref;
+      for (int i = threadIdx.x; i < 4 * 4 * RS / 4; i += 256) z[i] = 0u;
+    }
+    __syncthreads();
+    const size_t item = base + w;
+    const bool live = item < items;
+    const size_t pu = live ? item / num_modes : 0;
+    const int mode = live ? modes.m[item - pu * num_modes] : 0;
+    {
+      const u8 *g = (const u8 *)(refs + pu);
+      for (int i = lane; i < 130; i += 64) {
+        const int a = i >= 65, k = i - 65 * a;
+        if (k <= 2 * N) s_ref[w][a][k] = g[i];
+      }
+    }
+    wave_lds_fence();
+    for (int i = lane; i < 2 * (2 * N + 1); i += 64) {
+      const int a = i >= 2 * N + 1, k = i - (2 * N + 1) * a;
+      const u8 *src = s_ref[w][a];
+      int v;
+      if (k == 0) v = (s_ref[w][0][1] + 2 * s_ref[w][0][0] + s_ref[w][1][1] + 2) >> 2;
+      else if (k == 2 * N) v = src[k];
+      else v = (src[k - 1] + 2 * src[k] + src[k + 1] + 2) >> 2;
+      s_ref[w][2 + a][k] = (u8)v;
+    }
+    wave_lds_fence();
+    const bool fil = use_filtered(mode, LOG2, flags);
+    const bool edge = luma_edge_filters(LOG2, flags);
+    u8 *out = dst + item * (size_t)(N * N);
+    if (mode >= 2) {
+      const ang_t a = ang_of(mode);
+      for (int k = lane; k < 3 * N + 2; k += 64) s_ext[w][k] = ext_entry<N>(s_ref[w], fil, a, k - N);
+      wave_lds_fence();
+      const u8 *e = &s_ext[w][N];
+      const u8 *side = s_ref[w][2 * fil + (a.vertical ? 0 : 1)];
+      const bool pp = edge && (flags & KVZ_HIP_INTRA_FILTER_BOUNDARY) && a.disp == 0;
+      if (live)
+        for (int px = lane; px < N * N; px += 64) {
+          const int y = px >> LOG2, x = px & (N - 1);
+          const int r = a.vertical ? y : x, c = a.vertical ? x : y;
+          int v = ang_px(e, a.disp, r, c);
+          if (pp && c == 0) v = post_px(v, side, r);
+          out[px] = (u8)v;
+        }
+    } else if (mode == 1) {
+      const int dc = dc_value(s_ref[w], N, LOG2);
+      if (live)
+        for (int px = lane; px < N * N; px += 64) out[px] = (u8)dc_px(s_ref[w], dc, edge, px & (N - 1), px >> LOG2);
+    } else {
+      const u8 *left = s_ref[w][2 * fil], *top = s_ref[w][2 * fil + 1];
+      if (live)
+        for (int px = lane; px < N * N; px += 64) out[px] = (u8)planar_px(left, top, N, LOG2, px & (N - 1), px >> LOG2);
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// rough search: 35 mode costs per PU.  A lane owns one NB x NB sub-block (NB = 8, or 4 for 4x4
+// PUs) of one PU for the whole kernel and keeps the matching original pixels (and their
+// transpose) in registers; the four waves of a workgroup walk the modes 4 apart, so the mode --
+// and with it every branch and the extended-reference build -- is uniform across a wave.
+// --------------------------------------------------------------------------------------------
+template <int NB> struct sub_block;
+template <> struct sub_block<8> {
+  v2s x[8][4];
+  __device__ __forceinline__ u32 satd() { return satd8x8_diff(x); }
+};
+template <> struct sub_block<4> {
+  v2s x[4][2];
+  __device__ __forceinline__ u32 satd() { return satd4x4_diff(x); }
+};
+
+template <int NB>
+__device__ __forceinline__ u32 sad_of(const sub_block<NB> &b)
+{
+  v2us acc = { 0, 0 };
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) {
+      const v2s n = -b.x[r][q];
+      acc += __builtin_bit_cast(v2us, __builtin_elementwise_max(b.x[r][q], n));
+    }
+  return (u32)acc.x + (u32)acc.y;
+}
+
+template <int LOG2, bool WITH_SAD>
+__global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_ref *__restrict__ refs, const u8 *__restrict__ orig,
+                                                         size_t count, int flags, u32 *__restrict__ satd_out, u32 *__restrict__ sad_out)
+{
+  constexpr int N = 1 << LOG2, NB = N < 8 ? 4 : 8, SB = N / NB, S = SB * SB, G = 64 / S;
+  constexpr int ES = 3 * N + 4;          // odd number of dwords: conflict-free across PUs
+  constexpr int OS = N * N + 8;
+  constexpr int NQ = NB / 2;             // packed pairs per sub-block row
+  __shared__ __align__(16) u8 s_ref[G][4][RS];
+  __shared__ __align__(16) u8 s_orig[G][OS];
+  __shared__ __align__(16) u8 s_ext[4][G][ES];
+  __shared__ int s_dc[G];
+  __shared__ u32 s_cost[WITH_SAD ? 2 : 1][G][35];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const size_t pu0 = (size_t)blockIdx.x * G;
+  stage_refs<N>(s_ref, G, refs, pu0, count, tid, 256);
+  {
+    const size_t left = count - pu0;
+    const int avail = (int)(left < (size_t)G ? left : (size_t)G);
+    const uint2 *g = (const uint2 *)(orig + pu0 * (size_t)(N * N));
+    for (int i = tid; i < G * N * N / 8; i += 256) {
+      const int p = i / (N * N / 8), o = (i - p * (N * N / 8)) * 8;
+      uint2 v = { 0u, 0u };
+      if (p < avail) v = g[i];
+      *(uint2 *)&s_orig[p][o] = v;
+    }
+    if (tid < G) s_dc[tid] = dc_value(s_ref[tid], N, LOG2);
+  }
+  __syncthreads();
+
+  const int p = lane / S, sub = lane % S, bx = sub % SB, by = sub / SB;
+  const int gx0 = bx * NB, gy0 = by * NB;
+  // original pixels of the lane's sub-block, and of the transposed block's sub-block at the same place
+  u32 o[NB * NB / 4], ot[NB * NB / 4];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const u8 *row = &s_orig[p][(gy0 + r) * N + gx0];
+    if (NB == 8) { const uint2 v = *(const uint2 *)row; o[2 * r] = v.x; o[2 * r + 1] = v.y; }
+    else o[r] = *(const u32 *)row;
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) {
+      u32 d = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d |= (u32)s_orig[p][(gx0 + 4 * q + k) * N + gy0 + r] << (8 * k);
+      ot[r * (NB / 4) + q] = d;
+    }
+  }
+  const bool edge = luma_edge_filters(LOG2, flags);
+  const u8 (*ref)[RS] = s_ref[p];
+
+  for (int mode = w; mode < 35; mode += 4) {
+    sub_block<NB> b;
+    const bool fil = use_filtered(mode, LOG2, flags);
+    if (mode >= 2) {
+      const ang_t a = ang_of(mode);
+      wave_lds_fence();
+      for (int i = lane; i < G * (3 * N + 2); i += 64) {
+        const int pp = i / (3 * N + 2), k = i - pp * (3 * N + 2);
+        s_ext[w][pp][k] = ext_entry<N>(s_ref[pp], fil, a, k - N);
+      }
+      wave_lds_fence();
+      const u8 *e = &s_ext[w][p][N + gx0];
+      const u8 *side = ref[2 * fil + (a.vertical ? 0 : 1)];
+      const bool post = edge && (flags & KVZ_HIP_INTRA_FILTER_BOUNDARY) && a.disp == 0 && gx0 == 0;
+      const u32 *src = a.vertical ? o : ot;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        const int pos = (gy0 + r + 1) * a.disp, di = pos >> 5, f = pos & 31;
+        const u8 *q0 = e + di;
+        u32 s[NB + 1];
+#pragma unroll
+        for (int j = 0; j <= NB; ++j) s[j] = q0[j];
+        const u32 wf = (u32)f * 0x10001u;
+        const v2us w1 = __builtin_bit_cast(v2us, wf), w0 = __builtin_bit_cast(v2us, 0x00200020u - wf);
+        const v2us rnd = { 16, 16 };
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const v2us pa = __builtin_bit_cast(v2us, s[2 * q] | (s[2 * q + 1] << 16));
+          const v2us pb = __builtin_bit_cast(v2us, s[2 * q + 1] | (s[2 * q + 2] << 16));
+          v2us v = (pa * w0 + pb * w1 + rnd) >> 5;
+          if (q == 0 && post) v.x = (unsigned short)post_px(v.x, side, gy0 + r);
+          const u32 od = src[(r * NB + 2 * q) >> 2];
+          const v2s ov = (q & 1) ? unpack_hi(od) : unpack_lo(od);
+          b.x[r][q] = __builtin_bit_cast(v2s, v) - ov;
+        }
+      }
+    } else {
+      const int dc = s_dc[p];
+      const u8 *left = ref[2 * fil], *top = ref[2 * fil + 1];
+#pragma unroll
+      for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int x = gx0 + 2 * q, y = gy0 + r;
+          int v0, v1;
+          if (mode == 1) { v0 = dc_px(ref, dc, edge, x, y); v1 = dc_px(ref, dc, edge, x + 1, y); }
+          else { v0 = planar_px(left, top, N, LOG2, x, y); v1 = planar_px(left, top, N, LOG2, x + 1, y); }
+          const u32 od = o[(r * NB + 2 * q) >> 2];
+          const v2s ov = (q & 1) ? unpack_hi(od) : unpack_lo(od);
+          const v2s pv = { (short)v0, (short)v1 };
+          b.x[r][q] = pv - ov;
+        }
+    }
+    if (WITH_SAD) {
+      const u32 sd = group_sum<S>(sad_of<NB>(b));
+      if (sub == 0) s_cost[WITH_SAD ? 1 : 0][p][mode] = sd;
+    }
+    const u32 c = group_sum<S>(b.satd());
+    if (sub == 0) s_cost[0][p][mode] = c;
+  }
+  __syncthreads();
+  const size_t total = count * 35, base = pu0 * 35;
+  for (int i = tid; i < G * 35; i += 256)
+    if (base + i < total) {
+      satd_out[base + i] = (&s_cost[0][0][0])[i];
+      if (WITH_SAD) sad_out[base + i] = (&s_cost[WITH_SAD ? 1 : 0][0][0])[i];
+    }
+}
+
+template <int LOG2>
+int launch_rough(const kvz_hip_intra_ref *refs, const u8 *orig, size_t count, int flags, u32 *satd, u32 *sad, hipStream_t st)
+{
+  constexpr int N = 1 << LOG2, NB = N < 8 ? 4 : 8, S = (N / NB) * (N / NB), G = 64 / S;
+  const size_t wgs = (count + G - 1) / G;
+  if (wgs > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (sad) hipLaunchKernelGGL((intra_rough_kernel<LOG2, true>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
+  else hipLaunchKernelGGL((intra_rough_kernel<LOG2, false>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
+  KVZ_CHECK_LAUNCH("intra_rough_kernel");
+  return KVZ_HIP_OK;
+}
+
+template <int LOG2>
+int launch_predict(const kvz_hip_intra_ref *refs, size_t count, const mode_list &ml, int num_modes, int flags, u8 *dst, hipStream_t st)
+{
+  const size_t items = count * (size_t)num_modes;
+  const unsigned grid = stream_grid(items, 4, 16);
+  hipLaunchKernelGGL((intra_predict_kernel<LOG2>), dim3(grid), dim3(256), 0, st, refs, count, ml, num_modes, flags, dst);
+  KVZ_CHECK_LAUNCH("intra_predict_kernel");
+  return KVZ_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kvz_hip_intra_predict_batch(int log2_width, int flags, const kvz_hip_intra_ref *refs, size_t count, const int8_t *modes,
+                                int num_modes, kvz_hip_pixel *dst, kvz_hip_stream stream)
+{
+  KVZ_CHECK_CTX();
+  if (log2_width < 2 || log2_width > 5 || num_modes < 1 || num_modes > 35 || !modes) {
+    set_error_msg("kvz_hip_intra_predict_batch: log2_width 2..5 and 1..35 modes required");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  mode_list ml;
+  for (int i = 0; i < num_modes; ++i) {
+    if (modes[i] < 0 || modes[i] > 34) { set_error_msg("kvz_hip_intra_predict_batch: mode outside 0..34"); return KVZ_HIP_ERR_INVALID; }
+    ml.m[i] = modes[i];
+  }
+  if (count == 0) return KVZ_HIP_OK;
+  if (!refs || !dst) { set_error_msg("kvz_hip_intra_predict_batch: null buffer"); return KVZ_HIP_ERR_INVALID; }
+  hipStream_t st = ctx_stream(stream);
+  switch (log2_width) {
+    case 2: return launch_predict<2>(refs, count, ml, num_modes, flags, dst, st);
+    case 3: return launch_predict<3>(refs, count, ml, num_modes, flags, dst, st);
+    case 4: return launch_predict<4>(refs, count, ml, num_modes, flags, dst, st);
+    default: return launch_predict<5>(refs, count, ml, num_modes, flags, dst, st);
+  }
+}
+
+int kvz_hip_intra_rough_batch(int log2_width, int flags, const kvz_hip_intra_ref *refs, const kvz_hip_pixel *orig, size_t count,
+                              uint32_t *satd_costs, uint32_t *sad_costs, kvz_hip_stream stream)
+{
+  KVZ_CHECK_CTX();
+  if (log2_width < 2 || log2_width > 5) { set_error_msg("kvz_hip_intra_rough_batch: log2_width must be 2..5"); return KVZ_HIP_ERR_INVALID; }
+  if (flags & KVZ_HIP_INTRA_RAW) { set_error_msg("kvz_hip_intra_rough_batch: KVZ_HIP_INTRA_RAW is not a search mode"); return KVZ_HIP_ERR_INVALID; }
+  if (count == 0) return KVZ_HIP_OK;
+  if (!refs || !orig || !satd_costs) { set_error_msg("kvz_hip_intra_rough_batch: null buffer"); return KVZ_HIP_ERR_INVALID; }
+  if (((uintptr_t)orig) & 7) { set_error_msg("kvz_hip_intra_rough_batch: orig must be 8-byte aligned"); return KVZ_HIP_ERR_INVALID; }
+  hipStream_t st = ctx_stream(stream);
+  switch (log2_width) {
+    case 2: return launch_rough<2>(refs, orig, count, flags, satd_costs, sad_costs, st);
+    case 3: return launch_rough<3>(refs, orig, count, flags, satd_costs, sad_costs, st);
+    case 4: return launch_rough<4>(refs, orig, count, flags, satd_costs, sad_costs, st);
+    default: return launch_rough<5>(refs, orig, count, flags, satd_costs, sad_costs, st);
+  }
+}
+
+}  // extern "C"

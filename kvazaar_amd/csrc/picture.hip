@@ -7,10 +7,10 @@
 // coalesced store per wave.  No LDS is needed for the contiguous-block kernels
 // (there is no reuse to exploit: every byte is read exactly once).
 #include "kvz_hip_internal.h"
+#include "satd_regs.h"
 
 using namespace kvzhip;
 
-typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -129,82 +129,6 @@ __global__ __launch_bounds__(256) void sad_nxn_kernel(const u8 *__restrict__ a, 
 // into the absolute sum: |a+b| + |a-b| = 2*max(|a|,|b|).
 // picture-generic.c:240-328 (8x8: (sum+2)>>2), :105-196 (4x4: (sum+1)>>1).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ v2s as_v2s(u32 x) { return __builtin_bit_cast(v2s, x); }
-__device__ __forceinline__ u32 as_u32(v2s x) { return __builtin_bit_cast(u32, x); }
-__device__ __forceinline__ v2s unpack_lo(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
-__device__ __forceinline__ v2s unpack_hi(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
-
-// sum over the register's two halves of max(|lo|,|hi|)  (the folded last stage)
-__device__ __forceinline__ u32 absmax_halves(v2s x)
-{
-  v2s n = -x;
-  v2s ax = __builtin_elementwise_max(x, n);
-  u32 w = as_u32(ax);
-  u32 lo = w & 0xffffu, hi = w >> 16;
-  return lo > hi ? lo : hi;
-}
-
-// a[16], b[16]: row r of the 8x8 = dwords 2r (cols 0..3) and 2r+1 (cols 4..7).
-// Returns the reference's satd_8x8_subblock value.
-__device__ __forceinline__ u32 satd8x8_regs(const u32 *a, const u32 *b)
-{
-  v2s x[8][4];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    x[r][0] = unpack_lo(a[2 * r]) - unpack_lo(b[2 * r]);
-    x[r][1] = unpack_hi(a[2 * r]) - unpack_hi(b[2 * r]);
-    x[r][2] = unpack_lo(a[2 * r + 1]) - unpack_lo(b[2 * r + 1]);
-    x[r][3] = unpack_hi(a[2 * r + 1]) - unpack_hi(b[2 * r + 1]);
-  }
-  // horizontal, column bit 2 (distance 4) and bit 1 (distance 2)
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    v2s s0 = x[r][0] + x[r][2], s1 = x[r][1] + x[r][3];
-    v2s d0 = x[r][0] - x[r][2], d1 = x[r][1] - x[r][3];
-    x[r][0] = s0 + s1; x[r][1] = s0 - s1;
-    x[r][2] = d0 + d1; x[r][3] = d0 - d1;
-  }
-  // vertical, three stages
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    v2s t[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { t[r] = x[r][q] + x[r + 4][q]; t[r + 4] = x[r][q] - x[r + 4][q]; }
-#pragma unroll
-    for (int h = 0; h < 8; h += 4) {
-      v2s u0 = t[h] + t[h + 2], u1 = t[h + 1] + t[h + 3], u2 = t[h] - t[h + 2], u3 = t[h + 1] - t[h + 3];
-      x[h][q] = u0 + u1; x[h + 1][q] = u0 - u1; x[h + 2][q] = u2 + u3; x[h + 3][q] = u2 - u3;
-    }
-  }
-  // column bit 0 (inside the register) folded into the absolute sum
-  u32 m = 0;
-#pragma unroll
-  for (int r = 0; r < 8; ++r)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) m += absmax_halves(x[r][q]);
-  return (m + 1) >> 1;                 // (2m + 2) >> 2
-}
-
-// a[4], b[4]: row r of the 4x4 = dword r.  Returns satd_4x4 ((sum+1)>>1 == m).
-__device__ __forceinline__ u32 satd4x4_regs(const u32 *a, const u32 *b)
-{
-  v2s x[4][2];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    x[r][0] = unpack_lo(a[r]) - unpack_lo(b[r]);
-    x[r][1] = unpack_hi(a[r]) - unpack_hi(b[r]);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { v2s s = x[r][0] + x[r][1], d = x[r][0] - x[r][1]; x[r][0] = s; x[r][1] = d; }
-  u32 m = 0;
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    v2s s0 = x[0][q] + x[2][q], s1 = x[1][q] + x[3][q], d0 = x[0][q] - x[2][q], d1 = x[1][q] - x[3][q];
-    m += absmax_halves(s0 + s1) + absmax_halves(s0 - s1) + absmax_halves(d0 + d1) + absmax_halves(d0 - d1);
-  }
-  return m;                            // (2m + 1) >> 1
-}
-
 // strategies-picture.h:40-56 (SATD_NxN) / picture-generic.c:357-390 (dual).
 // Lane = one 8x8 sub-block; the (N/8)^2 lanes of a block are consecutive.
 template <int N, bool DUAL>

@@ -1,0 +1,100 @@
+// satd_regs.h -- lane-private Hadamard cost of one 8x8 / 4x4 block held in registers.
+// Packed int16 arithmetic (|coef| <= 64*255 fits); the last butterfly stage is folded
+// into the absolute sum: |a+b| + |a-b| = 2*max(|a|,|b|).
+// picture-generic.c:240-328 (8x8: (sum+2)>>2), :105-196 (4x4: (sum+1)>>1).
+#pragma once
+#include "kvz_hip_internal.h"
+
+namespace kvzhip {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2s as_v2s(u32 x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ u32 as_u32(v2s x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ v2s unpack_lo(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
+__device__ __forceinline__ v2s unpack_hi(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
+
+// sum over the register's two halves of max(|lo|,|hi|)  (the folded last stage)
+__device__ __forceinline__ u32 absmax_halves(v2s x)
+{
+  v2s n = -x;
+  v2s ax = __builtin_elementwise_max(x, n);
+  u32 w = as_u32(ax);
+  u32 lo = w & 0xffffu, hi = w >> 16;
+  return lo > hi ? lo : hi;
+}
+
+// x[r][q]: difference row r, columns 2q (low half) and 2q+1 (high half).  Destroys x.
+// Returns the reference's satd_8x8_subblock value.
+__device__ __forceinline__ u32 satd8x8_diff(v2s (&x)[8][4])
+{
+  // horizontal, column bit 2 (distance 4) and bit 1 (distance 2)
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    v2s s0 = x[r][0] + x[r][2], s1 = x[r][1] + x[r][3];
+    v2s d0 = x[r][0] - x[r][2], d1 = x[r][1] - x[r][3];
+    x[r][0] = s0 + s1; x[r][1] = s0 - s1;
+    x[r][2] = d0 + d1; x[r][3] = d0 - d1;
+  }
+  // vertical, three stages
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v2s t[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { t[r] = x[r][q] + x[r + 4][q]; t[r + 4] = x[r][q] - x[r + 4][q]; }
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      v2s u0 = t[h] + t[h + 2], u1 = t[h + 1] + t[h + 3], u2 = t[h] - t[h + 2], u3 = t[h + 1] - t[h + 3];
+      x[h][q] = u0 + u1; x[h + 1][q] = u0 - u1; x[h + 2][q] = u2 + u3; x[h + 3][q] = u2 - u3;
+    }
+  }
+  // column bit 0 (inside the register) folded into the absolute sum
+  u32 m = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m += absmax_halves(x[r][q]);
+  return (m + 1) >> 1;                 // (2m + 2) >> 2
+}
+
+// a[16], b[16]: row r of the 8x8 = dwords 2r (cols 0..3) and 2r+1 (cols 4..7) of packed bytes.
+__device__ __forceinline__ u32 satd8x8_regs(const u32 *a, const u32 *b)
+{
+  v2s x[8][4];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    x[r][0] = unpack_lo(a[2 * r]) - unpack_lo(b[2 * r]);
+    x[r][1] = unpack_hi(a[2 * r]) - unpack_hi(b[2 * r]);
+    x[r][2] = unpack_lo(a[2 * r + 1]) - unpack_lo(b[2 * r + 1]);
+    x[r][3] = unpack_hi(a[2 * r + 1]) - unpack_hi(b[2 * r + 1]);
+  }
+  return satd8x8_diff(x);
+}
+
+// x[r][q]: difference row r of a 4x4, columns 2q, 2q+1.  Returns satd_4x4 ((sum+1)>>1 == m).
+__device__ __forceinline__ u32 satd4x4_diff(v2s (&x)[4][2])
+{
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { v2s s = x[r][0] + x[r][1], d = x[r][0] - x[r][1]; x[r][0] = s; x[r][1] = d; }
+  u32 m = 0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    v2s s0 = x[0][q] + x[2][q], s1 = x[1][q] + x[3][q], d0 = x[0][q] - x[2][q], d1 = x[1][q] - x[3][q];
+    m += absmax_halves(s0 + s1) + absmax_halves(s0 - s1) + absmax_halves(d0 + d1) + absmax_halves(d0 - d1);
+  }
+  return m;                            // (2m + 1) >> 1
+}
+
+// a[4], b[4]: row r of the 4x4 = dword r of packed bytes.
+__device__ __forceinline__ u32 satd4x4_regs(const u32 *a, const u32 *b)
+{
+  v2s x[4][2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    x[r][0] = unpack_lo(a[r]) - unpack_lo(b[r]);
+    x[r][1] = unpack_hi(a[r]) - unpack_hi(b[r]);
+  }
+  return satd4x4_diff(x);
+}
+
+}  // namespace kvzhip

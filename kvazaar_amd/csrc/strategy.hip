@@ -377,6 +377,40 @@ void hip_filter_step(const void *encoder, kvz_hip_pixel *src, int16_t src_stride
   }
 }
 
+// ---------------- intra group ----------------
+// angular_pred_func / intra_pred_planar_func (strategies-intra.h:33-45): the bare predictors on the caller's
+// reference rows (entry 0 = corner, 2N+1 entries each), N*N contiguous pixels out.
+void intra_call(int log2_width, int mode, const kvz_hip_pixel *ref_above, const kvz_hip_pixel *ref_left, kvz_hip_pixel *dst)
+{
+  const int n = 1 << log2_width;
+  call_ctx &c = tls(); stage s(c);
+  size_t orf = s.take(sizeof(kvz_hip_intra_ref)), in_end = s.off, oo = s.take((size_t)n * n);
+  kvz_hip_intra_ref r;
+  std::memset(&r, 0, sizeof(r));
+  std::memcpy(r.left, ref_left, (size_t)2 * n + 1);
+  std::memcpy(r.top, ref_above, (size_t)2 * n + 1);
+  std::memcpy(c.h + orf, &r, sizeof(r));
+  s.h2d(0, in_end);
+  const int8_t m = (int8_t)mode;
+  MUST(kvz_hip_intra_predict_batch(log2_width, KVZ_HIP_INTRA_RAW, (const kvz_hip_intra_ref *)(c.d + orf), 1, &m, 1, c.d + oo, c.st));
+  s.d2h(oo, (size_t)n * n); s.sync();
+  std::memcpy(dst, c.h + oo, (size_t)n * n);
+}
+
+void hip_angular_pred(const int_fast8_t log2_width, const int_fast8_t intra_mode, const kvz_hip_pixel *const in_ref_above,
+                      const kvz_hip_pixel *const in_ref_left, kvz_hip_pixel *const dst)
+{
+  if (log2_width < 2 || log2_width > 5 || intra_mode < 2 || intra_mode > 34) die("angular_pred: bad arguments", KVZ_HIP_ERR_INVALID);
+  intra_call(log2_width, intra_mode, in_ref_above, in_ref_left, dst);
+}
+
+void hip_intra_pred_planar(const int_fast8_t log2_width, const kvz_hip_pixel *const ref_top, const kvz_hip_pixel *const ref_left,
+                           kvz_hip_pixel *const dst)
+{
+  if (log2_width < 2 || log2_width > 5) die("intra_pred_planar: bad arguments", KVZ_HIP_ERR_INVALID);
+  intra_call(log2_width, 0, ref_top, ref_left, dst);
+}
+
 // inter_recon_bipred_func (strategies-picture.h:117-130, picture-generic.c:538-588): the lcu_t / hi_prec_buf_t
 // planes are reached through the accessor glue; luma w x h at (xpos, ypos) & 63 and chroma w/2 x h/2.
 void hip_inter_recon_bipred(const int hi_prec_luma_rec0, const int hi_prec_luma_rec1, const int hi_prec_chroma_rec0,
@@ -526,6 +560,16 @@ int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
   ok &= reg(opaque, "filter_hpel_blocks_diag_luma", (void *)&hip_filter_step<1>);
   ok &= reg(opaque, "filter_qpel_blocks_hor_ver_luma", (void *)&hip_filter_step<2>);
   ok &= reg(opaque, "filter_qpel_blocks_diag_luma", (void *)&hip_filter_step<3>);
+  return ok;
+}
+
+// STRATEGIES_INTRA_EXPORTS, strategies-intra.h:52-55
+int kvz_strategy_register_intra_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!hook_ready(bitdepth)) return 0;
+  int ok = 1;
+  ok &= reg(opaque, "angular_pred", (void *)&hip_angular_pred);
+  ok &= reg(opaque, "intra_pred_planar", (void *)&hip_intra_pred_planar);
   return ok;
 }
 

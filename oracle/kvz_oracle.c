@@ -833,3 +833,126 @@ void orc_ctu_sad_grid(const orc_pixel *pic, int pic_stride, int pic_w, int pic_h
     }
   }
 }
+
+/* =====================================================================
+ * intra group (intra-generic.c, intra.c)
+ * ===================================================================== */
+
+/* intra-generic.c:46-47: displacement per row in 1/32 sample for |mode - 26| (or |10 - mode|),
+ * and 256*32/disp for projecting the side reference */
+static const int orc_ang_disp[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const int orc_ang_inv[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+
+/* intra-generic.c:37-145.  Restated per pixel: the prediction is built in the "vertical"
+ * orientation from an extended main reference m[-N .. 2N] and transposed for modes < 18. */
+void orc_angular_pred(int log2_width, int mode, const orc_pixel *ref_above, const orc_pixel *ref_left, orc_pixel *dst)
+{
+  const int n = 1 << log2_width;
+  const int vertical = mode >= 18;
+  const int md = vertical ? mode - 26 : 10 - mode;
+  const int amd = md < 0 ? -md : md;
+  const int disp = md < 0 ? -orc_ang_disp[amd] : orc_ang_disp[amd];
+  const orc_pixel *mainr = vertical ? ref_above : ref_left;   /* index 0 = corner */
+  const orc_pixel *side = vertical ? ref_left : ref_above;
+  int ext_store[3 * 32 + 2];
+  int *m = ext_store + 32;                                    /* m[i], i = -n .. 2n */
+  for (int i = -n; i <= 2 * n; ++i) m[i] = 0;
+  for (int i = -1; i < 2 * n; ++i) m[i] = mainr[i + 1];
+  if (disp < 0) {
+    /* :78-93: indices below -1 are projected from the side reference */
+    const int most_negative = (n * disp) >> 5;
+    for (int i = -2; i >= most_negative; --i) m[i] = side[(128 + (-i - 1) * orc_ang_inv[amd]) >> 8];
+  }
+  for (int y = 0; y < n; ++y) {
+    const int pos = (y + 1) * disp;
+    const int di = pos >> 5, f = pos & 31;                    /* :107-108 (arithmetic shift) */
+    for (int x = 0; x < n; ++x) {
+      /* :110-123; with f == 0 the second tap has weight 0 and is not read by the reference */
+      const int v = f ? ((32 - f) * m[x + di] + f * m[x + di + 1] + 16) >> 5 : m[x + di];
+      if (vertical) dst[y * n + x] = (orc_pixel)v; else dst[x * n + y] = (orc_pixel)v;   /* :137-144 flip */
+    }
+  }
+}
+
+/* intra-generic.c:155-189 in its closed form (the #if 0 branch :167-175) */
+void orc_intra_pred_planar(int log2_width, const orc_pixel *ref_top, const orc_pixel *ref_left, orc_pixel *dst)
+{
+  const int n = 1 << log2_width;
+  const int tr = ref_top[n + 1], bl = ref_left[n + 1];
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      const int hor = (n - 1 - x) * ref_left[y + 1] + (x + 1) * tr;
+      const int ver = (n - 1 - y) * ref_top[x + 1] + (y + 1) * bl;
+      dst[y * n + x] = (orc_pixel)((hor + ver + n) >> (log2_width + 1));
+    }
+}
+
+/* intra.c:164-192 */
+void orc_intra_filter_reference(int log2_width, const orc_intra_ref *ref, orc_intra_ref *fil)
+{
+  const int last = 2 * (1 << log2_width);                     /* ref_width - 1 */
+  fil->left[0] = fil->top[0] = (orc_pixel)((ref->left[1] + 2 * ref->left[0] + ref->top[1] + 2) / 4);
+  for (int i = 1; i < last; ++i) {
+    fil->left[i] = (orc_pixel)((ref->left[i - 1] + 2 * ref->left[i] + ref->left[i + 1] + 2) / 4);
+    fil->top[i] = (orc_pixel)((ref->top[i - 1] + 2 * ref->top[i] + ref->top[i + 1] + 2) / 4);
+  }
+  fil->left[last] = ref->left[last];
+  fil->top[last] = ref->top[last];
+}
+
+/* intra.c:281-331 with intra_pred_dc :217-237, intra_pred_filtered_dc :247-278,
+ * intra_post_process_angular :195-208 */
+void orc_intra_predict(const orc_intra_ref *ref, int log2_width, int mode, int is_luma, int filter_boundary, orc_pixel *dst)
+{
+  const int n = 1 << log2_width;
+  orc_intra_ref fil;
+  const orc_intra_ref *used = ref;
+  if (!is_luma || mode == 1 || n == 4) {
+    /* :291-292 unfiltered */
+  } else if (mode == 0) {
+    used = &fil;
+  } else {
+    static const int thres[5] = { 0, 7, 1, 0, 0 };              /* :298 */
+    const int dv = mode > 26 ? mode - 26 : 26 - mode, dh = mode > 10 ? mode - 10 : 10 - mode;
+    if ((dv < dh ? dv : dh) > thres[log2_width - 2]) used = &fil;
+  }
+  if (used == &fil) orc_intra_filter_reference(log2_width, ref, &fil);
+
+  if (mode == 0) {
+    orc_intra_pred_planar(log2_width, used->top, used->left, dst);
+  } else if (mode == 1) {
+    int sum = 0;
+    for (int i = 1; i <= n; ++i) sum += used->top[i] + used->left[i];
+    const int dc = (orc_pixel)((sum + n) >> (log2_width + 1));
+    for (int i = 0; i < n * n; ++i) dst[i] = (orc_pixel)dc;
+    if (is_luma && n < 32) {
+      dst[0] = (orc_pixel)((used->left[1] + 2 * dc + used->top[1] + 2) / 4);
+      for (int x = 1; x < n; ++x) dst[x] = (orc_pixel)((used->top[x + 1] + 3 * dc + 2) / 4);
+      for (int y = 1; y < n; ++y) dst[y * n] = (orc_pixel)((used->left[y + 1] + 3 * dc + 2) / 4);
+    }
+  } else {
+    orc_angular_pred(log2_width, mode, used->top, used->left, dst);
+    if (is_luma && n < 32 && filter_boundary && (mode == 10 || mode == 26)) {
+      /* mode 10: first row corrected with the top gradient; mode 26: first column with the left gradient */
+      const orc_pixel *g = mode == 10 ? used->top : used->left;
+      const int stride = mode == 10 ? 1 : n;
+      for (int i = 0; i < n; ++i) {
+        int v = dst[i * stride] + ((g[i + 1] - g[0]) >> 1);
+        dst[i * stride] = (orc_pixel)(v < 0 ? 0 : v > 255 ? 255 : v);
+      }
+    }
+  }
+}
+
+void orc_intra_rough_costs(const orc_intra_ref *ref, int log2_width, int filter_boundary, const orc_pixel *orig,
+                           unsigned satd_out[35], unsigned sad_out[35])
+{
+  const int n = 1 << log2_width;
+  orc_pixel pred[32 * 32];
+  for (int mode = 0; mode < 35; ++mode) {
+    orc_intra_predict(ref, log2_width, mode, 1, filter_boundary, pred);
+    /* get_cost / get_cost_dual (search_intra.c:99-172): satd_func(pred, orig) and sad_func(pred, orig) */
+    if (satd_out) satd_out[mode] = n == 4 ? orc_satd_4x4(pred, orig) : orc_satd_nxn(n, pred, orig);
+    if (sad_out) sad_out[mode] = orc_sad_nxn(n, pred, orig);
+  }
+}

@@ -152,6 +152,25 @@ void orc_search_frac_costs(const orc_pixel *pic, int pic_stride,
                            int x, int y, int w, int h, int mvx, int mvy,
                            unsigned costs_out[17], int best_out[2]);
 
+/* ---- intra group: src/strategies/generic/intra-generic.c + src/intra.c ----
+ * SURVEY.md section 8(f) row 2.  A PU's reference pixels are the reference's
+ * kvz_intra_ref (intra.h:35-38): left[0] == top[0] == the top-left corner,
+ * left[1..2N] / top[1..2N] the neighbours. */
+typedef struct { orc_pixel left[2 * 32 + 1]; orc_pixel top[2 * 32 + 1]; } orc_intra_ref;
+/* kvz_angular_pred_generic (intra-generic.c:37-145), mode 2..34 */
+void orc_angular_pred(int log2_width, int mode, const orc_pixel *ref_above, const orc_pixel *ref_left, orc_pixel *dst);
+/* kvz_intra_pred_planar_generic (intra-generic.c:155-189) */
+void orc_intra_pred_planar(int log2_width, const orc_pixel *ref_top, const orc_pixel *ref_left, orc_pixel *dst);
+/* intra_filter_reference (intra.c:164-192) */
+void orc_intra_filter_reference(int log2_width, const orc_intra_ref *ref, orc_intra_ref *filtered);
+/* kvz_intra_predict (intra.c:281-331): reference smoothing decision, planar, DC (+ edge
+ * filter), angular (+ boundary post-process of modes 10 / 26).  is_luma = (color == COLOR_Y). */
+void orc_intra_predict(const orc_intra_ref *ref, int log2_width, int mode, int is_luma, int filter_boundary, orc_pixel *dst);
+/* the costs search_intra_rough (search_intra.c:404-520) can ask for: SATD (satd_NxN) and SAD
+ * (sad_NxN) of every mode 0..34 against the N x N original block (contiguous). */
+void orc_intra_rough_costs(const orc_intra_ref *ref, int log2_width, int filter_boundary, const orc_pixel *orig,
+                           unsigned satd_out[35], unsigned sad_out[35]);
+
 #ifdef __cplusplus
 }
 #endif

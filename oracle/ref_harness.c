@@ -18,6 +18,8 @@
 #include "scalinglist.h"
 #include "cu.h"
 #include "search_inter.h"
+#include "intra.h"
+#include "strategies/strategies-intra.h"
 
 static strategy_list_t g_list;
 static int g_ready = 0;
@@ -36,6 +38,7 @@ int ref_init(void)
   if (!kvz_strategy_register_dct(&g_list, 8)) return 0;
   if (!kvz_strategy_register_quant(&g_list, 8)) return 0;
   if (!kvz_strategy_register_ipol(&g_list, 8)) return 0;
+  if (!kvz_strategy_register_intra(&g_list, 8)) return 0;
 
   memset(&g_ctrl, 0, sizeof(g_ctrl));
   memset(&g_state, 0, sizeof(g_state));
@@ -347,14 +350,16 @@ int ref_register_hip(const char *lib_path)
   int (*reg_dct)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_dct_hip");
   int (*reg_quant)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_quant_hip");
   int (*reg_ipol)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_ipol_hip");
-  if (!set_reg || !set_acc || !reg_pic || !reg_dct || !reg_quant || !reg_ipol) return -1;
+  int (*reg_intra)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_intra_hip");
+  if (!set_reg || !set_acc || !reg_pic || !reg_dct || !reg_quant || !reg_ipol || !reg_intra) return -1;
   static const kvz_hip_state_accessors acc = { acc_qp, acc_slice_is_intra, acc_signhide, acc_sl_enable,
                                                acc_quant_coeff, acc_dequant_coeff, acc_rdoq, acc_cu_is_intra,
                                                acc_hp_y, acc_hp_u, acc_hp_v, acc_rec_y, acc_rec_u, acc_rec_v };
   set_reg(kvz_strategyselector_register);
   set_acc(&acc);
   unsigned before = g_list.count;
-  if (!reg_pic(&g_list, 8) || !reg_dct(&g_list, 8) || !reg_quant(&g_list, 8) || !reg_ipol(&g_list, 8)) return -1;
+  if (!reg_pic(&g_list, 8) || !reg_dct(&g_list, 8) || !reg_quant(&g_list, 8) || !reg_ipol(&g_list, 8) ||
+      !reg_intra(&g_list, 8)) return -1;
   return (int)(g_list.count - before);
 }
 
@@ -454,4 +459,58 @@ long ref_encode(const uint8_t *yuv, int w, int h, int nframes, const char *opts,
   api->encoder_close(enc);
   api->config_destroy(cfg);
   return pos;
+}
+
+/* ------------------------------------------------------------------------
+ * intra group (strategies-intra.h:33-55, intra.c:281-331).  refs_in = the
+ * kvz_intra_ref layout {left[65], top[65]} (intra.h:35-38).
+ * ------------------------------------------------------------------------ */
+
+
+void ref_angular_pred(const char *name, int log2_width, int mode, const kvz_pixel *above, const kvz_pixel *left, kvz_pixel *dst)
+{
+  ((angular_pred_func *)ref_strategy("angular_pred", name))(log2_width, mode, above, left, dst);
+}
+
+void ref_intra_pred_planar(const char *name, int log2_width, const kvz_pixel *top, const kvz_pixel *left, kvz_pixel *dst)
+{
+  ((intra_pred_planar_func *)ref_strategy("intra_pred_planar", name))(log2_width, top, left, dst);
+}
+
+/* kvz_intra_predict itself (intra.c:281), with the angular / planar strategies `name` installed in the globals */
+void ref_intra_predict(const char *name, const uint8_t *refs_in /*130 bytes*/, int log2_width, int mode, int color,
+                       int filter_boundary, kvz_pixel *dst)
+{
+  angular_pred_func *save_a = kvz_angular_pred;
+  intra_pred_planar_func *save_p = kvz_intra_pred_planar;
+  kvz_angular_pred = (angular_pred_func *)ref_strategy("angular_pred", name);
+  kvz_intra_pred_planar = (intra_pred_planar_func *)ref_strategy("intra_pred_planar", name);
+  kvz_intra_references refs;
+  memset(&refs, 0, sizeof(refs));
+  memcpy(refs.ref.left, refs_in, 65);
+  memcpy(refs.ref.top, refs_in + 65, 65);
+  refs.filtered_initialized = false;
+  kvz_intra_predict(&refs, log2_width, mode, (color_t)color, dst, filter_boundary != 0);
+  kvz_angular_pred = save_a;
+  kvz_intra_pred_planar = save_p;
+}
+
+/* kvz_intra_build_reference (intra.c:574-588) on an LCU whose rec planes the caller filled:
+ * used to produce realistic reference arrays (unavailable neighbours, picture edges). */
+void ref_intra_build_reference(int log2_width, int color, int luma_x, int luma_y, int pic_w, int pic_h,
+                               const kvz_pixel *rec_y, const kvz_pixel *top_y, const kvz_pixel *left_y, int top_left,
+                               uint8_t *refs_out /*130 bytes*/)
+{
+  lcu_t *lcu = calloc(1, sizeof(lcu_t));
+  memcpy(lcu->rec.y, rec_y, 64 * 64);
+  memcpy(lcu->top_ref.y, top_y, sizeof(lcu->top_ref.y));
+  memcpy(lcu->left_ref.y, left_y, sizeof(lcu->left_ref.y));
+  lcu->top_ref.y[0] = lcu->left_ref.y[0] = (kvz_pixel)top_left;
+  kvz_intra_references refs;
+  memset(&refs, 0, sizeof(refs));
+  vector2d_t luma_px = { luma_x, luma_y }, pic_px = { pic_w, pic_h };
+  kvz_intra_build_reference(log2_width, (color_t)color, &luma_px, &pic_px, lcu, &refs);
+  memcpy(refs_out, refs.ref.left, 65);
+  memcpy(refs_out + 65, refs.ref.top, 65);
+  free(lcu);
 }

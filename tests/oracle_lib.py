@@ -299,3 +299,66 @@ def ctu_sad_grid(pic, ref, ctus, mv_offsets):
                                ref.shape[1], ref.shape[0], int(x), int(y), int(mvx), int(mvy), _p(mv, i16p), mv.shape[0],
                                _p(out[i], u32p))
     return out
+
+
+# ---- intra group.  refs arrays are (count, 130) uint8 = kvz_intra_ref {left[65], top[65]} ----
+def _intra_sigs():
+    L = lib()
+    if getattr(L, "_intra_done", False):
+        return L
+    L.orc_angular_pred.restype = None
+    L.orc_angular_pred.argtypes = [C.c_int, C.c_int, u8p, u8p, u8p]
+    L.orc_intra_pred_planar.restype = None
+    L.orc_intra_pred_planar.argtypes = [C.c_int, u8p, u8p, u8p]
+    L.orc_intra_predict.restype = None
+    L.orc_intra_predict.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+    L.orc_intra_rough_costs.restype = None
+    L.orc_intra_rough_costs.argtypes = [u8p, C.c_int, C.c_int, u8p, u32p, u32p]
+    L._intra_done = True
+    return L
+
+
+def angular_pred(log2_width, mode, above, left):
+    L = _intra_sigs()
+    n = 1 << log2_width
+    above, left = _u8(above), _u8(left)
+    dst = np.zeros(n * n, dtype=np.uint8)
+    L.orc_angular_pred(log2_width, mode, _p(above, u8p), _p(left, u8p), _p(dst, u8p))
+    return dst
+
+
+def intra_pred_planar(log2_width, top, left):
+    L = _intra_sigs()
+    n = 1 << log2_width
+    top, left = _u8(top), _u8(left)
+    dst = np.zeros(n * n, dtype=np.uint8)
+    L.orc_intra_pred_planar(log2_width, _p(top, u8p), _p(left, u8p), _p(dst, u8p))
+    return dst
+
+
+def intra_predict_batch(refs, log2_width, modes, is_luma=1, filter_boundary=1):
+    """-> (count, len(modes), N*N)"""
+    L = _intra_sigs()
+    refs = _u8(refs).reshape(-1, 130)
+    n = 1 << log2_width
+    out = np.zeros((refs.shape[0], len(modes), n * n), dtype=np.uint8)
+    for i in range(refs.shape[0]):
+        r = np.ascontiguousarray(refs[i])
+        for j, m in enumerate(modes):
+            d = out[i, j]
+            L.orc_intra_predict(_p(r, u8p), log2_width, int(m), is_luma, filter_boundary, _p(d, u8p))
+    return out
+
+
+def intra_rough_costs_batch(refs, log2_width, orig, filter_boundary=1):
+    """-> (satd (count, 35), sad (count, 35)) uint32"""
+    L = _intra_sigs()
+    refs = _u8(refs).reshape(-1, 130)
+    n = 1 << log2_width
+    orig = _u8(orig).reshape(-1, n * n)
+    satd = np.zeros((refs.shape[0], 35), dtype=np.uint32)
+    sad = np.zeros((refs.shape[0], 35), dtype=np.uint32)
+    for i in range(refs.shape[0]):
+        r, o = np.ascontiguousarray(refs[i]), np.ascontiguousarray(orig[i])
+        L.orc_intra_rough_costs(_p(r, u8p), log2_width, filter_boundary, _p(o, u8p), _p(satd[i], u32p), _p(sad[i], u32p))
+    return satd, sad

@@ -96,3 +96,28 @@ def coeff_sum_input():
     c = (np.arange(64 * 64, dtype=np.int64) * 16 - 32768).astype(np.int16)
     expected = 2048 * (16 + 32768) // 2 + 2048 * 2047 * 16 // 2
     return c, expected
+
+
+def intra_ref_cases(log2_width, count, seed):
+    """kvz_intra_ref arrays {left[65], top[65]} with left[0] == top[0]: random, flat, ramps, 0/255 extremes"""
+    g = rng(seed)
+    n = 1 << log2_width
+    refs = np.zeros((count, 130), dtype=np.uint8)
+    for i in range(count):
+        kind = i % 5
+        if kind == 0:
+            r = g.integers(0, 256, 130)
+        elif kind == 1:
+            r = np.full(130, g.integers(0, 256))
+        elif kind == 2:
+            base, sl, st = g.integers(0, 200), g.integers(-3, 4), g.integers(-3, 4)
+            r = np.concatenate([base + sl * np.arange(65), base + st * np.arange(65)])
+        elif kind == 3:
+            r = np.where(g.integers(0, 2, 130) > 0, 255, 0)
+        else:
+            r = np.clip(128 + np.cumsum(g.integers(-6, 7, 130)), 0, 255)
+        refs[i] = np.clip(r, 0, 255)
+        refs[i, 65] = refs[i, 0]
+        refs[i, 2 * n + 1:65] = 0            # beyond the 2N+1 entries the reference never reads
+        refs[i, 65 + 2 * n + 1:] = 0
+    return refs

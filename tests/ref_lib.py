@@ -309,3 +309,58 @@ def encode(frames, w, h, opts, strategy=None, cap=1 << 22):
                      out.ctypes.data, cap, C.byref(inst))
     assert 0 < n <= cap, "ref_encode failed (%d)" % n
     return out[:n].tobytes(), inst.value
+
+
+# ---- intra group ----
+def _intra_sigs():
+    L = lib()
+    if getattr(L, "_intra_done", False):
+        return L
+    L.ref_angular_pred.restype = None
+    L.ref_angular_pred.argtypes = [S, C.c_int, C.c_int, u8p, u8p, u8p]
+    L.ref_intra_pred_planar.restype = None
+    L.ref_intra_pred_planar.argtypes = [S, C.c_int, u8p, u8p, u8p]
+    L.ref_intra_predict.restype = None
+    L.ref_intra_predict.argtypes = [S, u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
+    L.ref_intra_build_reference.restype = None
+    L.ref_intra_build_reference.argtypes = [C.c_int] * 6 + [u8p, u8p, u8p, C.c_int, u8p]
+    L._intra_done = True
+    return L
+
+
+def angular_pred(log2_width, mode, above, left, name="generic"):
+    L = _intra_sigs()
+    n = 1 << log2_width
+    above, left = _u8(above), _u8(left)
+    dst = _aligned(np.zeros(n * n, dtype=np.uint8))
+    L.ref_angular_pred(name.encode(), log2_width, mode, _p(above, u8p), _p(left, u8p), _p(dst, u8p))
+    return dst.copy()
+
+
+def intra_pred_planar(log2_width, top, left, name="generic"):
+    L = _intra_sigs()
+    n = 1 << log2_width
+    top, left = _u8(top), _u8(left)
+    dst = _aligned(np.zeros(n * n, dtype=np.uint8))
+    L.ref_intra_pred_planar(name.encode(), log2_width, _p(top, u8p), _p(left, u8p), _p(dst, u8p))
+    return dst.copy()
+
+
+def intra_predict(ref130, log2_width, mode, color=0, filter_boundary=1, name="generic"):
+    """kvz_intra_predict (color 0 = COLOR_Y) on one kvz_intra_ref {left[65], top[65]}"""
+    L = _intra_sigs()
+    n = 1 << log2_width
+    r = _u8(ref130)
+    dst = _aligned(np.zeros(n * n, dtype=np.uint8))
+    L.ref_intra_predict(name.encode(), _p(r, u8p), log2_width, mode, color, filter_boundary, _p(dst, u8p))
+    return dst.copy()
+
+
+def intra_build_reference(log2_width, x, y, pic_w, pic_h, rec_y, top_y, left_y, top_left):
+    """kvz_intra_build_reference for a luma PU at picture position (x, y) (LCU-relative planes supplied by the caller)"""
+    L = _intra_sigs()
+    out = np.zeros(130, dtype=np.uint8)
+    rec_y, top_y, left_y = _u8(rec_y), _u8(top_y), _u8(left_y)
+    L.ref_intra_build_reference(log2_width, 0, x, y, pic_w, pic_h, _p(rec_y, u8p), _p(top_y, u8p), _p(left_y, u8p),
+                                int(top_left), _p(out, u8p))
+    return out

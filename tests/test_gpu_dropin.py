@@ -219,3 +219,23 @@ def test_reference_encoder_bitstream_is_identical_with_hip_strategies(hip, w, h,
     print("hip strategy calls:", calls)
     assert len(gen) > 200
     assert hipb == gen, "bitstreams differ (%d vs %d bytes)" % (len(hipb), len(gen))
+
+
+def test_intra_group_through_registry_and_kvz_intra_predict(hip):
+    """angular_pred / intra_pred_planar registered as "hip": called by name like tests/test_strategies.c does, and
+    installed under the reference's own kvz_intra_predict (intra.c:281)"""
+    from patterns import intra_ref_cases
+    assert R.has_strategy("angular_pred", "hip") and R.has_strategy("intra_pred_planar", "hip")
+    for log2_width in (2, 3, 4, 5):
+        refs = intra_ref_cases(log2_width, 5, 800 + log2_width)
+        for r in refs:
+            left, top = r[:65], r[65:]
+            for mode in (2, 9, 10, 11, 17, 18, 25, 26, 27, 34):
+                np.testing.assert_array_equal(R.angular_pred(log2_width, mode, top, left, "hip"),
+                                              R.angular_pred(log2_width, mode, top, left, "generic"))
+            np.testing.assert_array_equal(R.intra_pred_planar(log2_width, top, left, "hip"),
+                                          R.intra_pred_planar(log2_width, top, left, "generic"))
+            for mode in (0, 1, 2, 10, 18, 26, 30):
+                for color, fb in ((0, 1), (0, 0), (1, 1)):
+                    np.testing.assert_array_equal(R.intra_predict(r, log2_width, mode, color, fb, "hip"),
+                                                  R.intra_predict(r, log2_width, mode, color, fb, "generic"))

@@ -382,3 +382,82 @@ def test_transform_alternate_kernels(api):
     finally:
         L.kvz_hip_set_tuning(b"idct16_use_mfma", -1)
     assert L.kvz_hip_set_tuning(b"no_such_key", 1) != 0
+
+
+# ---- intra group ----
+from patterns import intra_ref_cases  # noqa: E402
+
+
+def _intra_orig(refs, log2_width, seed):
+    """original blocks that resemble one of the predictions plus noise, so costs span small and large values"""
+    g = rng(seed)
+    n = 1 << log2_width
+    count = refs.shape[0]
+    base = O.intra_predict_batch(refs, log2_width, [int(g.integers(0, 35))])[:, 0, :].astype(np.int32)
+    noise = g.integers(-12, 13, (count, n * n))
+    orig = np.clip(base + noise, 0, 255).astype(np.uint8)
+    orig[::4] = g.integers(0, 256, (len(orig[::4]), n * n), dtype=np.uint8)
+    return orig
+
+
+@pytest.mark.parametrize("log2_width", [2, 3, 4, 5])
+@pytest.mark.parametrize("flags", [3, 1, 0, 2, 4])
+def test_intra_predict(api, log2_width, flags):
+    refs = intra_ref_cases(log2_width, 23, 500 + log2_width)
+    modes = list(range(35))
+    got = api.intra_predict_batch(refs, log2_width, modes, flags)
+    if flags & 4:
+        # bare strategies: angular_pred / intra_pred_planar on the given references, plain DC
+        for i, r in enumerate(refs):
+            left, top = r[:65], r[65:]
+            np.testing.assert_array_equal(got[i, 0], O.intra_pred_planar(log2_width, top, left))
+            for m in range(2, 35):
+                np.testing.assert_array_equal(got[i, m], O.angular_pred(log2_width, m, top, left), err_msg="pu %d mode %d" % (i, m))
+    else:
+        want = O.intra_predict_batch(refs, log2_width, modes, is_luma=flags & 1, filter_boundary=(flags >> 1) & 1)
+        np.testing.assert_array_equal(got, want)
+    # a short list in another order, one PU
+    got = api.intra_predict_batch(refs[:1], log2_width, [26, 0, 10], 3)
+    np.testing.assert_array_equal(got, O.intra_predict_batch(refs[:1], log2_width, [26, 0, 10]))
+
+
+@pytest.mark.parametrize("log2_width", [2, 3, 4, 5])
+@pytest.mark.parametrize("count", [1, 7, 64, 203])
+def test_intra_rough_costs(api, log2_width, count):
+    refs = intra_ref_cases(log2_width, count, 540 + log2_width)
+    orig = _intra_orig(refs, log2_width, 9 + count)
+    for fb in (1, 0):
+        satd, sad = api.intra_rough_batch(refs, log2_width, orig, 1 | (fb << 1), with_sad=True)
+        want_satd, want_sad = O.intra_rough_costs_batch(refs, log2_width, orig, fb)
+        np.testing.assert_array_equal(satd, want_satd)
+        np.testing.assert_array_equal(sad, want_sad)
+    np.testing.assert_array_equal(api.intra_rough_batch(refs, log2_width, orig), want_satd if fb == 1 else
+                                  O.intra_rough_costs_batch(refs, log2_width, orig, 1)[0])
+
+
+def test_intra_rough_matches_predict_plus_satd_at_frame_scale(api):
+    """size-independent property at one 1080p frame of 8x8 PUs: the fused costs equal satd_8x8 of the
+    predictions the predict kernel writes, for a sample of modes"""
+    g = rng(61)
+    count = 32400
+    refs = g.integers(0, 256, (count, 130), dtype=np.uint8)
+    refs[:, 65] = refs[:, 0]
+    orig = g.integers(0, 256, (count, 64), dtype=np.uint8)
+    satd = api.intra_rough_batch(refs, 3, orig)
+    modes = [0, 1, 2, 10, 17, 18, 26, 34]
+    pred = api.intra_predict_batch(refs, 3, modes)
+    for k, m in enumerate(modes):
+        c = api.cost_nxn_batch("satd", 8, np.ascontiguousarray(pred[:, k, :]), orig)
+        np.testing.assert_array_equal(satd[:, m], c, err_msg="mode %d" % m)
+
+
+def test_intra_argument_errors(api):
+    from kvazaar_amd._lib import KvzHipError
+    refs = intra_ref_cases(3, 2, 1)
+    with pytest.raises(KvzHipError):
+        api.intra_predict_batch(refs, 6, [0])
+    with pytest.raises(KvzHipError):
+        api.intra_predict_batch(refs, 3, [35])
+    with pytest.raises(KvzHipError):
+        api.intra_rough_batch(refs, 3, np.zeros((2, 64), np.uint8), flags=4)
+    assert api.intra_rough_batch(refs[:0], 3, np.zeros((0, 64), np.uint8)).shape == (0, 35)

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib as O
 import ref_lib as R
-from patterns import lcg_bytes, rng
+from patterns import intra_ref_cases, lcg_bytes, rng
 
 pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
 
@@ -261,3 +261,42 @@ def test_reference_encoder_harness_generic_equals_selected():
     a, n_inst = R.encode(frames, 128, 64, "preset=medium,rdoq=0,qp=30,threads=0", "generic")
     b, _ = R.encode(frames, 128, 64, "preset=medium,rdoq=0,qp=30,threads=0", None)
     assert n_inst >= 40 and len(a) > 200 and a == b
+
+
+# ---- intra group: angular_pred / intra_pred_planar strategies and kvz_intra_predict ----
+@pytest.mark.parametrize("log2_width", [2, 3, 4, 5])
+def test_intra_strategies(log2_width):
+    refs = intra_ref_cases(log2_width, 10, 300 + log2_width)
+    for r in refs:
+        left, top = r[:65], r[65:]
+        for name in ("generic", "avx2"):
+            if not R.has_strategy("angular_pred", name):
+                continue
+            for mode in range(2, 35):
+                np.testing.assert_array_equal(O.angular_pred(log2_width, mode, top, left),
+                                              R.angular_pred(log2_width, mode, top, left, name), err_msg="mode %d %s" % (mode, name))
+            np.testing.assert_array_equal(O.intra_pred_planar(log2_width, top, left), R.intra_pred_planar(log2_width, top, left, name))
+
+
+@pytest.mark.parametrize("log2_width", [2, 3, 4, 5])
+@pytest.mark.parametrize("color,filter_boundary", [(0, 1), (0, 0), (1, 1)])
+def test_intra_predict(log2_width, color, filter_boundary):
+    refs = intra_ref_cases(log2_width, 10, 340 + log2_width)
+    ours = O.intra_predict_batch(refs, log2_width, list(range(35)), is_luma=int(color == 0), filter_boundary=filter_boundary)
+    for i, r in enumerate(refs):
+        for mode in range(35):
+            np.testing.assert_array_equal(ours[i, mode], R.intra_predict(r, log2_width, mode, color, filter_boundary),
+                                          err_msg="ref %d mode %d" % (i, mode))
+
+
+def test_intra_predict_on_built_references():
+    """reference arrays as kvz_intra_build_reference makes them at picture corners / edges / inside an LCU"""
+    g = rng(77)
+    rec = g.integers(0, 256, 64 * 64, dtype=np.uint8)
+    top, left = g.integers(0, 256, 97, dtype=np.uint8), g.integers(0, 256, 97, dtype=np.uint8)
+    for log2_width in (2, 3, 4, 5):
+        n = 1 << log2_width
+        for (x, y) in ((0, 0), (64, 0), (0, 64), (64, 64), (64 + n, 64 + n), (128 - n, 64), (64, 128 - n)):
+            r = R.intra_build_reference(log2_width, x, y, 128, 128, rec, top, left, 99)
+            for mode in range(35):
+                np.testing.assert_array_equal(O.intra_predict_batch(r, log2_width, [mode])[0, 0], R.intra_predict(r, log2_width, mode))

@@ -127,6 +127,16 @@ def main():
                       lambda prs_d=prs_d, co=co, be=be, k=len(prs): L.kvz_hip_search_frac_batch(
                           picf.data_ptr(), W, reff.data_ptr(), W, W, F * H, prs_d.data_ptr(), k, co.data_ptr(), be.data_ptr(), st)))
 
+    # intra rough search: all 35 modes per PU; bytes per PU = refs 130 + orig N^2 + 35 costs
+    for lg in (2, 3, 4, 5):
+        n = 1 << lg
+        cnt = min((nbytes // 4) // (n * n), 1 << 20)
+        refs_d = torch.randint(0, 256, (cnt * 130,), dtype=torch.uint8, device=dev, generator=g)
+        costs_d = torch.empty(cnt * 35, dtype=torch.int32, device=dev)
+        cases.append(("intra_rough_%dx%d(PUs)" % (n, n), cnt, 130 + n * n + 140,
+                      lambda lg=lg, cnt=cnt, refs_d=refs_d, costs_d=costs_d: L.kvz_hip_intra_rough_batch(
+                          lg, 3, refs_d.data_ptr(), a8.data_ptr(), cnt, costs_d.data_ptr(), None, st)))
+
     tune_key, tune_vals = None, [None]
     if args.tune:
         tune_key, vals = args.tune.split("=")
