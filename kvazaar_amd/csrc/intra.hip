@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void intra_predict_kernel(const kvz_hip_intra_
   constexpr int N = 1 << LOG2, ES = 3 * N + 4;
   __shared__ __align__(16) u8 s_ref[4][4][RS];
   __shared__ __align__(16) u8 s_ext[4][ES];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // the wave index is uniform: say so, or every mode-dependent value becomes a per-lane quantity
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t items = count * (size_t)num_modes;
   for (size_t base = (size_t)blockIdx.x * 4; base < items; base += (size_t)gridDim.x * 4) {
     // the four waves of the workgroup take four consecutive items; stage their PUs' references
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_re
                                                          size_t count, int flags, u32 *__restrict__ satd_out, u32 *__restrict__ sad_out)
 {
   constexpr int N = 1 << LOG2, NB = N < 8 ? 4 : 8, SB = N / NB, S = SB * SB, G = 64 / S;
-  constexpr int ES = 3 * N + 4;          // odd number of dwords: conflict-free across PUs
+  constexpr int ES = 2 * N + 4;          // per-wave projected reference e[-N .. N-1] (+ pad: odd dword stride)
   constexpr int OS = N * N + 8;
   constexpr int NQ = NB / 2;             // packed pairs per sub-block row
   __shared__ __align__(16) u8 s_ref[G][4][RS];
@@ -257,7 +258,9 @@ __global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_re
   __shared__ int s_dc[G];
   __shared__ u32 s_cost[WITH_SAD ? 2 : 1][G][35];
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // the wave index (and with it the mode) is uniform: say so, or mode-dependent values, branches and table
+  // look-ups are compiled per lane
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t pu0 = (size_t)blockIdx.x * G;
   stage_refs<N>(s_ref, G, refs, pu0, count, tid, 256);
   {
@@ -299,30 +302,47 @@ __global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_re
     const bool fil = use_filtered(mode, LOG2, flags);
     if (mode >= 2) {
       const ang_t a = ang_of(mode);
-      wave_lds_fence();
-      for (int i = lane; i < G * (3 * N + 2); i += 64) {
-        const int pp = i / (3 * N + 2), k = i - pp * (3 * N + 2);
-        s_ext[w][pp][k] = ext_entry<N>(s_ref[pp], fil, a, k - N);
+      // Modes that lean away from the side reference (disp >= 0) read the main reference as it
+      // is; only the others need the side reference projected below index -1, and they never
+      // read beyond index N-1: a 2N-entry per-wave array e[-N .. N-1].
+      // The row reads below fetch NB+1 consecutive bytes at an arbitrary byte offset.  Unaligned wide DS
+      // reads are replayed by the hardware (SQ_LDS_UNALIGNED_STALL was 2/3 of the LDS time), so aligned
+      // dwords are read and shifted into place with v_alignbyte.  Both arrays are 16-byte aligned.
+      const u32 *words = (const u32 *)&s_ref[0][0][0];
+      int boff = (p * 4 + 2 * fil + (a.vertical ? 1 : 0)) * RS + 1 + gx0;
+      if (a.disp < 0) {
+        wave_lds_fence();
+        for (int i = lane; i < G * 2 * N; i += 64) {
+          const int pp = i / (2 * N), k = i - pp * (2 * N);
+          s_ext[w][pp][k] = ext_entry<N>(s_ref[pp], fil, a, k - N);
+        }
+        wave_lds_fence();
+        words = (const u32 *)&s_ext[0][0][0];
+        boff = (w * G + p) * ES + N + gx0;
       }
-      wave_lds_fence();
-      const u8 *e = &s_ext[w][p][N + gx0];
       const u8 *side = ref[2 * fil + (a.vertical ? 0 : 1)];
       const bool post = edge && (flags & KVZ_HIP_INTRA_FILTER_BOUNDARY) && a.disp == 0 && gx0 == 0;
       const u32 *src = a.vertical ? o : ot;
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
         const int pos = (gy0 + r + 1) * a.disp, di = pos >> 5, f = pos & 31;
-        const u8 *q0 = e + di;
-        u32 s[NB + 1];
+        const int at = boff + di;
+        const u32 *q0 = words + (at >> 2);
+        const u32 sh = (u32)at & 3u;
+        u32 raw[NB / 4 + 1], d[NB / 4 + 1];
 #pragma unroll
-        for (int j = 0; j <= NB; ++j) s[j] = q0[j];
+        for (int k = 0; k <= NB / 4; ++k) raw[k] = q0[k];
+#pragma unroll
+        for (int k = 0; k < NB / 4; ++k) d[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], sh);
+        d[NB / 4] = __builtin_amdgcn_alignbyte(0u, raw[NB / 4], sh);
         const u32 wf = (u32)f * 0x10001u;
         const v2us w1 = __builtin_bit_cast(v2us, wf), w0 = __builtin_bit_cast(v2us, 0x00200020u - wf);
         const v2us rnd = { 16, 16 };
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const v2us pa = __builtin_bit_cast(v2us, s[2 * q] | (s[2 * q + 1] << 16));
-          const v2us pb = __builtin_bit_cast(v2us, s[2 * q + 1] | (s[2 * q + 2] << 16));
+          const u32 lo = d[q >> 1], hi = d[(q >> 1) + 1];
+          const v2us pa = __builtin_bit_cast(v2us, (q & 1) ? __builtin_amdgcn_perm(0u, lo, 0x0c030c02u) : __builtin_amdgcn_perm(0u, lo, 0x0c010c00u));
+          const v2us pb = __builtin_bit_cast(v2us, (q & 1) ? __builtin_amdgcn_perm(hi, lo, 0x0c040c03u) : __builtin_amdgcn_perm(0u, lo, 0x0c020c01u));
           v2us v = (pa * w0 + pb * w1 + rnd) >> 5;
           if (q == 0 && post) v.x = (unsigned short)post_px(v.x, side, gy0 + r);
           const u32 od = src[(r * NB + 2 * q) >> 2];

@@ -14,7 +14,7 @@ __device__ __forceinline__ u32 as_u32(v2s x) { return __builtin_bit_cast(u32, x)
 __device__ __forceinline__ v2s unpack_lo(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
 __device__ __forceinline__ v2s unpack_hi(u32 d) { return as_v2s(__builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
 
-// sum over the register's two halves of max(|lo|,|hi|)  (the folded last stage)
+// sum over the register's two halves of max(|lo|,|hi|)  (the last stage folded: |a+b| + |a-b| = 2 max(|a|,|b|))
 __device__ __forceinline__ u32 absmax_halves(v2s x)
 {
   v2s n = -x;
@@ -22,6 +22,17 @@ __device__ __forceinline__ u32 absmax_halves(v2s x)
   u32 w = as_u32(ax);
   u32 lo = w & 0xffffu, hi = w >> 16;
   return lo > hi ? lo : hi;
+}
+
+// Last butterfly stage + absolute sum of one register in 4 instructions: v_pk_mad_u16 with op_sel builds
+// (lo + hi, lo - hi), v_pk_sub / v_pk_max take the absolute values, v_sad_u16 against 0 adds both halves
+// to the accumulator.  acc += |lo + hi| + |lo - hi|.
+__device__ __forceinline__ u32 abs_last_stage(v2s x, u32 acc)
+{
+  const v2s hh = { x.y, x.y }, ll = { x.x, x.x }, pm = { 1, -1 };
+  const v2s t = hh * pm + ll;
+  const v2s n = -t;
+  return __builtin_amdgcn_sad_u16(as_u32(__builtin_elementwise_max(t, n)), 0u, acc);
 }
 
 // x[r][q]: difference row r, columns 2q (low half) and 2q+1 (high half).  Destroys x.
@@ -48,13 +59,13 @@ __device__ __forceinline__ u32 satd8x8_diff(v2s (&x)[8][4])
       x[h][q] = u0 + u1; x[h + 1][q] = u0 - u1; x[h + 2][q] = u2 + u3; x[h + 3][q] = u2 - u3;
     }
   }
-  // column bit 0 (inside the register) folded into the absolute sum
-  u32 m = 0;
+  // column bit 0 (inside the register) and the absolute sum
+  u32 sum = 0;
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) m += absmax_halves(x[r][q]);
-  return (m + 1) >> 1;                 // (2m + 2) >> 2
+    for (int q = 0; q < 4; ++q) sum = abs_last_stage(x[r][q], sum);
+  return (sum + 2) >> 2;
 }
 
 // a[16], b[16]: row r of the 8x8 = dwords 2r (cols 0..3) and 2r+1 (cols 4..7) of packed bytes.
@@ -71,18 +82,21 @@ __device__ __forceinline__ u32 satd8x8_regs(const u32 *a, const u32 *b)
   return satd8x8_diff(x);
 }
 
-// x[r][q]: difference row r of a 4x4, columns 2q, 2q+1.  Returns satd_4x4 ((sum+1)>>1 == m).
+// x[r][q]: difference row r of a 4x4, columns 2q, 2q+1.  Returns satd_4x4.
 __device__ __forceinline__ u32 satd4x4_diff(v2s (&x)[4][2])
 {
 #pragma unroll
   for (int r = 0; r < 4; ++r) { v2s s = x[r][0] + x[r][1], d = x[r][0] - x[r][1]; x[r][0] = s; x[r][1] = d; }
-  u32 m = 0;
+  u32 sum = 0;
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     v2s s0 = x[0][q] + x[2][q], s1 = x[1][q] + x[3][q], d0 = x[0][q] - x[2][q], d1 = x[1][q] - x[3][q];
-    m += absmax_halves(s0 + s1) + absmax_halves(s0 - s1) + absmax_halves(d0 + d1) + absmax_halves(d0 - d1);
+    sum = abs_last_stage(s0 + s1, sum);
+    sum = abs_last_stage(s0 - s1, sum);
+    sum = abs_last_stage(d0 + d1, sum);
+    sum = abs_last_stage(d0 - d1, sum);
   }
-  return m;                            // (2m + 1) >> 1
+  return (sum + 1) >> 1;
 }
 
 // a[4], b[4]: row r of the 4x4 = dword r of packed bytes.
