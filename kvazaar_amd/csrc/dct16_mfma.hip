@@ -42,7 +42,7 @@ template <bool INVERSE>
 __global__ __launch_bounds__(256, 4) void dct16_mfma_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
 {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const signed char *M = c_m16.v;
   const i32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };

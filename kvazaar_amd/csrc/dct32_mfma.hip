@@ -37,7 +37,7 @@ template <bool INVERSE>
 __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
 {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const signed char *M = c_m32.v;
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
   }
   for (int n = 0; n < 32; ++n) { rowsum += M[r * 32 + n]; colsum += M[n * 32 + r]; }
   __shared__ __attribute__((aligned(16))) u8 s_tile[4][2048];
-  u8 *tile = s_tile[threadIdx.x >> 6];               // wave-private: DS ops of one wave execute in order, no barrier
+  u8 *tile = s_tile[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];               // wave-private: DS ops of one wave execute in order, no barrier
 
   // inverse pass 2: the plane offset 128 * (column sum of M) + rounding depends on the output ROW, i.e. on
   // (lane half, register): a 2 x 16 table in LDS, read back as broadcasts, instead of 16 live registers

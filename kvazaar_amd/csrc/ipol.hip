@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(refplane_t ref, const
 {
   __shared__ u8 s_win[4][(16 + TAPS - 1) * (16 + TAPS)];
   __shared__ i16 s_hor[4][(16 + TAPS - 1) * 16];
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: descriptor loads and block geometry go scalar
   const size_t i = (size_t)blockIdx.x * 4 + wv;
   if (i >= count) return;
   const kvz_hip_ipol_block b = blocks[i];
@@ -363,11 +363,12 @@ __global__ __launch_bounds__(256) void search_frac_small_kernel(const u8 *__rest
                                                                 u32 *__restrict__ costs, i32 *__restrict__ best)
 {
   __shared__ __attribute__((aligned(16))) u8 lds[4][(frac_geom<16>::TOTAL + 15) & ~15];
-  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: descriptor loads and block geometry go scalar
+  const size_t i = (size_t)blockIdx.x * 4 + wv;
   if (i >= count) return;
   const kvz_hip_block_pair d = pairs[i];
   if (!frac_shape_ok(d.width, d.height) || d.width > 16 || d.height > 16) return;
-  search_frac_core<16, 64, true>(threadIdx.x & 63, lds[threadIdx.x >> 6], pic, pic_stride, ref, d, costs + i * 17, best + i * 2);
+  search_frac_core<16, 64, true>(threadIdx.x & 63, lds[wv], pic, pic_stride, ref, d, costs + i * 17, best + i * 2);
 }
 
 // ---------------------------------------------------------------------------

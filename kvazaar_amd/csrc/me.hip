@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ctu_sad_grid_kernel(me_plane pic, me_plan
   }
   __syncthreads();
 
-  const int b = tid & 63, bx = b & 7, by = b >> 3, wv = tid >> 6;
+  const int b = tid & 63, bx = b & 7, by = b >> 3, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool blk_valid = (c.x + bx * 8 + 8 <= pic.w) && (c.y + by * 8 + 8 <= pic.h);
   u32 cur[16];
 #pragma unroll

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void sad_nxn_kernel(const u8 *__restrict__ a, 
   constexpr int UB = L > 64 ? L / 64 : 1;       // wave-loads that make up one block (N = 64: 4)
   static_assert(U % UB == 0, "U must cover whole blocks");
   const int lane = threadIdx.x & 63;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const size_t total_chunks = count * L;        // count = number of (block1, block2) pairs
   constexpr size_t CH = (size_t)64 * U;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void satd8_kernel(const u8 *__restrict__ a, co
                                                     u32 *__restrict__ costs, size_t count)
 {
   const int lane = threadIdx.x & 63;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const size_t total_chunks = count * 4;
   constexpr size_t CH = (size_t)64 * U;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void satd16_kernel(const u8 *__restrict__ a, c
                                                      u32 *__restrict__ costs, size_t count)
 {
   const int lane = threadIdx.x & 63;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const size_t total_chunks = count * 16;
   constexpr size_t CH = (size_t)64 * U;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void satd4_kernel(const u8 *__restrict__ a, co
                                                     u32 *__restrict__ costs, size_t count)
 {
   const int lane = threadIdx.x & 63;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   constexpr size_t CH = (size_t)64 * U;
   for (size_t base = wave * CH; base < count; base += nwaves * CH) {

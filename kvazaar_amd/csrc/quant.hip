@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) void sign_hide_kernel(const i16 *__restrict__ c
 __global__ __launch_bounds__(256) void coeff_abs_sum_kernel(const i16 *__restrict__ c, size_t length, size_t count, u32 *__restrict__ sums)
 {
   const int lane = threadIdx.x & 63;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   for (size_t b = wave; b < count; b += nwaves) {
     const i16 *p = c + b * length;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 3) void quantize_residual32_mfma_kernel(const 
                                                                            size_t count, q32_consts k)
 {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const signed char *M = c_m32.v;
 
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 3) void quantize_residual32_mfma_kernel(const 
   for (int n = 0; n < 32; ++n) { rowsum += M[r * 32 + n]; colsum += M[n * 32 + r]; }
   __shared__ __attribute__((aligned(16))) u8 s_tile[4][2048];
   __shared__ __attribute__((aligned(16))) int s_c2[2][16];
-  u8 *tile = s_tile[threadIdx.x >> 6];
+  u8 *tile = s_tile[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
   fill_inv_c2(s_c2);
   __syncthreads();
 
