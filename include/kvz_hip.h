@@ -220,6 +220,19 @@ KVZ_HIP_API int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, i
                                                 const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
                                                 kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
                                                 size_t count, kvz_hip_stream s);
+/* The same fused kernel with the two numbers the rd=0 TU cost is made of
+ * (kvz_cu_rd_cost_luma / _chroma, search.c:236-306, :309-383): ssd_out[i] =
+ * kvz_pixels_calc_ssd(ref_i, rec_i, width) (picture-generic.c:521-536) and
+ * coeff_abs_sum_out[i] = kvz_coeff_abs_sum(coeff_i, width*width) (rdo.c:219,
+ * quant-generic.c:323-330), taken from the registers / LDS the reconstruction
+ * and coefficients are in -- neither array is read back from HBM.
+ * SURVEY.md section 8(f) row 3. */
+KVZ_HIP_API int kvz_hip_quantize_residual_cost_batch(const kvz_hip_quant_params *p, int cu_is_intra, int width, int color,
+                                                     int scan_order, int use_trskip,
+                                                     const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
+                                                     kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
+                                                     uint32_t *ssd_out, uint32_t *coeff_abs_sum_out,
+                                                     size_t count, kvz_hip_stream s);
 
 /* ------------------------------------------------------------------ */
 /* (2) batched entries -- ipol group (strategies/strategies-ipol.h)    */

@@ -216,7 +216,8 @@ def coeff_abs_sum_batch(coeffs, length):
 
 
 def quantize_residual_batch(ref_in, pred_in, w, qp, color, scan_order, cu_is_intra, slice_is_intra=0, signhide=0,
-                            use_trskip=0, alias_rec=False):
+                            use_trskip=0, alias_rec=False, with_costs=False):
+    """-> (rec, coeff, has_coeffs) and, with_costs, (+ ssd(ref, rec), coeff_abs_sum) from the same launch"""
     L = _lib.init()
     ref_in = np.ascontiguousarray(ref_in, dtype=np.uint8).reshape(-1, w * w)
     pred_in = np.ascontiguousarray(pred_in, dtype=np.uint8).reshape(-1, w * w)
@@ -225,6 +226,13 @@ def quantize_residual_batch(ref_in, pred_in, w, qp, color, scan_order, cu_is_int
     r, pr = DeviceBuffer.from_numpy(ref_in), DeviceBuffer.from_numpy(pred_in)
     rec = pr if alias_rec else DeviceBuffer(ref_in.nbytes)
     co, has = DeviceBuffer(2 * ref_in.size), DeviceBuffer(4 * count)
+    if with_costs:
+        ssd, sab = DeviceBuffer(4 * count), DeviceBuffer(4 * count)
+        check(L.kvz_hip_quantize_residual_cost_batch(C.byref(p), int(cu_is_intra), w, color, scan_order, int(use_trskip),
+                                                     r.ptr, pr.ptr, rec.ptr, co.ptr, has.ptr, ssd.ptr, sab.ptr, count, None),
+              "quantize_residual_cost")
+        return (rec.to_numpy(np.uint8, ref_in.shape), co.to_numpy(np.int16, ref_in.shape), has.to_numpy(np.int32, (count,)),
+                ssd.to_numpy(np.uint32, (count,)), sab.to_numpy(np.uint32, (count,)))
     check(L.kvz_hip_quantize_residual_batch(C.byref(p), int(cu_is_intra), w, color, scan_order, int(use_trskip),
                                             r.ptr, pr.ptr, rec.ptr, co.ptr, has.ptr, count, None), "quantize_residual")
     return (rec.to_numpy(np.uint8, ref_in.shape), co.to_numpy(np.int16, ref_in.shape), has.to_numpy(np.int32, (count,)))

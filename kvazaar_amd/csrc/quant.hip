@@ -249,7 +249,8 @@ template <int N, int TRK>     // TRK: 0 DCT, 2 DST, 4 transform skip
 __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__restrict__ ref_in, const u8 *pred_in,
                                                                 u8 *rec_out, i16 *__restrict__ coeff_out,
                                                                 i32 *__restrict__ has_coeffs, size_t count,
-                                                                int scan_order, quant_consts k)
+                                                                int scan_order, quant_consts k,
+                                                                u32 *__restrict__ ssd_out, u32 *__restrict__ abs_sum_out)
 {
   constexpr int TPB = 256 / N;
   constexpr int LD = N >= 8 ? N + 8 : N;
@@ -346,6 +347,26 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
       }
     }
     if (valid && row == 0) has_coeffs[blk] = has;
+    if (ssd_out) {
+      // rd=0 TU cost inputs without re-reading anything: kvz_pixels_calc_ssd(ref, rec) (search.c:291) and
+      // kvz_coeff_abs_sum (rdo.c:219); the N threads of a TU are consecutive lanes
+      // the original row comes back from L2 (this workgroup streamed it a moment ago): keeping a copy in LDS
+      // would cost the plain entry a workgroup of occupancy
+      u32 rw[N / 4];
+#pragma unroll
+      for (int j = 0; j < N / 4; ++j) rw[j] = valid ? ((const u32 *)(ref_in + blk * (size_t)(N * N) + row * N))[j] : 0u;
+      u32 sq2 = 0, sab = 0;
+#pragma unroll
+      for (int x = 0; x < N; ++x) {
+        const int dd = (int)((rw[x >> 2] >> (8 * (x & 3))) & 255u) - (int)pp[x];
+        const int qq = q[row * N + x];
+        sq2 += (u32)(dd * dd);
+        sab += (u32)(qq < 0 ? -qq : qq);
+      }
+      sq2 = group_sum<N>(sq2);
+      sab = group_sum<N>(sab);
+      if (valid && row == 0) { ssd_out[blk] = sq2; abs_sum_out[blk] = sab; }
+    }
     __syncthreads();
     // stage out: coalesced 16-byte stores of the reconstruction and of the quantized coefficients
 #pragma unroll
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
 namespace kvzhip {
 int launch_quantize_residual32_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
                                     int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
-                                    int dq_scale, const int32_t *dqtable, hipStream_t st);
+                                    int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
 }
 
 extern "C" {
@@ -413,10 +434,10 @@ int kvz_hip_coeff_abs_sum_batch(const kvz_hip_coeff *coeffs, size_t length, size
   return KVZ_HIP_OK;
 }
 
-int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_intra, int width, int color, int scan_order,
-                                    int use_trskip, const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
-                                    kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
-                                    size_t count, kvz_hip_stream s)
+static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra, int width, int color, int scan_order,
+                                  int use_trskip, const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
+                                  kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
+                                  uint32_t *ssd_out, uint32_t *abs_sum_out, size_t count, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
   quant_consts k;
@@ -430,9 +451,9 @@ int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_int
   const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
   if (width == 32 && !use_trskip && !k.signhide)
     return launch_quantize_residual32_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
-                                           k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, st);
+                                           k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
 #define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, 16)), dim3(256), 0, st, \
-                                          ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, scan_order, k)
+                                          ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, scan_order, k, ssd_out, abs_sum_out)
   switch (width) {
     case 4: if (use_trskip) KVZ_QR(4, 4); else if (dst) KVZ_QR(4, 2); else KVZ_QR(4, 0); break;
     case 8: if (use_trskip) KVZ_QR(8, 4); else KVZ_QR(8, 0); break;
@@ -443,6 +464,25 @@ int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_int
 #undef KVZ_QR
   KVZ_CHECK_LAUNCH("quantize_residual_kernel");
   return KVZ_HIP_OK;
+}
+
+int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, int cu_is_intra, int width, int color, int scan_order,
+                                    int use_trskip, const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
+                                    kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
+                                    size_t count, kvz_hip_stream s)
+{
+  return quantize_residual_impl(p, cu_is_intra, width, color, scan_order, use_trskip, ref_in, pred_in, rec_out, coeff_out, has_coeffs,
+                                nullptr, nullptr, count, s);
+}
+
+int kvz_hip_quantize_residual_cost_batch(const kvz_hip_quant_params *p, int cu_is_intra, int width, int color, int scan_order,
+                                         int use_trskip, const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
+                                         kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
+                                         uint32_t *ssd_out, uint32_t *coeff_abs_sum_out, size_t count, kvz_hip_stream s)
+{
+  if (!ssd_out || !coeff_abs_sum_out) { set_error_msg("kvz_hip_quantize_residual_cost_batch: null cost buffer"); return KVZ_HIP_ERR_INVALID; }
+  return quantize_residual_impl(p, cu_is_intra, width, color, scan_order, use_trskip, ref_in, pred_in, rec_out, coeff_out, has_coeffs,
+                                ssd_out, coeff_abs_sum_out, count, s);
 }
 
 }  // extern "C"

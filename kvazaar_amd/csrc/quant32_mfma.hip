@@ -59,7 +59,8 @@ __device__ __forceinline__ int q32_dequant(int q, int n, const q32_consts &k)
 
 __global__ __launch_bounds__(256, 3) void quantize_residual32_mfma_kernel(const u8 *__restrict__ ref_in, const u8 *pred_in, u8 *rec_out,
                                                                            i16 *__restrict__ coeff_out, i32 *__restrict__ has_coeffs,
-                                                                           size_t count, q32_consts k)
+                                                                           size_t count, q32_consts k,
+                                                                           u32 *__restrict__ ssd_out, u32 *__restrict__ abs_sum_out)
 {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -140,6 +141,23 @@ __global__ __launch_bounds__(256, 3) void quantize_residual32_mfma_kernel(const 
         out[q] = w;
       }
     }
+    if (ssd_out) {
+      // rd=0 TU cost inputs from the registers: kvz_pixels_calc_ssd(ref, rec) (search.c:291; rf and out hold the
+      // same 16 pixels in the same order) and kvz_coeff_abs_sum (rdo.c:219)
+      u32 sq2 = 0, sab = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int dd = (int)((rf[q] >> (8 * i)) & 255u) - (int)((out[q] >> (8 * i)) & 255u);
+          sq2 += (u32)(dd * dd);
+        }
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sab += (u32)(qv[g] < 0 ? -qv[g] : qv[g]);
+      sq2 = group_sum<64>(sq2);
+      sab = group_sum<64>(sab);
+      if (lane == 0) { ssd_out[t] = sq2; abs_sum_out[t] = sab; }
+    }
     kappa_unswap(out);
     u32x4v ov = { out[0], out[1], out[2], out[3] };
     *((u32x4v *)(rec_out + t * 1024) + chunk) = ov;
@@ -152,13 +170,13 @@ namespace kvzhip {
 // consts are produced by quant.hip's make_consts (same field meaning)
 int launch_quantize_residual32_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
                                     int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
-                                    int dq_scale, const int32_t *dqtable, hipStream_t st)
+                                    int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st)
 {
   q32_consts k = { q_bits, add, flat_qc, qtable, dq_mode, dq_shift, dq_add, dq_scale, dqtable };
   size_t wgs = (count + 3) / 4;
   const size_t cap = (size_t)num_cus() * (size_t)tuning("qr32_wgs_per_cu", 3);
   if (wgs > cap) wgs = cap;
-  hipLaunchKernelGGL(quantize_residual32_mfma_kernel, dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k);
+  hipLaunchKernelGGL(quantize_residual32_mfma_kernel, dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
   KVZ_CHECK_LAUNCH("quantize_residual32_mfma_kernel");
   return KVZ_HIP_OK;
 }

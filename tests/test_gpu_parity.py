@@ -285,6 +285,27 @@ def test_quantize_residual(api, w):
     np.testing.assert_array_equal(got[0], want[0])
 
 
+@pytest.mark.parametrize("w", [4, 8, 16, 32])
+def test_quantize_residual_fused_rd0_costs(api, w):
+    """kvz_hip_quantize_residual_cost_batch: the SSD(ref, rec) and coeff_abs_sum the rd=0 TU cost is made of
+    (search.c:291, rdo.c:219) equal the oracle's pixels_calc_ssd / coeff_abs_sum of the same launch's outputs"""
+    g = rng(150 + w)
+    ref_in = g.integers(0, 256, (77, w * w), dtype=np.uint8)
+    pred = np.clip(ref_in.astype(np.int32) + g.integers(-60, 61, ref_in.shape), 0, 255).astype(np.uint8)
+    pred[0] = ref_in[0]
+    pred[1] = 255 - ref_in[1]
+    for qp in (17, 32, 47):
+        for (intra, signhide, trskip) in ((0, 0, 0), (1, 1, 0)) + (((0, 0, 1),) if w == 4 else ()):
+            rec, coeff, has, ssd, sab = api.quantize_residual_batch(ref_in, pred, w, qp, 0, 0, intra, intra, signhide, trskip,
+                                                                    with_costs=True)
+            want = O.quantize_residual_batch(ref_in, pred, w, qp, 0, 0, intra, intra, signhide, trskip)
+            for a, b in zip((rec, coeff, has), want):
+                np.testing.assert_array_equal(a, b)
+            for i in range(ref_in.shape[0]):
+                assert ssd[i] == O.pixels_calc_ssd(ref_in[i], 0, want[0][i], 0, w, w, w), (qp, i)
+                assert sab[i] == O.coeff_abs_sum(want[1][i]), (qp, i)
+
+
 # ------------------------------------------------------------------ ipol
 @pytest.mark.parametrize("kind", ["luma", "luma14", "chroma", "chroma14"])
 def test_sample_filters(api, kind):
