@@ -762,11 +762,72 @@ int orc_get_extended_block(int xpos, int ypos, int mv_x, int mv_y, int off_x, in
   return 1;
 }
 
-/* search_inter.c:965-1128 without MV bit costs / tile constraints */
-void orc_search_frac_costs(const orc_pixel *pic, int pic_stride,
-                           const orc_pixel *ref, int ref_w, int ref_h,
-                           int x, int y, int w, int h, int mvx, int mvy,
-                           unsigned costs_out[17], int best_out[2])
+/* ---- MV cost model: search_inter.c:87-176, :235-412 ---- */
+typedef struct { const orc_me_pu *pu; const orc_me_params *prm; } me_ctx;
+
+/* fracmv_within_tile (:87-176) for mv_constraint == NONE; x, y in quarter-pel */
+static int me_within(const me_ctx *mc, int x, int y)
+{
+  if (!mc || !mc->prm->wpp_owf) return 1;
+  const orc_me_pu *pu = mc->pu;
+  int margin = 0;
+  if (x % 4 != 0 || y % 4 != 0) margin = 4;
+  else if (x % 8 != 0 || y % 8 != 0) margin = 2;
+  margin += mc->prm->ref_delay_px;
+  const int lcu_x = pu->x / 64, lcu_y = pu->y / 64;
+  const int mv_lcu_x = ((pu->x + pu->width + margin) * 4 + x) / (64 << 2) - lcu_x;
+  const int mv_lcu_y = ((pu->y + pu->height + margin) * 4 + y) / (64 << 2) - lcu_y;
+  if (mv_lcu_y > mc->prm->max_ref_lcu_down) return 0;
+  if (mv_lcu_x + mv_lcu_y > mc->prm->max_ref_lcu_down + mc->prm->max_ref_lcu_right) return 0;
+  return 1;
+}
+
+/* get_ep_ex_golomb_bitcost (:235-254) */
+static unsigned me_golomb(unsigned symbol)
+{
+  unsigned bins = 0;
+  symbol += 2;
+  if (symbol >= 1u << 8) { bins += 16; symbol >>= 8; }
+  if (symbol >= 1u << 4) { bins += 8; symbol >>= 4; }
+  if (symbol >= 1u << 2) { bins += 4; symbol >>= 2; }
+  if (symbol >= 1u << 1) { bins += 2; }
+  return bins;
+}
+/* get_mvd_coding_cost (:310-323): both terms are whole bits, so the fixed-point rounding is exact */
+static unsigned me_mvd_bits(int dx, int dy) { return me_golomb((unsigned)abs(dx)) + me_golomb((unsigned)abs(dy)); }
+
+/* select_mv_cand (:326-370): returns the chosen candidate, *cost_out = the smaller cost */
+static int me_select_cand(const orc_me_pu *pu, int mvx, int mvy, unsigned *cost_out)
+{
+  const unsigned c1 = me_mvd_bits(mvx - pu->mv_cand[0][0], mvy - pu->mv_cand[0][1]);
+  const unsigned c2 = me_mvd_bits(mvx - pu->mv_cand[1][0], mvy - pu->mv_cand[1][1]);
+  if (cost_out) *cost_out = c1 < c2 ? c1 : c2;
+  return c2 < c1 ? 1 : 0;
+}
+
+/* calc_mvd_cost (:373-412) */
+static unsigned me_mv_cost(const me_ctx *mc, int x, int y, int mv_shift, unsigned *bitcost)
+{
+  if (!mc) { *bitcost = 0; return 0; }
+  const orc_me_pu *pu = mc->pu;
+  unsigned bits = 0;
+  int merged = 0;
+  x *= 1 << mv_shift;
+  y *= 1 << mv_shift;
+  for (int i = 0; i < pu->num_merge_cand; ++i) {
+    if (!pu->merge[i].usable) continue;
+    if (pu->merge[i].mv[0] == x && pu->merge[i].mv[1] == y && pu->merge[i].same_ref) { bits += (unsigned)i; merged = 1; break; }
+  }
+  if (!merged) { unsigned c; me_select_cand(pu, x, y, &c); bits += c; }
+  *bitcost = bits;
+  return bits * (unsigned)mc->prm->lambda_cost;
+}
+
+/* search_frac (:965-1128).  mc == NULL: no MV costs, no constraint (the 17 raw SATD costs).
+ * mv_io: in = integer-pel MV, out = info->best_mv (quarter-pel). */
+static void frac_search(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
+                        int x, int y, int w, int h, int mv_io[2], const me_ctx *mc, int fme_level,
+                        unsigned costs_out[17], int best_out[2], unsigned *best_cost_out, unsigned *best_bitcost_out)
 {
   static const int sq[9][2] = { {0,0}, {-1,0}, {1,0}, {0,-1}, {0,1}, {-1,-1}, {1,-1}, {-1,1}, {1,1} };
   const int iw = ((w + 7) >> 3) << 3, ih = ((h + 7) >> 3) << 3;
@@ -775,36 +836,182 @@ void orc_search_frac_costs(const orc_pixel *pic, int pic_stride,
   orc_pixel *filtered = (orc_pixel *)malloc(4 * 64 * 64);
   orc_ipol_state *st = (orc_ipol_state *)calloc(1, sizeof(*st));
   const orc_pixel *src_tl; int src_stride; long off;
+  int mx = mv_io[0], my = mv_io[1];
 
-  if (orc_get_extended_block(x, y, mvx - 1, mvy - 1, 0, 0, ref, ref_w, ref_h, 8, iw + 1, ih + 1, ext, &off)) {
+  if (orc_get_extended_block(x, y, mx - 1, my - 1, 0, 0, ref, ref_w, ref_h, 8, iw + 1, ih + 1, ext, &off)) {
     src_tl = ext + es * 4 + 4; src_stride = es;
   } else {
     src_tl = ref + off + (long)ref_w * 4 + 4; src_stride = ref_w;
   }
   const orc_pixel *cur = pic + (long)y * pic_stride + x;
 
+  unsigned best_bitcost = 0;
   unsigned best_cost = orc_satd_any_size(w, h, cur, pic_stride, src_tl + src_stride + 1, src_stride);
-  costs_out[0] = best_cost;
+  if (costs_out) costs_out[0] = best_cost;
+  best_cost += me_mv_cost(mc, mx, my, 2, &best_bitcost);
+  mx *= 2; my *= 2;                                   /* half-pel precision (:1031-1032) */
   int best_index = 0, i = 1, offx = 0, offy = 0;
   memset(filtered, 0, 4 * 64 * 64);
-  for (int step = 0; step < 4; ++step) {
-    unsigned c[4];
+  for (int step = 0; step < fme_level; ++step) {
+    const int mv_shift = step < 2 ? 1 : 0;
+    unsigned c[4], bits[4] = { 0, 0, 0, 0 };
+    int within[4];
     const orc_pixel *fp[4] = { filtered, filtered + 4096, filtered + 8192, filtered + 12288 };
-    orc_filter_frac_blocks(step, src_tl, src_stride, iw, ih, filtered, st, 4, offx, offy);
+    orc_filter_frac_blocks(step, src_tl, src_stride, iw, ih, filtered, st, fme_level, offx, offy);
+    for (int j = 0; j < 4; ++j)
+      within[j] = me_within(mc, (mx + sq[i + j][0]) * (1 << mv_shift), (my + sq[i + j][1]) * (1 << mv_shift));
     orc_satd_any_size_quad(w, h, fp, 64, cur, pic_stride, c);
     for (int j = 0; j < 4; ++j) {
-      costs_out[(step >= 2 ? 8 : 0) + i + j] = c[j];
-      if (c[j] < best_cost) { best_cost = c[j]; best_index = i + j; }
+      if (costs_out) costs_out[(step >= 2 ? 8 : 0) + i + j] = c[j];
+      if (within[j]) c[j] += me_mv_cost(mc, mx + sq[i + j][0], my + sq[i + j][1], mv_shift, &bits[j]);
     }
+    for (int j = 0; j < 4; ++j)
+      if (within[j] && c[j] < best_cost) { best_cost = c[j]; best_bitcost = bits[j]; best_index = i + j; }
     i += 4;
-    if (step == 1) {
-      best_out[0] = best_index; offx = sq[best_index][0]; offy = sq[best_index][1];
-      best_index = 0; i = 1;
-    } else if (step == 3) {
-      best_out[1] = best_index;
+    if (step == 1 || step == fme_level - 1) {          /* :1107-1122 */
+      if (best_out && step == 3) best_out[1] = best_index;
+      mx += sq[best_index][0]; my += sq[best_index][1];
+      if (step == (fme_level - 1 < 1 ? fme_level - 1 : 1)) {
+        if (best_out) best_out[0] = best_index;
+        mx *= 2; my *= 2;                             /* quarter-pel precision */
+        offx = sq[best_index][0]; offy = sq[best_index][1];
+        best_index = 0; i = 1;
+      }
     }
   }
+  mv_io[0] = mx; mv_io[1] = my;
+  if (best_cost_out) *best_cost_out = best_cost;
+  if (best_bitcost_out) *best_bitcost_out = best_bitcost;
   free(st); free(filtered); free(ext);
+}
+
+/* search_inter.c:965-1128 without MV bit costs / tile constraints */
+void orc_search_frac_costs(const orc_pixel *pic, int pic_stride,
+                           const orc_pixel *ref, int ref_w, int ref_h,
+                           int x, int y, int w, int h, int mvx, int mvy,
+                           unsigned costs_out[17], int best_out[2])
+{
+  int mv[2] = { mvx, mvy };
+  frac_search(pic, pic_stride, ref, ref_w, ref_h, x, y, w, h, mv, NULL, 4, costs_out, best_out, NULL, NULL);
+}
+
+/* ---- integer search state: inter_search_info_t's best_* fields (:40-76) ---- */
+typedef struct {
+  const orc_pixel *pic, *ref;
+  int pic_stride, ref_w, ref_h;
+  me_ctx mc;
+  int best_mv[2];                  /* quarter-pel */
+  unsigned best_cost, best_bitcost;
+} me_info;
+
+/* check_mv_cost (:195-232) */
+static int me_check(me_info *in, int x, int y)
+{
+  const orc_me_pu *pu = in->mc.pu;
+  if (!me_within(&in->mc, x * 4, y * 4)) return 0;
+  unsigned bits = 0;
+  unsigned cost = orc_image_calc_sad(in->pic, in->pic_stride, in->ref, in->ref_w, in->ref_w, in->ref_h,
+                                     pu->x, pu->y, pu->x + x, pu->y + y, pu->width, pu->height);
+  if (cost >= in->best_cost) return 0;
+  cost += me_mv_cost(&in->mc, x, y, 2, &bits);
+  if (cost >= in->best_cost) return 0;
+  in->best_mv[0] = x * 4; in->best_mv[1] = y * 4;
+  in->best_cost = cost; in->best_bitcost = bits;
+  return 1;
+}
+
+/* mv_in_merge (:260-273) */
+static int me_in_merge(const orc_me_pu *pu, int x, int y)
+{
+  for (int i = 0; i < pu->num_merge_cand; ++i) {
+    if (!pu->merge[i].usable) continue;
+    if (((pu->merge[i].mv[0] + 2) >> 2) == x && ((pu->merge[i].mv[1] + 2) >> 2) == y) return 1;
+  }
+  return 0;
+}
+
+/* hexagon_search (:690-778) incl. select_starting_point (:282-307) and early_terminate (:415-460) */
+static void me_hexagon(me_info *in)
+{
+  static const int large[9][2] = { {0,0}, {1,-2}, {2,0}, {1,2}, {-1,2}, {-2,0}, {-1,-2}, {1,-2}, {2,0} };
+  static const int small[9][2] = { {0,0}, {0,-1}, {-1,0}, {1,0}, {0,1}, {-1,-1}, {1,-1}, {-1,1}, {1,1} };
+  static const int et[7][2] = { {0,-1}, {-1,0}, {0,1}, {1,0}, {0,-1}, {-1,0}, {0,0} };
+  const orc_me_pu *pu = in->mc.pu;
+  const orc_me_params *prm = in->mc.prm;
+  in->best_cost = 0xffffffffu;
+
+  me_check(in, 0, 0);
+  const int ex = pu->extra_mv[0] >> 2, ey = pu->extra_mv[1] >> 2;
+  if ((ex != 0 || ey != 0) && !me_in_merge(pu, ex, ey)) me_check(in, ex, ey);
+  for (int i = 0; i < pu->num_merge_cand; ++i) {
+    if (!pu->merge[i].usable) continue;
+    const int x = (pu->merge[i].mv[0] + 2) >> 2, y = (pu->merge[i].mv[1] + 2) >> 2;
+    if (x == 0 && y == 0) continue;
+    me_check(in, x, y);
+  }
+
+  if (prm->early_termination) {
+    int mvx = in->best_mv[0] >> 2, mvy = in->best_mv[1] >> 2;
+    int first = 0, last = 3;
+    for (int k = 0; k < 2; ++k) {
+      const double threshold = prm->early_termination == 2 ? in->best_cost * 0.95 : (double)in->best_cost;
+      int best_index = 6;
+      for (int i = first; i <= last; ++i)
+        if (me_check(in, mvx + et[i][0], mvy + et[i][1])) best_index = i;
+      mvx += et[best_index][0]; mvy += et[best_index][1];
+      if (in->best_cost >= threshold) return;
+      first = (best_index + 3) % 4;
+      last = first + 2;
+    }
+  }
+
+  int mvx = in->best_mv[0] >> 2, mvy = in->best_mv[1] >> 2;
+  int best_index = 0;
+  unsigned steps = prm->max_steps;
+  for (int i = 1; i < 7; ++i)
+    if (me_check(in, mvx + large[i][0], mvy + large[i][1])) best_index = i;
+  while (best_index != 0 && steps != 0) {
+    if (steps > 0) steps -= 1;
+    const int start = best_index == 1 ? 6 : (best_index == 8 ? 1 : best_index - 1);
+    mvx += large[best_index][0]; mvy += large[best_index][1];
+    best_index = 0;
+    for (int i = 0; i < 3; ++i)
+      if (me_check(in, mvx + large[start + i][0], mvy + large[start + i][1])) best_index = start + i;
+  }
+  for (int i = 1; i < 9; ++i) me_check(in, mvx + small[i][0], mvy + small[i][1]);
+}
+
+/* the hexbs path of search_pu_inter_ref (:1134-1300) for one reference picture */
+void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
+                   const orc_me_pu *pu, const orc_me_params *prm, orc_me_result *res)
+{
+  me_info in;
+  memset(&in, 0, sizeof(in));
+  in.pic = pic; in.ref = ref; in.pic_stride = pic_stride; in.ref_w = ref_w; in.ref_h = ref_h;
+  in.mc.pu = pu; in.mc.prm = prm;
+  me_hexagon(&in);
+  if (prm->fme_level > 0 && in.best_cost < 0xffffffffu) {   /* inter_cost starts at its maximum (:1456) */
+    int mv[2] = { in.best_mv[0] >> 2, in.best_mv[1] >> 2 };
+    frac_search(pic, pic_stride, ref, ref_w, ref_h, pu->x, pu->y, pu->width, pu->height, mv, &in.mc, prm->fme_level,
+                NULL, NULL, &in.best_cost, &in.best_bitcost);
+    in.best_mv[0] = mv[0]; in.best_mv[1] = mv[1];
+  } else if (in.best_cost < 0xffffffffu) {                  /* :1236-1248 */
+    in.best_cost = orc_image_calc_satd(pic, pic_stride, ref, ref_w, ref_w, ref_h, pu->x, pu->y,
+                                       pu->x + (in.best_mv[0] >> 2), pu->y + (in.best_mv[1] >> 2), pu->width, pu->height);
+    in.best_cost += in.best_bitcost * (unsigned)prm->lambda_cost;
+  }
+  memset(res, 0, sizeof(*res));
+  res->mv[0] = in.best_mv[0]; res->mv[1] = in.best_mv[1];
+  res->cost = in.best_cost; res->bitcost = in.best_bitcost;
+  int idx = 0;
+  for (idx = 0; idx < pu->num_merge_cand; ++idx)
+    if (pu->merge[idx].usable && pu->merge[idx].mv[0] == in.best_mv[0] && pu->merge[idx].mv[1] == in.best_mv[1] &&
+        pu->merge[idx].same_ref) { res->merged = 1; break; }
+  res->merge_idx = idx;
+  if (!res->merged) {
+    /* select_mv_cand with cost_out == NULL returns 0 for identical candidates (:332-338): same answer */
+    res->mv_cand = me_select_cand(pu, in.best_mv[0], in.best_mv[1], NULL);
+  }
 }
 
 /* Batched ME costs of one CTU: the values check_mv_cost (search_inter.c:195-232) obtains

@@ -171,6 +171,45 @@ void orc_intra_predict(const orc_intra_ref *ref, int log2_width, int mode, int i
 void orc_intra_rough_costs(const orc_intra_ref *ref, int log2_width, int filter_boundary, const orc_pixel *orig,
                            unsigned satd_out[35], unsigned sad_out[35]);
 
+/* ---- integer + fractional motion search of one PU against one reference picture:
+ * hexagon_search (search_inter.c:690-778: select_starting_point :282-307, early_terminate
+ * :415-460, check_mv_cost :195-232) followed by search_frac (:965-1128) with the MV bit
+ * costs of calc_mvd_cost (:373-412), as search_pu_inter_ref (:1134-1300) runs them for
+ * --me hexbs.  SURVEY.md section 8(f) row 1.  The encoder state these functions read is
+ * flattened into the two structs below (no tiles: tile offset 0; mv_rdo off). */
+typedef struct {
+  int16_t mv[2];        /* merge_cand[i].mv[dir - 1], quarter-pel */
+  uint8_t usable;       /* merge_cand[i].dir != 3 */
+  uint8_t same_ref;     /* state->frame->ref_LX[dir - 1][merge_cand[i].ref[dir - 1]] == ref_idx */
+} orc_me_merge;
+typedef struct {
+  int32_t x, y, width, height;   /* PU inside the picture; width, height multiples of 8, 8..64 */
+  int16_t mv_cand[2][2];         /* AMVP candidates (kvz_inter_get_mv_cand), quarter-pel */
+  int16_t extra_mv[2];           /* start vector taken from the co-located CU (:1190-1206), quarter-pel */
+  int16_t num_merge_cand;        /* 0..5 */
+  int16_t reserved;
+  orc_me_merge merge[5];
+  int16_t pad;
+} orc_me_pu;                     /* 64 bytes */
+typedef struct {
+  int32_t lambda_cost;           /* (int32_t)(state->lambda_sqrt + 0.5) */
+  int32_t early_termination;     /* cfg.me_early_termination: 0 off, 1 on, 2 sensitive */
+  uint32_t max_steps;            /* cfg.me_max_steps */
+  int32_t fme_level;             /* cfg.fme_level 0..4 */
+  int32_t wpp_owf;               /* cfg.owf && cfg.wpp: enforce fracmv_within_tile's availability rule (:95-139) */
+  int32_t ref_delay_px;          /* SAO_DELAY_PX (sao on), DEBLOCK_DELAY_PX (deblock only) or 0 */
+  int32_t max_ref_lcu_down, max_ref_lcu_right;   /* ctrl->max_inter_ref_lcu */
+} orc_me_params;
+typedef struct {
+  int32_t mv[2];                 /* info->best_mv, quarter-pel */
+  uint32_t cost, bitcost;        /* info->best_cost, info->best_bitcost */
+  int32_t merged, merge_idx;     /* the match loop of :1253-1266 */
+  int32_t mv_cand;               /* select_mv_cand(..., NULL) when not merged (:1268-1273), else 0 */
+  int32_t reserved;
+} orc_me_result;
+void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
+                   const orc_me_pu *pu, const orc_me_params *prm, orc_me_result *res);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+/* ref_me_harness.c -- TEST INFRASTRUCTURE ONLY.  Gives the tests access to the reference's
+ * file-local motion search (hexagon_search, search_frac, calc_mvd_cost, select_mv_cand:
+ * search_inter.c:195-1128) by compiling that translation unit a second time, from where it lies
+ * under /root/reference, with its exported names moved out of the way.  Nothing of the reference is
+ * copied into this repository; oracle/Makefile builds this file into oracle/_ref/libkvzref.so. */
+#define kvz_tz_pattern_search  refme_dup_tz_pattern_search
+#define kvz_tz_raster_search   refme_dup_tz_raster_search
+#define kvz_cu_cost_inter_rd2  refme_dup_cu_cost_inter_rd2
+#define kvz_search_cu_inter    refme_dup_search_cu_inter
+#define kvz_search_cu_smp      refme_dup_search_cu_smp
+#include "search_inter.c"
+#undef kvz_tz_pattern_search
+#undef kvz_tz_raster_search
+#undef kvz_cu_cost_inter_rd2
+#undef kvz_search_cu_inter
+#undef kvz_search_cu_smp
+
+#include <string.h>
+
+/* same layouts as orc_me_pu / orc_me_params / orc_me_result (oracle/kvz_oracle.h) */
+typedef struct { int16_t mv[2]; uint8_t usable; uint8_t same_ref; } me_merge_t;
+typedef struct {
+  int32_t x, y, width, height;
+  int16_t mv_cand[2][2];
+  int16_t extra_mv[2];
+  int16_t num_merge_cand, reserved;
+  me_merge_t merge[5];
+  int16_t pad;
+} me_pu_t;
+typedef struct {
+  int32_t lambda_cost, early_termination;
+  uint32_t max_steps;
+  int32_t fme_level, wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right;
+} me_params_t;
+typedef struct { int32_t mv[2]; uint32_t cost, bitcost; int32_t merged, merge_idx, mv_cand, reserved; } me_result_t;
+
+/* the hexbs path of search_pu_inter_ref (search_inter.c:1134-1300) on a fabricated encoder state:
+ * one reference picture (ref_idx 0 = L0[0]), no tiles, mv_constraint none, mv_rdo off */
+void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_w, int frame_h,
+                      const me_pu_t *pu, const me_params_t *prm, me_result_t *res)
+{
+  static encoder_control_t ctrl;
+  static encoder_state_t state;
+  static encoder_state_config_frame_t frame;
+  static encoder_state_config_tile_t tile;
+  static videoframe_t vframe;
+  memset(&ctrl, 0, sizeof(ctrl)); memset(&state, 0, sizeof(state)); memset(&frame, 0, sizeof(frame));
+  memset(&tile, 0, sizeof(tile)); memset(&vframe, 0, sizeof(vframe));
+  ctrl.bitdepth = 8;
+  ctrl.cfg.me_early_termination = prm->early_termination;
+  ctrl.cfg.me_max_steps = prm->max_steps;
+  ctrl.cfg.fme_level = prm->fme_level;
+  ctrl.cfg.owf = prm->wpp_owf ? 1 : 0;
+  ctrl.cfg.wpp = prm->wpp_owf ? 1 : 0;
+  ctrl.cfg.sao_type = prm->ref_delay_px == SAO_DELAY_PX ? 1 : 0;
+  ctrl.cfg.deblock_enable = prm->ref_delay_px == DEBLOCK_DELAY_PX ? 1 : 0;
+  ctrl.cfg.mv_constraint = KVZ_MV_CONSTRAIN_NONE;
+  ctrl.cfg.mv_rdo = 0;
+  ctrl.max_inter_ref_lcu.down = prm->max_ref_lcu_down;
+  ctrl.max_inter_ref_lcu.right = prm->max_ref_lcu_right;
+  vframe.width = frame_w; vframe.height = frame_h;
+  tile.frame = &vframe;
+  frame.ref_LX[0][0] = 0; frame.ref_LX[0][1] = 1; frame.ref_LX_size[0] = 2;
+  state.encoder_control = &ctrl;
+  state.tile = &tile;
+  state.frame = &frame;
+  /* calc_mvd_cost multiplies by (int32_t)(lambda_sqrt + 0.5) */
+  state.lambda_sqrt = (double)prm->lambda_cost;
+
+  kvz_picture pic, ref;
+  memset(&pic, 0, sizeof(pic)); memset(&ref, 0, sizeof(ref));
+  pic.y = (kvz_pixel *)pic_y; pic.width = frame_w; pic.height = frame_h; pic.stride = frame_w;
+  ref.y = (kvz_pixel *)ref_y; ref.width = frame_w; ref.height = frame_h; ref.stride = frame_w;
+
+  inter_search_info_t info = {
+    .state = &state, .pic = &pic, .ref = &ref, .ref_idx = 0,
+    .origin = { pu->x, pu->y }, .width = pu->width, .height = pu->height,
+    .mvd_cost_func = calc_mvd_cost,
+  };
+  memcpy(info.mv_cand, pu->mv_cand, sizeof(info.mv_cand));
+  info.num_merge_cand = pu->num_merge_cand;
+  for (int i = 0; i < pu->num_merge_cand; ++i) {
+    memset(&info.merge_cand[i], 0, sizeof(info.merge_cand[i]));
+    info.merge_cand[i].dir = pu->merge[i].usable ? 1 : 3;
+    info.merge_cand[i].ref[0] = pu->merge[i].same_ref ? 0 : 1;
+    info.merge_cand[i].mv[0][0] = pu->merge[i].mv[0];
+    info.merge_cand[i].mv[0][1] = pu->merge[i].mv[1];
+  }
+  const vector2d_t extra = { pu->extra_mv[0], pu->extra_mv[1] };
+
+  info.best_cost = UINT32_MAX;
+  hexagon_search(&info, extra, prm->max_steps);
+  if (prm->fme_level > 0 && info.best_cost < UINT32_MAX) {
+    search_frac(&info);
+  } else if (info.best_cost < UINT32_MAX) {
+    info.best_cost = kvz_image_calc_satd(&pic, &ref, pu->x, pu->y, pu->x + (info.best_mv.x >> 2), pu->y + (info.best_mv.y >> 2),
+                                         pu->width, pu->height);
+    info.best_cost += info.best_bitcost * (int)(state.lambda_sqrt + 0.5);
+  }
+  memset(res, 0, sizeof(*res));
+  res->mv[0] = info.best_mv.x; res->mv[1] = info.best_mv.y;
+  res->cost = info.best_cost; res->bitcost = info.best_bitcost;
+  int idx;
+  for (idx = 0; idx < info.num_merge_cand; ++idx)
+    if (info.merge_cand[idx].dir != 3 && info.merge_cand[idx].mv[0][0] == info.best_mv.x &&
+        info.merge_cand[idx].mv[0][1] == info.best_mv.y && frame.ref_LX[0][info.merge_cand[idx].ref[0]] == 0) { res->merged = 1; break; }
+  res->merge_idx = idx;
+  if (!res->merged) res->mv_cand = select_mv_cand(&state, info.mv_cand, info.best_mv.x, info.best_mv.y, NULL);
+}

@@ -362,3 +362,20 @@ def intra_rough_costs_batch(refs, log2_width, orig, filter_boundary=1):
         r, o = np.ascontiguousarray(refs[i]), np.ascontiguousarray(orig[i])
         L.orc_intra_rough_costs(_p(r, u8p), log2_width, filter_boundary, _p(o, u8p), _p(satd[i], u32p), _p(sad[i], u32p))
     return satd, sad
+
+
+# ---- motion search ----
+def search_pu_batch(pic, ref, pus, params):
+    """orc_search_pu over a structured array of patterns.ME_PU; returns patterns.ME_RESULT array"""
+    from patterns import ME_RESULT
+    L = lib()
+    L.orc_search_pu.restype = None
+    L.orc_search_pu.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    pic, ref = _u8(pic), _u8(ref)
+    pus = np.ascontiguousarray(pus)
+    params = np.ascontiguousarray(params)
+    out = np.zeros(len(pus), dtype=ME_RESULT)
+    for i in range(len(pus)):
+        L.orc_search_pu(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],
+                        pus.ctypes.data + 64 * i, params.ctypes.data, out.ctypes.data + 32 * i)
+    return out

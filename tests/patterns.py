@@ -121,3 +121,70 @@ def intra_ref_cases(log2_width, count, seed):
         refs[i, 2 * n + 1:65] = 0            # beyond the 2N+1 entries the reference never reads
         refs[i, 65 + 2 * n + 1:] = 0
     return refs
+
+
+# ---- motion search: layouts of kvz_hip_me_pu / _params / _result (= orc_me_*) ----
+ME_PU = np.dtype([("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"), ("mv_cand", "<i2", (2, 2)),
+                  ("extra_mv", "<i2", (2,)), ("num_merge_cand", "<i2"), ("reserved", "<i2"),
+                  ("merge", [("mv", "<i2", (2,)), ("usable", "u1"), ("same_ref", "u1")], (5,)), ("pad", "<i2")])
+ME_PARAMS = np.dtype([("lambda_cost", "<i4"), ("early_termination", "<i4"), ("max_steps", "<u4"), ("fme_level", "<i4"),
+                      ("wpp_owf", "<i4"), ("ref_delay_px", "<i4"), ("max_ref_lcu_down", "<i4"), ("max_ref_lcu_right", "<i4")])
+ME_RESULT = np.dtype([("mv", "<i4", (2,)), ("cost", "<u4"), ("bitcost", "<u4"), ("merged", "<i4"), ("merge_idx", "<i4"),
+                      ("mv_cand", "<i4"), ("reserved", "<i4")])
+assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 32 and ME_RESULT.itemsize == 32
+
+
+def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_level=4, wpp_owf=0, ref_delay_px=0,
+              max_ref_lcu_down=1, max_ref_lcu_right=1):
+    p = np.zeros(1, dtype=ME_PARAMS)
+    p["lambda_cost"], p["early_termination"], p["max_steps"], p["fme_level"] = lambda_cost, early_termination, max_steps, fme_level
+    p["wpp_owf"], p["ref_delay_px"], p["max_ref_lcu_down"], p["max_ref_lcu_right"] = wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right
+    return p
+
+
+def me_frames(w, h, seed, motion=(3, -2)):
+    """current / reference luma planes: band-limited texture, the reference displaced by `motion` (+ half a pixel of
+    blur) and noisy, so the search has a real minimum away from the start vectors"""
+    g = np.random.default_rng(seed)
+    big = g.integers(0, 256, (h + 64, w + 64)).astype(np.float64)
+    for _ in range(2):
+        big = (big + np.roll(big, 1, 0) + np.roll(big, 1, 1) + np.roll(big, (1, 1), (0, 1))) / 4
+    big = np.clip((big - big.mean()) * 5 + 128, 0, 255)
+    cur = big[32:32 + h, 32:32 + w]
+    dx, dy = motion
+    r = big[32 + dy:32 + dy + h, 32 + dx:32 + dx + w]
+    r = (r + np.roll(r, 1, 1)) / 2 + g.normal(0, 2.0, (h, w))
+    return np.clip(cur, 0, 255).astype(np.uint8), np.clip(r, 0, 255).astype(np.uint8)
+
+
+def me_random_pus(w, h, count, seed, hint=None,
+                  sizes=((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (64, 32), (24, 32), (32, 8))):
+    """hint: a quarter-pel MV (the sequence's true motion) planted as merge / AMVP candidate in a third of the PUs,
+    so that the merged and cheap-MVD paths of calc_mvd_cost are taken"""
+    g = np.random.default_rng(seed)
+    pus = np.zeros(count, dtype=ME_PU)
+    for i in range(count):
+        bw, bh = sizes[int(g.integers(0, len(sizes)))]
+        pus[i]["width"], pus[i]["height"] = bw, bh
+        pus[i]["x"] = int(g.integers(0, (w - bw) // 8 + 1)) * 8
+        pus[i]["y"] = int(g.integers(0, (h - bh) // 8 + 1)) * 8
+        style = i % 4
+        rng_mv = (lambda: g.integers(-40, 41, 2)) if style else (lambda: g.integers(-6, 7, 2))
+        pus[i]["mv_cand"][0] = rng_mv()
+        pus[i]["mv_cand"][1] = pus[i]["mv_cand"][0] if style == 1 else rng_mv()
+        pus[i]["extra_mv"] = rng_mv() if style != 2 else (0, 0)
+        n = int(g.integers(0, 6))
+        pus[i]["num_merge_cand"] = n
+        for k in range(n):
+            pus[i]["merge"][k]["mv"] = rng_mv() if g.integers(0, 3) else pus[i]["mv_cand"][int(g.integers(0, 2))]
+            pus[i]["merge"][k]["usable"] = int(g.integers(0, 4) != 0)
+            pus[i]["merge"][k]["same_ref"] = int(g.integers(0, 3) != 0)
+        if hint is not None and i % 3 == 0:
+            if n and i % 2 == 0:
+                k = int(g.integers(0, n))
+                pus[i]["merge"][k]["mv"] = hint
+                pus[i]["merge"][k]["usable"] = 1
+                pus[i]["merge"][k]["same_ref"] = int(i % 4 != 0)
+            else:
+                pus[i]["mv_cand"][int(g.integers(0, 2))] = hint
+    return pus

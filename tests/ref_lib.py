@@ -364,3 +364,20 @@ def intra_build_reference(log2_width, x, y, pic_w, pic_h, rec_y, top_y, left_y, 
     L.ref_intra_build_reference(log2_width, 0, x, y, pic_w, pic_h, _p(rec_y, u8p), _p(top_y, u8p), _p(left_y, u8p),
                                 int(top_left), _p(out, u8p))
     return out
+
+
+# ---- motion search: the reference's static hexagon_search + search_frac (oracle/ref_me_harness.c) ----
+def search_pu_batch(pic, ref, pus, params):
+    from patterns import ME_RESULT
+    L = lib()
+    L.ref_me_search_pu.restype = None
+    L.ref_me_search_pu.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    pic, ref = _u8(pic), _u8(ref)
+    assert pic.shape == ref.shape
+    pus = np.ascontiguousarray(pus)
+    params = np.ascontiguousarray(params)
+    out = np.zeros(len(pus), dtype=ME_RESULT)
+    for i in range(len(pus)):
+        L.ref_me_search_pu(_p(pic, u8p), _p(ref, u8p), pic.shape[1], pic.shape[0],
+                           pus.ctypes.data + 64 * i, params.ctypes.data, out.ctypes.data + 32 * i)
+    return out

@@ -300,3 +300,33 @@ def test_intra_predict_on_built_references():
             r = R.intra_build_reference(log2_width, x, y, 128, 128, rec, top, left, 99)
             for mode in range(35):
                 np.testing.assert_array_equal(O.intra_predict_batch(r, log2_width, [mode])[0, 0], R.intra_predict(r, log2_width, mode))
+
+
+# ---- motion search: hexagon_search + search_frac with MV costs ----
+from patterns import me_frames, me_params, me_random_pus  # noqa: E402
+
+ME_CONFIGS = [
+    dict(),                                                        # preset medium: hexbs, early termination on, subme 4
+    dict(early_termination=2, fme_level=2, lambda_cost=35),        # ultrafast/veryfast style
+    dict(early_termination=0, lambda_cost=4),
+    dict(fme_level=0, lambda_cost=60),
+    dict(fme_level=1), dict(fme_level=3, max_steps=2),
+    dict(wpp_owf=1, ref_delay_px=10, max_ref_lcu_down=1, max_ref_lcu_right=1),
+    dict(wpp_owf=1, ref_delay_px=8, max_ref_lcu_down=0, max_ref_lcu_right=2, lambda_cost=9),
+]
+
+
+@pytest.mark.parametrize("cfg", range(len(ME_CONFIGS)))
+def test_search_pu(cfg):
+    prm = me_params(**ME_CONFIGS[cfg])
+    for k, motion in enumerate(((3, -2), (-7, 5), (0, 0), (14, 9))):
+        pic, ref = me_frames(192, 128, 900 + k, motion)
+        pus = me_random_pus(192, 128, 40, 77 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1]))
+        a, b = O.search_pu_batch(pic, ref, pus, prm), R.search_pu_batch(pic, ref, pus, prm)
+        for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+            np.testing.assert_array_equal(a[f], b[f], err_msg="%s cfg %d motion %s" % (f, cfg, motion))
+    # flat frames: every candidate ties, the reference's first-wins order decides
+    flat = np.full((128, 192), 77, np.uint8)
+    pus = me_random_pus(192, 128, 12, 5)
+    a, b = O.search_pu_batch(flat, flat, pus, prm), R.search_pu_batch(flat, flat, pus, prm)
+    np.testing.assert_array_equal(a.view(np.int32), b.view(np.int32))
