@@ -269,6 +269,57 @@ KVZ_HIP_API int kvz_hip_search_frac_batch(const kvz_hip_pixel *pic, uint32_t pic
                                           uint32_t *costs, int32_t *best, kvz_hip_stream s);
 
 /* ------------------------------------------------------------------ */
+/* (2) batched entries -- motion search of whole PUs                   */
+/*     SURVEY.md section 8(f) row 1                                    */
+/* ------------------------------------------------------------------ */
+/* One merge candidate as calc_mvd_cost / select_starting_point see it
+ * (inter_merge_cand_t, inter.h): */
+typedef struct {
+  int16_t mv[2];       /* merge_cand[i].mv[dir - 1], quarter-pel */
+  uint8_t usable;      /* merge_cand[i].dir != 3 */
+  uint8_t same_ref;    /* state->frame->ref_LX[dir - 1][merge_cand[i].ref[dir - 1]] == ref_idx */
+} kvz_hip_me_merge;
+/* inter_search_info_t (search_inter.c:40-76) of one PU for one reference picture */
+typedef struct {
+  int32_t x, y, width, height;   /* PU inside the picture; width, height multiples of 8 in 8..64 */
+  int16_t mv_cand[2][2];         /* AMVP candidates (kvz_inter_get_mv_cand), quarter-pel */
+  int16_t extra_mv[2];           /* start vector from the co-located CU (search_inter.c:1190-1206), quarter-pel */
+  int16_t num_merge_cand;        /* 0..5 */
+  int16_t reserved;
+  kvz_hip_me_merge merge[5];
+  int16_t pad;
+} kvz_hip_me_pu;                 /* 64 bytes */
+/* the encoder settings the search reads (no tiles, mv_constraint none, mv_rdo off) */
+typedef struct {
+  int32_t lambda_cost;           /* (int32_t)(state->lambda_sqrt + 0.5), search_inter.c:411 */
+  int32_t early_termination;     /* cfg.me_early_termination: 0 off, 1 on, 2 sensitive */
+  uint32_t max_steps;            /* cfg.me_max_steps */
+  int32_t fme_level;             /* cfg.fme_level, 0..4 */
+  int32_t wpp_owf;               /* cfg.owf && cfg.wpp: enforce the reference-availability rule of fracmv_within_tile */
+  int32_t ref_delay_px;          /* SAO_DELAY_PX (sao on), DEBLOCK_DELAY_PX (deblock only) or 0 (global.h:163,175) */
+  int32_t max_ref_lcu_down, max_ref_lcu_right;   /* ctrl->max_inter_ref_lcu (encoder.c:240-241) */
+} kvz_hip_me_params;
+typedef struct {
+  int32_t mv[2];                 /* info->best_mv, quarter-pel */
+  uint32_t cost, bitcost;        /* info->best_cost, info->best_bitcost; cost 0xFFFFFFFF: nothing allowed / bad descriptor */
+  int32_t merged, merge_idx;     /* the match loop of search_inter.c:1253-1266 */
+  int32_t mv_cand;               /* select_mv_cand (search_inter.c:1268-1273) */
+  int32_t reserved;              /* -1 flags a malformed descriptor */
+} kvz_hip_me_result;
+
+/* The --me hexbs path of search_pu_inter_ref (search_inter.c:1134-1300) for
+ * `count` PUs against one reference plane in one launch: hexagon_search
+ * (:690-778, with select_starting_point and early_terminate) over
+ * kvz_image_calc_sad + calc_mvd_cost, then search_frac (:965-1128) -- or, for
+ * fme_level 0, the SATD re-cost of :1236-1248.  Same visiting order and
+ * tie-breaks as the reference, so results[i] equals what the reference leaves
+ * in inter_search_info_t.  pus / results are device arrays. */
+KVZ_HIP_API int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
+                                        const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                        const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
+                                        kvz_hip_me_result *results, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
 /* (2) batched entries -- intra group (strategies/strategies-intra.h)  */
 /*     SURVEY.md section 8(f) row 2                                    */
 /* ------------------------------------------------------------------ */

@@ -302,3 +302,21 @@ def intra_rough_batch(refs, log2_width, orig, flags=INTRA_LUMA | INTRA_FILTER_BO
     check(L.kvz_hip_intra_rough_batch(log2_width, flags, r.ptr, o.ptr, count, satd.ptr, sad.ptr if sad else None, None), "intra_rough batch")
     a = satd.to_numpy(np.uint32, (count, 35))
     return (a, sad.to_numpy(np.uint32, (count, 35))) if with_sad else a
+
+
+# ---- motion search of whole PUs ----
+def search_pu_batch(pic, ref, pus, params):
+    """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (32 bytes).
+    Returns the raw results as int32 [count, 8] (= kvz_hip_me_result)."""
+    L = _lib.init()
+    pic = np.ascontiguousarray(pic, dtype=np.uint8)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    pus = np.ascontiguousarray(pus)
+    params = np.ascontiguousarray(params)
+    assert pus.dtype.itemsize == 64 and params.nbytes == 32
+    count = pus.shape[0]
+    a, b, d = DeviceBuffer.from_numpy(pic), DeviceBuffer.from_numpy(ref), DeviceBuffer.from_numpy(pus.view(np.uint8))
+    out = DeviceBuffer(max(1, 32 * count))
+    check(L.kvz_hip_search_pu_batch(a.ptr, pic.shape[1], pic.shape[1], pic.shape[0], b.ptr, ref.shape[1], ref.shape[1], ref.shape[0],
+                                    d.ptr, count, params.ctypes.data, out.ptr, None), "search_pu batch")
+    return out.to_numpy(np.int32, (count, 8))

@@ -9,24 +9,14 @@
 // ipol-generic.c:731-784), staged in LDS, and every intermediate (horizontal
 // pass planes, candidate blocks) stays on chip.
 #include "kvz_hip_internal.h"
+#include "frac_core.h"
 
 using namespace kvzhip;
 
-__constant__ signed char c_luma_filter[4][8] = {       // filter.c:54-60
-  { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
 __constant__ signed char c_chroma_filter[8][4] = {     // filter.c:62-72
   { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
   { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
-struct refplane_t { const u8 *p; u32 stride; int w, h; };
-
-__device__ __forceinline__ u8 ref_px(const refplane_t &r, int x, int y)
-{
-  return r.p[(size_t)clampi(y, 0, r.h - 1) * r.stride + clampi(x, 0, r.w - 1)];
-}
-
-// (int16 sample + 32) >> 6 through the int16-argument clip (ipol-generic.c:285-287 etc.)
-__device__ __forceinline__ u8 round_clip16(i16 sample) { return fast_clip16((i16)(((int)sample + 32) >> 6)); }
 
 // ---------------------------------------------------------------------------
 // kvz_sample_quarterpel_luma / kvz_sample_octpel_chroma (+14-bit variants),
@@ -134,211 +124,6 @@ __global__ __launch_bounds__(256) void sample_small_kernel(refplane_t ref, const
   sample_core<TAPS, OUT14, 16, 64, true>(threadIdx.x & 63, s_win[wv], s_hor[wv], ref, b, (size_t)out_offsets[i], dst);
 }
 
-// ---------------------------------------------------------------------------
-// Fused fractional motion search (search_inter.c:965-1128 without MV bit
-// costs).  For the integer position P(0,0) = ref(x2, y2):
-//   H_f(r, c) = sum_i f[i] * P[r][c-3+i]                 (int16, never overflows)
-//   S(fx, fy; r, c) = round_clip16((int16)(sum_j f_fy[j] * H_fx(r-3+j, c) >> 6))
-// Every block the four reference filter steps produce (ipol-generic.c:192-658)
-// is S at a quarter-pel offset (qx, qy): fx = qx & 3, fy = qy & 3, r = y + (qy >> 2),
-// c = x + (qx >> 2) -- including the int16 truncation of the vertical sum and the
-// cases where the reference skips a pass (a pass with taps {0,0,0,64,0,0,0,0} is
-// exact).  Candidates are filtered into LDS and scored with the 8x8 Hadamard
-// SATD by one lane per (candidate, 8x8 sub-block).
-// ---------------------------------------------------------------------------
-typedef short v2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2s f_unpack_lo(u32 d) { return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
-__device__ __forceinline__ v2s f_unpack_hi(u32 d) { return __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
-__device__ __forceinline__ u32 f_absmax(v2s x)
-{
-  v2s ax = __builtin_elementwise_max(x, -x);
-  u32 w = __builtin_bit_cast(u32, ax);
-  u32 lo = w & 0xffffu, hi = w >> 16;
-  return lo > hi ? lo : hi;
-}
-// 8x8 Hadamard SATD of two LDS blocks (picture-generic.c:240-328), rows of 8 bytes
-__device__ __forceinline__ u32 satd8x8_lds(const u8 *a, int sa, const u8 *b, int sb)
-{
-  v2s x[8][4];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    u32 a0, a1, b0, b1;
-    __builtin_memcpy(&a0, a + r * sa, 4); __builtin_memcpy(&a1, a + r * sa + 4, 4);
-    __builtin_memcpy(&b0, b + r * sb, 4); __builtin_memcpy(&b1, b + r * sb + 4, 4);
-    x[r][0] = f_unpack_lo(a0) - f_unpack_lo(b0); x[r][1] = f_unpack_hi(a0) - f_unpack_hi(b0);
-    x[r][2] = f_unpack_lo(a1) - f_unpack_lo(b1); x[r][3] = f_unpack_hi(a1) - f_unpack_hi(b1);
-  }
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    v2s s0 = x[r][0] + x[r][2], s1 = x[r][1] + x[r][3], d0 = x[r][0] - x[r][2], d1 = x[r][1] - x[r][3];
-    x[r][0] = s0 + s1; x[r][1] = s0 - s1; x[r][2] = d0 + d1; x[r][3] = d0 - d1;
-  }
-  u32 m = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    v2s t[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { t[r] = x[r][q] + x[r + 4][q]; t[r + 4] = x[r][q] - x[r + 4][q]; }
-#pragma unroll
-    for (int h = 0; h < 8; h += 4) {
-      v2s u0 = t[h] + t[h + 2], u1 = t[h + 1] + t[h + 3], u2 = t[h] - t[h + 2], u3 = t[h + 1] - t[h + 3];
-      m += f_absmax(u0 + u1) + f_absmax(u0 - u1) + f_absmax(u2 + u3) + f_absmax(u2 - u3);
-    }
-  }
-  return (m + 1) >> 1;
-}
-
-#define FR_HS 65                 /* H plane row stride of the per-call filter step kernel */
-
-struct frac_cand { int fx, fy, ry, cx; };
-// square[] of search_inter.c:972-976
-__constant__ signed char c_sq_x[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 };
-__constant__ signed char c_sq_y[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
-
-// LDS geometry of one block's working set.  BIG: blocks up to 64x64, the whole 256-thread workgroup
-// cooperates (barriers).  SMALL: blocks up to 16x16, ONE WAVE per block, four blocks per workgroup,
-// wave-private LDS slices and no barrier (DS operations of a wave execute in order).
-template <int MAXW>
-struct frac_geom {
-  static constexpr int PS = MAXW + 8;                 // P window stride: cols -4 .. w+3
-  static constexpr int PR = MAXW + 8;                 // P rows -4 .. h+3
-  static constexpr int HS = MAXW + 1;                 // H plane stride: cols -1 .. w-1
-  static constexpr int CS = MAXW;                     // cur / candidate stride
-  static constexpr int P_BYTES = PS * PR, CUR_BYTES = CS * MAXW, H_ELEMS = PR * HS, CAND_BYTES = CS * MAXW;
-  static constexpr int TOTAL = ((P_BYTES + CUR_BYTES + 4 * CAND_BYTES + 15) & ~15) + 3 * H_ELEMS * 2 + 32;
-};
-
-template <int MAXW, int T, bool WAVE>
-__device__ __forceinline__ void search_frac_core(int tid, u8 *lds, const u8 *__restrict__ pic, u32 pic_stride, const refplane_t &ref,
-                                                 const kvz_hip_block_pair &d, u32 *__restrict__ out, i32 *__restrict__ best)
-{
-  typedef frac_geom<MAXW> G;
-  u8 *s_p = lds, *s_cur = s_p + G::P_BYTES, *s_cand = s_cur + G::CUR_BYTES;
-  i16 *s_h = (i16 *)(lds + ((G::P_BYTES + G::CUR_BYTES + 4 * G::CAND_BYTES + 15) & ~15));
-  u32 *s_cost = (u32 *)(s_h + 3 * G::H_ELEMS);
-  int *s_sel = (int *)(s_cost + 4);
-  auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
-
-  const int w = d.width, h = d.height;
-  const int pw = w + 8, ph = h + 8;
-  for (int i = tid; i < pw * ph; i += T) {
-    const int y = i / pw, x = i - y * pw;
-    s_p[y * G::PS + x] = ref_px(ref, d.x2 - 4 + x, d.y2 - 4 + y);
-  }
-  for (int i = tid; i < w * h; i += T) {
-    const int y = i / w, x = i - y * w;
-    s_cur[y * G::CS + x] = pic[(size_t)(d.y1 + y) * pic_stride + d.x1 + x];
-  }
-  sync();
-
-  // H plane for filter f: rows r = -4 .. h+3 (index r+4), cols c = -1 .. w-1 (index c+1)
-  auto hor_plane = [&](int f, i16 *dst) {
-    const signed char *fl = c_luma_filter[f];
-    for (int i = tid; i < ph * (w + 1); i += T) {
-      const int y = i / (w + 1), x = i - y * (w + 1);     // c = x - 1 -> P cols c-3 .. c+4 -> window index x .. x+7
-      int acc = 0;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) acc += fl[t] * (int)s_p[y * G::PS + x + t];
-      dst[y * G::HS + x] = (i16)acc;
-    }
-  };
-  // candidate: S(fx, fy; y + ry, x + cx) for the whole block
-  auto filter_cand = [&](const frac_cand &c, int plane, u8 *dst) {
-    const signed char *vf = c_luma_filter[c.fy];
-    for (int i = tid; i < w * h; i += T) {
-      const int y = i / w, x = i - y * w;
-      const int r = y + c.ry, cc = x + c.cx;              // H row index of (r-3+j) is r+1+j, col index cc+1
-      int acc = 0;
-      if (plane < 0) {                                    // fx == 0: H_0 = 64 * P
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += vf[j] * 64 * (int)s_p[(r + 1 + j) * G::PS + cc + 4];
-      } else {
-        const i16 *pl = s_h + plane * G::H_ELEMS;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += vf[j] * (int)pl[(r + 1 + j) * G::HS + cc + 1];
-      }
-      dst[y * G::CS + x] = round_clip16((i16)(acc >> 6));
-    }
-  };
-  // SATD of candidates 0..ncand-1 against s_cur -> s_cost
-  auto score = [&](int ncand, const u8 *cand0, int cand_stride, int cand_pitch) {
-    if (tid < 4) s_cost[tid] = 0;
-    sync();
-    const int w8 = w >> 3, n8 = w8 * (h >> 3);
-    for (int i = tid; i < ncand * n8; i += T) {
-      const int k = i / n8, sb = i - k * n8, by = sb / w8, bx = sb - by * w8;
-      const u32 v = satd8x8_lds(s_cur + by * 8 * G::CS + bx * 8, G::CS, cand0 + (size_t)k * cand_pitch + by * 8 * cand_stride + bx * 8, cand_stride);
-      atomicAdd(&s_cost[k], v);
-    }
-    sync();
-  };
-
-  // integer position: candidate = P[y][x]
-  score(1, s_p + 4 * G::PS + 4, G::PS, 0);
-  u32 best_cost = s_cost[0];
-  if (tid == 0) out[0] = best_cost;
-
-  hor_plane(2, s_h);
-  sync();
-
-  int best_index = 0;
-  for (int step = 0; step < 4; ++step) {
-    frac_cand c[4];
-    int plane[4];
-    if (step < 2) {
-      if (step == 0) {
-        c[0] = { 2, 0, 0, -1 }; c[1] = { 2, 0, 0, 0 }; c[2] = { 0, 2, -1, 0 }; c[3] = { 0, 2, 0, 0 };
-        plane[0] = 0; plane[1] = 0; plane[2] = -1; plane[3] = -1;
-      } else {
-        c[0] = { 2, 2, -1, -1 }; c[1] = { 2, 2, -1, 0 }; c[2] = { 2, 2, 0, -1 }; c[3] = { 2, 2, 0, 0 };
-        plane[0] = plane[1] = plane[2] = plane[3] = 0;
-      }
-    } else {
-      const int hx = s_sel[0], hy = s_sel[1];              // best half-pel offset in {-1,0,1}^2
-      const int bx = 2 * hx, by = 2 * hy;
-      const int hp = (bx & 3) ? 0 : -1;                    // plane of the half-pel column itself: fx 2 -> plane 0, fx 0 -> P
-      if (step == 2) {
-        c[0] = { (bx - 1) & 3, by & 3, by >> 2, (bx - 1) >> 2 };
-        c[1] = { (bx + 1) & 3, by & 3, by >> 2, (bx + 1) >> 2 };
-        c[2] = { bx & 3, (by - 1) & 3, (by - 1) >> 2, bx >> 2 };
-        c[3] = { bx & 3, (by + 1) & 3, (by + 1) >> 2, bx >> 2 };
-        plane[0] = 1; plane[1] = 2; plane[2] = hp; plane[3] = hp;
-        hor_plane((bx - 1) & 3, s_h + G::H_ELEMS);
-        hor_plane((bx + 1) & 3, s_h + 2 * G::H_ELEMS);
-        sync();
-      } else {
-        c[0] = { (bx - 1) & 3, (by - 1) & 3, (by - 1) >> 2, (bx - 1) >> 2 };
-        c[1] = { (bx + 1) & 3, (by - 1) & 3, (by - 1) >> 2, (bx + 1) >> 2 };
-        c[2] = { (bx - 1) & 3, (by + 1) & 3, (by + 1) >> 2, (bx - 1) >> 2 };
-        c[3] = { (bx + 1) & 3, (by + 1) & 3, (by + 1) >> 2, (bx + 1) >> 2 };
-        plane[0] = 1; plane[1] = 2; plane[2] = 1; plane[3] = 2;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) filter_cand(c[k], plane[k], s_cand + k * G::CAND_BYTES);
-    sync();
-    score(4, s_cand, G::CS, G::CAND_BYTES);
-    // decision: same order and strict '<' as search_inter.c:1096-1102
-    const int i0 = (step & 1) ? 5 : 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u32 cj = s_cost[j];
-      if (tid == 0) out[(step >= 2 ? 8 : 0) + i0 + j] = cj;
-      if (cj < best_cost) { best_cost = cj; best_index = i0 + j; }
-    }
-    if (step == 1 || step == 3) {
-      if (tid == 0) best[step == 3] = best_index;
-      if (step == 1) {
-        sync();
-        if (tid == 0) { s_sel[0] = c_sq_x[best_index]; s_sel[1] = c_sq_y[best_index]; }
-        best_index = 0;
-      }
-    }
-    sync();
-  }
-}
-
-__device__ __forceinline__ bool frac_shape_ok(int w, int h) { return !(w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7)); }
 
 // blocks larger than 16x16 (and malformed descriptors, which are flagged): one workgroup per descriptor
 __global__ __launch_bounds__(256) void search_frac_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, refplane_t ref,
@@ -354,7 +139,7 @@ __global__ __launch_bounds__(256) void search_frac_big_kernel(const u8 *__restri
     return;
   }
   if (d.width <= 16 && d.height <= 16) return;        // handled by search_frac_small_kernel
-  search_frac_core<64, 256, false>(tid, lds, pic, pic_stride, ref, d, costs + (size_t)blockIdx.x * 17, best + (size_t)blockIdx.x * 2);
+  search_frac_core<64, 256, false>(tid, lds, pic, pic_stride, ref, d, 4, frac_no_cost(), costs + (size_t)blockIdx.x * 17, best + (size_t)blockIdx.x * 2);
 }
 
 // blocks up to 16x16: one wave per descriptor, four descriptors per workgroup, no barrier
@@ -368,7 +153,7 @@ __global__ __launch_bounds__(256) void search_frac_small_kernel(const u8 *__rest
   if (i >= count) return;
   const kvz_hip_block_pair d = pairs[i];
   if (!frac_shape_ok(d.width, d.height) || d.width > 16 || d.height > 16) return;
-  search_frac_core<16, 64, true>(threadIdx.x & 63, lds[wv], pic, pic_stride, ref, d, costs + i * 17, best + i * 2);
+  search_frac_core<16, 64, true>(threadIdx.x & 63, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
 }
 
 // ---------------------------------------------------------------------------

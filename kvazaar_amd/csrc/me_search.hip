@@ -1,0 +1,310 @@
+// me_search.hip -- one motion search per PU, entirely on the device: hexagon search with MV bit
+// costs, then the fused fractional search.
+//
+// Reference: the --me hexbs path of search_pu_inter_ref (src/search_inter.c:1134-1300):
+// hexagon_search (:690-778) = select_starting_point (:282-307) + early_terminate (:415-460) +
+// the 6/3/8-point patterns, every candidate through check_mv_cost (:195-232) = kvz_image_calc_sad
+// (image.c:455-486) + calc_mvd_cost (:373-412); then search_frac (:965-1128).  SURVEY.md 8(f) row 1.
+//
+// The reference walks each pattern one candidate at a time and keeps the running best with a
+// strict '<', i.e. it takes the first minimum of the group in visiting order.  Here the SADs of a
+// whole group (up to 8 candidates) are computed at once -- work item = (candidate, 8-pixel row
+// segment), spread over the wave / workgroup that owns the PU, partial sums through LDS atomics --
+// and the same first-minimum rule is applied to the group, so every decision (and therefore the
+// path the search takes) is the reference's.  The current block lives in LDS for the whole search;
+// reference pixels come from L2/HBM with the clamp addressing of image_interpolated_sad
+// (image.c:320-444).  The fractional stage is frac_core.h with the MV cost model plugged in.
+#include "kvz_hip_internal.h"
+#include "frac_core.h"
+
+using namespace kvzhip;
+
+namespace {
+
+// calc_mvd_cost / fracmv_within_tile on the flattened encoder state (include/kvz_hip.h)
+struct me_cost_model {
+  const kvz_hip_me_pu &pu;
+  const kvz_hip_me_params &prm;
+
+  // fracmv_within_tile (search_inter.c:87-176) for mv_constraint == NONE; quarter-pel vector
+  __device__ __forceinline__ bool within(int x, int y) const
+  {
+    if (!prm.wpp_owf) return true;
+    int margin = 0;
+    if (x % 4 != 0 || y % 4 != 0) margin = 4;
+    else if (x % 8 != 0 || y % 8 != 0) margin = 2;
+    margin += prm.ref_delay_px;
+    const int lcu_x = pu.x / 64, lcu_y = pu.y / 64;
+    const int mv_lcu_x = ((pu.x + pu.width + margin) * 4 + x) / (64 << 2) - lcu_x;
+    const int mv_lcu_y = ((pu.y + pu.height + margin) * 4 + y) / (64 << 2) - lcu_y;
+    if (mv_lcu_y > prm.max_ref_lcu_down) return false;
+    if (mv_lcu_x + mv_lcu_y > prm.max_ref_lcu_down + prm.max_ref_lcu_right) return false;
+    return true;
+  }
+  // get_ep_ex_golomb_bitcost (:235-254)
+  static __device__ __forceinline__ u32 golomb(u32 symbol)
+  {
+    u32 bins = 0;
+    symbol += 2;
+    if (symbol >= 1u << 8) { bins += 16; symbol >>= 8; }
+    if (symbol >= 1u << 4) { bins += 8; symbol >>= 4; }
+    if (symbol >= 1u << 2) { bins += 4; symbol >>= 2; }
+    if (symbol >= 1u << 1) { bins += 2; }
+    return bins;
+  }
+  // get_mvd_coding_cost (:310-323): whole bits, the fixed-point rounding is exact
+  static __device__ __forceinline__ u32 mvd_bits(int dx, int dy)
+  {
+    return golomb((u32)(dx < 0 ? -dx : dx)) + golomb((u32)(dy < 0 ? -dy : dy));
+  }
+  // select_mv_cand (:326-370)
+  __device__ __forceinline__ int select_cand(int mvx, int mvy, u32 &cost) const
+  {
+    const u32 c1 = mvd_bits(mvx - pu.mv_cand[0][0], mvy - pu.mv_cand[0][1]);
+    const u32 c2 = mvd_bits(mvx - pu.mv_cand[1][0], mvy - pu.mv_cand[1][1]);
+    cost = c1 < c2 ? c1 : c2;
+    return c2 < c1 ? 1 : 0;
+  }
+  // index of the first merge candidate that codes (x, y) (quarter-pel) for this reference, or -1
+  __device__ __forceinline__ int merge_match(int x, int y) const
+  {
+    for (int i = 0; i < pu.num_merge_cand; ++i)
+      if (pu.merge[i].usable && pu.merge[i].mv[0] == x && pu.merge[i].mv[1] == y && pu.merge[i].same_ref) return i;
+    return -1;
+  }
+  // calc_mvd_cost (:373-412)
+  __device__ __forceinline__ u32 cost(int x, int y, int mv_shift, u32 &bits) const
+  {
+    x *= 1 << mv_shift;
+    y *= 1 << mv_shift;
+    const int m = merge_match(x, y);
+    if (m >= 0) bits = (u32)m;
+    else select_cand(x, y, bits);
+    return bits * (u32)prm.lambda_cost;
+  }
+  // mv_in_merge (:260-273), integer-pel vector
+  __device__ __forceinline__ bool in_merge(int x, int y) const
+  {
+    for (int i = 0; i < pu.num_merge_cand; ++i)
+      if (pu.merge[i].usable && ((pu.merge[i].mv[0] + 2) >> 2) == x && ((pu.merge[i].mv[1] + 2) >> 2) == y) return true;
+    return false;
+  }
+};
+
+__constant__ signed char c_large_hex[9][2] = { { 0, 0 }, { 1, -2 }, { 2, 0 }, { 1, 2 }, { -1, 2 }, { -2, 0 }, { -1, -2 }, { 1, -2 }, { 2, 0 } };
+__constant__ signed char c_small_hex[9][2] = { { 0, 0 }, { 0, -1 }, { -1, 0 }, { 1, 0 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+__constant__ signed char c_et_hex[7][2] = { { 0, -1 }, { -1, 0 }, { 0, 1 }, { 1, 0 }, { 0, -1 }, { -1, 0 }, { 0, 0 } };
+
+struct me_shared { u32 sad[8]; int cx[8], cy[8]; };
+
+// One PU.  T threads (a wave with wave-private LDS, or the whole workgroup) share the work; every thread
+// carries the same search state, so all decisions are uniform across them.
+template <int MAXW, int T, bool WAVE>
+__device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, const u8 *__restrict__ pic, u32 pic_stride,
+                                               const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm,
+                                               kvz_hip_me_result *__restrict__ out)
+{
+  typedef frac_geom<MAXW> G;
+  u8 *s_cur = lds + G::P_BYTES;                        // same place search_frac_core keeps the current block
+  auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
+  const me_cost_model mvc = { pu, prm };
+  const int w = pu.width, h = pu.height, w8 = w >> 3, segs = w8 * h;
+
+  for (int i = tid; i < segs; i += T) {
+    const int y = i / w8, x = (i - y * w8) * 8;
+    uint2 v;
+    __builtin_memcpy(&v, pic + (size_t)(pu.y + y) * pic_stride + pu.x + x, 8);
+    *(uint2 *)(s_cur + y * G::CS + x) = v;
+  }
+
+  int best_x = 0, best_y = 0;                          // info->best_mv, integer-pel here
+  u32 best_cost = 0xffffffffu, best_bits = 0;
+
+  // SADs of candidates 0 .. n-1 (offsets in sh->cx / cy, written by the caller) -> sh->sad
+  auto group_sads = [&](int n) {
+    if (tid < 8) sh->sad[tid] = 0;
+    sync();
+    for (int it = tid; it < n * segs; it += T) {
+      const int k = it / segs, s = it - k * segs, y = s / w8, x = (s - y * w8) * 8;
+      const int rx = pu.x + sh->cx[k] + x, ry = pu.y + sh->cy[k] + y;
+      const uint2 c = *(const uint2 *)(s_cur + y * G::CS + x);
+      uint2 r;
+      if (rx >= 0 && rx + 8 <= ref.w && ry >= 0 && ry < ref.h) {
+        __builtin_memcpy(&r, ref.p + (size_t)ry * ref.stride + rx, 8);
+      } else {
+        u32 b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = ref_px(ref, rx + i, ry);
+        r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+      }
+      atomicAdd(&sh->sad[k], __builtin_amdgcn_sad_u8(c.y, r.y, __builtin_amdgcn_sad_u8(c.x, r.x, 0u)));
+    }
+    sync();
+  };
+  // check_mv_cost (:195-232) on candidate k of the evaluated group; true if it became the best
+  auto take = [&](int k) -> bool {
+    const int x = sh->cx[k], y = sh->cy[k];
+    if (!mvc.within(x * 4, y * 4)) return false;
+    u32 cost = sh->sad[k], bits = 0;
+    if (cost >= best_cost) return false;
+    cost += mvc.cost(x, y, 2, bits);
+    if (cost >= best_cost) return false;
+    best_x = x; best_y = y; best_cost = cost; best_bits = bits;
+    return true;
+  };
+  auto set_cand = [&](int k, int x, int y) { if (tid == 0) { sh->cx[k] = x; sh->cy[k] = y; } };
+
+  // ---- select_starting_point (:282-307) ----
+  int n = 0;
+  sync();                                              // s_cur complete; previous readers of sh are done
+  set_cand(n++, 0, 0);
+  {
+    const int ex = pu.extra_mv[0] >> 2, ey = pu.extra_mv[1] >> 2;
+    if ((ex != 0 || ey != 0) && !mvc.in_merge(ex, ey)) set_cand(n++, ex, ey);
+    for (int i = 0; i < pu.num_merge_cand; ++i) {
+      if (!pu.merge[i].usable) continue;
+      const int x = (pu.merge[i].mv[0] + 2) >> 2, y = (pu.merge[i].mv[1] + 2) >> 2;
+      if (x == 0 && y == 0) continue;
+      set_cand(n++, x, y);
+    }
+  }
+  group_sads(n);
+  for (int k = 0; k < n; ++k) take(k);
+
+  // ---- early_terminate (:415-460) ----
+  bool done = false;
+  if (prm.early_termination) {
+    int mvx = best_x, mvy = best_y, first = 0, last = 3;
+    for (int round = 0; round < 2 && !done; ++round) {
+      const double threshold = prm.early_termination == 2 ? (double)best_cost * 0.95 : (double)best_cost;
+      sync();
+      for (int i = first; i <= last; ++i) set_cand(i - first, mvx + c_et_hex[i][0], mvy + c_et_hex[i][1]);
+      group_sads(last - first + 1);
+      int best_index = 6;
+      for (int i = first; i <= last; ++i)
+        if (take(i - first)) best_index = i;
+      mvx += c_et_hex[best_index][0]; mvy += c_et_hex[best_index][1];
+      if ((double)best_cost >= threshold) done = true;
+      first = (best_index + 3) % 4;
+      last = first + 2;
+    }
+  }
+
+  if (!done) {
+    // ---- the hexagon (:723-777) ----
+    int mvx = best_x, mvy = best_y, best_index = 0;
+    u32 steps = prm.max_steps;
+    sync();
+    for (int i = 1; i < 7; ++i) set_cand(i - 1, mvx + c_large_hex[i][0], mvy + c_large_hex[i][1]);
+    group_sads(6);
+    for (int i = 1; i < 7; ++i)
+      if (take(i - 1)) best_index = i;
+    while (best_index != 0 && steps != 0) {
+      steps -= 1;
+      const int start = best_index == 1 ? 6 : (best_index == 8 ? 1 : best_index - 1);
+      mvx += c_large_hex[best_index][0]; mvy += c_large_hex[best_index][1];
+      best_index = 0;
+      sync();
+      for (int i = 0; i < 3; ++i) set_cand(i, mvx + c_large_hex[start + i][0], mvy + c_large_hex[start + i][1]);
+      group_sads(3);
+      for (int i = 0; i < 3; ++i)
+        if (take(i)) best_index = start + i;
+    }
+    sync();
+    for (int i = 1; i < 9; ++i) set_cand(i - 1, mvx + c_small_hex[i][0], mvy + c_small_hex[i][1]);
+    group_sads(8);
+    for (int i = 1; i < 9; ++i) take(i - 1);
+  }
+
+  // ---- search_frac, or the SATD re-cost of :1236-1248 when cfg.fme_level == 0 ----
+  int mv_x = best_x * 4, mv_y = best_y * 4;
+  if (best_cost != 0xffffffffu) {
+    sync();
+    const kvz_hip_block_pair d = { pu.x, pu.y, pu.x + best_x, pu.y + best_y, w, h };
+    const frac_result fr = search_frac_core<MAXW, T, WAVE>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
+    best_cost = fr.cost;                               // level 0: satd + bits(int mv) * lambda, the same bits as best_bits
+    if (prm.fme_level > 0) { mv_x = fr.mvx; mv_y = fr.mvy; best_bits = fr.bitcost; }
+  }
+
+  if (tid == 0) {
+    kvz_hip_me_result r;
+    r.mv[0] = mv_x; r.mv[1] = mv_y;
+    r.cost = best_cost; r.bitcost = best_bits;
+    const int m = mvc.merge_match(mv_x, mv_y);          // :1253-1266
+    r.merged = m >= 0;
+    r.merge_idx = m >= 0 ? m : pu.num_merge_cand;
+    u32 unused;
+    r.mv_cand = m >= 0 ? 0 : mvc.select_cand(mv_x, mv_y, unused);   // :1268-1273
+    r.reserved = 0;
+    *out = r;
+  }
+}
+
+__device__ __forceinline__ bool pu_ok(const kvz_hip_me_pu &pu, int pic_w, int pic_h)
+{
+  return frac_shape_ok(pu.width, pu.height) && pu.x >= 0 && pu.y >= 0 && pu.x + pu.width <= pic_w && pu.y + pu.height <= pic_h &&
+         pu.num_merge_cand >= 0 && pu.num_merge_cand <= 5;
+}
+
+__device__ __forceinline__ void flag_bad(kvz_hip_me_result *out)
+{
+  kvz_hip_me_result r = { { 0, 0 }, 0xffffffffu, 0, 0, 0, 0, -1 };
+  *out = r;
+}
+
+// PUs larger than 16x16 (and malformed descriptors, which are flagged): one workgroup per PU
+__global__ __launch_bounds__(256) void search_pu_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
+                                                            const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
+                                                            kvz_hip_me_result *__restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
+  __shared__ me_shared sh;
+  const kvz_hip_me_pu &pu = pus[blockIdx.x];            // uniform address: the compiler reads it with scalar loads
+  if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  if (pu.width <= 16 && pu.height <= 16) return;       // search_pu_small_kernel's
+  search_pu_core<64, 256, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+}
+
+// PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier
+__global__ __launch_bounds__(256) void search_pu_small_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
+                                                              const kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_me_params prm,
+                                                              kvz_hip_me_result *__restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[4][(frac_geom<16>::TOTAL + 15) & ~15];
+  __shared__ me_shared sh[4];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t i = (size_t)blockIdx.x * 4 + wv;
+  if (i >= count) return;
+  const kvz_hip_me_pu &pu = pus[i];
+  if (!pu_ok(pu, pic_w, pic_h) || pu.width > 16 || pu.height > 16) return;
+  search_pu_core<16, 64, true>(threadIdx.x & 63, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+}
+
+}  // namespace
+
+extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
+                                       const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                       const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
+                                       kvz_hip_me_result *results, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!pic || !ref || !pus || !params || !results || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0) {
+    set_error_msg("kvz_hip_search_pu_batch: null buffer or empty plane");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  if (params->fme_level < 0 || params->fme_level > 4 || params->early_termination < 0 || params->early_termination > 2) {
+    set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4 and early_termination 0..2");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  if (count == 0) return KVZ_HIP_OK;
+  if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  hipStream_t st = ctx_stream(s);
+  const refplane_t r = { ref, ref_stride, ref_w, ref_h };
+  hipLaunchKernelGGL(search_pu_big_kernel, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+  KVZ_CHECK_LAUNCH("search_pu_big_kernel");
+  hipLaunchKernelGGL(search_pu_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
+                     *params, results);
+  KVZ_CHECK_LAUNCH("search_pu_small_kernel");
+  return KVZ_HIP_OK;
+}

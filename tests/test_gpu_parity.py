@@ -482,3 +482,67 @@ def test_intra_argument_errors(api):
     with pytest.raises(KvzHipError):
         api.intra_rough_batch(refs, 3, np.zeros((2, 64), np.uint8), flags=4)
     assert api.intra_rough_batch(refs[:0], 3, np.zeros((0, 64), np.uint8)).shape == (0, 35)
+
+
+# ---- motion search of whole PUs ----
+from patterns import ME_RESULT, me_frames, me_params, me_random_pus  # noqa: E402
+
+ME_CONFIGS = [
+    dict(), dict(early_termination=2, fme_level=2, lambda_cost=35), dict(early_termination=0, lambda_cost=4),
+    dict(fme_level=0, lambda_cost=60), dict(fme_level=1), dict(fme_level=3, max_steps=2),
+    dict(wpp_owf=1, ref_delay_px=10, max_ref_lcu_down=1, max_ref_lcu_right=1),
+    dict(wpp_owf=1, ref_delay_px=8, max_ref_lcu_down=0, max_ref_lcu_right=2, lambda_cost=9),
+]
+
+
+def _me_compare(api, pic, ref, pus, prm, msg):
+    got = api.search_pu_batch(pic, ref, pus, prm).view(ME_RESULT).reshape(-1)
+    want = O.search_pu_batch(pic, ref, pus, prm)
+    for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+        np.testing.assert_array_equal(got[f], want[f], err_msg="%s %s" % (f, msg))
+
+
+@pytest.mark.parametrize("cfg", range(len(ME_CONFIGS)))
+def test_search_pu(api, cfg):
+    prm = me_params(**ME_CONFIGS[cfg])
+    for k, motion in enumerate(((3, -2), (-7, 5), (0, 0), (14, 9))):
+        pic, ref = me_frames(192, 128, 900 + k, motion)
+        pus = me_random_pus(192, 128, 60, 177 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1]))
+        _me_compare(api, pic, ref, pus, prm, "cfg %d motion %s" % (cfg, motion))
+
+
+def test_search_pu_flat_and_borders(api):
+    """flat frames (every candidate ties: the reference's first-wins order decides) and vectors that leave the frame"""
+    prm = me_params(lambda_cost=3, early_termination=0)
+    flat = np.full((128, 192), 77, np.uint8)
+    pus = me_random_pus(192, 128, 30, 5)
+    _me_compare(api, flat, flat, pus, prm, "flat")
+    pic, ref = me_frames(192, 128, 31, (20, -17))
+    pus = me_random_pus(192, 128, 60, 6, sizes=((8, 8), (16, 16), (64, 64), (32, 32)))
+    pus["x"] = np.where(np.arange(60) % 2 == 0, 0, 192 - pus["width"])       # hug the left / right border
+    pus["y"] = np.where(np.arange(60) % 3 == 0, 0, 128 - pus["height"])
+    pus["extra_mv"] = np.array([[-130, 90], [150, -120], [4, 300]] * 20, dtype=np.int16)   # start outside the frame
+    _me_compare(api, pic, ref, pus, prm, "borders")
+
+
+def test_search_pu_frame_of_ctus_and_bad_descriptors(api):
+    """every 8x8..64x64 PU of a 6 x 4 CTU frame in one launch; malformed descriptors are flagged, not searched"""
+    prm = me_params()
+    pic, ref = me_frames(384, 256, 77, (-5, 3))
+    rows = []
+    for n in (64, 32, 16, 8):
+        for y in range(0, 256, n):
+            for x in range(0, 384, n):
+                rows.append((x, y, n))
+    pus = me_random_pus(384, 256, len(rows), 8, hint=(22, -12))
+    for i, (x, y, n) in enumerate(rows):
+        pus[i]["x"], pus[i]["y"], pus[i]["width"], pus[i]["height"] = x, y, n, n
+    sel = np.arange(0, len(rows), 7)                       # the oracle takes ~1 ms per PU: compare a strided subset
+    got = api.search_pu_batch(pic, ref, pus, prm).view(ME_RESULT).reshape(-1)
+    want = O.search_pu_batch(pic, ref, pus[sel], prm)
+    for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+        np.testing.assert_array_equal(got[sel][f], want[f], err_msg=f)
+    bad = pus[:4].copy()
+    bad[0]["width"] = 12; bad[1]["x"] = 380; bad[2]["num_merge_cand"] = 9; bad[3]["height"] = 0
+    r = api.search_pu_batch(pic, ref, bad, prm).view(ME_RESULT).reshape(-1)
+    assert (r["cost"] == 0xFFFFFFFF).all() and (r["reserved"] == -1).all()

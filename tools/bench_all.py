@@ -127,6 +127,19 @@ def main():
                       lambda prs_d=prs_d, co=co, be=be, k=len(prs): L.kvz_hip_search_frac_batch(
                           picf.data_ptr(), W, reff.data_ptr(), W, W, F * H, prs_d.data_ptr(), k, co.data_ptr(), be.data_ptr(), st)))
 
+    # whole-PU motion search (hexagon + fractional, with MV costs): every n x n PU of 4 frames
+    me_prm = np.zeros(8, dtype=np.int32); me_prm[:] = (20, 1, -1, 4, 0, 0, 1, 1)
+    for n in (8, 16, 64):
+        rows = [(x, f * H + y) for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)]
+        pus = np.zeros((len(rows), 16), dtype=np.int32)
+        pus[:, 0] = [r[0] for r in rows]; pus[:, 1] = [r[1] for r in rows]; pus[:, 2] = n; pus[:, 3] = n
+        pus_d = torch.from_numpy(pus).to(dev)
+        res_d = torch.empty((len(rows), 8), dtype=torch.int32, device=dev)
+        cases.append(("search_pu_%dx%d" % (n, n), len(rows), 2 * n * n + 96,
+                      lambda pus_d=pus_d, res_d=res_d, k=len(rows): L.kvz_hip_search_pu_batch(
+                          picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), k,
+                          me_prm.ctypes.data, res_d.data_ptr(), st)))
+
     # intra rough search: all 35 modes per PU; bytes per PU = refs 130 + orig N^2 + 35 costs
     for lg in (2, 3, 4, 5):
         n = 1 << lg
