@@ -357,6 +357,49 @@ KVZ_HIP_API int kvz_hip_intra_rough_batch(int log2_width, int flags, const kvz_h
                                           uint32_t *satd_costs, uint32_t *sad_costs, kvz_hip_stream s);
 
 /* ------------------------------------------------------------------ */
+/* (2) batched entries -- SAO group (strategies/strategies-sao.h)      */
+/*     SURVEY.md section 8(f) row 4                                    */
+/* ------------------------------------------------------------------ */
+/* Statistics / distortion entries: `count` contiguous block_width x
+ * block_height blocks (stride = block_width, at most 64 x 64), the way
+ * sao.c blits an LCU plane before calling the strategies. */
+
+/* calc_sao_edge_dir (sao-generic.c:80-109) for the four edge classes at once:
+ * cat_sum_cnt[((i * 4 + eo_class) * 2 + {0 sum, 1 count}) * 5 + category]. */
+KVZ_HIP_API int kvz_hip_sao_edge_stats_batch(const kvz_hip_pixel *orig, const kvz_hip_pixel *rec, int block_width, int block_height,
+                                             size_t count, int32_t *cat_sum_cnt, kvz_hip_stream s);
+/* sao_edge_ddistortion (sao-generic.c:46-77) for the four classes:
+ * ddistortion[i * 4 + eo_class] with offsets[(i * 4 + eo_class) * 5 + category]. */
+KVZ_HIP_API int kvz_hip_sao_edge_ddistortion_batch(const kvz_hip_pixel *orig, const kvz_hip_pixel *rec, int block_width, int block_height,
+                                                   size_t count, const int32_t *offsets, int32_t *ddistortion, kvz_hip_stream s);
+/* calc_sao_bands (sao.c:247-261): sao_bands[(i * 2 + {0 sum, 1 count}) * 32 + band] */
+KVZ_HIP_API int kvz_hip_sao_band_stats_batch(const kvz_hip_pixel *orig, const kvz_hip_pixel *rec, int block_width, int block_height,
+                                             size_t count, int32_t *sao_bands, kvz_hip_stream s);
+/* sao_band_ddistortion (sao-generic.c:157-183): ddistortion[i] for band_pos[i], sao_bands[i * 4 + k] */
+KVZ_HIP_API int kvz_hip_sao_band_ddistortion_batch(const kvz_hip_pixel *orig, const kvz_hip_pixel *rec, int block_width, int block_height,
+                                                   size_t count, const int32_t *band_pos, const int32_t *sao_bands,
+                                                   int32_t *ddistortion, kvz_hip_stream s);
+
+/* the fields of sao_info_t (sao.h:42-50) the reconstruction reads */
+typedef struct {
+  int32_t type;                 /* SAO_TYPE_NONE 0 (copy), SAO_TYPE_BAND 1, SAO_TYPE_EDGE 2 */
+  int32_t eo_class;
+  int32_t band_position[2];     /* [0] Y / U, [1] V */
+  int32_t offsets[10];          /* [0..4] Y / U, [5..9] V */
+} kvz_hip_sao_info;
+typedef struct { int32_t x, y, width, height, sao_index; } kvz_hip_sao_block;
+/* sao_reconstruct_color (sao-generic.c:112-154, with kvz_calc_sao_offset_array,
+ * sao.c:164-180) for `count` blocks of one plane: new_rec <- filter(rec) inside
+ * each block.  Edge blocks read one pixel beyond the block in the directions of
+ * their class, so the caller trims them at the picture border like
+ * kvz_sao_reconstruct (sao.c:296-318); a descriptor whose reads would leave the
+ * plane is skipped.  color 0 Y, 1 U, 2 V. */
+KVZ_HIP_API int kvz_hip_sao_reconstruct_color_batch(const kvz_hip_pixel *rec, uint32_t stride, int plane_w, int plane_h,
+                                                    kvz_hip_pixel *new_rec, uint32_t new_stride,
+                                                    const kvz_hip_sao_block *blocks, size_t count,
+                                                    const kvz_hip_sao_info *infos, int n_infos, int color, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
 /* (1) strategy registration -- the drop-in boundary                   */
 /* ------------------------------------------------------------------ */
 /* kvz_strategyselector_register (strategyselector.h:87, strategyselector.c:216-256) */
@@ -406,6 +449,7 @@ KVZ_HIP_API int kvz_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);
 KVZ_HIP_API int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);
 KVZ_HIP_API int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);
 KVZ_HIP_API int kvz_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);   /* strategies-intra.h:52-55 */
+KVZ_HIP_API int kvz_strategy_register_sao_hip(void *opaque, uint8_t bitdepth);     /* strategies-sao.h:64-69 */
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,11 @@ SIGNATURES = {
     "kvz_hip_search_pu_batch": (_I, [_P, _U, _I, _I, _P, _U, _I, _I, _P, _SZ, _P, _P, _P]),
     "kvz_hip_intra_predict_batch": (_I, [_I, _I, _P, _SZ, _P, _I, _P, _P]),
     "kvz_hip_intra_rough_batch": (_I, [_I, _I, _P, _P, _SZ, _P, _P, _P]),
+    "kvz_hip_sao_edge_stats_batch": (_I, [_P, _P, _I, _I, _SZ, _P, _P]),
+    "kvz_hip_sao_edge_ddistortion_batch": (_I, [_P, _P, _I, _I, _SZ, _P, _P, _P]),
+    "kvz_hip_sao_band_stats_batch": (_I, [_P, _P, _I, _I, _SZ, _P, _P]),
+    "kvz_hip_sao_band_ddistortion_batch": (_I, [_P, _P, _I, _I, _SZ, _P, _P, _P, _P]),
+    "kvz_hip_sao_reconstruct_color_batch": (_I, [_P, _U, _I, _I, _P, _U, _P, _SZ, _P, _I, _I, _P]),
     "kvz_hip_set_registrar": (None, [_P]),
     "kvz_hip_dropin_calls": (C.c_ulonglong, []),
     "kvz_hip_set_state_accessors": (None, [_P]),
@@ -90,6 +95,7 @@ SIGNATURES = {
     "kvz_strategy_register_quant_hip": (_I, [_P, C.c_uint8]),
     "kvz_strategy_register_ipol_hip": (_I, [_P, C.c_uint8]),
     "kvz_strategy_register_intra_hip": (_I, [_P, C.c_uint8]),
+    "kvz_strategy_register_sao_hip": (_I, [_P, C.c_uint8]),
 }
 
 

@@ -320,3 +320,64 @@ def search_pu_batch(pic, ref, pus, params):
     check(L.kvz_hip_search_pu_batch(a.ptr, pic.shape[1], pic.shape[1], pic.shape[0], b.ptr, ref.shape[1], ref.shape[1], ref.shape[0],
                                     d.ptr, count, params.ctypes.data, out.ptr, None), "search_pu batch")
     return out.to_numpy(np.int32, (count, 8))
+
+
+# ---- SAO group ----
+def sao_edge_stats_batch(orig, rec, bw, bh):
+    """-> int32 [count, 4 classes, 2 (sum, count), 5 categories]"""
+    L = _lib.init()
+    orig = np.ascontiguousarray(orig, dtype=np.uint8).reshape(-1, bw * bh)
+    rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1, bw * bh)
+    count = orig.shape[0]
+    a, b, o = DeviceBuffer.from_numpy(orig), DeviceBuffer.from_numpy(rec), DeviceBuffer(max(1, 160 * count))
+    check(L.kvz_hip_sao_edge_stats_batch(a.ptr, b.ptr, bw, bh, count, o.ptr, None), "sao_edge_stats")
+    return o.to_numpy(np.int32, (count, 4, 2, 5))
+
+
+def sao_edge_ddistortion_batch(orig, rec, bw, bh, offsets):
+    """offsets int32 [count, 4, 5] -> int32 [count, 4]"""
+    L = _lib.init()
+    orig = np.ascontiguousarray(orig, dtype=np.uint8).reshape(-1, bw * bh)
+    rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1, bw * bh)
+    count = orig.shape[0]
+    offs = np.ascontiguousarray(offsets, dtype=np.int32).reshape(count, 4, 5)
+    a, b, f, o = DeviceBuffer.from_numpy(orig), DeviceBuffer.from_numpy(rec), DeviceBuffer.from_numpy(offs), DeviceBuffer(max(1, 16 * count))
+    check(L.kvz_hip_sao_edge_ddistortion_batch(a.ptr, b.ptr, bw, bh, count, f.ptr, o.ptr, None), "sao_edge_ddistortion")
+    return o.to_numpy(np.int32, (count, 4))
+
+
+def sao_band_stats_batch(orig, rec, bw, bh):
+    L = _lib.init()
+    orig = np.ascontiguousarray(orig, dtype=np.uint8).reshape(-1, bw * bh)
+    rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1, bw * bh)
+    count = orig.shape[0]
+    a, b, o = DeviceBuffer.from_numpy(orig), DeviceBuffer.from_numpy(rec), DeviceBuffer(max(1, 256 * count))
+    check(L.kvz_hip_sao_band_stats_batch(a.ptr, b.ptr, bw, bh, count, o.ptr, None), "sao_band_stats")
+    return o.to_numpy(np.int32, (count, 2, 32))
+
+
+def sao_band_ddistortion_batch(orig, rec, bw, bh, band_pos, bands):
+    L = _lib.init()
+    orig = np.ascontiguousarray(orig, dtype=np.uint8).reshape(-1, bw * bh)
+    rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1, bw * bh)
+    count = orig.shape[0]
+    bp = np.ascontiguousarray(band_pos, dtype=np.int32).reshape(count)
+    bd = np.ascontiguousarray(bands, dtype=np.int32).reshape(count, 4)
+    a, b, p, d, o = (DeviceBuffer.from_numpy(orig), DeviceBuffer.from_numpy(rec), DeviceBuffer.from_numpy(bp), DeviceBuffer.from_numpy(bd),
+                     DeviceBuffer(max(1, 4 * count)))
+    check(L.kvz_hip_sao_band_ddistortion_batch(a.ptr, b.ptr, bw, bh, count, p.ptr, d.ptr, o.ptr, None), "sao_band_ddistortion")
+    return o.to_numpy(np.int32, (count,))
+
+
+def sao_reconstruct_color_batch(plane, blocks, infos, color):
+    """plane uint8 2-D; blocks int32 [count, 5] (x, y, w, h, sao_index); infos int32 [n, 14]; returns the filtered plane
+    (pixels outside every block are copied from `plane`)"""
+    L = _lib.init()
+    plane = np.ascontiguousarray(plane, dtype=np.uint8)
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32).reshape(-1, 5)
+    infos = np.ascontiguousarray(infos, dtype=np.int32).reshape(-1, 14)
+    a, d = DeviceBuffer.from_numpy(plane), DeviceBuffer.from_numpy(plane)
+    b, f = DeviceBuffer.from_numpy(blocks), DeviceBuffer.from_numpy(infos)
+    check(L.kvz_hip_sao_reconstruct_color_batch(a.ptr, plane.shape[1], plane.shape[1], plane.shape[0], d.ptr, plane.shape[1],
+                                                b.ptr, blocks.shape[0], f.ptr, infos.shape[0], color, None), "sao_reconstruct")
+    return d.to_numpy(np.uint8, plane.shape)

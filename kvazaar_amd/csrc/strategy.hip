@@ -411,6 +411,101 @@ void hip_intra_pred_planar(const int_fast8_t log2_width, const kvz_hip_pixel *co
   intra_call(log2_width, 0, ref_top, ref_left, dst);
 }
 
+// ---------------- sao group ----------------
+// sao_info_t as laid out by sao.h:42-50 (two enums and 15 ints; tests/test_oracle_vs_ref.py checks the size
+// against the compiled reference)
+struct sao_info_mirror { int type, eo_class, ddistortion, merge_left_flag, merge_up_flag, band_position[2], offsets[10]; };
+
+// orig / rec are contiguous bw x bh blocks (sao-generic.c:46-109)
+static void sao_stage_pair(call_ctx &c, stage &s, const kvz_hip_pixel *orig, const kvz_hip_pixel *rec, int n, size_t &oo, size_t &orr)
+{
+  oo = s.take((size_t)n); orr = s.take((size_t)n);
+  std::memcpy(c.h + oo, orig, (size_t)n);
+  std::memcpy(c.h + orr, rec, (size_t)n);
+}
+
+int hip_sao_edge_ddistortion(const kvz_hip_pixel *orig_data, const kvz_hip_pixel *rec_data, int block_width, int block_height,
+                             int eo_class, int offsets[5])
+{
+  if (block_width < 1 || block_height < 1 || block_width > 64 || block_height > 64 || eo_class < 0 || eo_class > 3)
+    die("sao_edge_ddistortion: bad arguments", KVZ_HIP_ERR_INVALID);
+  call_ctx &c = tls(); stage s(c);
+  size_t oo, orr;
+  sao_stage_pair(c, s, orig_data, rec_data, block_width * block_height, oo, orr);
+  size_t of = s.take(80), in_end = s.off, od = s.take(16);
+  int32_t offs[20] = { 0 };
+  for (int k = 0; k < 5; ++k) offs[eo_class * 5 + k] = offsets[k];
+  std::memcpy(c.h + of, offs, sizeof(offs));
+  s.h2d(0, in_end);
+  MUST(kvz_hip_sao_edge_ddistortion_batch(c.d + oo, c.d + orr, block_width, block_height, 1, (const int32_t *)(c.d + of), (int32_t *)(c.d + od), c.st));
+  s.d2h(od, 16); s.sync();
+  return ((const int32_t *)(c.h + od))[eo_class];
+}
+
+void hip_calc_sao_edge_dir(const kvz_hip_pixel *orig_data, const kvz_hip_pixel *rec_data, int eo_class, int block_width, int block_height,
+                           int cat_sum_cnt[2][5])
+{
+  if (block_width < 1 || block_height < 1 || block_width > 64 || block_height > 64 || eo_class < 0 || eo_class > 3)
+    die("calc_sao_edge_dir: bad arguments", KVZ_HIP_ERR_INVALID);
+  call_ctx &c = tls(); stage s(c);
+  size_t oo, orr;
+  sao_stage_pair(c, s, orig_data, rec_data, block_width * block_height, oo, orr);
+  size_t in_end = s.off, od = s.take(160);
+  s.h2d(0, in_end);
+  MUST(kvz_hip_sao_edge_stats_batch(c.d + oo, c.d + orr, block_width, block_height, 1, (int32_t *)(c.d + od), c.st));
+  s.d2h(od, 160); s.sync();
+  const int32_t *r = (const int32_t *)(c.h + od) + eo_class * 10;
+  for (int k = 0; k < 5; ++k) { cat_sum_cnt[0][k] += r[k]; cat_sum_cnt[1][k] += r[5 + k]; }   // the reference accumulates
+}
+
+int hip_sao_band_ddistortion(const void *state, const kvz_hip_pixel *orig_data, const kvz_hip_pixel *rec_data, int block_width,
+                             int block_height, int band_pos, int sao_bands[4])
+{
+  (void)state;                                         // only encoder_control->bitdepth is read; the hooks register for 8 bits
+  if (block_width < 1 || block_height < 1 || block_width > 64 || block_height > 64) die("sao_band_ddistortion: bad arguments", KVZ_HIP_ERR_INVALID);
+  call_ctx &c = tls(); stage s(c);
+  size_t oo, orr;
+  sao_stage_pair(c, s, orig_data, rec_data, block_width * block_height, oo, orr);
+  size_t ob = s.take(32), in_end = s.off, od = s.take(16);
+  int32_t v[5] = { band_pos, sao_bands[0], sao_bands[1], sao_bands[2], sao_bands[3] };
+  std::memcpy(c.h + ob, v, sizeof(v));
+  s.h2d(0, in_end);
+  MUST(kvz_hip_sao_band_ddistortion_batch(c.d + oo, c.d + orr, block_width, block_height, 1, (const int32_t *)(c.d + ob),
+                                          (const int32_t *)(c.d + ob) + 1, (int32_t *)(c.d + od), c.st));
+  s.d2h(od, 16); s.sync();
+  return *(const int32_t *)(c.h + od);
+}
+
+void hip_sao_reconstruct_color(const void *encoder, const kvz_hip_pixel *rec_data, kvz_hip_pixel *new_rec_data, const void *sao_in,
+                               int stride, int new_stride, int block_width, int block_height, int color_i)
+{
+  (void)encoder;
+  if (block_width < 1 || block_height < 1) return;
+  const sao_info_mirror *sao = (const sao_info_mirror *)sao_in;
+  // like the reference, everything that is not band is filtered as edge (sao-generic.c:124-153); only the edge
+  // filter reads around the block, and only in the directions of its class (the caller guarantees no more)
+  const int band = sao->type == 1, cls = sao->eo_class & 3;
+  const int rx = (!band && cls != 1) ? 1 : 0, ry = (!band && cls != 0) ? 1 : 0;
+  const int ww = block_width + 2 * rx, wh = block_height + 2 * ry;
+  call_ctx &c = tls(); stage s(c);
+  size_t ow = s.take((size_t)ww * wh), ob = s.take(sizeof(kvz_hip_sao_block)), oi = s.take(sizeof(kvz_hip_sao_info)), in_end = s.off;
+  size_t oo = s.take((size_t)ww * wh);
+  pack_rows(c.h + ow, rec_data - (ptrdiff_t)ry * stride - rx, ww, wh, (size_t)stride);
+  kvz_hip_sao_block b = { rx, ry, block_width, block_height, 0 };
+  kvz_hip_sao_info info;
+  info.type = band ? 1 : 2; info.eo_class = sao->eo_class;
+  info.band_position[0] = sao->band_position[0]; info.band_position[1] = sao->band_position[1];
+  for (int k = 0; k < 10; ++k) info.offsets[k] = sao->offsets[k];
+  std::memcpy(c.h + ob, &b, sizeof(b));
+  std::memcpy(c.h + oi, &info, sizeof(info));
+  s.h2d(0, in_end);
+  MUST(kvz_hip_sao_reconstruct_color_batch(c.d + ow, (u32)ww, ww, wh, c.d + oo, (u32)ww, (const kvz_hip_sao_block *)(c.d + ob), 1,
+                                           (const kvz_hip_sao_info *)(c.d + oi), 1, color_i, c.st));
+  s.d2h(oo, (size_t)ww * wh); s.sync();
+  for (int y = 0; y < block_height; ++y)
+    std::memcpy(new_rec_data + (size_t)y * new_stride, c.h + oo + (size_t)(y + ry) * ww + rx, (size_t)block_width);
+}
+
 // inter_recon_bipred_func (strategies-picture.h:117-130, picture-generic.c:538-588): the lcu_t / hi_prec_buf_t
 // planes are reached through the accessor glue; luma w x h at (xpos, ypos) & 63 and chroma w/2 x h/2.
 void hip_inter_recon_bipred(const int hi_prec_luma_rec0, const int hi_prec_luma_rec1, const int hi_prec_chroma_rec0,
@@ -570,6 +665,18 @@ int kvz_strategy_register_intra_hip(void *opaque, uint8_t bitdepth)
   int ok = 1;
   ok &= reg(opaque, "angular_pred", (void *)&hip_angular_pred);
   ok &= reg(opaque, "intra_pred_planar", (void *)&hip_intra_pred_planar);
+  return ok;
+}
+
+// STRATEGIES_SAO_EXPORTS, strategies-sao.h:64-69
+int kvz_strategy_register_sao_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!hook_ready(bitdepth)) return 0;
+  int ok = 1;
+  ok &= reg(opaque, "sao_edge_ddistortion", (void *)&hip_sao_edge_ddistortion);
+  ok &= reg(opaque, "calc_sao_edge_dir", (void *)&hip_calc_sao_edge_dir);
+  ok &= reg(opaque, "sao_reconstruct_color", (void *)&hip_sao_reconstruct_color);
+  ok &= reg(opaque, "sao_band_ddistortion", (void *)&hip_sao_band_ddistortion);
   return ok;
 }
 

@@ -1163,3 +1163,97 @@ void orc_intra_rough_costs(const orc_intra_ref *ref, int log2_width, int filter_
     if (sad_out) sad_out[mode] = orc_sad_nxn(n, pred, orig);
   }
 }
+
+/* =====================================================================
+ * SAO group (sao-generic.c, sao.c)
+ * ===================================================================== */
+
+/* g_sao_edge_offsets (sao.h:58-63): neighbours a and b of c per edge class */
+static const int orc_sao_ofs[4][2][2] = { { { -1, 0 }, { 1, 0 } }, { { 0, -1 }, { 0, 1 } }, { { -1, -1 }, { 1, 1 } }, { { 1, -1 }, { -1, 1 } } };
+
+/* sao_calc_eo_cat (sao-generic.c:34-43): 2 + sign(c-a) + sign(c-b) mapped through {1,2,0,3,4} */
+static int orc_sao_cat(int a, int b, int c)
+{
+  static const int map[5] = { 1, 2, 0, 3, 4 };
+  const int sa = (c > a) - (c < a), sb = (c > b) - (c < b);
+  return map[2 + sa + sb];
+}
+
+static int orc_sao_cat_at(const orc_pixel *rec, int stride, int x, int y, int eo_class)
+{
+  const int a = rec[(y + orc_sao_ofs[eo_class][0][1]) * stride + x + orc_sao_ofs[eo_class][0][0]];
+  const int b = rec[(y + orc_sao_ofs[eo_class][1][1]) * stride + x + orc_sao_ofs[eo_class][1][0]];
+  return orc_sao_cat(a, b, rec[y * stride + x]);
+}
+
+int orc_sao_edge_ddistortion(const orc_pixel *orig, const orc_pixel *rec, int bw, int bh, int eo_class, const int offsets[5])
+{
+  int sum = 0;
+  for (int y = 1; y < bh - 1; ++y)
+    for (int x = 1; x < bw - 1; ++x) {
+      const int offset = offsets[orc_sao_cat_at(rec, bw, x, y, eo_class)];
+      if (offset != 0) {
+        const int diff = orig[y * bw + x] - rec[y * bw + x];
+        sum += (diff - offset) * (diff - offset) - diff * diff;
+      }
+    }
+  return sum;
+}
+
+void orc_calc_sao_edge_dir(const orc_pixel *orig, const orc_pixel *rec, int eo_class, int bw, int bh, int cat_sum_cnt[2][5])
+{
+  for (int y = 1; y < bh - 1; ++y)
+    for (int x = 1; x < bw - 1; ++x) {
+      const int cat = orc_sao_cat_at(rec, bw, x, y, eo_class);
+      cat_sum_cnt[0][cat] += orig[y * bw + x] - rec[y * bw + x];
+      cat_sum_cnt[1][cat] += 1;
+    }
+}
+
+void orc_sao_reconstruct_color(const orc_pixel *rec, orc_pixel *new_rec, const orc_sao_info *sao, int stride, int new_stride,
+                               int bw, int bh, int color)
+{
+  const int is_v = color == 2;
+  if (sao->type == 1) {
+    /* kvz_calc_sao_offset_array (sao.c:164-180) applied per pixel; bitdepth 8: band = value >> 3 */
+    const int bp = sao->band_position[is_v];
+    for (int y = 0; y < bh; ++y)
+      for (int x = 0; x < bw; ++x) {
+        const int val = rec[y * stride + x], band = val >> 3;
+        int v = val;
+        if (band >= bp && band < bp + 4) {
+          v = val + sao->offsets[band - bp + 1 + 5 * is_v];
+          v = v < 0 ? 0 : v > 255 ? 255 : v;
+        }
+        new_rec[y * new_stride + x] = (orc_pixel)v;
+      }
+  } else {
+    for (int y = 0; y < bh; ++y)
+      for (int x = 0; x < bw; ++x) {
+        int v = rec[y * stride + x] + sao->offsets[orc_sao_cat_at(rec, stride, x, y, sao->eo_class) + 5 * is_v];
+        new_rec[y * new_stride + x] = (orc_pixel)(v < 0 ? 0 : v > 255 ? 255 : v);
+      }
+  }
+}
+
+int orc_sao_band_ddistortion(const orc_pixel *orig, const orc_pixel *rec, int bw, int bh, int band_pos, const int sao_bands[4])
+{
+  int sum = 0;
+  for (int i = 0; i < bw * bh; ++i) {
+    const int band = (rec[i] >> 3) - band_pos;
+    const int offset = (band >= 0 && band < 4) ? sao_bands[band] : 0;
+    if (offset != 0) {
+      const int diff = orig[i] - rec[i];
+      sum += (diff - offset) * (diff - offset) - diff * diff;
+    }
+  }
+  return sum;
+}
+
+void orc_calc_sao_bands(const orc_pixel *orig, const orc_pixel *rec, int bw, int bh, int sao_bands[2][32])
+{
+  for (int i = 0; i < bw * bh; ++i) {
+    sao_bands[0][rec[i] >> 3] += orig[i] - rec[i];
+    sao_bands[1][rec[i] >> 3] += 1;
+  }
+}

@@ -210,6 +210,27 @@ typedef struct {
 void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
                    const orc_me_pu *pu, const orc_me_params *prm, orc_me_result *res);
 
+/* ---- SAO group: src/strategies/generic/sao-generic.c, src/sao.c.  SURVEY.md section 8(f) row 4.
+ * Blocks are contiguous (stride = block_width), as the callers in sao.c blit them. ---- */
+typedef struct {                 /* sao_info_t (sao.h:42-50) */
+  int32_t type;                  /* 0 none, 1 band, 2 edge */
+  int32_t eo_class;
+  int32_t ddistortion, merge_left_flag, merge_up_flag;
+  int32_t band_position[2];
+  int32_t offsets[10];
+} orc_sao_info;
+/* sao_edge_ddistortion_generic (sao-generic.c:46-77) */
+int orc_sao_edge_ddistortion(const orc_pixel *orig, const orc_pixel *rec, int bw, int bh, int eo_class, const int offsets[5]);
+/* calc_sao_edge_dir_generic (:80-109): accumulates into cat_sum_cnt */
+void orc_calc_sao_edge_dir(const orc_pixel *orig, const orc_pixel *rec, int eo_class, int bw, int bh, int cat_sum_cnt[2][5]);
+/* sao_reconstruct_color_generic (:112-154) incl. kvz_calc_sao_offset_array (sao.c:164-180); color 0 Y, 1 U, 2 V */
+void orc_sao_reconstruct_color(const orc_pixel *rec, orc_pixel *new_rec, const orc_sao_info *sao, int stride, int new_stride,
+                               int bw, int bh, int color);
+/* sao_band_ddistortion_generic (:157-183) */
+int orc_sao_band_ddistortion(const orc_pixel *orig, const orc_pixel *rec, int bw, int bh, int band_pos, const int sao_bands[4]);
+/* calc_sao_bands (sao.c:247-261): accumulates into sao_bands */
+void orc_calc_sao_bands(const orc_pixel *orig, const orc_pixel *rec, int bw, int bh, int sao_bands[2][32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,8 @@
 #include "search_inter.h"
 #include "intra.h"
 #include "strategies/strategies-intra.h"
+#include "sao.h"
+#include "strategies/strategies-sao.h"
 
 static strategy_list_t g_list;
 static int g_ready = 0;
@@ -39,6 +41,7 @@ int ref_init(void)
   if (!kvz_strategy_register_quant(&g_list, 8)) return 0;
   if (!kvz_strategy_register_ipol(&g_list, 8)) return 0;
   if (!kvz_strategy_register_intra(&g_list, 8)) return 0;
+  if (!kvz_strategy_register_sao(&g_list, 8)) return 0;
 
   memset(&g_ctrl, 0, sizeof(g_ctrl));
   memset(&g_state, 0, sizeof(g_state));
@@ -351,7 +354,8 @@ int ref_register_hip(const char *lib_path)
   int (*reg_quant)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_quant_hip");
   int (*reg_ipol)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_ipol_hip");
   int (*reg_intra)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_intra_hip");
-  if (!set_reg || !set_acc || !reg_pic || !reg_dct || !reg_quant || !reg_ipol || !reg_intra) return -1;
+  int (*reg_sao)(void *, uint8_t) = (int (*)(void *, uint8_t))dlsym(h, "kvz_strategy_register_sao_hip");
+  if (!set_reg || !set_acc || !reg_pic || !reg_dct || !reg_quant || !reg_ipol || !reg_intra || !reg_sao) return -1;
   static const kvz_hip_state_accessors acc = { acc_qp, acc_slice_is_intra, acc_signhide, acc_sl_enable,
                                                acc_quant_coeff, acc_dequant_coeff, acc_rdoq, acc_cu_is_intra,
                                                acc_hp_y, acc_hp_u, acc_hp_v, acc_rec_y, acc_rec_u, acc_rec_v };
@@ -359,7 +363,7 @@ int ref_register_hip(const char *lib_path)
   set_acc(&acc);
   unsigned before = g_list.count;
   if (!reg_pic(&g_list, 8) || !reg_dct(&g_list, 8) || !reg_quant(&g_list, 8) || !reg_ipol(&g_list, 8) ||
-      !reg_intra(&g_list, 8)) return -1;
+      !reg_intra(&g_list, 8) || !reg_sao(&g_list, 8)) return -1;
   return (int)(g_list.count - before);
 }
 
@@ -514,3 +518,38 @@ void ref_intra_build_reference(int log2_width, int color, int luma_x, int luma_y
   memcpy(refs_out + 65, refs.ref.top, 65);
   free(lcu);
 }
+
+/* ------------------------------------------------------------------------
+ * SAO group (strategies-sao.h:36-57).  sao14 = the 14 ints of the test-side
+ * sao record {type, eo_class, band_position[2], offsets[10]}.
+ * ------------------------------------------------------------------------ */
+
+int ref_sao_edge_ddistortion(const char *name, const kvz_pixel *orig, const kvz_pixel *rec, int bw, int bh, int eo_class, int *offsets)
+{
+  return ((sao_edge_ddistortion_func *)ref_strategy("sao_edge_ddistortion", name))(orig, rec, bw, bh, eo_class, offsets);
+}
+
+void ref_calc_sao_edge_dir(const char *name, const kvz_pixel *orig, const kvz_pixel *rec, int eo_class, int bw, int bh, int *cat_sum_cnt)
+{
+  ((calc_sao_edge_dir_func *)ref_strategy("calc_sao_edge_dir", name))(orig, rec, eo_class, bw, bh, (int (*)[NUM_SAO_EDGE_CATEGORIES])cat_sum_cnt);
+}
+
+int ref_sao_band_ddistortion(const char *name, const kvz_pixel *orig, const kvz_pixel *rec, int bw, int bh, int band_pos, int *bands)
+{
+  set_state(27, 0, 0, 0);
+  return ((sao_band_ddistortion_func *)ref_strategy("sao_band_ddistortion", name))(&g_state, orig, rec, bw, bh, band_pos, bands);
+}
+
+void ref_sao_reconstruct_color(const char *name, const kvz_pixel *rec, kvz_pixel *new_rec, const int32_t *sao14, int stride, int new_stride,
+                               int bw, int bh, int color)
+{
+  sao_info_t sao;
+  memset(&sao, 0, sizeof(sao));
+  sao.type = (sao_type)sao14[0];
+  sao.eo_class = (sao_eo_class)sao14[1];
+  sao.band_position[0] = sao14[2]; sao.band_position[1] = sao14[3];
+  for (int i = 0; i < 10; ++i) sao.offsets[i] = sao14[4 + i];
+  ((sao_reconstruct_color_func *)ref_strategy("sao_reconstruct_color", name))(&g_ctrl, rec, new_rec, &sao, stride, new_stride, bw, bh, (color_t)color);
+}
+
+int ref_sizeof_sao_info(void) { return (int)sizeof(sao_info_t); }

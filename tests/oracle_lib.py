@@ -379,3 +379,70 @@ def search_pu_batch(pic, ref, pus, params):
         L.orc_search_pu(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],
                         pus.ctypes.data + 64 * i, params.ctypes.data, out.ctypes.data + 32 * i)
     return out
+
+
+# ---- SAO group.  sao records are 14 int32: type, eo_class, band_position[2], offsets[10] ----
+def _sao17(sao14):
+    """-> orc_sao_info layout {type, eo_class, ddistortion, merge_left, merge_up, band_position[2], offsets[10]}"""
+    s = np.asarray(sao14, dtype=np.int32)
+    return np.ascontiguousarray(np.concatenate([s[:2], [0, 0, 0], s[2:]]).astype(np.int32))
+
+
+def _sao_sigs():
+    L = lib()
+    if getattr(L, "_sao_done", False):
+        return L
+    i32p = C.POINTER(C.c_int32)
+    L.orc_sao_edge_ddistortion.restype = C.c_int
+    L.orc_sao_edge_ddistortion.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, i32p]
+    L.orc_calc_sao_edge_dir.restype = None
+    L.orc_calc_sao_edge_dir.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, i32p]
+    L.orc_sao_band_ddistortion.restype = C.c_int
+    L.orc_sao_band_ddistortion.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, i32p]
+    L.orc_calc_sao_bands.restype = None
+    L.orc_calc_sao_bands.argtypes = [u8p, u8p, C.c_int, C.c_int, i32p]
+    L.orc_sao_reconstruct_color.restype = None
+    L.orc_sao_reconstruct_color.argtypes = [C.c_void_p, C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L._sao_done = True
+    return L
+
+
+def sao_edge_ddistortion(orig, rec, bw, bh, eo_class, offsets):
+    L = _sao_sigs()
+    orig, rec = _u8(orig), _u8(rec)
+    o = np.ascontiguousarray(offsets, dtype=np.int32)
+    return L.orc_sao_edge_ddistortion(_p(orig, u8p), _p(rec, u8p), bw, bh, eo_class, _p(o, C.POINTER(C.c_int32)))
+
+
+def calc_sao_edge_dir(orig, rec, eo_class, bw, bh):
+    L = _sao_sigs()
+    orig, rec = _u8(orig), _u8(rec)
+    out = np.zeros((2, 5), dtype=np.int32)
+    L.orc_calc_sao_edge_dir(_p(orig, u8p), _p(rec, u8p), eo_class, bw, bh, _p(out, C.POINTER(C.c_int32)))
+    return out
+
+
+def sao_band_ddistortion(orig, rec, bw, bh, band_pos, bands):
+    L = _sao_sigs()
+    orig, rec = _u8(orig), _u8(rec)
+    b = np.ascontiguousarray(bands, dtype=np.int32)
+    return L.orc_sao_band_ddistortion(_p(orig, u8p), _p(rec, u8p), bw, bh, band_pos, _p(b, C.POINTER(C.c_int32)))
+
+
+def calc_sao_bands(orig, rec, bw, bh):
+    L = _sao_sigs()
+    orig, rec = _u8(orig), _u8(rec)
+    out = np.zeros((2, 32), dtype=np.int32)
+    L.orc_calc_sao_bands(_p(orig, u8p), _p(rec, u8p), bw, bh, _p(out, C.POINTER(C.c_int32)))
+    return out
+
+
+def sao_reconstruct_color(plane, x, y, bw, bh, sao14, color):
+    """plane: 2-D uint8 with at least one pixel around the block; returns the bw x bh filtered block"""
+    L = _sao_sigs()
+    plane = _u8(plane)
+    stride = plane.shape[1]
+    out = np.zeros((bh, bw), dtype=np.uint8)
+    s = _sao17(sao14)
+    L.orc_sao_reconstruct_color(plane.ctypes.data + y * stride + x, out.ctypes.data, _p(s, C.POINTER(C.c_int32)), stride, bw, bw, bh, color)
+    return out

@@ -188,3 +188,33 @@ def me_random_pus(w, h, count, seed, hint=None,
             else:
                 pus[i]["mv_cand"][int(g.integers(0, 2))] = hint
     return pus
+
+
+# ---- SAO ----
+def sao_blocks(bw, bh, count, seed):
+    """(orig, rec) uint8 [count, bh*bw]: rec = orig + coding-like noise; flat, ramp and 0/255 extreme cases included"""
+    g = np.random.default_rng(seed)
+    orig = g.integers(0, 256, (count, bh * bw), dtype=np.uint8)
+    for i in range(count):
+        k = i % 4
+        if k == 1:
+            yy, xx = np.mgrid[0:bh, 0:bw]
+            orig[i] = np.clip(40 + 2 * xx + 3 * yy + g.integers(-3, 4, (bh, bw)), 0, 255).astype(np.uint8).ravel()
+        elif k == 2:
+            orig[i] = np.where(g.integers(0, 2, bh * bw) > 0, 255, 0)
+    rec = np.clip(orig.astype(np.int32) + g.integers(-9, 10, orig.shape), 0, 255).astype(np.uint8)
+    rec[::5] = orig[::5]
+    return orig, rec
+
+
+def sao_records(count, seed):
+    """int32 [count, 14]: type (1 band / 2 edge), eo_class, band_position[2], offsets[10]"""
+    g = np.random.default_rng(seed)
+    s = np.zeros((count, 14), dtype=np.int32)
+    s[:, 0] = 1 + (np.arange(count) % 2)
+    s[:, 1] = g.integers(0, 4, count)
+    s[:, 2:4] = g.integers(0, 29, (count, 2))
+    s[:, 4:] = g.integers(-7, 8, (count, 10))
+    s[:, 4] = 0
+    s[:, 9] = 0
+    return s

@@ -381,3 +381,55 @@ def search_pu_batch(pic, ref, pus, params):
         L.ref_me_search_pu(_p(pic, u8p), _p(ref, u8p), pic.shape[1], pic.shape[0],
                            pus.ctypes.data + 64 * i, params.ctypes.data, out.ctypes.data + 32 * i)
     return out
+
+
+# ---- SAO group ----
+def _sao_sigs():
+    L = lib()
+    if getattr(L, "_sao_done", False):
+        return L
+    i32p = C.POINTER(C.c_int32)
+    L.ref_sao_edge_ddistortion.restype = C.c_int
+    L.ref_sao_edge_ddistortion.argtypes = [S, u8p, u8p, C.c_int, C.c_int, C.c_int, i32p]
+    L.ref_calc_sao_edge_dir.restype = None
+    L.ref_calc_sao_edge_dir.argtypes = [S, u8p, u8p, C.c_int, C.c_int, C.c_int, i32p]
+    L.ref_sao_band_ddistortion.restype = C.c_int
+    L.ref_sao_band_ddistortion.argtypes = [S, u8p, u8p, C.c_int, C.c_int, C.c_int, i32p]
+    L.ref_sao_reconstruct_color.restype = None
+    L.ref_sao_reconstruct_color.argtypes = [S, C.c_void_p, C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ref_sizeof_sao_info.restype = C.c_int
+    L._sao_done = True
+    return L
+
+
+def sao_edge_ddistortion(orig, rec, bw, bh, eo_class, offsets, name="generic"):
+    L = _sao_sigs()
+    orig, rec = _aligned(_u8(orig)), _aligned(_u8(rec))
+    o = np.ascontiguousarray(offsets, dtype=np.int32)
+    return L.ref_sao_edge_ddistortion(name.encode(), _p(orig, u8p), _p(rec, u8p), bw, bh, eo_class, _p(o, C.POINTER(C.c_int32)))
+
+
+def calc_sao_edge_dir(orig, rec, eo_class, bw, bh, name="generic"):
+    L = _sao_sigs()
+    orig, rec = _aligned(_u8(orig)), _aligned(_u8(rec))
+    out = np.zeros((2, 5), dtype=np.int32)
+    L.ref_calc_sao_edge_dir(name.encode(), _p(orig, u8p), _p(rec, u8p), eo_class, bw, bh, _p(out, C.POINTER(C.c_int32)))
+    return out
+
+
+def sao_band_ddistortion(orig, rec, bw, bh, band_pos, bands, name="generic"):
+    L = _sao_sigs()
+    orig, rec = _aligned(_u8(orig)), _aligned(_u8(rec))
+    b = np.ascontiguousarray(bands, dtype=np.int32)
+    return L.ref_sao_band_ddistortion(name.encode(), _p(orig, u8p), _p(rec, u8p), bw, bh, band_pos, _p(b, C.POINTER(C.c_int32)))
+
+
+def sao_reconstruct_color(plane, x, y, bw, bh, sao14, color, name="generic"):
+    L = _sao_sigs()
+    plane = _u8(plane)
+    stride = plane.shape[1]
+    out = np.zeros((bh, bw), dtype=np.uint8)
+    s = np.ascontiguousarray(sao14, dtype=np.int32)
+    L.ref_sao_reconstruct_color(name.encode(), plane.ctypes.data + y * stride + x, out.ctypes.data, _p(s, C.POINTER(C.c_int32)),
+                                stride, bw, bw, bh, color)
+    return out

@@ -239,3 +239,26 @@ def test_intra_group_through_registry_and_kvz_intra_predict(hip):
                 for color, fb in ((0, 1), (0, 0), (1, 1)):
                     np.testing.assert_array_equal(R.intra_predict(r, log2_width, mode, color, fb, "hip"),
                                                   R.intra_predict(r, log2_width, mode, color, fb, "generic"))
+
+
+def test_sao_group_through_registry(hip):
+    """the four SAO strategies registered as "hip", called by name like tests/test_strategies.c does"""
+    from patterns import sao_blocks, sao_records
+    for t in ("sao_edge_ddistortion", "calc_sao_edge_dir", "sao_reconstruct_color", "sao_band_ddistortion"):
+        assert R.has_strategy(t, "hip")
+    g = rng(3)
+    for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):
+        orig, rec = sao_blocks(bw, bh, 4, bw + bh)
+        for i in range(4):
+            for eo in range(4):
+                np.testing.assert_array_equal(R.calc_sao_edge_dir(orig[i], rec[i], eo, bw, bh, "hip"), R.calc_sao_edge_dir(orig[i], rec[i], eo, bw, bh))
+                offs = g.integers(-7, 8, 5)
+                assert R.sao_edge_ddistortion(orig[i], rec[i], bw, bh, eo, offs, "hip") == R.sao_edge_ddistortion(orig[i], rec[i], bw, bh, eo, offs)
+            bands, bp = g.integers(-7, 8, 4), int(g.integers(0, 32))
+            assert R.sao_band_ddistortion(orig[i], rec[i], bw, bh, bp, bands, "hip") == R.sao_band_ddistortion(orig[i], rec[i], bw, bh, bp, bands)
+    plane = g.integers(0, 256, (80, 96), dtype=np.uint8)
+    for color in (0, 2):
+        for s in sao_records(8, 4 + color):
+            for (x, y, bw, bh) in ((1, 1, 64, 64), (5, 3, 32, 32), (1, 7, 61, 13)):
+                np.testing.assert_array_equal(R.sao_reconstruct_color(plane, x, y, bw, bh, s, color, "hip"),
+                                              R.sao_reconstruct_color(plane, x, y, bw, bh, s, color))

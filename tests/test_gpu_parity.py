@@ -546,3 +546,55 @@ def test_search_pu_frame_of_ctus_and_bad_descriptors(api):
     bad[0]["width"] = 12; bad[1]["x"] = 380; bad[2]["num_merge_cand"] = 9; bad[3]["height"] = 0
     r = api.search_pu_batch(pic, ref, bad, prm).view(ME_RESULT).reshape(-1)
     assert (r["cost"] == 0xFFFFFFFF).all() and (r["reserved"] == -1).all()
+
+
+# ---- SAO group ----
+from patterns import sao_blocks, sao_records  # noqa: E402
+
+
+@pytest.mark.parametrize("bw,bh", [(64, 64), (32, 32), (64, 56), (16, 24), (8, 8), (3, 3), (40, 2), (1, 1)])
+def test_sao_statistics_and_ddistortion(api, bw, bh):
+    orig, rec = sao_blocks(bw, bh, 21, 40 + bw + bh)
+    g = rng(5)
+    stats = api.sao_edge_stats_batch(orig, rec, bw, bh)
+    offs = g.integers(-7, 8, (len(orig), 4, 5)).astype(np.int32)
+    offs[::2, :, 0] = 0
+    dd = api.sao_edge_ddistortion_batch(orig, rec, bw, bh, offs)
+    bands = api.sao_band_stats_batch(orig, rec, bw, bh)
+    bp = g.integers(0, 32, len(orig)).astype(np.int32)
+    bo = g.integers(-7, 8, (len(orig), 4)).astype(np.int32)
+    bdd = api.sao_band_ddistortion_batch(orig, rec, bw, bh, bp, bo)
+    for i in range(len(orig)):
+        for eo in range(4):
+            np.testing.assert_array_equal(stats[i, eo], O.calc_sao_edge_dir(orig[i], rec[i], eo, bw, bh), err_msg="blk %d class %d" % (i, eo))
+            assert dd[i, eo] == O.sao_edge_ddistortion(orig[i], rec[i], bw, bh, eo, offs[i, eo])
+        np.testing.assert_array_equal(bands[i], O.calc_sao_bands(orig[i], rec[i], bw, bh))
+        assert bdd[i] == O.sao_band_ddistortion(orig[i], rec[i], bw, bh, int(bp[i]), bo[i])
+
+
+@pytest.mark.parametrize("color", [0, 1, 2])
+def test_sao_reconstruct_plane(api, color):
+    """an LCU grid over a plane, blocks trimmed at the border the way kvz_sao_reconstruct does; one sao record per LCU"""
+    g = rng(21 + color)
+    H, W, n = 136, 200, 64
+    plane = g.integers(0, 256, (H, W), dtype=np.uint8)
+    plane[20:60, 30:90] = np.where(g.integers(0, 2, (40, 60)) > 0, 252, 2)
+    blocks, k = [], 0
+    for y in range(0, H, n):
+        for x in range(0, W, n):
+            x0, y0, x1, y1 = max(x, 1), max(y, 1), min(x + n, W - 1), min(y + n, H - 1)
+            blocks.append((x0, y0, x1 - x0, y1 - y0, k))
+            k += 1
+    infos = sao_records(k, 9 + color)
+    infos[2, 0] = 0                                       # SAO_TYPE_NONE: plain copy
+    got = api.sao_reconstruct_color_batch(plane, blocks, infos, color)
+    want = plane.copy()
+    for (x, y, w, h, idx) in blocks:
+        if infos[idx, 0] != 0:
+            want[y:y + h, x:x + w] = O.sao_reconstruct_color(plane, x, y, w, h, infos[idx], color)
+    np.testing.assert_array_equal(got, want)
+    # a descriptor that would read outside the plane is skipped, not executed
+    edge = sao_records(2, 1)[1:2]
+    bad = [(0, 0, 8, 8, 0), (W - 8, H - 8, 8, 8, 0), (4, 4, 8, 8, 3)]
+    edge[0, 1] = 2
+    np.testing.assert_array_equal(api.sao_reconstruct_color_batch(plane, bad, edge, color), plane)

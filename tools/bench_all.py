@@ -140,6 +140,14 @@ def main():
                           picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), k,
                           me_prm.ctypes.data, res_d.data_ptr(), st)))
 
+    # SAO statistics: every 64x64 luma LCU of 16 frames (blocks contiguous, as sao.c blits them)
+    sao_cnt = min(nbytes // 4096, 510 * 16)
+    sao_stats = torch.empty(sao_cnt * 64, dtype=torch.int32, device=dev)
+    cases.append(("sao_edge_stats_64x64(4 classes)", sao_cnt, 2 * 4096 + 160,
+                  lambda: L.kvz_hip_sao_edge_stats_batch(a8.data_ptr(), b8.data_ptr(), 64, 64, sao_cnt, sao_stats.data_ptr(), st)))
+    cases.append(("sao_band_stats_64x64", sao_cnt, 2 * 4096 + 256,
+                  lambda: L.kvz_hip_sao_band_stats_batch(a8.data_ptr(), b8.data_ptr(), 64, 64, sao_cnt, sao_stats.data_ptr(), st)))
+
     # intra rough search: all 35 modes per PU; bytes per PU = refs 130 + orig N^2 + 35 costs
     for lg in (2, 3, 4, 5):
         n = 1 << lg
