@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ 
     for (int c = tid; c < CHUNKS; c += 256) {
       const int t = c / CPB, e = (c % CPB) * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (first + t < count) v = *(const uint4 *)(in + (first + t) * (size_t)(N * N) + e);
+      if (first + t < count) v = ld_stream_u4(in + (first + t) * (size_t)(N * N) + e);
       if (LD == N) *(uint4 *)(sa + t * N * LD + e) = v;
       else *(uint4 *)(sa + t * N * LD + (e / N) * LD + (e % N)) = v;
     }
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ 
         uint4 v;
         if (LD == N) v = *(const uint4 *)(sa + t * N * LD + e);
         else v = *(const uint4 *)(sa + t * N * LD + (e / N) * LD + (e % N));
-        *(uint4 *)(out + (first + t) * (size_t)(N * N) + e) = v;
+        st_stream_u4(out + (first + t) * (size_t)(N * N) + e, v);
       }
     }
     __syncthreads();

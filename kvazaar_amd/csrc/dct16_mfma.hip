@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 4) void dct16_mfma_kernel(const i16 *__restric
     const u32x2w sx = __builtin_amdgcn_permlane32_swap(p0x, p1x, false, false);
     const u32x2w sy = __builtin_amdgcn_permlane32_swap(p0y, p1y, false, false);
     const u32x4v ov = { sx.x, sy.x, sx.y, sy.y };
-    if (2 * p + 1 < count || chunk < 32) *((u32x4v *)(out + p * 512) + chunk) = ov;
+    if (2 * p + 1 < count || chunk < 32) __builtin_nontemporal_store(ov, (u32x4v *)(out + p * 512) + chunk);
 #pragma unroll
     for (int i = 0; i < DEPTH - 1; ++i) q[i] = q[i + 1];
   }

@@ -89,8 +89,8 @@ __device__ __forceinline__ void rows_to_chunks_store(u8 *tile, int lane, int r, 
   const u32x4v a = *(const u32x4v *)(tile + slot_of(lane) * 16);
   const u32x4v b = *(const u32x4v *)(tile + slot_of(64 + lane) * 16);
   wave_lds_fence();               // the tile is rewritten by the next block only after these reads
-  *((u32x4v *)blk + lane) = a;
-  *((u32x4v *)blk + 64 + lane) = b;
+  __builtin_nontemporal_store(a, (u32x4v *)blk + lane);
+  __builtin_nontemporal_store(b, (u32x4v *)blk + 64 + lane);
 }
 
 

@@ -94,14 +94,14 @@ __global__ __launch_bounds__(256) void quant_kernel(const i16 *__restrict__ coef
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   for (size_t i = tid * 8; i < total; i += nthreads * 8) {
     union { uint4 v; i16 s[8]; } in, out;
-    in.v = *(const uint4 *)(coef + i);
+    in.v = ld_stream_u4(coef + i);
     const int n0 = (int)(i % (size_t)block_elems);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int qc = k.qtable ? k.qtable[n0 + j] : k.flat_qc;
       out.s[j] = (i16)quant_one(in.s[j], qc, k);
     }
-    *(uint4 *)(q_coef + i) = out.v;
+    st_stream_u4(q_coef + i, out.v);
   }
 }
 
@@ -112,11 +112,11 @@ __global__ __launch_bounds__(256) void dequant_kernel(const i16 *__restrict__ q_
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   for (size_t i = tid * 8; i < total; i += nthreads * 8) {
     union { uint4 v; i16 s[8]; } in, out;
-    in.v = *(const uint4 *)(q_coef + i);
+    in.v = ld_stream_u4(q_coef + i);
     const int n0 = (int)(i % (size_t)block_elems);
 #pragma unroll
     for (int j = 0; j < 8; ++j) out.s[j] = (i16)dequant_one(in.s[j], n0 + j, k);
-    *(uint4 *)(coef + i) = out.v;
+    st_stream_u4(coef + i, out.v);
   }
 }
 

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void read_span_kernel(const uint4* __restrict_
   if (acc == 0x12345678u) out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
-template <int U>
+template <int U, bool NTL = false, bool NTS = false>
 __global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ a, uint4* __restrict__ o, size_t n16)
 {
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
@@ -67,7 +67,13 @@ __global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ a, 
   const size_t lane = threadIdx.x & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   for (size_t base = wave * 64 * U; base < n16; base += nwaves * 64 * U) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) { size_t i = base + u * 64 + lane; if (i < n16) o[i] = a[i]; }
+    for (int u = 0; u < U; ++u) {
+      size_t i = base + u * 64 + lane;
+      if (i < n16) {
+        uint4 v = NTL ? ntload(a + i) : a[i];
+        if (NTS) { u32x4 w = { v.x, v.y, v.z, v.w }; __builtin_nontemporal_store(w, (u32x4*)(o + i)); } else o[i] = v;
+      }
+    }
   }
 }
 
@@ -106,5 +112,9 @@ int main()
     float ms = timeit([&] { hipLaunchKernelGGL((copy_kernel<U>), dim3(g), dim3(256), 0, 0, a, o, n16); }); \
     printf("copy U=%d (read+write bytes)         %8d %10.1f\n", U, g, 2.0 * bytes / ms / 1e6); }
   RUN_COPY(1) RUN_COPY(4)
+#define RUN_COPY_NT(U, NTL, NTS) for (int g : grids) { \
+    float ms = timeit([&] { hipLaunchKernelGGL((copy_kernel<U, NTL, NTS>), dim3(g), dim3(256), 0, 0, a, o, n16); }); \
+    printf("copy U=%d ntl=%d nts=%d              %8d %10.1f\n", U, (int)NTL, (int)NTS, g, 2.0 * bytes / ms / 1e6); }
+  RUN_COPY_NT(4, true, false) RUN_COPY_NT(4, false, true) RUN_COPY_NT(4, true, true) RUN_COPY_NT(2, true, true)
   return 0;
 }
