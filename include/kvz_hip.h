@@ -60,7 +60,7 @@ enum {
 KVZ_HIP_API int kvz_hip_init(int device);
 KVZ_HIP_API void kvz_hip_shutdown(void);
 KVZ_HIP_API int kvz_hip_device_count(void);
-KVZ_HIP_API const char *kvz_hip_last_error(void);
+KVZ_HIP_API const char *kvz_hip_last_error(void);    /* text of the calling thread's last failure */
 KVZ_HIP_API const char *kvz_hip_device_name(void);
 
 /* Launch-geometry knobs for tuning runs (tools/tune.py); value < 0 restores the

@@ -15,7 +15,7 @@ static std::atomic<bool> g_ready{false};
 static int g_device = -1;
 static int g_num_cus = 256;
 static hipStream_t g_stream = nullptr;
-static char g_err[512] = "";
+static thread_local char g_err[512] = "";     // last error of the calling thread
 static char g_name[256] = "";
 
 struct tune_entry { const char *key; int value; };
@@ -29,6 +29,19 @@ int tuning(const char *key, int dflt)
 }
 
 bool ctx_ready() { return g_ready.load(std::memory_order_acquire); }
+
+// HIP's current device is a per-thread setting that starts at device 0: every thread that enters the library
+// (encoder worker threads call the strategy functions directly) is bound to the context's device once.
+bool ctx_enter()
+{
+  if (!ctx_ready()) return false;
+  static thread_local int bound = -1;
+  if (bound != g_device) {
+    if (hipSetDevice(g_device) != hipSuccess) return false;
+    bound = g_device;
+  }
+  return true;
+}
 hipStream_t ctx_stream(kvz_hip_stream s) { return s ? (hipStream_t)s : g_stream; }
 int num_cus() { return g_num_cus; }
 
@@ -110,7 +123,7 @@ const char *kvz_hip_device_name(void) { return g_name; }
 
 void *kvz_hip_malloc(size_t bytes)
 {
-  if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return nullptr;
+  if (!ctx_enter() && (kvz_hip_init(-1) != KVZ_HIP_OK || !ctx_enter())) return nullptr;
   void *p = nullptr;
   hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
   if (e != hipSuccess) { set_error("hipMalloc", e); return nullptr; }
@@ -139,7 +152,7 @@ int kvz_hip_memset(void *dst, int value, size_t bytes, kvz_hip_stream s)
 }
 kvz_hip_stream kvz_hip_stream_create(void)
 {
-  if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return nullptr;
+  if (!ctx_enter() && (kvz_hip_init(-1) != KVZ_HIP_OK || !ctx_enter())) return nullptr;
   hipStream_t st = nullptr;
   hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
   if (e != hipSuccess) { set_error("hipStreamCreate", e); return nullptr; }
@@ -155,7 +168,7 @@ int kvz_hip_stream_sync(kvz_hip_stream s)
 
 void *kvz_hip_event_create(void)
 {
-  if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return nullptr;
+  if (!ctx_enter() && (kvz_hip_init(-1) != KVZ_HIP_OK || !ctx_enter())) return nullptr;
   hipEvent_t ev = nullptr;
   if (hipEventCreate(&ev) != hipSuccess) return nullptr;
   return (void *)ev;

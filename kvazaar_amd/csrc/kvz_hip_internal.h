@@ -17,6 +17,7 @@ namespace kvzhip {
 
 // ---- context (api.hip) ----
 bool ctx_ready();
+bool ctx_enter();                               // ready, and the calling thread bound to the context's device
 hipStream_t ctx_stream(kvz_hip_stream s);      // NULL -> library default stream
 void set_error(const char *what, hipError_t e);
 void set_error_msg(const char *what);
@@ -25,8 +26,8 @@ int tuning(const char *key, int dflt);     // kvz_hip_set_tuning override or dfl
 
 #define KVZ_CHECK_CTX()                         \
   do {                                          \
-    if (!kvzhip::ctx_ready()) {                 \
-      if (kvz_hip_init(-1) != KVZ_HIP_OK) return KVZ_HIP_ERR_NO_DEVICE; \
+    if (!kvzhip::ctx_enter()) {                 \
+      if (kvz_hip_init(-1) != KVZ_HIP_OK || !kvzhip::ctx_enter()) return KVZ_HIP_ERR_NO_DEVICE; \
     }                                           \
   } while (0)
 

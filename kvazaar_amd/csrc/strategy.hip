@@ -44,7 +44,7 @@ struct call_ctx {
   bool ok = false;
   call_ctx()
   {
-    if (!ctx_ready() && kvz_hip_init(-1) != KVZ_HIP_OK) return;
+    if (!ctx_enter() && (kvz_hip_init(-1) != KVZ_HIP_OK || !ctx_enter())) return;   // also binds this thread to the device
     cap = 1u << 20;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return;
     if (hipHostMalloc((void **)&h, cap, hipHostMallocDefault) != hipSuccess) return;
