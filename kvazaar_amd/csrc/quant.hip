@@ -387,6 +387,9 @@ namespace kvzhip {
 int launch_quantize_residual32_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
                                     int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
                                     int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
+int launch_quantize_residual16_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
+                                    int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
+                                    int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
 }
 
 extern "C" {
@@ -451,6 +454,9 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
   if (width == 32 && !use_trskip && !k.signhide)
     return launch_quantize_residual32_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
+                                           k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
+  if (width == 16 && !use_trskip && !k.signhide && tuning("qr16_use_mfma", 1))
+    return launch_quantize_residual16_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
                                            k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
 #define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, 16)), dim3(256), 0, st, \
                                           ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, scan_order, k, ssd_out, abs_sum_out)

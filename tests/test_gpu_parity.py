@@ -285,6 +285,29 @@ def test_quantize_residual(api, w):
     np.testing.assert_array_equal(got[0], want[0])
 
 
+def test_quantize_residual_16_both_kernels(api):
+    """16x16 TUs run on the matrix cores by default (two TUs per MFMA tile); the VALU kernel stays selectable.  Odd and
+    even counts (the pair tail), TUs with and without coefficients inside one pair."""
+    from kvazaar_amd import _lib
+    L = _lib.init(0)
+    g = rng(160)
+    for count in (1, 2, 7, 64):
+        ref_in = g.integers(0, 256, (count, 256), dtype=np.uint8)
+        pred = np.clip(ref_in.astype(np.int32) + g.integers(-50, 51, ref_in.shape), 0, 255).astype(np.uint8)
+        pred[::2] = ref_in[::2]                              # every other TU quantises to nothing
+        for qp in (10, 27, 44):
+            want = O.quantize_residual_batch(ref_in, pred, 16, qp, 0, 0, 0)
+            for use in (1, 0):
+                _lib.check(L.kvz_hip_set_tuning(b"qr16_use_mfma", use), "tuning")
+                got = api.quantize_residual_batch(ref_in, pred, 16, qp, 0, 0, 0, with_costs=True)
+                for a, b, nm in zip(got[:3], want, ("rec", "coeff", "has")):
+                    np.testing.assert_array_equal(a, b, err_msg="%s count=%d qp=%d mfma=%d" % (nm, count, qp, use))
+                for i in range(count):
+                    assert got[3][i] == O.pixels_calc_ssd(ref_in[i], 0, want[0][i], 0, 16, 16, 16)
+                    assert got[4][i] == O.coeff_abs_sum(want[1][i])
+    L.kvz_hip_set_tuning(b"qr16_use_mfma", -1)
+
+
 @pytest.mark.parametrize("w", [4, 8, 16, 32])
 def test_quantize_residual_fused_rd0_costs(api, w):
     """kvz_hip_quantize_residual_cost_batch: the SSD(ref, rec) and coeff_abs_sum the rd=0 TU cost is made of
