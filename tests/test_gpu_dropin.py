@@ -199,6 +199,12 @@ ENCODER_CONFIGS = [
     (128, 128, 3, "preset=veryfast,rdoq=0,qp=37,threads=4,owf=2,wpp=1"),
     (256, 128, 6, "preset=slow,rdoq=0,signhide=1,qp=27,threads=4"),
     (192, 128, 4, "preset=medium,rdoq=0,me=tz,subme=4,smp=1,amp=1,bipred=1,gop=8,qp=24,threads=2"),
+    (128, 128, 4, "preset=medium,rdoq=0,rd=2,qp=30,threads=2"),                       # full RD: SSD / coefficient costs everywhere
+    (128, 64, 4, "preset=fast,rdoq=0,transform-skip=1,rd=1,qp=26,threads=0"),          # 4x4 transform skip + its SAD test
+    (128, 128, 3, "preset=medium,rdoq=0,scaling-list=default,qp=28,threads=2"),        # scaling-list tables through the accessors
+    (128, 64, 4, "preset=fast,rdoq=0,me=dia,full-intra-search=1,mv-rdo=1,qp=35,threads=0"),
+    (64, 64, 3, "preset=medium,rdoq=0,lossless=1,threads=0"),
+    (192, 128, 3, "preset=medium,rdoq=0,tiles=2x2,qp=31,threads=3"),
 ]
 
 
