@@ -220,6 +220,13 @@ KVZ_HIP_API int kvz_hip_quantize_residual_batch(const kvz_hip_quant_params *p, i
                                                 const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in,
                                                 kvz_hip_pixel *rec_out, kvz_hip_coeff *coeff_out, int32_t *has_coeffs,
                                                 size_t count, kvz_hip_stream s);
+/* The two elementwise ends of kvz_quantize_residual as separate entries (quant-generic.c:196-204 and :253-259), for
+ * callers that run something of their own between transform and dequantisation (the drop-in does, when RDOQ is on):
+ * residual[i] = ref[i] - pred[i];  rec[i] = clip((int16)(residual[i] + pred[i])).  n = number of pixels. */
+KVZ_HIP_API int kvz_hip_residual_batch(const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in, kvz_hip_coeff *residual,
+                                       size_t n, kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_reconstruct_batch(const kvz_hip_coeff *residual, const kvz_hip_pixel *pred_in, kvz_hip_pixel *rec_out,
+                                          size_t n, kvz_hip_stream s);
 /* The same fused kernel with the two numbers the rd=0 TU cost is made of
  * (kvz_cu_rd_cost_luma / _chroma, search.c:236-306, :309-383): ssd_out[i] =
  * kvz_pixels_calc_ssd(ref_i, rec_i, width) (picture-generic.c:521-536) and
@@ -434,6 +441,15 @@ typedef struct {
   kvz_hip_pixel *(*lcu_rec_y)(void *lcu);
   kvz_hip_pixel *(*lcu_rec_u)(void *lcu);
   kvz_hip_pixel *(*lcu_rec_v)(void *lcu);
+  /* optional (may be NULL): what quantize_residual needs when cfg.rdoq_enable (quant-generic.c:214-221).  kvz_rdoq
+   * (rdo.c:548) is the encoder's CABAC-context dependent quantiser -- control plane, not part of this library; like
+   * the avx2 strategy, the hip quantize_residual calls the host's own function between the transform and the
+   * dequantisation.  Without these four the function refuses to run with RDOQ enabled. */
+  int (*rdoq_skip)(const void *state);                 /* cfg.rdoq_skip */
+  int (*cu_rdoq_tr_depth)(const void *cur_cu);         /* tr_depth - depth + (part_size == SIZE_NxN) */
+  int (*cu_type)(const void *cur_cu);                  /* cur_cu->type, handed to kvz_rdoq as block_type */
+  void (*rdoq)(void *state, kvz_hip_coeff *coef, kvz_hip_coeff *dest_coeff, int32_t width, int32_t height,
+               int8_t type, int8_t scan_mode, int8_t block_type, int8_t tr_depth);
 } kvz_hip_state_accessors;
 KVZ_HIP_API void kvz_hip_set_state_accessors(const kvz_hip_state_accessors *acc);
 

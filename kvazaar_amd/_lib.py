@@ -75,6 +75,8 @@ SIGNATURES = {
     "kvz_hip_dequant_batch": (_I, [C.POINTER(QuantParams), _P, _P, _I, _I, _SZ, _P]),
     "kvz_hip_coeff_abs_sum_batch": (_I, [_P, _SZ, _SZ, _P, _P]),
     "kvz_hip_quantize_residual_batch": (_I, [C.POINTER(QuantParams), _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _SZ, _P]),
+    "kvz_hip_residual_batch": (_I, [_P, _P, _P, _SZ, _P]),
+    "kvz_hip_reconstruct_batch": (_I, [_P, _P, _P, _SZ, _P]),
     "kvz_hip_quantize_residual_cost_batch": (_I, [C.POINTER(QuantParams), _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "kvz_hip_sample_luma_batch": (_I, [_P, _U, _I, _I, _P, _P, _SZ, _I, _P, _P]),
     "kvz_hip_sample_chroma_batch": (_I, [_P, _U, _I, _I, _P, _P, _SZ, _I, _P, _P]),

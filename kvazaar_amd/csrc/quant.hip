@@ -383,6 +383,19 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
   }
 }
 
+// quant-generic.c:196-204 / :253-259 as stand-alone elementwise kernels (the RDOQ route of the drop-in)
+__global__ __launch_bounds__(256) void residual_kernel(const u8 *__restrict__ ref_in, const u8 *__restrict__ pred_in, i16 *__restrict__ res, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) res[i] = (i16)((int)ref_in[i] - (int)pred_in[i]);
+}
+__global__ __launch_bounds__(256) void reconstruct_kernel(const i16 *__restrict__ res, const u8 *pred_in, u8 *rec_out, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const i16 val = (i16)((int)res[i] + (int)pred_in[i]);
+    rec_out[i] = (u8)(val < 0 ? 0 : (val > 255 ? 255 : val));
+  }
+}
+
 namespace kvzhip {
 int launch_quantize_residual32_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
                                     int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
@@ -469,6 +482,26 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   }
 #undef KVZ_QR
   KVZ_CHECK_LAUNCH("quantize_residual_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_residual_batch(const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pred_in, kvz_hip_coeff *residual, size_t n, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (n == 0) return KVZ_HIP_OK;
+  if (!ref_in || !pred_in || !residual) return KVZ_HIP_ERR_INVALID;
+  hipLaunchKernelGGL(residual_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, ctx_stream(s), ref_in, pred_in, residual, n);
+  KVZ_CHECK_LAUNCH("residual_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_reconstruct_batch(const kvz_hip_coeff *residual, const kvz_hip_pixel *pred_in, kvz_hip_pixel *rec_out, size_t n, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (n == 0) return KVZ_HIP_OK;
+  if (!residual || !pred_in || !rec_out) return KVZ_HIP_ERR_INVALID;
+  hipLaunchKernelGGL(reconstruct_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, ctx_stream(s), residual, pred_in, rec_out, n);
+  KVZ_CHECK_LAUNCH("reconstruct_kernel");
   return KVZ_HIP_OK;
 }
 

@@ -299,12 +299,43 @@ unsigned hip_quantize_residual(void *state, const void *cur_cu, const int width,
   call_ctx &c = tls(); stage s(c);
   const int w = width;
   const int intra = g_acc.cu_is_intra(cur_cu);
-  if (g_acc.rdoq_enable && g_acc.rdoq_enable(state)) {
-    std::fprintf(stderr, "kvzhip: quantize_residual with rdoq enabled is not offloaded; select the generic strategy "
-                         "(KVAZAAR_OVERRIDE_quantize_residual=generic) or run with --no-rdoq\n");
-    std::abort();
-  }
   const int tq = color == 0 ? 0 : 2, tdq = color == 0 ? 0 : (color == 1 ? 2 : 3);
+  if (g_acc.rdoq_enable && g_acc.rdoq_enable(state) && (w > 4 || !(g_acc.rdoq_skip && g_acc.rdoq_skip(state)))) {
+    // quant-generic.c:214-221: the quantiser is the host's kvz_rdoq (CABAC-context dependent control plane, called
+    // by every strategy's quantize_residual); residual, transforms, dequantisation and reconstruction stay on the GPU
+    if (!g_acc.rdoq || !g_acc.rdoq_skip || !g_acc.cu_rdoq_tr_depth || !g_acc.cu_type || use_trskip) {
+      std::fprintf(stderr, "kvzhip: quantize_residual with rdoq enabled needs the rdoq accessors of kvz_hip_state_accessors "
+                           "(INTEGRATION.md) and no transform skip; select another strategy with KVAZAAR_OVERRIDE_quantize_residual\n");
+      std::abort();
+    }
+    const size_t n = (size_t)w * w;
+    const bool dst = (w == 4 && color == 0 && intra);               // strategies-dct.c:66-85
+    kvz_hip_quant_params p = flatten_state(state, w, tq, tdq, intra, s, c);
+    size_t orf = s.take(n), opr = s.take(n), in_end = s.off;
+    size_t ors = s.take(n * 2), oco = s.take(n * 2);
+    pack_rows(c.h + orf, ref_in, w, w, (size_t)in_stride); pack_rows(c.h + opr, pred_in, w, w, (size_t)in_stride);
+    s.h2d(0, in_end);
+    MUST(kvz_hip_residual_batch(c.d + orf, c.d + opr, (kvz_hip_coeff *)(c.d + ors), n, c.st));
+    MUST(kvz_hip_transform_batch(dst ? KVZ_HIP_DST : KVZ_HIP_DCT, w, (const kvz_hip_coeff *)(c.d + ors), (kvz_hip_coeff *)(c.d + oco), 1, c.st));
+    s.d2h(oco, n * 2); s.sync();
+    g_acc.rdoq(state, (kvz_hip_coeff *)(c.h + oco), coeff_out, w, w, (int8_t)tq, (int8_t)scan_order, (int8_t)g_acc.cu_type(cur_cu),
+               (int8_t)g_acc.cu_rdoq_tr_depth(cur_cu));
+    int has = 0;
+    for (size_t i = 0; i < n; ++i) has |= coeff_out[i] != 0;
+    if (has) {
+      size_t oq = s.take(n * 2), q_end = s.off, odq = s.take(n * 2), ore = s.take(n);
+      std::memcpy(c.h + oq, coeff_out, n * 2);
+      s.h2d(oq, q_end - oq);
+      MUST(kvz_hip_dequant_batch(&p, (const kvz_hip_coeff *)(c.d + oq), (kvz_hip_coeff *)(c.d + odq), w, tdq, 1, c.st));
+      MUST(kvz_hip_transform_batch(dst ? KVZ_HIP_IDST : KVZ_HIP_IDCT, w, (const kvz_hip_coeff *)(c.d + odq), (kvz_hip_coeff *)(c.d + ors), 1, c.st));
+      MUST(kvz_hip_reconstruct_batch((const kvz_hip_coeff *)(c.d + ors), c.d + opr, c.d + ore, n, c.st));
+      s.d2h(ore, n); s.sync();
+      for (int y = 0; y < w; ++y) std::memcpy(rec_out + (size_t)y * out_stride, c.h + ore + (size_t)y * w, (size_t)w);
+    } else if (rec_out != pred_in) {
+      for (int y = 0; y < w; ++y) std::memcpy(rec_out + (size_t)y * out_stride, pred_in + (size_t)y * in_stride, (size_t)w);
+    }
+    return (unsigned)has;
+  }
   kvz_hip_quant_params p = flatten_state(state, w, tq, tdq, intra, s, c);
   size_t orf = s.take((size_t)w * w), opr = s.take((size_t)w * w), in_end = s.off;
   size_t ore = s.take((size_t)w * w), oco = s.take((size_t)w * w * 2), oha = s.take(4), out_end = s.off;

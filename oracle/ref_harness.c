@@ -18,6 +18,7 @@
 #include "scalinglist.h"
 #include "cu.h"
 #include "search_inter.h"
+#include "rdo.h"
 #include "intra.h"
 #include "strategies/strategies-intra.h"
 #include "sao.h"
@@ -335,6 +336,17 @@ static const int32_t *acc_dequant_coeff(const void *s, int log2_tr, int list, in
 { return ((const encoder_state_t *)s)->encoder_control->scaling_list.de_quant_coeff[log2_tr - 2][list][rem]; }
 static int acc_rdoq(const void *s) { return ((const encoder_state_t *)s)->encoder_control->cfg.rdoq_enable; }
 static int acc_cu_is_intra(const void *cu) { return ((const cu_info_t *)cu)->type == CU_INTRA; }
+static int acc_rdoq_skip(const void *s) { return ((const encoder_state_t *)s)->encoder_control->cfg.rdoq_skip; }
+static int acc_cu_rdoq_tr_depth(const void *cu)
+{
+  const cu_info_t *c = (const cu_info_t *)cu;
+  return c->tr_depth - c->depth + (c->part_size == SIZE_NxN ? 1 : 0);
+}
+static int acc_cu_type(const void *cu) { return ((const cu_info_t *)cu)->type; }
+static void acc_rdoq_fn(void *state, coeff_t *coef, coeff_t *dest, int32_t w, int32_t h, int8_t type, int8_t scan, int8_t block_type, int8_t tr_depth)
+{
+  kvz_rdoq((encoder_state_t *)state, coef, dest, w, h, type, scan, block_type, tr_depth);
+}
 static const int16_t *acc_hp_y(const void *b) { return ((const hi_prec_buf_t *)b)->y; }
 static const int16_t *acc_hp_u(const void *b) { return ((const hi_prec_buf_t *)b)->u; }
 static const int16_t *acc_hp_v(const void *b) { return ((const hi_prec_buf_t *)b)->v; }
@@ -358,7 +370,8 @@ int ref_register_hip(const char *lib_path)
   if (!set_reg || !set_acc || !reg_pic || !reg_dct || !reg_quant || !reg_ipol || !reg_intra || !reg_sao) return -1;
   static const kvz_hip_state_accessors acc = { acc_qp, acc_slice_is_intra, acc_signhide, acc_sl_enable,
                                                acc_quant_coeff, acc_dequant_coeff, acc_rdoq, acc_cu_is_intra,
-                                               acc_hp_y, acc_hp_u, acc_hp_v, acc_rec_y, acc_rec_u, acc_rec_v };
+                                               acc_hp_y, acc_hp_u, acc_hp_v, acc_rec_y, acc_rec_u, acc_rec_v,
+                                               acc_rdoq_skip, acc_cu_rdoq_tr_depth, acc_cu_type, acc_rdoq_fn };
   set_reg(kvz_strategyselector_register);
   set_acc(&acc);
   unsigned before = g_list.count;

@@ -192,7 +192,11 @@ def test_inter_recon_bipred(hip):
 
 
 ENCODER_CONFIGS = [
-    # (w, h, frames, options): RDOQ must be off (the hip quantize_residual does not implement it)
+    # (w, h, frames, options).  With RDOQ on (presets medium and slower) the hip quantize_residual runs residual,
+    # transforms, dequantisation and reconstruction on the GPU around the encoder's own kvz_rdoq, like the avx2 strategy.
+    (128, 128, 4, "preset=medium,qp=30,threads=2"),
+    (128, 64, 4, "preset=slow,qp=24,threads=0"),
+    (128, 64, 3, "preset=medium,rdoq-skip=1,qp=36,signhide=1,threads=0"),
     (128, 64, 4, "preset=ultrafast,qp=27,threads=0"),
     (128, 64, 4, "preset=medium,rdoq=0,qp=32,threads=0"),
     (64, 64, 5, "preset=fast,rdoq=0,signhide=1,bipred=1,gop=8,qp=22,threads=0"),
