@@ -15,7 +15,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_lib as R  # noqa: E402
-from patterns import dct_test_input, rng  # noqa: E402
+from patterns import (dct_test_input, intra_ref_cases, me_frames, me_params, me_random_pus, rng, sao_blocks,  # noqa: E402
+                      sao_records)
 
 OUT = os.path.join(ROOT, "tests", "golden")
 SEED = 20261004
@@ -123,10 +124,71 @@ def ipol():
     np.savez_compressed(os.path.join(OUT, "ipol.npz"), **d)
 
 
+def intra():
+    """kvz_intra_predict (with the generic angular / planar strategies) for every mode, and the rough-search costs
+    satd_NxN / sad_NxN of those predictions (search_intra.c:99-172)"""
+    g = rng(SEED + 4)
+    d = {}
+    for lg in (2, 3, 4, 5):
+        n = 1 << lg
+        refs = intra_ref_cases(lg, 10, SEED + 40 + lg)
+        orig = g.integers(0, 256, (len(refs), n * n), dtype=np.uint8)
+        d["refs%d" % lg], d["orig%d" % lg] = refs, orig
+        for fb in (0, 1):
+            pred = np.array([[R.intra_predict(r, lg, m, 0, fb) for m in range(35)] for r in refs], dtype=np.uint8)
+            d["pred%d_fb%d" % (lg, fb)] = pred
+            satd = np.array([[R.cost_nxn_batch("satd", n, pred[i, m][None], orig[i][None])[0] for m in range(35)]
+                             for i in range(len(refs))], dtype=np.uint32)
+            sad = np.array([[R.cost_nxn_batch("sad", n, pred[i, m][None], orig[i][None])[0] for m in range(35)]
+                            for i in range(len(refs))], dtype=np.uint32)
+            d["satd%d_fb%d" % (lg, fb)], d["sad%d_fb%d" % (lg, fb)] = satd, sad
+        d["pred%d_chroma" % lg] = np.array([[R.intra_predict(r, lg, m, 1, 1) for m in range(35)] for r in refs], dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "intra.npz"), **d)
+
+
+def sao():
+    g = rng(SEED + 5)
+    d = {}
+    for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):
+        orig, rec = sao_blocks(bw, bh, 6, SEED + bw + bh)
+        key = "%dx%d" % (bw, bh)
+        d["orig" + key], d["rec" + key] = orig, rec
+        d["edge" + key] = np.array([[R.calc_sao_edge_dir(orig[i], rec[i], eo, bw, bh) for eo in range(4)] for i in range(6)], dtype=np.int32)
+        offs = g.integers(-7, 8, (6, 4, 5)).astype(np.int32)
+        offs[:, :, 0] = 0
+        d["offs" + key] = offs
+        d["edge_dd" + key] = np.array([[R.sao_edge_ddistortion(orig[i], rec[i], bw, bh, eo, offs[i, eo]) for eo in range(4)] for i in range(6)], dtype=np.int32)
+        bp, bo = g.integers(0, 32, 6).astype(np.int32), g.integers(-7, 8, (6, 4)).astype(np.int32)
+        d["band_pos" + key], d["band_offs" + key] = bp, bo
+        d["band_dd" + key] = np.array([R.sao_band_ddistortion(orig[i], rec[i], bw, bh, int(bp[i]), bo[i]) for i in range(6)], dtype=np.int32)
+    plane = g.integers(0, 256, (72, 88), dtype=np.uint8)
+    recs = sao_records(8, SEED + 6)
+    blocks = [(1, 1, 64, 64), (5, 3, 32, 32), (1, 7, 61, 13)]
+    d["plane"], d["records"], d["blocks"] = plane, recs, np.array(blocks, dtype=np.int32)
+    for color in (0, 2):
+        d["recon_c%d" % color] = np.concatenate([R.sao_reconstruct_color(plane, x, y, w, h, s, color).ravel()
+                                                 for s in recs for (x, y, w, h) in blocks])
+    np.savez_compressed(os.path.join(OUT, "sao.npz"), **d)
+
+
+def me():
+    """the reference's static hexagon_search + search_frac (oracle/ref_me_harness.c) for three encoder settings"""
+    d = {}
+    cfgs = [dict(), dict(early_termination=2, fme_level=2, lambda_cost=35), dict(wpp_owf=1, ref_delay_px=10, lambda_cost=9, early_termination=0)]
+    pic, ref = me_frames(192, 128, SEED + 7, (5, -3))
+    pus = me_random_pus(192, 128, 48, SEED + 8, hint=(-18, 12))
+    d["pic"], d["ref"], d["pus"] = pic, ref, pus.view(np.uint8).reshape(len(pus), 64)
+    for i, c in enumerate(cfgs):
+        prm = me_params(**c)
+        d["params%d" % i] = prm.view(np.int32).reshape(8)
+        d["results%d" % i] = R.search_pu_batch(pic, ref, pus, prm).view(np.int32).reshape(len(pus), 8)
+    np.savez_compressed(os.path.join(OUT, "me.npz"), **d)
+
+
 if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    picture(); dct(); quant(); ipol()
+    picture(); dct(); quant(); ipol(); intra(); sao(); me()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -74,3 +74,43 @@ def test_golden_ipol(api):
     costs, best = api.search_frac_batch(pic, frame, pairs)
     np.testing.assert_array_equal(costs, d["sf_costs"])
     np.testing.assert_array_equal(best, d["sf_best"])
+
+
+# ---- fixtures of the rows added after the core path: intra, SAO, motion search ----
+def test_golden_intra(api):
+    d = gold("intra.npz")
+    for lg in (2, 3, 4, 5):
+        refs, orig = d["refs%d" % lg], d["orig%d" % lg]
+        for fb in (0, 1):
+            np.testing.assert_array_equal(api.intra_predict_batch(refs, lg, list(range(35)), 1 | (fb << 1)), d["pred%d_fb%d" % (lg, fb)])
+            satd, sad = api.intra_rough_batch(refs, lg, orig, 1 | (fb << 1), with_sad=True)
+            np.testing.assert_array_equal(satd, d["satd%d_fb%d" % (lg, fb)])
+            np.testing.assert_array_equal(sad, d["sad%d_fb%d" % (lg, fb)])
+        np.testing.assert_array_equal(api.intra_predict_batch(refs, lg, list(range(35)), 2), d["pred%d_chroma" % lg])
+
+
+def test_golden_sao(api):
+    d = gold("sao.npz")
+    for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):
+        key = "%dx%d" % (bw, bh)
+        orig, rec = d["orig" + key], d["rec" + key]
+        np.testing.assert_array_equal(api.sao_edge_stats_batch(orig, rec, bw, bh), d["edge" + key])
+        np.testing.assert_array_equal(api.sao_edge_ddistortion_batch(orig, rec, bw, bh, d["offs" + key]), d["edge_dd" + key])
+        np.testing.assert_array_equal(api.sao_band_ddistortion_batch(orig, rec, bw, bh, d["band_pos" + key], d["band_offs" + key]), d["band_dd" + key])
+    plane, recs, blocks = d["plane"], d["records"], d["blocks"]
+    for color in (0, 2):
+        want = d["recon_c%d" % color]
+        pos = 0
+        for k, s in enumerate(recs):
+            for (x, y, w, h) in blocks:
+                out = api.sao_reconstruct_color_batch(plane, [(int(x), int(y), int(w), int(h), 0)], s[None], color)
+                np.testing.assert_array_equal(out[y:y + h, x:x + w].ravel(), want[pos:pos + w * h], err_msg="record %d" % k)
+                pos += w * h
+
+
+def test_golden_motion_search(api):
+    d = gold("me.npz")
+    for i in range(3):
+        got = api.search_pu_batch(d["pic"], d["ref"], np.ascontiguousarray(d["pus"]).view(np.dtype(("V", 64))).reshape(-1),
+                                  np.ascontiguousarray(d["params%d" % i]))
+        np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])

@@ -132,3 +132,43 @@ def test_golden_ipol():
     for i, (ox, oy) in enumerate(((0, 0), (-1, 1), (1, -1))):
         got = O.filter_frac_steps(frame, 20, 18, 16, 16, (ox, oy))[:, :, :16, :16]
         np.testing.assert_array_equal(got, d["filter_steps"][i])
+
+
+# ---- fixtures of the rows added after the core path: intra, SAO, motion search ----
+def test_golden_intra():
+    d = gold("intra.npz")
+    for lg in (2, 3, 4, 5):
+        refs, orig = d["refs%d" % lg], d["orig%d" % lg]
+        for fb in (0, 1):
+            np.testing.assert_array_equal(O.intra_predict_batch(refs, lg, list(range(35)), 1, fb), d["pred%d_fb%d" % (lg, fb)])
+            satd, sad = O.intra_rough_costs_batch(refs, lg, orig, fb)
+            np.testing.assert_array_equal(satd, d["satd%d_fb%d" % (lg, fb)])
+            np.testing.assert_array_equal(sad, d["sad%d_fb%d" % (lg, fb)])
+        np.testing.assert_array_equal(O.intra_predict_batch(refs, lg, list(range(35)), 0, 1), d["pred%d_chroma" % lg])
+
+
+def test_golden_sao():
+    d = gold("sao.npz")
+    for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):
+        key = "%dx%d" % (bw, bh)
+        orig, rec = d["orig" + key], d["rec" + key]
+        for i in range(len(orig)):
+            for eo in range(4):
+                np.testing.assert_array_equal(O.calc_sao_edge_dir(orig[i], rec[i], eo, bw, bh), d["edge" + key][i, eo])
+                assert O.sao_edge_ddistortion(orig[i], rec[i], bw, bh, eo, d["offs" + key][i, eo]) == d["edge_dd" + key][i, eo]
+            assert O.sao_band_ddistortion(orig[i], rec[i], bw, bh, int(d["band_pos" + key][i]), d["band_offs" + key][i]) == d["band_dd" + key][i]
+    plane, recs, blocks = d["plane"], d["records"], d["blocks"]
+    for color in (0, 2):
+        got = np.concatenate([O.sao_reconstruct_color(plane, int(x), int(y), int(w), int(h), s, color).ravel()
+                              for s in recs for (x, y, w, h) in blocks])
+        np.testing.assert_array_equal(got, d["recon_c%d" % color])
+
+
+def test_golden_motion_search():
+    from patterns import ME_PARAMS, ME_PU
+    d = gold("me.npz")
+    pus = np.ascontiguousarray(d["pus"]).view(ME_PU).reshape(-1)
+    for i in range(3):
+        prm = np.ascontiguousarray(d["params%d" % i]).view(ME_PARAMS)
+        got = O.search_pu_batch(d["pic"], d["ref"], pus, prm).view(np.int32).reshape(len(pus), 8)
+        np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])
