@@ -45,3 +45,34 @@ def max_over_ranks(dt, dist=None, device=None):
     t = torch.tensor([dt], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def exchange_halo(own_rows, margin, dist):
+    """The one exchange step a CTU-row sharded ENCODER needs: after a frame is reconstructed, every rank
+    sends the `margin` pixel rows at the top / bottom of its shard to the rank above / below, so that the next frame's
+    motion search (kvz_hip_search_pu_batch) can read margin rows beyond its own CTU rows of the reference.
+
+    own_rows: torch uint8 tensor [rows, width] (this rank's rows of the reconstructed plane; on the GPU with the nccl
+    backend -- RCCL send/recv between ring neighbours over one xGMI link -- or on the CPU with gloo).  Returns
+    (extended tensor, first_row_offset): own rows with up to `margin` neighbour rows attached above and below.
+    Point-to-point only: 2 * margin * width bytes per interior boundary per plane (4K luma, margin 80: 0.3 MB)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1 or margin <= 0:
+        return own_rows, 0
+    rows = own_rows.shape[0]
+    if rows < margin:
+        raise ValueError("shard of %d rows is thinner than the halo margin %d: use fewer ranks or a multi-hop exchange" % (rows, margin))
+    up = torch.empty((margin,) + tuple(own_rows.shape[1:]), dtype=own_rows.dtype, device=own_rows.device) if rank > 0 else None
+    down = torch.empty((margin,) + tuple(own_rows.shape[1:]), dtype=own_rows.dtype, device=own_rows.device) if rank < world - 1 else None
+    ops = []
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, own_rows[:margin].contiguous(), rank - 1))
+        ops.append(dist.P2POp(dist.irecv, up, rank - 1))
+    if rank < world - 1:
+        ops.append(dist.P2POp(dist.isend, own_rows[rows - margin:].contiguous(), rank + 1))
+        ops.append(dist.P2POp(dist.irecv, down, rank + 1))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    parts = ([up] if up is not None else []) + [own_rows] + ([down] if down is not None else [])
+    return torch.cat(parts, dim=0), (margin if up is not None else 0)

@@ -78,3 +78,36 @@ def test_two_rank_ctu_row_sharding_gloo():
     assert ok, "sharded result differs from the single-rank result"
     assert abs(dt - 0.020) < 1e-9          # MAX over ranks
     assert ranges[0][1] == ranges[1][0]    # contiguous, disjoint shards
+
+
+def _halo_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.random.default_rng(9)
+    W, H, margin = 128, 64 * 7 + 24, 40            # 8 CTU rows, the last one ragged
+    plane = torch.from_numpy(g.integers(0, 256, (H, W), dtype=np.uint8))
+    lo, hi = shard.pixel_rows(H, world, rank)
+    ext, off = shard.exchange_halo(plane[lo:hi].clone(), margin, dist)
+    want_lo, want_hi = shard.halo_rows(H, world, rank, margin)
+    ok = (lo - off == want_lo) and (ext.shape[0] == want_hi - want_lo) and bool(torch.equal(ext, plane[want_lo:want_hi]))
+    res = [None] * world
+    dist.all_gather_object(res, ok)
+    if rank == 0:
+        q.put(all(res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_of_reconstructed_rows(world):
+    """the one exchange step of a CTU-row sharded encoder: neighbour rows arrive in place (gloo stands in for RCCL)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + world
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    for p_ in procs:
+        p_.join(120)
+        assert p_.exitcode == 0
+    assert q.get(timeout=10) is True
