@@ -1,7 +1,7 @@
 // me_search.hip -- one motion search per PU, entirely on the device: hexagon search with MV bit
 // costs, then the fused fractional search.
 //
-// Reference: the --me hexbs path of search_pu_inter_ref (src/search_inter.c:1134-1300):
+// Reference: the --me hexbs (and --me dia, diamond_search :796-883) path of search_pu_inter_ref (src/search_inter.c:1134-1300):
 // hexagon_search (:690-778) = select_starting_point (:282-307) + early_terminate (:415-460) +
 // the 6/3/8-point patterns, every candidate through check_mv_cost (:195-232) = kvz_image_calc_sad
 // (image.c:455-486) + calc_mvd_cost (:373-412); then search_frac (:965-1128).  SURVEY.md 8(f) row 1.
@@ -93,6 +93,7 @@ struct me_cost_model {
 
 __constant__ signed char c_large_hex[9][2] = { { 0, 0 }, { 1, -2 }, { 2, 0 }, { 1, 2 }, { -1, 2 }, { -2, 0 }, { -1, -2 }, { 1, -2 }, { 2, 0 } };
 __constant__ signed char c_small_hex[9][2] = { { 0, 0 }, { 0, -1 }, { -1, 0 }, { 1, 0 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
+__constant__ signed char c_diamond[5][2] = { { 0, -1 }, { 1, 0 }, { 0, 1 }, { -1, 0 }, { 0, 0 } };
 __constant__ signed char c_et_hex[7][2] = { { 0, -1 }, { -1, 0 }, { 0, 1 }, { 1, 0 }, { 0, -1 }, { -1, 0 }, { 0, 0 } };
 
 struct me_shared { u32 sad[8]; int cx[8], cy[8]; };
@@ -191,7 +192,39 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     }
   }
 
-  if (!done) {
+  if (!done && prm.algorithm == 1) {
+    // ---- diamond_search (:826-882) ----
+    int mvx = best_x, mvy = best_y, best_index = 4;
+    u32 steps = prm.max_steps;
+    sync();
+    for (int i = 0; i < 5; ++i) set_cand(i, mvx + c_diamond[i][0], mvy + c_diamond[i][1]);
+    group_sads(5);
+    for (int i = 0; i < 5; ++i)
+      if (take(i)) best_index = i;
+    if (best_index != 4) {
+      mvx += c_diamond[best_index][0]; mvy += c_diamond[best_index][1];
+      int from_dir = 4;
+      bool better;
+      do {
+        better = false;
+        if (steps > 0) steps -= 1;
+        sync();
+        int n = 0, idx[4];
+        for (int i = 0; i < 4; ++i) {
+          if (i == from_dir) continue;                  // where we came from is checked already
+          idx[n] = i;
+          set_cand(n++, mvx + c_diamond[i][0], mvy + c_diamond[i][1]);
+        }
+        group_sads(n);
+        for (int k = 0; k < n; ++k)
+          if (take(k)) { best_index = idx[k]; better = true; }
+        if (better) {
+          mvx += c_diamond[best_index][0]; mvy += c_diamond[best_index][1];
+          from_dir = best_index ^ 3;
+        }
+      } while (better && steps != 0);
+    }
+  } else if (!done) {
     // ---- the hexagon (:723-777) ----
     int mvx = best_x, mvy = best_y, best_index = 0;
     u32 steps = prm.max_steps;
@@ -293,8 +326,9 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     set_error_msg("kvz_hip_search_pu_batch: null buffer or empty plane");
     return KVZ_HIP_ERR_INVALID;
   }
-  if (params->fme_level < 0 || params->fme_level > 4 || params->early_termination < 0 || params->early_termination > 2) {
-    set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4 and early_termination 0..2");
+  if (params->fme_level < 0 || params->fme_level > 4 || params->early_termination < 0 || params->early_termination > 2 ||
+      params->algorithm < 0 || params->algorithm > 1) {
+    set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4, early_termination 0..2, algorithm 0 (hexbs) or 1 (dia)");
     return KVZ_HIP_ERR_INVALID;
   }
   if (count == 0) return KVZ_HIP_OK;

@@ -174,13 +174,14 @@ def sao():
 def me():
     """the reference's static hexagon_search + search_frac (oracle/ref_me_harness.c) for three encoder settings"""
     d = {}
-    cfgs = [dict(), dict(early_termination=2, fme_level=2, lambda_cost=35), dict(wpp_owf=1, ref_delay_px=10, lambda_cost=9, early_termination=0)]
+    cfgs = [dict(), dict(early_termination=2, fme_level=2, lambda_cost=35), dict(wpp_owf=1, ref_delay_px=10, lambda_cost=9, early_termination=0),
+            dict(algorithm=1, lambda_cost=25)]
     pic, ref = me_frames(192, 128, SEED + 7, (5, -3))
     pus = me_random_pus(192, 128, 48, SEED + 8, hint=(-18, 12))
     d["pic"], d["ref"], d["pus"] = pic, ref, pus.view(np.uint8).reshape(len(pus), 64)
     for i, c in enumerate(cfgs):
         prm = me_params(**c)
-        d["params%d" % i] = prm.view(np.int32).reshape(8)
+        d["params%d" % i] = prm.view(np.int32).reshape(12)
         d["results%d" % i] = R.search_pu_batch(pic, ref, pus, prm).view(np.int32).reshape(len(pus), 8)
     np.savez_compressed(os.path.join(OUT, "me.npz"), **d)
 

@@ -930,11 +930,10 @@ static int me_in_merge(const orc_me_pu *pu, int x, int y)
   return 0;
 }
 
-/* hexagon_search (:690-778) incl. select_starting_point (:282-307) and early_terminate (:415-460) */
-static void me_hexagon(me_info *in)
+/* the common opening of hexagon_search and diamond_search: select_starting_point (:282-307) and, if enabled,
+ * early_terminate (:415-460).  Returns 1 when the search is finished. */
+static int me_start(me_info *in)
 {
-  static const int large[9][2] = { {0,0}, {1,-2}, {2,0}, {1,2}, {-1,2}, {-2,0}, {-1,-2}, {1,-2}, {2,0} };
-  static const int small[9][2] = { {0,0}, {0,-1}, {-1,0}, {1,0}, {0,1}, {-1,-1}, {1,-1}, {-1,1}, {1,1} };
   static const int et[7][2] = { {0,-1}, {-1,0}, {0,1}, {1,0}, {0,-1}, {-1,0}, {0,0} };
   const orc_me_pu *pu = in->mc.pu;
   const orc_me_params *prm = in->mc.prm;
@@ -959,11 +958,48 @@ static void me_hexagon(me_info *in)
       for (int i = first; i <= last; ++i)
         if (me_check(in, mvx + et[i][0], mvy + et[i][1])) best_index = i;
       mvx += et[best_index][0]; mvy += et[best_index][1];
-      if (in->best_cost >= threshold) return;
+      if (in->best_cost >= threshold) return 1;
       first = (best_index + 3) % 4;
       last = first + 2;
     }
   }
+  return 0;
+}
+
+/* diamond_search (:796-883) */
+static void me_diamond(me_info *in)
+{
+  static const int dia[5][2] = { {0,-1}, {1,0}, {0,1}, {-1,0}, {0,0} };
+  if (me_start(in)) return;
+  int mvx = in->best_mv[0] >> 2, mvy = in->best_mv[1] >> 2;
+  int best_index = 4;
+  unsigned steps = in->mc.prm->max_steps;
+  for (int i = 0; i < 5; ++i)
+    if (me_check(in, mvx + dia[i][0], mvy + dia[i][1])) best_index = i;
+  if (best_index == 4) return;
+  mvx += dia[best_index][0]; mvy += dia[best_index][1];
+  int from_dir = 4, better;
+  do {
+    better = 0;
+    if (steps > 0) steps -= 1;
+    for (int i = 0; i < 4; ++i) {
+      if (i == from_dir) continue;
+      if (me_check(in, mvx + dia[i][0], mvy + dia[i][1])) { best_index = i; better = 1; }
+    }
+    if (better) {
+      mvx += dia[best_index][0]; mvy += dia[best_index][1];
+      from_dir = best_index ^ 3;
+    }
+  } while (better && steps != 0);
+}
+
+/* hexagon_search (:690-778) */
+static void me_hexagon(me_info *in)
+{
+  static const int large[9][2] = { {0,0}, {1,-2}, {2,0}, {1,2}, {-1,2}, {-2,0}, {-1,-2}, {1,-2}, {2,0} };
+  static const int small[9][2] = { {0,0}, {0,-1}, {-1,0}, {1,0}, {0,1}, {-1,-1}, {1,-1}, {-1,1}, {1,1} };
+  const orc_me_params *prm = in->mc.prm;
+  if (me_start(in)) return;
 
   int mvx = in->best_mv[0] >> 2, mvy = in->best_mv[1] >> 2;
   int best_index = 0;
@@ -989,7 +1025,7 @@ void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, i
   memset(&in, 0, sizeof(in));
   in.pic = pic; in.ref = ref; in.pic_stride = pic_stride; in.ref_w = ref_w; in.ref_h = ref_h;
   in.mc.pu = pu; in.mc.prm = prm;
-  me_hexagon(&in);
+  if (prm->algorithm == 1) me_diamond(&in); else me_hexagon(&in);
   if (prm->fme_level > 0 && in.best_cost < 0xffffffffu) {   /* inter_cost starts at its maximum (:1456) */
     int mv[2] = { in.best_mv[0] >> 2, in.best_mv[1] >> 2 };
     frac_search(pic, pic_stride, ref, ref_w, ref_h, pu->x, pu->y, pu->width, pu->height, mv, &in.mc, prm->fme_level,

@@ -31,6 +31,7 @@ typedef struct {
   int32_t lambda_cost, early_termination;
   uint32_t max_steps;
   int32_t fme_level, wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right;
+  int32_t algorithm, reserved[3];
 } me_params_t;
 typedef struct { int32_t mv[2]; uint32_t cost, bitcost; int32_t merged, merge_idx, mv_cand, reserved; } me_result_t;
 
@@ -89,7 +90,8 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   const vector2d_t extra = { pu->extra_mv[0], pu->extra_mv[1] };
 
   info.best_cost = UINT32_MAX;
-  hexagon_search(&info, extra, prm->max_steps);
+  if (prm->algorithm == 1) diamond_search(&info, extra, prm->max_steps);
+  else hexagon_search(&info, extra, prm->max_steps);
   if (prm->fme_level > 0 && info.best_cost < UINT32_MAX) {
     search_frac(&info);
   } else if (info.best_cost < UINT32_MAX) {
