@@ -29,20 +29,8 @@ __device__ __forceinline__ u8 round_clip16(i16 sample) { return fast_clip16((i16
 // c = x + (qx >> 2) -- including the int16 truncation of the vertical sum and the
 // cases where the reference skips a pass (a pass with taps {0,0,0,64,0,0,0,0} is
 // exact).  Candidates are filtered into LDS and scored with the 8x8 Hadamard
-// SATD by one lane per (candidate, 8x8 sub-block).
+// SATD by a quad of lanes per (candidate, 8x8 sub-block).
 // ---------------------------------------------------------------------------
-// 8x8 Hadamard SATD of two LDS blocks (picture-generic.c:240-328), rows of 8 bytes
-__device__ __forceinline__ u32 satd8x8_lds(const u8 *a, int sa, const u8 *b, int sb)
-{
-  u32 av[16], bv[16];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    __builtin_memcpy(&av[2 * r], a + r * sa, 4); __builtin_memcpy(&av[2 * r + 1], a + r * sa + 4, 4);
-    __builtin_memcpy(&bv[2 * r], b + r * sb, 4); __builtin_memcpy(&bv[2 * r + 1], b + r * sb + 4, 4);
-  }
-  return satd8x8_regs(av, bv);
-}
-
 #define FR_HS 65                 /* H plane row stride of the per-call filter step kernel */
 
 struct frac_cand { int fx, fy, ry, cx; };
@@ -73,7 +61,9 @@ struct frac_result { int mvx, mvy; u32 cost, bitcost; };   // info->best_mv (qua
 
 // d: (x1, y1) block in pic, (x2, y2) its integer-pel position in ref.  fme_level = cfg.fme_level (number of filter
 // steps, 0..4).  out (17 raw SATD costs) and best (hpel / qpel indices) may be null.
-template <int MAXW, int T, bool WAVE, class MVC>
+// FW, FH: the block size when it is known at compile time (0 = read it from d): the many index divisions of the
+// staging and filter loops then reduce to shifts, which is what bounds the latency of the one-wave-per-block kernels.
+template <int MAXW, int T, bool WAVE, class MVC, int FW = 0, int FH = 0>
 __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const u8 *__restrict__ pic, u32 pic_stride, const refplane_t &ref,
                                                         const kvz_hip_block_pair &d, int fme_level, const MVC &mvc,
                                                         u32 *__restrict__ out, i32 *__restrict__ best)
@@ -85,7 +75,7 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   int *s_sel = (int *)(s_cost + 4);
   auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
 
-  const int w = d.width, h = d.height;
+  const int w = FW ? FW : d.width, h = FH ? FH : d.height;
   const int pw = w + 8, ph = h + 8;
   for (int i = tid; i < pw * ph; i += T) {
     const int y = i / pw, x = i - y * pw;
@@ -126,15 +116,26 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
       dst[y * G::CS + x] = round_clip16((i16)(acc >> 6));
     }
   };
-  // SATD of candidates 0..ncand-1 against s_cur -> s_cost
+  // SATD of candidates 0..ncand-1 against s_cur -> s_cost.  Four lanes per (candidate, 8x8 sub-block): lane p takes rows
+  // 2p, 2p+1 and the last two vertical Hadamard stages cross the quad with DPP (satd8_quad_part), a quarter of the
+  // instructions of one lane per sub-block -- the scoring rounds are the largest part of a small block's search.
   auto score = [&](int ncand, const u8 *cand0, int cand_stride, int cand_pitch) {
     if (tid < 4) s_cost[tid] = 0;
     sync();
     const int w8 = w >> 3, n8 = w8 * (h >> 3);
-    for (int i = tid; i < ncand * n8; i += T) {
-      const int k = i / n8, sb = i - k * n8, by = sb / w8, bx = sb - by * w8;
-      const u32 v = satd8x8_lds(s_cur + by * 8 * G::CS + bx * 8, G::CS, cand0 + (size_t)k * cand_pitch + by * 8 * cand_stride + bx * 8, cand_stride);
-      atomicAdd(&s_cost[k], v);
+    const int p = tid & 3;
+    const short sg1 = (p & 1) ? (short)-1 : (short)1, sg2 = (p & 2) ? (short)-1 : (short)1;
+    const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 };
+    for (int i = tid; i < ncand * n8 * 4; i += T) {        // whole quads are active or idle together: counts are multiples of 4
+      const int q = i >> 2, k = q / n8, sb = q - k * n8, by = sb / w8, bx = sb - by * w8;
+      const u8 *a = s_cur + (by * 8 + 2 * p) * G::CS + bx * 8;
+      const u8 *b = cand0 + (size_t)k * cand_pitch + (by * 8 + 2 * p) * cand_stride + bx * 8;
+      uint4 x, y;
+      __builtin_memcpy(&x.x, a, 4); __builtin_memcpy(&x.y, a + 4, 4); __builtin_memcpy(&x.z, a + G::CS, 4); __builtin_memcpy(&x.w, a + G::CS + 4, 4);
+      __builtin_memcpy(&y.x, b, 4); __builtin_memcpy(&y.y, b + 4, 4); __builtin_memcpy(&y.z, b + cand_stride, 4); __builtin_memcpy(&y.w, b + cand_stride + 4, 4);
+      u32 m = satd8_quad_part(x, y, m1, m2);
+      m = group_sum<4>(m);
+      if (p == 0) atomicAdd(&s_cost[k], (m + 1) >> 1);
     }
     sync();
   };

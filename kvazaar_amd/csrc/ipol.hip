@@ -153,7 +153,14 @@ __global__ __launch_bounds__(256) void search_frac_small_kernel(const u8 *__rest
   if (i >= count) return;
   const kvz_hip_block_pair d = pairs[i];
   if (!frac_shape_ok(d.width, d.height) || d.width > 16 || d.height > 16) return;
-  search_frac_core<16, 64, true>(threadIdx.x & 63, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
+  const int lane = threadIdx.x & 63;
+  // the four shapes a wave can own, with the size as a compile-time constant
+  if (d.width == 8 && d.height == 8)
+    search_frac_core<16, 64, true, frac_no_cost, 8, 8>(lane, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
+  else if (d.width == 16 && d.height == 16)
+    search_frac_core<16, 64, true, frac_no_cost, 16, 16>(lane, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
+  else
+    search_frac_core<16, 64, true, frac_no_cost>(lane, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
 }
 
 // ---------------------------------------------------------------------------

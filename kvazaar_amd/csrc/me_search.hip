@@ -100,7 +100,7 @@ struct me_shared { u32 sad[8]; int cx[8], cy[8]; };
 
 // One PU.  T threads (a wave with wave-private LDS, or the whole workgroup) share the work; every thread
 // carries the same search state, so all decisions are uniform across them.
-template <int MAXW, int T, bool WAVE>
+template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0>
 __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, const u8 *__restrict__ pic, u32 pic_stride,
                                                const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm,
                                                kvz_hip_me_result *__restrict__ out)
@@ -109,7 +109,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   u8 *s_cur = lds + G::P_BYTES;                        // same place search_frac_core keeps the current block
   auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
   const me_cost_model mvc = { pu, prm };
-  const int w = pu.width, h = pu.height, w8 = w >> 3, segs = w8 * h;
+  const int w = FW ? FW : pu.width, h = FH ? FH : pu.height, w8 = w >> 3, segs = w8 * h;   // FW, FH: compile-time size (0 = runtime)
 
   for (int i = tid; i < segs; i += T) {
     const int y = i / w8, x = (i - y * w8) * 8;
@@ -255,7 +255,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   if (best_cost != 0xffffffffu) {
     sync();
     const kvz_hip_block_pair d = { pu.x, pu.y, pu.x + best_x, pu.y + best_y, w, h };
-    const frac_result fr = search_frac_core<MAXW, T, WAVE>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
+    const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model, FW, FH>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
     best_cost = fr.cost;                               // level 0: satd + bits(int mv) * lambda, the same bits as best_bits
     if (prm.fme_level > 0) { mv_x = fr.mvx; mv_y = fr.mvy; best_bits = fr.bitcost; }
   }
@@ -311,7 +311,10 @@ __global__ __launch_bounds__(256) void search_pu_small_kernel(const u8 *__restri
   if (i >= count) return;
   const kvz_hip_me_pu &pu = pus[i];
   if (!pu_ok(pu, pic_w, pic_h) || pu.width > 16 || pu.height > 16) return;
-  search_pu_core<16, 64, true>(threadIdx.x & 63, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  const int lane = threadIdx.x & 63;
+  if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  else search_pu_core<16, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
 }
 
 }  // namespace

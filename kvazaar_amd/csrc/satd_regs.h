@@ -111,4 +111,40 @@ __device__ __forceinline__ u32 satd4x4_regs(const u32 *a, const u32 *b)
   return satd4x4_diff(x);
 }
 
+// ---- an 8x8 block spread over a quad of lanes (lane p = rows 2p, 2p+1) ----
+template <int CTRL>
+__device__ __forceinline__ v2s dpp_v2s(v2s v)
+{
+  return as_v2s((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(v), CTRL, 0xF, 0xF, true));
+}
+
+// x, y: the lane's 16-byte chunk of each block (rows 2p and 2p+1).  Returns the
+// lane's share of m = sum max(|a|,|b|); the block's SATD is (sum over the quad + 1) >> 1.
+__device__ __forceinline__ u32 satd8_quad_part(uint4 x, uint4 y, v2s m1, v2s m2)
+{
+  v2s d[2][4];
+  d[0][0] = unpack_lo(x.x) - unpack_lo(y.x); d[0][1] = unpack_hi(x.x) - unpack_hi(y.x);
+  d[0][2] = unpack_lo(x.y) - unpack_lo(y.y); d[0][3] = unpack_hi(x.y) - unpack_hi(y.y);
+  d[1][0] = unpack_lo(x.z) - unpack_lo(y.z); d[1][1] = unpack_hi(x.z) - unpack_hi(y.z);
+  d[1][2] = unpack_lo(x.w) - unpack_lo(y.w); d[1][3] = unpack_hi(x.w) - unpack_hi(y.w);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {          // column bits 2 and 1
+    v2s s0 = d[j][0] + d[j][2], s1 = d[j][1] + d[j][3], e0 = d[j][0] - d[j][2], e1 = d[j][1] - d[j][3];
+    d[j][0] = s0 + s1; d[j][1] = s0 - s1; d[j][2] = e0 + e1; d[j][3] = e0 - e1;
+  }
+  v2s w[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { w[q] = d[0][q] + d[1][q]; w[q + 4] = d[0][q] - d[1][q]; }   // row bit 0
+  u32 m = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v2s t = dpp_v2s<0xB1>(w[i]);         // quad_perm [1,0,3,2]: row bit 1
+    v2s u = w[i] * m1 + t;
+    t = dpp_v2s<0x4E>(u);                // quad_perm [2,3,0,1]: row bit 2
+    u = u * m2 + t;
+    m += absmax_halves(u);               // column bit 0 folded into the absolute sum
+  }
+  return m;
+}
+
 }  // namespace kvzhip
