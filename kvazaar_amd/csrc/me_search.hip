@@ -21,24 +21,46 @@ using namespace kvzhip;
 
 namespace {
 
-// calc_mvd_cost / fracmv_within_tile on the flattened encoder state (include/kvz_hip.h)
+// calc_mvd_cost / fracmv_within_tile on the flattened encoder state (include/kvz_hip.h).  The descriptor is copied
+// into (scalar) registers once per PU: the cost model runs for every one of the ~60 candidates of a search, and
+// reading the merge list from memory each time made scalar loads the longest chain of the kernel.
 struct me_cost_model {
-  const kvz_hip_me_pu &pu;
-  const kvz_hip_me_params &prm;
+  int px, py, pw, ph;
+  int cand[2][2];
+  int n_merge;
+  int mx[5], my[5];
+  u32 usable, same_ref;                                // bit i = merge[i].usable / .same_ref
+  int lambda_cost, wpp_owf, ref_delay_px, max_down, max_right;
+
+  __device__ __forceinline__ me_cost_model(const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm)
+  {
+    px = pu.x; py = pu.y; pw = pu.width; ph = pu.height;
+    cand[0][0] = pu.mv_cand[0][0]; cand[0][1] = pu.mv_cand[0][1]; cand[1][0] = pu.mv_cand[1][0]; cand[1][1] = pu.mv_cand[1][1];
+    n_merge = pu.num_merge_cand;
+    usable = 0; same_ref = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      mx[i] = pu.merge[i].mv[0]; my[i] = pu.merge[i].mv[1];
+      if (i < n_merge && pu.merge[i].usable) usable |= 1u << i;
+      if (pu.merge[i].same_ref) same_ref |= 1u << i;
+    }
+    lambda_cost = prm.lambda_cost; wpp_owf = prm.wpp_owf; ref_delay_px = prm.ref_delay_px;
+    max_down = prm.max_ref_lcu_down; max_right = prm.max_ref_lcu_right;
+  }
 
   // fracmv_within_tile (search_inter.c:87-176) for mv_constraint == NONE; quarter-pel vector
   __device__ __forceinline__ bool within(int x, int y) const
   {
-    if (!prm.wpp_owf) return true;
+    if (!wpp_owf) return true;
     int margin = 0;
     if (x % 4 != 0 || y % 4 != 0) margin = 4;
     else if (x % 8 != 0 || y % 8 != 0) margin = 2;
-    margin += prm.ref_delay_px;
-    const int lcu_x = pu.x / 64, lcu_y = pu.y / 64;
-    const int mv_lcu_x = ((pu.x + pu.width + margin) * 4 + x) / (64 << 2) - lcu_x;
-    const int mv_lcu_y = ((pu.y + pu.height + margin) * 4 + y) / (64 << 2) - lcu_y;
-    if (mv_lcu_y > prm.max_ref_lcu_down) return false;
-    if (mv_lcu_x + mv_lcu_y > prm.max_ref_lcu_down + prm.max_ref_lcu_right) return false;
+    margin += ref_delay_px;
+    const int lcu_x = px / 64, lcu_y = py / 64;
+    const int mv_lcu_x = ((px + pw + margin) * 4 + x) / (64 << 2) - lcu_x;
+    const int mv_lcu_y = ((py + ph + margin) * 4 + y) / (64 << 2) - lcu_y;
+    if (mv_lcu_y > max_down) return false;
+    if (mv_lcu_x + mv_lcu_y > max_down + max_right) return false;
     return true;
   }
   // get_ep_ex_golomb_bitcost (:235-254)
@@ -60,17 +82,19 @@ struct me_cost_model {
   // select_mv_cand (:326-370)
   __device__ __forceinline__ int select_cand(int mvx, int mvy, u32 &cost) const
   {
-    const u32 c1 = mvd_bits(mvx - pu.mv_cand[0][0], mvy - pu.mv_cand[0][1]);
-    const u32 c2 = mvd_bits(mvx - pu.mv_cand[1][0], mvy - pu.mv_cand[1][1]);
+    const u32 c1 = mvd_bits(mvx - cand[0][0], mvy - cand[0][1]);
+    const u32 c2 = mvd_bits(mvx - cand[1][0], mvy - cand[1][1]);
     cost = c1 < c2 ? c1 : c2;
     return c2 < c1 ? 1 : 0;
   }
   // index of the first merge candidate that codes (x, y) (quarter-pel) for this reference, or -1
   __device__ __forceinline__ int merge_match(int x, int y) const
   {
-    for (int i = 0; i < pu.num_merge_cand; ++i)
-      if (pu.merge[i].usable && pu.merge[i].mv[0] == x && pu.merge[i].mv[1] == y && pu.merge[i].same_ref) return i;
-    return -1;
+    int m = -1;
+#pragma unroll
+    for (int i = 4; i >= 0; --i)
+      if (((usable & same_ref) >> i & 1u) && mx[i] == x && my[i] == y) m = i;
+    return m;
   }
   // calc_mvd_cost (:373-412)
   __device__ __forceinline__ u32 cost(int x, int y, int mv_shift, u32 &bits) const
@@ -80,14 +104,16 @@ struct me_cost_model {
     const int m = merge_match(x, y);
     if (m >= 0) bits = (u32)m;
     else select_cand(x, y, bits);
-    return bits * (u32)prm.lambda_cost;
+    return bits * (u32)lambda_cost;
   }
   // mv_in_merge (:260-273), integer-pel vector
   __device__ __forceinline__ bool in_merge(int x, int y) const
   {
-    for (int i = 0; i < pu.num_merge_cand; ++i)
-      if (pu.merge[i].usable && ((pu.merge[i].mv[0] + 2) >> 2) == x && ((pu.merge[i].mv[1] + 2) >> 2) == y) return true;
-    return false;
+    bool hit = false;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if ((usable >> i & 1u) && ((mx[i] + 2) >> 2) == x && ((my[i] + 2) >> 2) == y) hit = true;
+    return hit;
   }
 };
 
@@ -108,7 +134,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   typedef frac_geom<MAXW> G;
   u8 *s_cur = lds + G::P_BYTES;                        // same place search_frac_core keeps the current block
   auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
-  const me_cost_model mvc = { pu, prm };
+  const me_cost_model mvc(pu, prm);
   const int w = FW ? FW : pu.width, h = FH ? FH : pu.height, w8 = w >> 3, segs = w8 * h;   // FW, FH: compile-time size (0 = runtime)
 
   for (int i = tid; i < segs; i += T) {
@@ -163,9 +189,10 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   {
     const int ex = pu.extra_mv[0] >> 2, ey = pu.extra_mv[1] >> 2;
     if ((ex != 0 || ey != 0) && !mvc.in_merge(ex, ey)) set_cand(n++, ex, ey);
-    for (int i = 0; i < pu.num_merge_cand; ++i) {
-      if (!pu.merge[i].usable) continue;
-      const int x = (pu.merge[i].mv[0] + 2) >> 2, y = (pu.merge[i].mv[1] + 2) >> 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (!(mvc.usable >> i & 1u)) continue;
+      const int x = (mvc.mx[i] + 2) >> 2, y = (mvc.my[i] + 2) >> 2;
       if (x == 0 && y == 0) continue;
       set_cand(n++, x, y);
     }
@@ -266,7 +293,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     r.cost = best_cost; r.bitcost = best_bits;
     const int m = mvc.merge_match(mv_x, mv_y);          // :1253-1266
     r.merged = m >= 0;
-    r.merge_idx = m >= 0 ? m : pu.num_merge_cand;
+    r.merge_idx = m >= 0 ? m : mvc.n_merge;
     u32 unused;
     r.mv_cand = m >= 0 ? 0 : mvc.select_cand(mv_x, mv_y, unused);   // :1268-1273
     r.reserved = 0;
