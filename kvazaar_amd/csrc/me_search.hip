@@ -1,7 +1,7 @@
 // me_search.hip -- one motion search per PU, entirely on the device: hexagon search with MV bit
 // costs, then the fused fractional search.
 //
-// Reference: the --me hexbs (and --me dia, diamond_search :796-883) path of search_pu_inter_ref (src/search_inter.c:1134-1300):
+// Reference: the --me hexbs (and --me dia, diamond_search :796-883; --me tz, tz_search :595-672) path of search_pu_inter_ref (src/search_inter.c:1134-1300):
 // hexagon_search (:690-778) = select_starting_point (:282-307) + early_terminate (:415-460) +
 // the 6/3/8-point patterns, every candidate through check_mv_cost (:195-232) = kvz_image_calc_sad
 // (image.c:455-486) + calc_mvd_cost (:373-412); then search_frac (:965-1128).  SURVEY.md 8(f) row 1.
@@ -219,7 +219,43 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     }
   }
 
-  if (!done && prm.algorithm == 1) {
+  if (!done && prm.algorithm == 2) {
+    // ---- tz_search (:595-672): search range 96, 8-point diamond patterns (4 points at distance 1), no raster
+    // scan, star refinement; kvz_tz_pattern_search (:463-577) is one group ----
+    int best_dist = 0;
+    auto pattern = [&](int dist, int sx, int sy) {
+      const int hd = dist / 2, n = dist == 1 ? 4 : 8;
+      sync();
+      set_cand(0, sx, sy + dist); set_cand(1, sx + dist, sy); set_cand(2, sx, sy - dist); set_cand(3, sx - dist, sy);
+      if (n == 8) {
+        set_cand(4, sx + hd, sy + hd); set_cand(5, sx + hd, sy - hd); set_cand(6, sx - hd, sy - hd); set_cand(7, sx - hd, sy + hd);
+      }
+      group_sads(n);
+      bool improved = false;
+      for (int k = 0; k < n; ++k)
+        if (take(k)) improved = true;
+      if (improved) best_dist = dist;
+    };
+    int sx = best_x, sy = best_y, rounds = 0;
+    for (int dist = 1; dist <= 96; dist *= 2) {
+      pattern(dist, sx, sy);
+      if (best_dist != dist) rounds++;
+      if (rounds >= 3) break;
+    }
+    if (sx != 0 || sy != 0) {
+      rounds = 0;
+      for (int dist = 1; dist <= 48; dist *= 2) {
+        pattern(dist, 0, 0);
+        if (best_dist != dist) rounds++;
+        if (rounds >= 3) break;
+      }
+    }
+    while (best_dist > 0) {
+      best_dist = 0;
+      sx = best_x; sy = best_y;
+      for (int dist = 1; dist <= 96; dist *= 2) pattern(dist, sx, sy);
+    }
+  } else if (!done && prm.algorithm == 1) {
     // ---- diamond_search (:826-882) ----
     int mvx = best_x, mvy = best_y, best_index = 4;
     u32 steps = prm.max_steps;
@@ -357,8 +393,8 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     return KVZ_HIP_ERR_INVALID;
   }
   if (params->fme_level < 0 || params->fme_level > 4 || params->early_termination < 0 || params->early_termination > 2 ||
-      params->algorithm < 0 || params->algorithm > 1) {
-    set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4, early_termination 0..2, algorithm 0 (hexbs) or 1 (dia)");
+      params->algorithm < 0 || params->algorithm > 2) {
+    set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4, early_termination 0..2, algorithm 0 (hexbs), 1 (dia) or 2 (tz)");
     return KVZ_HIP_ERR_INVALID;
   }
   if (count == 0) return KVZ_HIP_OK;

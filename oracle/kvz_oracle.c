@@ -993,6 +993,46 @@ static void me_diamond(me_info *in)
   } while (better && steps != 0);
 }
 
+/* kvz_tz_pattern_search (:463-577) with pattern_type 0, the 8-point diamond (4 points at distance 1) */
+static void me_tz_pattern(me_info *in, int dist, int sx, int sy, int *best_dist)
+{
+  const int pat[8][2] = { {0, dist}, {dist, 0}, {0, -dist}, {-dist, 0},
+                          {dist / 2, dist / 2}, {dist / 2, -dist / 2}, {-dist / 2, -dist / 2}, {-dist / 2, dist / 2} };
+  const int n = dist == 1 ? 4 : 8;
+  int improved = 0;
+  for (int i = 0; i < n; ++i)
+    if (me_check(in, sx + pat[i][0], sy + pat[i][1])) improved = 1;
+  if (improved) *best_dist = dist;
+}
+
+/* tz_search (:595-672) with its fixed parameters: search range 96, diamond patterns, no raster scan, star refinement */
+static void me_tz(me_info *in)
+{
+  const int range = 96;
+  int best_dist = 0;
+  if (me_start(in)) return;
+  int sx = in->best_mv[0] >> 2, sy = in->best_mv[1] >> 2;
+  int rounds = 0;
+  for (int dist = 1; dist <= range; dist *= 2) {
+    me_tz_pattern(in, dist, sx, sy, &best_dist);
+    if (best_dist != dist) rounds++;
+    if (rounds >= 3) break;
+  }
+  if (sx != 0 || sy != 0) {
+    rounds = 0;
+    for (int dist = 1; dist <= range / 2; dist *= 2) {
+      me_tz_pattern(in, dist, 0, 0, &best_dist);
+      if (best_dist != dist) rounds++;
+      if (rounds >= 3) break;
+    }
+  }
+  while (best_dist > 0) {
+    best_dist = 0;
+    sx = in->best_mv[0] >> 2; sy = in->best_mv[1] >> 2;
+    for (int dist = 1; dist <= range; dist *= 2) me_tz_pattern(in, dist, sx, sy, &best_dist);
+  }
+}
+
 /* hexagon_search (:690-778) */
 static void me_hexagon(me_info *in)
 {
@@ -1025,7 +1065,9 @@ void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, i
   memset(&in, 0, sizeof(in));
   in.pic = pic; in.ref = ref; in.pic_stride = pic_stride; in.ref_w = ref_w; in.ref_h = ref_h;
   in.mc.pu = pu; in.mc.prm = prm;
-  if (prm->algorithm == 1) me_diamond(&in); else me_hexagon(&in);
+  if (prm->algorithm == 1) me_diamond(&in);
+  else if (prm->algorithm == 2) me_tz(&in);
+  else me_hexagon(&in);
   if (prm->fme_level > 0 && in.best_cost < 0xffffffffu) {   /* inter_cost starts at its maximum (:1456) */
     int mv[2] = { in.best_mv[0] >> 2, in.best_mv[1] >> 2 };
     frac_search(pic, pic_stride, ref, ref_w, ref_h, pu->x, pu->y, pu->width, pu->height, mv, &in.mc, prm->fme_level,
