@@ -305,8 +305,10 @@ typedef struct {
   int32_t wpp_owf;               /* cfg.owf && cfg.wpp: enforce the reference-availability rule of fracmv_within_tile */
   int32_t ref_delay_px;          /* SAO_DELAY_PX (sao on), DEBLOCK_DELAY_PX (deblock only) or 0 (global.h:163,175) */
   int32_t max_ref_lcu_down, max_ref_lcu_right;   /* ctrl->max_inter_ref_lcu (encoder.c:240-241) */
-  int32_t algorithm;             /* cfg.ime_algorithm: 0 hexbs (hexagon_search), 1 dia (diamond_search, :796-883), 2 tz (tz_search, :595-672) */
-  int32_t reserved[3];
+  int32_t algorithm;             /* cfg.ime_algorithm: 0 hexbs (hexagon_search), 1 dia (diamond_search, :796-883), 2 tz (tz_search, :595-672),
+                                    3 full (search_mv_full, :886-962; no early termination) */
+  int32_t search_range;          /* algorithm 3 only: 8, 16, 32 or 64 (search_inter.c:1208-1215), any value 1..64 accepted */
+  int32_t reserved[2];
 } kvz_hip_me_params;             /* 48 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */
@@ -316,7 +318,7 @@ typedef struct {
   int32_t reserved;              /* -1 flags a malformed descriptor */
 } kvz_hip_me_result;
 
-/* The --me hexbs / dia / tz paths of search_pu_inter_ref (search_inter.c:1134-1300) for
+/* The --me hexbs / dia / tz / full paths of search_pu_inter_ref (search_inter.c:1134-1300) for
  * `count` PUs against one reference plane in one launch: hexagon_search
  * diamond_search or tz_search (:463-883, with select_starting_point and early_terminate) over
  * kvz_image_calc_sad + calc_mvd_cost, then search_frac (:965-1128) -- or, for

@@ -122,7 +122,8 @@ __constant__ signed char c_small_hex[9][2] = { { 0, 0 }, { 0, -1 }, { -1, 0 }, {
 __constant__ signed char c_diamond[5][2] = { { 0, -1 }, { 1, 0 }, { 0, 1 }, { -1, 0 }, { 0, 0 } };
 __constant__ signed char c_et_hex[7][2] = { { 0, -1 }, { -1, 0 }, { 0, 1 }, { 1, 0 }, { 0, -1 }, { -1, 0 }, { 0, 0 } };
 
-struct me_shared { u32 sad[8]; int cx[8], cy[8]; };
+constexpr int ME_GROUP = 64;                          // candidates evaluated per round (the patterns use at most 8)
+struct me_shared { u32 sad[ME_GROUP]; int cx[ME_GROUP], cy[ME_GROUP]; };
 
 // One PU.  T threads (a wave with wave-private LDS, or the whole workgroup) share the work; every thread
 // carries the same search state, so all decisions are uniform across them.
@@ -149,7 +150,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
 
   // SADs of candidates 0 .. n-1 (offsets in sh->cx / cy, written by the caller) -> sh->sad
   auto group_sads = [&](int n) {
-    if (tid < 8) sh->sad[tid] = 0;
+    if (tid < ME_GROUP) sh->sad[tid] = 0;
     sync();
     for (int it = tid; it < n * segs; it += T) {
       const int k = it / segs, s = it - k * segs, y = s / w8, x = (s - y * w8) * 8;
@@ -182,9 +183,64 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   };
   auto set_cand = [&](int k, int x, int y) { if (tid == 0) { sh->cx[k] = x; sh->cy[k] = y; } };
 
+  bool done = false;
+  if (prm.algorithm == 3) {
+    // ---- search_mv_full (:886-962): the windows around the zero vector, extra_mv and the merge candidates, in the
+    // reference's visiting order, ME_GROUP positions per round ----
+    const int R = prm.search_range;
+    int n = 0;
+    sync();
+    auto push = [&](int x, int y) {
+      set_cand(n++, x, y);
+      if (n == ME_GROUP) {
+        group_sads(n);
+        for (int k = 0; k < n; ++k) take(k);
+        n = 0;
+        sync();
+      }
+    };
+    for (int y = -R; y <= R; ++y)
+      for (int x = -R; x <= R; ++x) push(x, y);
+    const int ex = pu.extra_mv[0] >> 2, ey = pu.extra_mv[1] >> 2;
+    if (!mvc.in_merge(ex, ey))
+      for (int y = -R; y <= R; ++y)
+        for (int x = -R; x <= R; ++x) push(ex + x, ey + y);
+#pragma unroll                                              // i and j are unrolled so that mx[] / my[] stay in registers
+    for (int i = 0; i < 5; ++i) {
+      if (!(mvc.usable >> i & 1u)) continue;
+      const int cx0 = mvc.mx[i] >> 2, cy0 = mvc.my[i] >> 2;        // plain shift here (:917-920)
+      if (cx0 == 0 && cy0 == 0) continue;
+      for (int y = cy0 - R; y <= cy0 + R; ++y)
+        for (int x = cx0 - R; x <= cx0 + R; ++x) {
+          if (!mvc.within(x * 4, y * 4)) continue;
+          bool tested = false;
+#pragma unroll
+          for (int j = -1; j < 4; ++j) {
+            if (j >= i || tested) continue;
+            int xx = 0, yy = 0;
+            if (j >= 0) {
+              if (!(mvc.usable >> j & 1u)) continue;
+              xx = mvc.mx[j >= 0 ? j : 0] >> 2; yy = mvc.my[j >= 0 ? j : 0] >> 2;
+            }
+            if (x >= xx - R && x <= xx + R && y >= yy - R && y <= yy + R) {
+              tested = true;
+              x = xx + R;                                          // jump past the earlier window (:948)
+            }
+          }
+          if (!tested) push(x, y);
+        }
+    }
+    if (n > 0) {
+      group_sads(n);
+      for (int k = 0; k < n; ++k) take(k);
+    }
+    done = true;
+  }
+
   // ---- select_starting_point (:282-307) ----
   int n = 0;
   sync();                                              // s_cur complete; previous readers of sh are done
+  if (!done) {
   set_cand(n++, 0, 0);
   {
     const int ex = pu.extra_mv[0] >> 2, ey = pu.extra_mv[1] >> 2;
@@ -199,10 +255,10 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   }
   group_sads(n);
   for (int k = 0; k < n; ++k) take(k);
+  }
 
   // ---- early_terminate (:415-460) ----
-  bool done = false;
-  if (prm.early_termination) {
+  if (!done && prm.early_termination) {
     int mvx = best_x, mvy = best_y, first = 0, last = 3;
     for (int round = 0; round < 2 && !done; ++round) {
       const double threshold = prm.early_termination == 2 ? (double)best_cost * 0.95 : (double)best_cost;
@@ -393,8 +449,9 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     return KVZ_HIP_ERR_INVALID;
   }
   if (params->fme_level < 0 || params->fme_level > 4 || params->early_termination < 0 || params->early_termination > 2 ||
-      params->algorithm < 0 || params->algorithm > 2) {
-    set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4, early_termination 0..2, algorithm 0 (hexbs), 1 (dia) or 2 (tz)");
+      params->algorithm < 0 || params->algorithm > 3 ||
+      (params->algorithm == 3 && (params->search_range < 1 || params->search_range > 64))) {
+    set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4, early_termination 0..2, algorithm 0 (hexbs), 1 (dia), 2 (tz) or 3 (full, search_range 1..64)");
     return KVZ_HIP_ERR_INVALID;
   }
   if (count == 0) return KVZ_HIP_OK;

@@ -175,7 +175,8 @@ def me():
     """the reference's static hexagon_search + search_frac (oracle/ref_me_harness.c) for three encoder settings"""
     d = {}
     cfgs = [dict(), dict(early_termination=2, fme_level=2, lambda_cost=35), dict(wpp_owf=1, ref_delay_px=10, lambda_cost=9, early_termination=0),
-            dict(algorithm=1, lambda_cost=25), dict(algorithm=2, lambda_cost=15)]
+            dict(algorithm=1, lambda_cost=25), dict(algorithm=2, lambda_cost=15),
+            dict(algorithm=3, search_range=8, lambda_cost=30)]
     pic, ref = me_frames(192, 128, SEED + 7, (5, -3))
     pus = me_random_pus(192, 128, 48, SEED + 8, hint=(-18, 12))
     d["pic"], d["ref"], d["pus"] = pic, ref, pus.view(np.uint8).reshape(len(pus), 64)

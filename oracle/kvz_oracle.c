@@ -1033,6 +1033,44 @@ static void me_tz(me_info *in)
   }
 }
 
+/* search_mv_full (:886-962): every position of a (2R+1)^2 window around the zero vector, around extra_mv (unless it
+ * is a merge candidate) and around each merge candidate, skipping positions inside a window visited earlier */
+static void me_full(me_info *in, int range)
+{
+  const orc_me_pu *pu = in->mc.pu;
+  in->best_cost = 0xffffffffu;
+  for (int y = -range; y <= range; ++y)
+    for (int x = -range; x <= range; ++x) me_check(in, x, y);
+  const int ex = pu->extra_mv[0] >> 2, ey = pu->extra_mv[1] >> 2;
+  if (!me_in_merge(pu, ex, ey))
+    for (int y = -range; y <= range; ++y)
+      for (int x = -range; x <= range; ++x) me_check(in, ex + x, ey + y);
+  for (int i = 0; i < pu->num_merge_cand; ++i) {
+    if (!pu->merge[i].usable) continue;
+    const int mx = pu->merge[i].mv[0] >> 2, my = pu->merge[i].mv[1] >> 2;     /* plain shift here (:917-920) */
+    if (mx == 0 && my == 0) continue;
+    for (int y = my - range; y <= my + range; ++y)
+      for (int x = mx - range; x <= mx + range; ++x) {
+        if (!me_within(&in->mc, x * 4, y * 4)) continue;
+        int tested = 0;
+        for (int j = -1; j < i; ++j) {
+          int xx = 0, yy = 0;
+          if (j >= 0) {
+            if (!pu->merge[j].usable) continue;
+            xx = pu->merge[j].mv[0] >> 2; yy = pu->merge[j].mv[1] >> 2;
+          }
+          if (x >= xx - range && x <= xx + range && y >= yy - range && y <= yy + range) {
+            tested = 1;
+            x = xx + range;                                                    /* jump past the earlier window (:948) */
+            break;
+          }
+        }
+        if (tested) continue;
+        me_check(in, x, y);
+      }
+  }
+}
+
 /* hexagon_search (:690-778) */
 static void me_hexagon(me_info *in)
 {
@@ -1067,6 +1105,7 @@ void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, i
   in.mc.pu = pu; in.mc.prm = prm;
   if (prm->algorithm == 1) me_diamond(&in);
   else if (prm->algorithm == 2) me_tz(&in);
+  else if (prm->algorithm == 3) me_full(&in, prm->reserved[0]);
   else me_hexagon(&in);
   if (prm->fme_level > 0 && in.best_cost < 0xffffffffu) {   /* inter_cost starts at its maximum (:1456) */
     int mv[2] = { in.best_mv[0] >> 2, in.best_mv[1] >> 2 };

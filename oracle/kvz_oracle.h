@@ -199,7 +199,8 @@ typedef struct {
   int32_t wpp_owf;               /* cfg.owf && cfg.wpp: enforce fracmv_within_tile's availability rule (:95-139) */
   int32_t ref_delay_px;          /* SAO_DELAY_PX (sao on), DEBLOCK_DELAY_PX (deblock only) or 0 */
   int32_t max_ref_lcu_down, max_ref_lcu_right;   /* ctrl->max_inter_ref_lcu */
-  int32_t algorithm;             /* cfg.ime_algorithm: 0 hexbs (hexagon_search), 1 dia (diamond_search :796-883), 2 tz (tz_search :595-672) */
+  int32_t algorithm;             /* cfg.ime_algorithm: 0 hexbs (hexagon_search), 1 dia (diamond_search :796-883), 2 tz (tz_search :595-672),
+                                    3 full (search_mv_full :886-962) with search_range in reserved[0] (8, 16, 32 or 64) */
   int32_t reserved[3];
 } orc_me_params;                 /* 48 bytes */
 typedef struct {

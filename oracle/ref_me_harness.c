@@ -92,6 +92,7 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   info.best_cost = UINT32_MAX;
   if (prm->algorithm == 1) diamond_search(&info, extra, prm->max_steps);
   else if (prm->algorithm == 2) tz_search(&info, extra);
+  else if (prm->algorithm == 3) search_mv_full(&info, prm->reserved[0], extra);
   else hexagon_search(&info, extra, prm->max_steps);
   if (prm->fme_level > 0 && info.best_cost < UINT32_MAX) {
     search_frac(&info);

@@ -136,11 +136,12 @@ assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 48 and ME_RESULT.itemsize 
 
 
 def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_level=4, wpp_owf=0, ref_delay_px=0,
-              max_ref_lcu_down=1, max_ref_lcu_right=1, algorithm=0):
+              max_ref_lcu_down=1, max_ref_lcu_right=1, algorithm=0, search_range=0):
     p = np.zeros(1, dtype=ME_PARAMS)
     p["lambda_cost"], p["early_termination"], p["max_steps"], p["fme_level"] = lambda_cost, early_termination, max_steps, fme_level
     p["wpp_owf"], p["ref_delay_px"], p["max_ref_lcu_down"], p["max_ref_lcu_right"] = wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right
     p["algorithm"] = algorithm
+    p["reserved"][0, 0] = search_range
     return p
 
 

@@ -110,7 +110,7 @@ def test_golden_sao(api):
 
 def test_golden_motion_search(api):
     d = gold("me.npz")
-    for i in range(5):
+    for i in range(6):
         got = api.search_pu_batch(d["pic"], d["ref"], np.ascontiguousarray(d["pus"]).view(np.dtype(("V", 64))).reshape(-1),
                                   np.ascontiguousarray(d["params%d" % i]))
         np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])

@@ -168,7 +168,7 @@ def test_golden_motion_search():
     from patterns import ME_PARAMS, ME_PU
     d = gold("me.npz")
     pus = np.ascontiguousarray(d["pus"]).view(ME_PU).reshape(-1)
-    for i in range(5):
+    for i in range(6):
         prm = np.ascontiguousarray(d["params%d" % i]).view(ME_PARAMS)
         got = O.search_pu_batch(d["pic"], d["ref"], pus, prm).view(np.int32).reshape(len(pus), 8)
         np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])

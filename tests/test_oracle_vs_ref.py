@@ -317,6 +317,7 @@ ME_CONFIGS = [
     dict(wpp_owf=1, ref_delay_px=8, max_ref_lcu_down=0, max_ref_lcu_right=2, lambda_cost=9),
     dict(algorithm=1), dict(algorithm=1, early_termination=0, max_steps=3, lambda_cost=50), dict(algorithm=1, fme_level=2, early_termination=2),
     dict(algorithm=2), dict(algorithm=2, early_termination=0, lambda_cost=6), dict(algorithm=2, wpp_owf=1, ref_delay_px=10, fme_level=3),
+    dict(algorithm=3, search_range=8), dict(algorithm=3, search_range=16, lambda_cost=40, wpp_owf=1, ref_delay_px=8, fme_level=2),
 ]
 
 

@@ -139,6 +139,13 @@ def main():
                       lambda pus_d=pus_d, res_d=res_d, k=len(rows): L.kvz_hip_search_pu_batch(
                           picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), k,
                           me_prm.ctypes.data, res_d.data_ptr(), st)))
+        if n == 16:
+            full_prm = me_prm.copy(); full_prm[8] = 3; full_prm[9] = 16        # --me full16: 1089 positions per PU
+            kk = len(rows) // 8
+            cases.append(("search_pu_16x16_full16", kk, 2 * n * n + 96,
+                          lambda pus_d=pus_d, res_d=res_d, kk=kk, full_prm=full_prm: L.kvz_hip_search_pu_batch(
+                              picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), kk,
+                              full_prm.ctypes.data, res_d.data_ptr(), st)))
 
     # SAO statistics: every 64x64 luma LCU of 16 frames (blocks contiguous, as sao.c blits them)
     sao_cnt = min(nbytes // 4096, 510 * 16)

@@ -38,7 +38,7 @@ def main():
                         max_steps=int(g.choice([0xFFFFFFFF, 0, 1, 3, 8])), fme_level=int(g.integers(0, 5)),
                         wpp_owf=int(g.integers(0, 2)), ref_delay_px=int(g.choice([0, 8, 10])),
                         max_ref_lcu_down=int(g.integers(0, 3)), max_ref_lcu_right=int(g.integers(0, 3)),
-                        algorithm=int(g.integers(0, 3)))
+                        algorithm=int(g.integers(0, 4)), search_range=int(g.integers(1, 13)))
         w, h = int(g.choice([128, 192, 320])), int(g.choice([64, 128, 200]))
         motion = (int(g.integers(-20, 21)), int(g.integers(-20, 21)))
         pic, ref = me_frames(w, h, int(g.integers(0, 1 << 30)), motion)
