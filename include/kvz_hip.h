@@ -330,6 +330,20 @@ KVZ_HIP_API int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_s
                                         const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
                                         kvz_hip_me_result *results, kvz_hip_stream s);
 
+/* Bi-prediction candidate cost of search_pu_inter_bipred (search_inter.c:1304-1440): for candidate i the luma of
+ * kvz_inter_recon_bipred (inter.c:430-477; a 14-bit quarter-pel sample per reference when its vector is fractional,
+ * else the edge-clamped pixels << 6, blended and clipped) scored with kvz_satd_any_size against the source block
+ * (:1359-1362).  The caller adds the MV bit costs (:1366-1389).  Quarter-pel vectors; both reference planes have
+ * ref_w x ref_h pixels; width, height multiples of 8 in 8..64, block inside the picture (else cost 0xFFFFFFFF). */
+typedef struct {
+  int32_t x, y, width, height;
+  int16_t mv0[2], mv1[2];
+} kvz_hip_bipred_cand;
+KVZ_HIP_API int kvz_hip_bipred_cost_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
+                                          const kvz_hip_pixel *ref0, uint32_t ref0_stride,
+                                          const kvz_hip_pixel *ref1, uint32_t ref1_stride, int ref_w, int ref_h,
+                                          const kvz_hip_bipred_cand *cands, size_t count, uint32_t *costs, kvz_hip_stream s);
+
 /* ------------------------------------------------------------------ */
 /* (2) batched entries -- intra group (strategies/strategies-intra.h)  */
 /*     SURVEY.md section 8(f) row 2                                    */

@@ -381,3 +381,21 @@ def sao_reconstruct_color_batch(plane, blocks, infos, color):
     check(L.kvz_hip_sao_reconstruct_color_batch(a.ptr, plane.shape[1], plane.shape[1], plane.shape[0], d.ptr, plane.shape[1],
                                                 b.ptr, blocks.shape[0], f.ptr, infos.shape[0], color, None), "sao_reconstruct")
     return d.to_numpy(np.uint8, plane.shape)
+
+
+def bipred_cost_batch(pic, ref0, ref1, cands):
+    """cands: iterable of (x, y, w, h, mv0x, mv0y, mv1x, mv1y) (quarter-pel vectors) -> uint32 [count] SATD costs"""
+    L = _lib.init()
+    pic = np.ascontiguousarray(pic, dtype=np.uint8)
+    ref0 = np.ascontiguousarray(ref0, dtype=np.uint8)
+    ref1 = np.ascontiguousarray(ref1, dtype=np.uint8)
+    assert ref0.shape == ref1.shape
+    rec = np.zeros(len(cands), dtype=np.dtype([("g", "<i4", (4,)), ("mv", "<i2", (4,))]))
+    for i, c in enumerate(cands):
+        rec[i]["g"] = c[:4]
+        rec[i]["mv"] = c[4:8]
+    a, b, d, e = DeviceBuffer.from_numpy(pic), DeviceBuffer.from_numpy(ref0), DeviceBuffer.from_numpy(ref1), DeviceBuffer.from_numpy(rec.view(np.uint8))
+    out = DeviceBuffer(max(1, 4 * len(rec)))
+    check(L.kvz_hip_bipred_cost_batch(a.ptr, pic.shape[1], pic.shape[1], pic.shape[0], b.ptr, ref0.shape[1], d.ptr, ref1.shape[1],
+                                      ref0.shape[1], ref0.shape[0], e.ptr, len(rec), out.ptr, None), "bipred_cost batch")
+    return out.to_numpy(np.uint32, (len(rec),))

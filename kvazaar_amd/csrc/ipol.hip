@@ -164,6 +164,70 @@ __global__ __launch_bounds__(256) void search_frac_small_kernel(const u8 *__rest
 }
 
 // ---------------------------------------------------------------------------
+// Bi-prediction candidate cost (search_pu_inter_bipred, search_inter.c:1304-1440): the luma of
+// kvz_inter_recon_bipred (inter.c:430-477) -- per reference the 14-bit quarter-pel sample when its vector is
+// fractional (inter.c:86-122), else the edge-clamped pixels << 6 (inter.c:277-298, :355-371) -- blended like
+// inter_recon_bipred_generic (picture-generic.c:538-588) and scored with satd_any_size against the source block.
+// One workgroup per candidate; both predictors, the blend and the source block stay in LDS.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bipred_cost_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h,
+                                                         refplane_t ref0, refplane_t ref1, const kvz_hip_bipred_cand *__restrict__ cands,
+                                                         u32 *__restrict__ costs)
+{
+  __shared__ u8 s_win[(64 + 7) * (64 + 8)];
+  __shared__ i16 s_hor[(64 + 7) * 64];
+  __shared__ __attribute__((aligned(16))) i16 s_s[2][64 * 64];
+  __shared__ __attribute__((aligned(16))) u8 s_pred[64 * 64], s_cur[64 * 64];
+  __shared__ u32 s_cost;
+  const kvz_hip_bipred_cand &c = cands[blockIdx.x];
+  const int tid = threadIdx.x, w = c.width, h = c.height;
+  if (!frac_shape_ok(w, h) || c.x < 0 || c.y < 0 || c.x + w > pic_w || c.y + h > pic_h) {
+    if (tid == 0) costs[blockIdx.x] = 0xffffffffu;
+    return;
+  }
+  if (tid == 0) s_cost = 0;
+  for (int k = 0; k < 2; ++k) {
+    const refplane_t &ref = k ? ref1 : ref0;
+    const int mvx = k ? c.mv1[0] : c.mv0[0], mvy = k ? c.mv1[1] : c.mv0[1];
+    const int ix = c.x + (mvx >> 2), iy = c.y + (mvy >> 2);
+    if ((mvx & 3) || (mvy & 3)) {
+      const kvz_hip_ipol_block b = { ix, iy, mvx & 3, mvy & 3, w, h };
+      sample_core<8, true, 64, 256, false>(tid, s_win, s_hor, ref, b, 0, s_s[k]);
+    } else {
+      for (int i = tid; i < w * h; i += 256) {
+        const int y = i / w, x = i - y * w;
+        s_s[k][i] = (i16)((int)ref_px(ref, ix + x, iy + y) << 6);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < w * h; i += 256) {
+    const int y = i / w, x = i - y * w;
+    s_pred[i] = fast_clip32(((int)s_s[0][i] + (int)s_s[1][i] + 64) >> 7);
+    s_cur[i] = pic[(size_t)(c.y + y) * pic_stride + c.x + x];
+  }
+  __syncthreads();
+  {
+    const int w8 = w >> 3, n8 = w8 * (h >> 3), p = tid & 3;
+    const short sg1 = (p & 1) ? (short)-1 : (short)1, sg2 = (p & 2) ? (short)-1 : (short)1;
+    const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 };
+    u32 acc = 0;
+    for (int i = tid; i < n8 * 4; i += 256) {
+      const int sb = i >> 2, by = sb / w8, bx = sb - by * w8;
+      const u8 *a = s_pred + (by * 8 + 2 * p) * w + bx * 8, *b = s_cur + (by * 8 + 2 * p) * w + bx * 8;
+      const uint2 a0 = *(const uint2 *)a, a1 = *(const uint2 *)(a + w), b0 = *(const uint2 *)b, b1 = *(const uint2 *)(b + w);
+      u32 m = satd8_quad_part(make_uint4(a0.x, a0.y, a1.x, a1.y), make_uint4(b0.x, b0.y, b1.x, b1.y), m1, m2);
+      m = group_sum<4>(m);
+      if (p == 0) acc += (m + 1) >> 1;
+    }
+    acc = group_sum<64>(acc);
+    if ((tid & 63) == 0 && acc) atomicAdd(&s_cost, acc);
+  }
+  __syncthreads();
+  if (tid == 0) costs[blockIdx.x] = s_cost;
+}
+
+// ---------------------------------------------------------------------------
 // One reference filter step (ipol_blocks_func, strategies-ipol.h:36-38) for the
 // per-call strategy shim: produces exactly what the generic step writes -- the
 // four filtered blocks and the horizontal planes / first-column arrays the
@@ -323,6 +387,20 @@ int kvz_hip_search_frac_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, con
   KVZ_CHECK_LAUNCH("search_frac_small_kernel");
   hipLaunchKernelGGL(search_frac_big_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), pic, pic_stride, r, pairs, costs, best);
   KVZ_CHECK_LAUNCH("search_frac_big_kernel");
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_bipred_cost_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
+                              const kvz_hip_pixel *ref0, uint32_t ref0_stride, const kvz_hip_pixel *ref1, uint32_t ref1_stride,
+                              int ref_w, int ref_h, const kvz_hip_bipred_cand *cands, size_t count, uint32_t *costs, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!pic || !ref0 || !ref1 || !cands || !costs || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (count == 0) return KVZ_HIP_OK;
+  if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  const refplane_t r0 = { ref0, ref0_stride, ref_w, ref_h }, r1 = { ref1, ref1_stride, ref_w, ref_h };
+  hipLaunchKernelGGL(bipred_cost_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), pic, pic_stride, pic_w, pic_h, r0, r1, cands, costs);
+  KVZ_CHECK_LAUNCH("bipred_cost_kernel");
   return KVZ_HIP_OK;
 }
 

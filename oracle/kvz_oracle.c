@@ -1374,3 +1374,48 @@ void orc_calc_sao_bands(const orc_pixel *orig, const orc_pixel *rec, int bw, int
     sao_bands[1][rec[i] >> 3] += 1;
   }
 }
+
+/* =====================================================================
+ * bi-prediction candidate cost (search_inter.c:1304-1440, inter.c:300-477)
+ * ===================================================================== */
+
+/* one reference's luma predictor as the blend sees it: *hi = 1 and hp[] (stride w) for a fractional vector
+ * (inter_recon_14bit_frac_luma, inter.c:86-122), else *hi = 0 and px[] (stride w) (inter.c:355-371) */
+static void bipred_luma_part(const orc_pixel *ref, int ref_w, int ref_h, int x, int y, int w, int h, const int16_t mv[2],
+                             int *hi, int16_t *hp, orc_pixel *px)
+{
+  *hi = (mv[0] & 3) || (mv[1] & 3);
+  const int ix = x + (mv[0] >> 2), iy = y + (mv[1] >> 2);
+  if (*hi) {
+    const int es = w + 8;
+    orc_pixel *ext = (orc_pixel *)malloc((size_t)es * (size_t)(h + 8));
+    const orc_pixel *src; int stride; long off;
+    if (orc_get_extended_block(x, y, mv[0] >> 2, mv[1] >> 2, 0, 0, ref, ref_w, ref_h, 8, w, h, ext, &off)) {
+      src = ext + es * 4 + 4; stride = es;                /* orig_topleft: half the filter size inside the copy */
+    } else {
+      src = ref + off + (long)ref_w * 4 + 4; stride = ref_w;
+    }
+    orc_sample_14bit_quarterpel_luma(src, stride, w, h, hp, w, mv);
+    free(ext);
+  } else {
+    for (int r = 0; r < h; ++r)
+      for (int c = 0; c < w; ++c)
+        px[r * w + c] = ref[ORC_CLIP(0, ref_h - 1, iy + r) * ref_w + ORC_CLIP(0, ref_w - 1, ix + c)];
+  }
+}
+
+unsigned orc_bipred_luma_satd(const orc_pixel *pic, int pic_stride, const orc_pixel *ref0, const orc_pixel *ref1, int ref_w, int ref_h,
+                              int x, int y, int w, int h, const int16_t mv0[2], const int16_t mv1[2], orc_pixel *out)
+{
+  int16_t *hp0 = (int16_t *)malloc((size_t)w * h * 2), *hp1 = (int16_t *)malloc((size_t)w * h * 2);
+  orc_pixel *px0 = (orc_pixel *)malloc((size_t)w * h), *px1 = (orc_pixel *)malloc((size_t)w * h), *pred = (orc_pixel *)malloc((size_t)w * h);
+  int hi0, hi1;
+  bipred_luma_part(ref0, ref_w, ref_h, x, y, w, h, mv0, &hi0, hp0, px0);
+  bipred_luma_part(ref1, ref_w, ref_h, x, y, w, h, mv1, &hi1, hp1, px1);
+  orc_bipred_blend_plane(w, h, hi0, hp0, px0, w, hi1, hp1, px1, w, pred, w);
+  /* search_inter.c:1359-1362: kvz_satd_any_size(width, height, rec, LCU_WIDTH, src, stride) */
+  const unsigned cost = orc_satd_any_size(w, h, pred, w, pic + (long)y * pic_stride + x, pic_stride);
+  if (out) memcpy(out, pred, (size_t)w * h);
+  free(hp0); free(hp1); free(px0); free(px1); free(pred);
+  return cost;
+}

@@ -234,6 +234,14 @@ int orc_sao_band_ddistortion(const orc_pixel *orig, const orc_pixel *rec, int bw
 /* calc_sao_bands (sao.c:247-261): accumulates into sao_bands */
 void orc_calc_sao_bands(const orc_pixel *orig, const orc_pixel *rec, int bw, int bh, int sao_bands[2][32]);
 
+/* ---- bi-prediction candidate cost (search_pu_inter_bipred, search_inter.c:1304-1440): the luma of
+ * kvz_inter_recon_bipred (inter.c:430-477: per reference a 14-bit quarter-pel sample, inter.c:86-122, when its vector is
+ * fractional, else the clamped pixels, inter.c:277-298, << 6; blended by inter_recon_bipred_generic) scored with
+ * satd_any_size against the source block.  mv0 / mv1 quarter-pel; ref0 / ref1 planes of one size.  out (may be NULL)
+ * receives the w x h prediction. */
+unsigned orc_bipred_luma_satd(const orc_pixel *pic, int pic_stride, const orc_pixel *ref0, const orc_pixel *ref1, int ref_w, int ref_h,
+                              int x, int y, int w, int h, const int16_t mv0[2], const int16_t mv1[2], orc_pixel *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,3 +111,37 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   res->merge_idx = idx;
   if (!res->merged) res->mv_cand = select_mv_cand(&state, info.mv_cand, info.best_mv.x, info.best_mv.y, NULL);
 }
+
+/* luma of kvz_inter_recon_bipred (inter.c:430-477) + kvz_satd_any_size against the source, as search_pu_inter_bipred
+ * scores a candidate pair (search_inter.c:1349-1362); two reference pictures of the frame's size; 4:0:0 so that the
+ * fabricated pictures need no chroma planes.  pred_out (may be NULL) receives the w x h prediction. */
+#include "inter.h"
+unsigned ref_bipred_luma_satd(const kvz_pixel *pic_y, const kvz_pixel *ref0_y, const kvz_pixel *ref1_y, int frame_w, int frame_h,
+                              int x, int y, int w, int h, const int16_t *mv0, const int16_t *mv1, kvz_pixel *pred_out)
+{
+  static encoder_control_t ctrl;
+  static encoder_state_t state;
+  static encoder_state_config_tile_t tile;
+  static videoframe_t vframe;
+  memset(&ctrl, 0, sizeof(ctrl)); memset(&state, 0, sizeof(state)); memset(&tile, 0, sizeof(tile)); memset(&vframe, 0, sizeof(vframe));
+  ctrl.bitdepth = 8;
+  ctrl.cfg.bipred = 1;
+  ctrl.chroma_format = KVZ_CSP_400;
+  vframe.width = frame_w; vframe.height = frame_h;
+  tile.frame = &vframe;
+  state.encoder_control = &ctrl;
+  state.tile = &tile;
+  kvz_picture r0, r1;
+  memset(&r0, 0, sizeof(r0)); memset(&r1, 0, sizeof(r1));
+  r0.y = (kvz_pixel *)ref0_y; r0.width = frame_w; r0.height = frame_h; r0.stride = frame_w;
+  r1.y = (kvz_pixel *)ref1_y; r1.width = frame_w; r1.height = frame_h; r1.stride = frame_w;
+  lcu_t *lcu = calloc(1, sizeof(lcu_t));
+  int16_t mv[2][2] = { { mv0[0], mv0[1] }, { mv1[0], mv1[1] } };
+  kvz_inter_recon_bipred(&state, &r0, &r1, x, y, w, h, mv, lcu);
+  const kvz_pixel *rec = &lcu->rec.y[(y % LCU_WIDTH) * LCU_WIDTH + (x % LCU_WIDTH)];
+  const unsigned cost = kvz_satd_any_size(w, h, rec, LCU_WIDTH, pic_y + (size_t)y * frame_w + x, frame_w);
+  if (pred_out)
+    for (int r = 0; r < h; ++r) memcpy(pred_out + (size_t)r * w, rec + r * LCU_WIDTH, (size_t)w);
+  free(lcu);
+  return cost;
+}

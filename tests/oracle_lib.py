@@ -446,3 +446,17 @@ def sao_reconstruct_color(plane, x, y, bw, bh, sao14, color):
     s = _sao17(sao14)
     L.orc_sao_reconstruct_color(plane.ctypes.data + y * stride + x, out.ctypes.data, _p(s, C.POINTER(C.c_int32)), stride, bw, bw, bh, color)
     return out
+
+
+# ---- bi-prediction candidate cost ----
+def bipred_luma_satd(pic, ref0, ref1, x, y, w, h, mv0, mv1):
+    """-> (cost, w x h prediction)"""
+    L = lib()
+    L.orc_bipred_luma_satd.restype = C.c_uint
+    L.orc_bipred_luma_satd.argtypes = [u8p, C.c_int, u8p, u8p, C.c_int, C.c_int] + [C.c_int] * 4 + [i16p, i16p, u8p]
+    pic, ref0, ref1 = _u8(pic), _u8(ref0), _u8(ref1)
+    a, b = np.ascontiguousarray(mv0, dtype=np.int16), np.ascontiguousarray(mv1, dtype=np.int16)
+    out = np.zeros((h, w), dtype=np.uint8)
+    c = L.orc_bipred_luma_satd(_p(pic, u8p), pic.shape[1], _p(ref0, u8p), _p(ref1, u8p), ref0.shape[1], ref0.shape[0], x, y, w, h,
+                               _p(a, i16p), _p(b, i16p), _p(out, u8p))
+    return c, out

@@ -624,3 +624,28 @@ def test_sao_reconstruct_plane(api, color):
     bad = [(0, 0, 8, 8, 0), (W - 8, H - 8, 8, 8, 0), (4, 4, 8, 8, 3)]
     edge[0, 1] = 2
     np.testing.assert_array_equal(api.sao_reconstruct_color_batch(plane, bad, edge, color), plane)
+
+
+def test_bipred_candidate_cost(api):
+    """search_pu_inter_bipred's candidate score for integer / half / quarter-pel vector pairs, inside and across the frame"""
+    g = rng(91)
+    pic, ref0 = me_frames(192, 128, 12, (2, -1))
+    _, ref1 = me_frames(192, 128, 13, (-3, 2))
+    ref1 = np.where(g.integers(0, 40, ref1.shape) == 0, 255, ref1).astype(np.uint8)
+    cands = []
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (32, 64), (24, 8)):
+        for k in range(14):
+            x = int(g.integers(0, 3)) * 64 + int(g.integers(0, (64 - w) // 8 + 1)) * 8
+            y = int(g.integers(0, 2)) * 64 + int(g.integers(0, (64 - h) // 8 + 1)) * 8
+            big = 400 if k % 5 == 4 else 24
+            mv0, mv1 = g.integers(-big, big + 1, 2), g.integers(-big, big + 1, 2)
+            if k % 3 == 0:
+                mv0 = (mv0 // 4) * 4
+            if k % 4 == 1:
+                mv1 = (mv1 // 4) * 4
+            cands.append((x, y, w, h, int(mv0[0]), int(mv0[1]), int(mv1[0]), int(mv1[1])))
+    got = api.bipred_cost_batch(pic, ref0, ref1, cands)
+    for c, v in zip(cands, got):
+        assert v == O.bipred_luma_satd(pic, ref0, ref1, c[0], c[1], c[2], c[3], c[4:6], c[6:8])[0], c
+    bad = api.bipred_cost_batch(pic, ref0, ref1, [(0, 0, 12, 8, 0, 0, 0, 0), (190, 0, 8, 8, 0, 0, 0, 0)])
+    assert (bad == 0xFFFFFFFF).all()

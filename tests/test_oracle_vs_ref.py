@@ -384,3 +384,27 @@ def test_sao_info_layout_matches_the_mirror_used_by_the_drop_in():
     L = R.lib()
     L.ref_sizeof_sao_info.restype = C.c_int
     assert L.ref_sizeof_sao_info() == 17 * 4
+
+
+def test_bipred_candidate_cost():
+    """search_pu_inter_bipred's candidate score: luma of kvz_inter_recon_bipred + satd_any_size, for integer, half- and
+    quarter-pel vector pairs, inside the frame and across its borders"""
+    g = rng(91)
+    pic, ref0 = me_frames(192, 128, 12, (2, -1))
+    _, ref1 = me_frames(192, 128, 13, (-3, 2))
+    ref1 = np.where(g.integers(0, 40, ref1.shape) == 0, 255, ref1).astype(np.uint8)
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (32, 64), (24, 8)):
+        for k in range(14):
+            # a PU never straddles an LCU (the reference writes the prediction into the 64x64 lcu->rec)
+            x = int(g.integers(0, 3)) * 64 + int(g.integers(0, (64 - w) // 8 + 1)) * 8
+            y = int(g.integers(0, 2)) * 64 + int(g.integers(0, (64 - h) // 8 + 1)) * 8
+            big = 400 if k % 5 == 4 else 24
+            mv0, mv1 = g.integers(-big, big + 1, 2), g.integers(-big, big + 1, 2)
+            if k % 3 == 0:
+                mv0 = (mv0 // 4) * 4
+            if k % 4 == 1:
+                mv1 = (mv1 // 4) * 4
+            a = O.bipred_luma_satd(pic, ref0, ref1, x, y, w, h, mv0, mv1)
+            b = R.bipred_luma_satd(pic, ref0, ref1, x, y, w, h, mv0, mv1)
+            assert a[0] == b[0], (w, h, x, y, mv0, mv1)
+            np.testing.assert_array_equal(a[1], b[1])
