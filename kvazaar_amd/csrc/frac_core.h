@@ -135,7 +135,7 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
       __builtin_memcpy(&y.x, b, 4); __builtin_memcpy(&y.y, b + 4, 4); __builtin_memcpy(&y.z, b + cand_stride, 4); __builtin_memcpy(&y.w, b + cand_stride + 4, 4);
       u32 m = satd8_quad_part(x, y, m1, m2);
       m = group_sum<4>(m);
-      if (p == 0) atomicAdd(&s_cost[k], (m + 1) >> 1);
+      if (p == 0) atomicAdd(&s_cost[k], (m + 2) >> 2);
     }
     sync();
   };

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void bipred_cost_kernel(const u8 *__restrict__
       const uint2 a0 = *(const uint2 *)a, a1 = *(const uint2 *)(a + w), b0 = *(const uint2 *)b, b1 = *(const uint2 *)(b + w);
       u32 m = satd8_quad_part(make_uint4(a0.x, a0.y, a1.x, a1.y), make_uint4(b0.x, b0.y, b1.x, b1.y), m1, m2);
       m = group_sum<4>(m);
-      if (p == 0) acc += (m + 1) >> 1;
+      if (p == 0) acc += (m + 2) >> 2;
     }
     acc = group_sum<64>(acc);
     if ((tid & 63) == 0 && acc) atomicAdd(&s_cost, acc);

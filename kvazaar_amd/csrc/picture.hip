@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void satd8_kernel(const u8 *__restrict__ a, co
       u32 m = satd8_quad_part(x[u], y[u], m1, m2);
       m += dpp_mov<0xB1>(m);
       m += dpp_mov<0x4E>(m);
-      r[u] = (m + 1) >> 1;
+      r[u] = (m + 2) >> 2;
     }
     // lane (g = lane >> 2, p = lane & 3) stores result p of quad g: one coalesced 256-byte store per wave
     const int g = lane >> 2, p = lane & 3;
@@ -281,13 +281,13 @@ __device__ __forceinline__ u32 satd16_row_part(uint4 x, uint4 y, v2s m1, v2s m2,
       u = u * m2 + t;
       t = dpp_xor4_v2s(u);               // row bit 2
       u = u * m4 + t;
-      acc += absmax_halves(u);           // column bit 0 folded
+      acc = abs_last_stage(u, acc);      // column bit 0 and the absolute sum
     }
     // sum over the 8 rows of the sub-block, then its rounding
     acc += dpp_mov<0xB1>(acc);
     acc += dpp_mov<0x4E>(acc);
     acc += dpp_xor4_u32(acc);
-    m[s] = (acc + 1) >> 1;
+    m[s] = (acc + 2) >> 2;
   }
   u32 r = m[0] + m[1];                   // top (lanes 0-7) or bottom (lanes 8-15) pair of sub-blocks
   r += dpp_mov<0x128>(r);                // row_ror:8 -> the other pair

@@ -118,8 +118,8 @@ __device__ __forceinline__ v2s dpp_v2s(v2s v)
   return as_v2s((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(v), CTRL, 0xF, 0xF, true));
 }
 
-// x, y: the lane's 16-byte chunk of each block (rows 2p and 2p+1).  Returns the
-// lane's share of m = sum max(|a|,|b|); the block's SATD is (sum over the quad + 1) >> 1.
+// x, y: the lane's 16-byte chunk of each block (rows 2p and 2p+1).  Returns the lane's share of the
+// block's absolute Hadamard sum; the block's SATD is (sum over the quad + 2) >> 2.
 __device__ __forceinline__ u32 satd8_quad_part(uint4 x, uint4 y, v2s m1, v2s m2)
 {
   v2s d[2][4];
@@ -142,7 +142,7 @@ __device__ __forceinline__ u32 satd8_quad_part(uint4 x, uint4 y, v2s m1, v2s m2)
     v2s u = w[i] * m1 + t;
     t = dpp_v2s<0x4E>(u);                // quad_perm [2,3,0,1]: row bit 2
     u = u * m2 + t;
-    m += absmax_halves(u);               // column bit 0 folded into the absolute sum
+    m = abs_last_stage(u, m);            // column bit 0 and the absolute sum
   }
   return m;
 }
