@@ -451,21 +451,36 @@ __global__ __launch_bounds__(256) void pair_sad_kernel(plane_t p1, plane_t p2, c
       const int w = d.width, h = SSD ? d.width : d.height;
       const int spr = (w + 7) >> 3;
       const int nseg = spr * h;
-      for (int t = sub; t < nseg; t += 8) {
-        const int y = t / spr, sx = (t - y * spr) << 3;
-        const int n = (w - sx) < 8 ? (w - sx) : 8;
-        uint2 a = load_seg8(p1, d.x1 + sx, d.y1 + y, n);
-        uint2 b = load_seg8(p2, d.x2 + sx, d.y2 + y, n);
-        if (SSD) {
+      // four segments per lane in flight (a 64x64 pair is 64 segments per lane; issued one at a time their latencies
+      // add up); segments past the end load nothing and contribute zeros.  Measured alternative: a second launch
+      // that gives large pairs a whole wave is 1.5-3x faster on them but its fixed cost doubles the time of the
+      // (far more common) small-pair batches, which are launch bound at a few microseconds.
+      for (int t0 = sub; t0 < nseg; t0 += 32) {
+        uint2 a[4], b[4];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            int e0 = (int)((a.x >> (8 * k)) & 255) - (int)((b.x >> (8 * k)) & 255);
-            int e1 = (int)((a.y >> (8 * k)) & 255) - (int)((b.y >> (8 * k)) & 255);
-            acc += (u32)(e0 * e0 + e1 * e1);
+        for (int k = 0; k < 4; ++k) {
+          const int t = t0 + 8 * k;
+          a[k] = make_uint2(0u, 0u); b[k] = a[k];
+          if (t < nseg) {
+            const int y = t / spr, sx = (t - y * spr) << 3;
+            const int n = (w - sx) < 8 ? (w - sx) : 8;
+            a[k] = load_seg8(p1, d.x1 + sx, d.y1 + y, n);
+            b[k] = load_seg8(p2, d.x2 + sx, d.y2 + y, n);
           }
-        } else {
-          acc = sad_dword(a.x, b.x, acc);
-          acc = sad_dword(a.y, b.y, acc);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (SSD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              int e0 = (int)((a[k].x >> (8 * q)) & 255) - (int)((b[k].x >> (8 * q)) & 255);
+              int e1 = (int)((a[k].y >> (8 * q)) & 255) - (int)((b[k].y >> (8 * q)) & 255);
+              acc += (u32)(e0 * e0 + e1 * e1);
+            }
+          } else {
+            acc = sad_dword(a[k].x, b[k].x, acc);
+            acc = sad_dword(a[k].y, b[k].y, acc);
+          }
         }
       }
     }
