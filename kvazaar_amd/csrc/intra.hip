@@ -13,9 +13,10 @@
 //                          against 35 predictions + 35 Hadamard transforms.
 //
 // Angular modes are evaluated in the reference's "vertical" orientation (rows advance along the
-// prediction direction) from an extended main reference e[-N .. 2N] held in LDS; horizontal
-// modes are the transpose, and because SATD / SAD are invariant under transposing both blocks
-// the rough kernel compares them against the transposed original instead of flipping.
+// prediction direction) from the main reference as staged in LDS -- extended below index -1 by
+// the projected side reference only for the modes that need it; horizontal modes are the
+// transpose, and because SATD / SAD are invariant under transposing both blocks the rough
+// kernel compares them against the transposed original instead of flipping.
 #include "kvz_hip_internal.h"
 #include "satd_regs.h"
 
