@@ -148,38 +148,81 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   int best_x = 0, best_y = 0;                          // info->best_mv, integer-pel here
   u32 best_cost = 0xffffffffu, best_bits = 0;
 
+  // Exhaustive search only: the reference pixels of one (2R+1)^2 window, staged in LDS behind the current block
+  // (the fractional stage's buffers are idle until the integer search is over) when they fit.
+  u8 *const s_win = lds + G::P_BYTES + G::CUR_BYTES;
+  constexpr int WIN_BYTES = G::TOTAL - (G::P_BYTES + G::CUR_BYTES);
+  int win_cx = 0, win_cy = 0, win_R = 0, win_stride = 0;
+  bool win_on = false;
+
+  const bool seg_pow2 = (segs & (segs - 1)) == 0 && segs >= 8;
+  const int run = segs < 64 ? segs : 64;
+
   // SADs of candidates 0 .. n-1 (offsets in sh->cx / cy, written by the caller) -> sh->sad
   auto group_sads = [&](int n) {
     if (tid < ME_GROUP) sh->sad[tid] = 0;
     sync();
     for (int it = tid; it < n * segs; it += T) {
       const int k = it / segs, s = it - k * segs, y = s / w8, x = (s - y * w8) * 8;
-      const int rx = pu.x + sh->cx[k] + x, ry = pu.y + sh->cy[k] + y;
       const uint2 c = *(const uint2 *)(s_cur + y * G::CS + x);
       uint2 r;
-      if (rx >= 0 && rx + 8 <= ref.w && ry >= 0 && ry < ref.h) {
-        __builtin_memcpy(&r, ref.p + (size_t)ry * ref.stride + rx, 8);
+      if (win_on) {
+        // 8 bytes at a byte-granular column of the window: aligned dwords + v_alignbyte (unaligned wide DS reads replay)
+        const int col = sh->cx[k] - win_cx + win_R + x, row = sh->cy[k] - win_cy + win_R + y;
+        const u32 *q = (const u32 *)(s_win + row * win_stride + (col & ~3));
+        const u32 sh8 = (u32)col & 3u;
+        const u32 d0 = q[0], d1 = q[1], d2 = q[2];
+        r.x = __builtin_amdgcn_alignbyte(d1, d0, sh8);
+        r.y = __builtin_amdgcn_alignbyte(d2, d1, sh8);
       } else {
-        u32 b[8];
+        const int rx = pu.x + sh->cx[k] + x, ry = pu.y + sh->cy[k] + y;
+        if (rx >= 0 && rx + 8 <= ref.w && ry >= 0 && ry < ref.h) {
+          __builtin_memcpy(&r, ref.p + (size_t)ry * ref.stride + rx, 8);
+        } else {
+          u32 b[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = ref_px(ref, rx + i, ry);
-        r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+          for (int i = 0; i < 8; ++i) b[i] = ref_px(ref, rx + i, ry);
+          r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+          r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        }
       }
-      atomicAdd(&sh->sad[k], __builtin_amdgcn_sad_u8(c.y, r.y, __builtin_amdgcn_sad_u8(c.x, r.x, 0u)));
+      u32 v = __builtin_amdgcn_sad_u8(c.y, r.y, __builtin_amdgcn_sad_u8(c.x, r.x, 0u));
+      if (seg_pow2) {
+        // the lanes that share a candidate are an aligned run of min(segs, 64): add them up in registers first --
+        // 32 lanes hitting one LDS address with an atomic serialise (this was the cost of the exhaustive search)
+        v = run == 8 ? group_sum<8>(v) : run == 16 ? group_sum<16>(v) : run == 32 ? group_sum<32>(v) : group_sum<64>(v);   // DPP up to 16 lanes
+        if (((tid & 63) & (run - 1)) == 0) atomicAdd(&sh->sad[k], v);
+      } else {
+        atomicAdd(&sh->sad[k], v);
+      }
     }
     sync();
   };
-  // check_mv_cost (:195-232) on candidate k of the evaluated group; true if it became the best
-  auto take = [&](int k) -> bool {
-    const int x = sh->cx[k], y = sh->cy[k];
-    if (!mvc.within(x * 4, y * 4)) return false;
-    u32 cost = sh->sad[k], bits = 0;
-    if (cost >= best_cost) return false;
-    cost += mvc.cost(x, y, 2, bits);
-    if (cost >= best_cost) return false;
-    best_x = x; best_y = y; best_cost = cost; best_bits = bits;
-    return true;
+  // check_mv_cost (:195-232) over the evaluated group at once.  The reference walks the candidates in order and
+  // replaces the best on a strictly smaller cost, i.e. it ends on the FIRST candidate that attains the group's minimum,
+  // provided that minimum beats the incoming best -- and that candidate is also the last one that "improved", which is
+  // what the patterns record as best_index.  Lane k prices candidate k; a wave-wide minimum and a ballot pick the
+  // same winner.  Returns its index in the group, or -1 when nothing improved.  (Every wave of a workgroup computes
+  // this redundantly from the same LDS values, so the result is uniform without another barrier.)
+  auto decide = [&](int n) -> int {
+    const int k = tid & 63;
+    u32 cost = 0xffffffffu, bits = 0;
+    int x = 0, y = 0;
+    if (k < n) {
+      x = sh->cx[k]; y = sh->cy[k];
+      if (mvc.within(x * 4, y * 4)) cost = sh->sad[k] + mvc.cost(x, y, 2, bits);   // < 2^32: lambda_cost is bounded by the entry
+    }
+    u32 m = cost;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 o = (u32)__shfl_xor((int)m, off, 64);
+      m = o < m ? o : m;
+    }
+    if (m >= best_cost) return -1;
+    const int win = __builtin_ctzll(__ballot(cost == m));
+    best_x = __shfl(x, win, 64); best_y = __shfl(y, win, 64);
+    best_cost = m; best_bits = (u32)__shfl((int)bits, win, 64);
+    return win;
   };
   auto set_cand = [&](int k, int x, int y) { if (tid == 0) { sh->cx[k] = x; sh->cy[k] = y; } };
 
@@ -190,26 +233,55 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     const int R = prm.search_range;
     int n = 0;
     sync();
-    auto push = [&](int x, int y) {
-      set_cand(n++, x, y);
-      if (n == ME_GROUP) {
+    auto flush = [&]() {
+      if (n > 0) {
         group_sads(n);
-        for (int k = 0; k < n; ++k) take(k);
+        decide(n);
         n = 0;
         sync();
       }
     };
+    auto push = [&](int x, int y) {
+      set_cand(n++, x, y);
+      if (n == ME_GROUP) flush();
+    };
+    // a window's (w + 2R) x (h + 2R) reference pixels (edge replicated, image.c:320-444) go to LDS when they fit
+    auto begin_window = [&](int cx, int cy) {
+      flush();
+      const int stride = ((w + 2 * R + 3) & ~3) + 4, rows = h + 2 * R;
+      win_on = stride * rows <= WIN_BYTES;
+      if (win_on) {
+        win_cx = cx; win_cy = cy; win_R = R; win_stride = stride;
+        const int x0 = pu.x + cx - R, y0 = pu.y + cy - R, wq = stride >> 2;
+        for (int i = tid; i < wq * rows; i += T) {
+          const int y = i / wq, q = (i - y * wq) * 4;
+          u32 v;
+          if (x0 + q >= 0 && x0 + q + 4 <= ref.w && y0 + y >= 0 && y0 + y < ref.h) {
+            __builtin_memcpy(&v, ref.p + (size_t)(y0 + y) * ref.stride + x0 + q, 4);
+          } else {
+            v = (u32)ref_px(ref, x0 + q, y0 + y) | ((u32)ref_px(ref, x0 + q + 1, y0 + y) << 8) |
+                ((u32)ref_px(ref, x0 + q + 2, y0 + y) << 16) | ((u32)ref_px(ref, x0 + q + 3, y0 + y) << 24);
+          }
+          *(u32 *)(s_win + y * stride + q) = v;
+        }
+        sync();
+      }
+    };
+    begin_window(0, 0);
     for (int y = -R; y <= R; ++y)
       for (int x = -R; x <= R; ++x) push(x, y);
     const int ex = pu.extra_mv[0] >> 2, ey = pu.extra_mv[1] >> 2;
-    if (!mvc.in_merge(ex, ey))
+    if (!mvc.in_merge(ex, ey)) {
+      begin_window(ex, ey);
       for (int y = -R; y <= R; ++y)
         for (int x = -R; x <= R; ++x) push(ex + x, ey + y);
+    }
 #pragma unroll                                              // i and j are unrolled so that mx[] / my[] stay in registers
     for (int i = 0; i < 5; ++i) {
       if (!(mvc.usable >> i & 1u)) continue;
       const int cx0 = mvc.mx[i] >> 2, cy0 = mvc.my[i] >> 2;        // plain shift here (:917-920)
       if (cx0 == 0 && cy0 == 0) continue;
+      begin_window(cx0, cy0);
       for (int y = cy0 - R; y <= cy0 + R; ++y)
         for (int x = cx0 - R; x <= cx0 + R; ++x) {
           if (!mvc.within(x * 4, y * 4)) continue;
@@ -230,10 +302,8 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
           if (!tested) push(x, y);
         }
     }
-    if (n > 0) {
-      group_sads(n);
-      for (int k = 0; k < n; ++k) take(k);
-    }
+    flush();
+    win_on = false;
     done = true;
   }
 
@@ -254,7 +324,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     }
   }
   group_sads(n);
-  for (int k = 0; k < n; ++k) take(k);
+  decide(n);
   }
 
   // ---- early_terminate (:415-460) ----
@@ -265,9 +335,8 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
       sync();
       for (int i = first; i <= last; ++i) set_cand(i - first, mvx + c_et_hex[i][0], mvy + c_et_hex[i][1]);
       group_sads(last - first + 1);
-      int best_index = 6;
-      for (int i = first; i <= last; ++i)
-        if (take(i - first)) best_index = i;
+      const int hit = decide(last - first + 1);
+      const int best_index = hit >= 0 ? first + hit : 6;
       mvx += c_et_hex[best_index][0]; mvy += c_et_hex[best_index][1];
       if ((double)best_cost >= threshold) done = true;
       first = (best_index + 3) % 4;
@@ -287,10 +356,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
         set_cand(4, sx + hd, sy + hd); set_cand(5, sx + hd, sy - hd); set_cand(6, sx - hd, sy - hd); set_cand(7, sx - hd, sy + hd);
       }
       group_sads(n);
-      bool improved = false;
-      for (int k = 0; k < n; ++k)
-        if (take(k)) improved = true;
-      if (improved) best_dist = dist;
+      if (decide(n) >= 0) best_dist = dist;
     };
     int sx = best_x, sy = best_y, rounds = 0;
     for (int dist = 1; dist <= 96; dist *= 2) {
@@ -318,8 +384,10 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     sync();
     for (int i = 0; i < 5; ++i) set_cand(i, mvx + c_diamond[i][0], mvy + c_diamond[i][1]);
     group_sads(5);
-    for (int i = 0; i < 5; ++i)
-      if (take(i)) best_index = i;
+    {
+      const int hit = decide(5);
+      if (hit >= 0) best_index = hit;
+    }
     if (best_index != 4) {
       mvx += c_diamond[best_index][0]; mvy += c_diamond[best_index][1];
       int from_dir = 4;
@@ -335,8 +403,8 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
           set_cand(n++, mvx + c_diamond[i][0], mvy + c_diamond[i][1]);
         }
         group_sads(n);
-        for (int k = 0; k < n; ++k)
-          if (take(k)) { best_index = idx[k]; better = true; }
+        const int hit = decide(n);
+        if (hit >= 0) { best_index = hit == 0 ? idx[0] : (hit == 1 ? idx[1] : (hit == 2 ? idx[2] : idx[3])); better = true; }
         if (better) {
           mvx += c_diamond[best_index][0]; mvy += c_diamond[best_index][1];
           from_dir = best_index ^ 3;
@@ -350,8 +418,10 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     sync();
     for (int i = 1; i < 7; ++i) set_cand(i - 1, mvx + c_large_hex[i][0], mvy + c_large_hex[i][1]);
     group_sads(6);
-    for (int i = 1; i < 7; ++i)
-      if (take(i - 1)) best_index = i;
+    {
+      const int hit = decide(6);
+      if (hit >= 0) best_index = hit + 1;
+    }
     while (best_index != 0 && steps != 0) {
       steps -= 1;
       const int start = best_index == 1 ? 6 : (best_index == 8 ? 1 : best_index - 1);
@@ -360,13 +430,13 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
       sync();
       for (int i = 0; i < 3; ++i) set_cand(i, mvx + c_large_hex[start + i][0], mvy + c_large_hex[start + i][1]);
       group_sads(3);
-      for (int i = 0; i < 3; ++i)
-        if (take(i)) best_index = start + i;
+      const int hit = decide(3);
+      if (hit >= 0) best_index = start + hit;
     }
     sync();
     for (int i = 1; i < 9; ++i) set_cand(i - 1, mvx + c_small_hex[i][0], mvy + c_small_hex[i][1]);
     group_sads(8);
-    for (int i = 1; i < 9; ++i) take(i - 1);
+    decide(8);
   }
 
   // ---- search_frac, or the SATD re-cost of :1236-1248 when cfg.fme_level == 0 ----
@@ -446,6 +516,10 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   KVZ_CHECK_CTX();
   if (!pic || !ref || !pus || !params || !results || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0) {
     set_error_msg("kvz_hip_search_pu_batch: null buffer or empty plane");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  if (params->lambda_cost < 0 || params->lambda_cost > (1 << 20)) {
+    set_error_msg("kvz_hip_search_pu_batch: lambda_cost must be within 0 .. 2^20 (costs are 32-bit like the reference's)");
     return KVZ_HIP_ERR_INVALID;
   }
   if (params->fme_level < 0 || params->fme_level > 4 || params->early_termination < 0 || params->early_termination > 2 ||
