@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void search_frac_big_kernel(const u8 *__restri
     if (tid < 2) best[(size_t)blockIdx.x * 2 + tid] = -1;
     return;
   }
-  if (d.width <= 16 && d.height <= 16) return;        // handled by search_frac_small_kernel
+  if (d.width <= 32 && d.height <= 32) return;        // handled by the one-wave-per-block kernels
   search_frac_core<64, 256, false>(tid, lds, pic, pic_stride, ref, d, 4, frac_no_cost(), costs + (size_t)blockIdx.x * 17, best + (size_t)blockIdx.x * 2);
 }
 
@@ -161,6 +161,24 @@ __global__ __launch_bounds__(256) void search_frac_small_kernel(const u8 *__rest
     search_frac_core<16, 64, true, frac_no_cost, 16, 16>(lane, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
   else
     search_frac_core<16, 64, true, frac_no_cost>(lane, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
+}
+
+// blocks up to 32x32 that are not the small kernel's: one wave per descriptor too (two per workgroup)
+__global__ __launch_bounds__(128) void search_frac_medium_kernel(const u8 *__restrict__ pic, u32 pic_stride, refplane_t ref,
+                                                                 const kvz_hip_block_pair *__restrict__ pairs, size_t count,
+                                                                 u32 *__restrict__ costs, i32 *__restrict__ best)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[2][(frac_geom<32>::TOTAL + 15) & ~15];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t i = (size_t)blockIdx.x * 2 + wv;
+  if (i >= count) return;
+  const kvz_hip_block_pair d = pairs[i];
+  if (!frac_shape_ok(d.width, d.height) || d.width > 32 || d.height > 32 || (d.width <= 16 && d.height <= 16)) return;
+  const int lane = threadIdx.x & 63;
+  if (d.width == 32 && d.height == 32)
+    search_frac_core<32, 64, true, frac_no_cost, 32, 32>(lane, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
+  else
+    search_frac_core<32, 64, true, frac_no_cost>(lane, lds[wv], pic, pic_stride, ref, d, 4, frac_no_cost(), costs + i * 17, best + i * 2);
 }
 
 // ---------------------------------------------------------------------------
@@ -382,11 +400,13 @@ int kvz_hip_search_frac_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, con
   if (count == 0) return KVZ_HIP_OK;
   if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
   refplane_t r = { ref, ref_stride, ref_w, ref_h };
-  // two passes over the same descriptor list: each kernel takes the size class it is built for and skips the rest
+  // three passes over the same descriptor list: each kernel takes the size class it is built for and skips the rest
   hipLaunchKernelGGL(search_frac_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, ctx_stream(s), pic, pic_stride, r, pairs, count, costs, best);
   KVZ_CHECK_LAUNCH("search_frac_small_kernel");
   hipLaunchKernelGGL(search_frac_big_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), pic, pic_stride, r, pairs, costs, best);
   KVZ_CHECK_LAUNCH("search_frac_big_kernel");
+  hipLaunchKernelGGL(search_frac_medium_kernel, dim3((unsigned)((count + 1) / 2)), dim3(128), 0, ctx_stream(s), pic, pic_stride, r, pairs, count, costs, best);
+  KVZ_CHECK_LAUNCH("search_frac_medium_kernel");
   return KVZ_HIP_OK;
 }
 

@@ -475,7 +475,7 @@ __device__ __forceinline__ void flag_bad(kvz_hip_me_result *out)
   *out = r;
 }
 
-// PUs larger than 16x16 (and malformed descriptors, which are flagged): one workgroup per PU
+// PUs larger than 32x32 in either direction (and malformed descriptors, which are flagged): one workgroup per PU
 __global__ __launch_bounds__(256) void search_pu_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                             const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
                                                             kvz_hip_me_result *__restrict__ out)
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void search_pu_big_kernel(const u8 *__restrict
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];            // uniform address: the compiler reads it with scalar loads
   if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
-  if (pu.width <= 16 && pu.height <= 16) return;       // search_pu_small_kernel's
+  if (pu.width <= 32 && pu.height <= 32) return;       // the one-wave-per-PU kernels'
   search_pu_core<64, 256, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
 
@@ -504,6 +504,24 @@ __global__ __launch_bounds__(256) void search_pu_small_kernel(const u8 *__restri
   if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else search_pu_core<16, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+}
+
+// PUs up to 32x32 that are not the small kernel's: one wave per PU as well (two per workgroup: 15 KiB of LDS each).
+// With a workgroup per PU a 32x32 search spent its time in barriers around little work per thread (11 M PUs/s).
+__global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
+                                                               const kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_me_params prm,
+                                                               kvz_hip_me_result *__restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[2][(frac_geom<32>::TOTAL + 15) & ~15];
+  __shared__ me_shared sh[2];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t i = (size_t)blockIdx.x * 2 + wv;
+  if (i >= count) return;
+  const kvz_hip_me_pu &pu = pus[i];
+  if (!pu_ok(pu, pic_w, pic_h) || pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
+  const int lane = threadIdx.x & 63;
+  if (pu.width == 32 && pu.height == 32) search_pu_core<32, 64, true, 32, 32>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  else search_pu_core<32, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
 }
 
 }  // namespace
@@ -537,5 +555,8 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   hipLaunchKernelGGL(search_pu_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
                      *params, results);
   KVZ_CHECK_LAUNCH("search_pu_small_kernel");
+  hipLaunchKernelGGL(search_pu_medium_kernel, dim3((unsigned)((count + 1) / 2)), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
+                     *params, results);
+  KVZ_CHECK_LAUNCH("search_pu_medium_kernel");
   return KVZ_HIP_OK;
 }

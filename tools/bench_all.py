@@ -110,7 +110,7 @@ def main():
         cases.append(("image_satd_frame_%dx%d" % (n, n), len(prs), 2 * n * n + 4 + 24,
                       lambda prs_d=prs_d, outp=outp, k=len(prs): L.kvz_hip_image_calc_satd_batch(picf.data_ptr(), W, reff.data_ptr(), W, W, F * H, prs_d.data_ptr(), k, outp.data_ptr(), st)))
     # ipol: quarter-pel luma samples and the fused fractional search, all blocks of 4 frames
-    for n in (8, 16, 64):
+    for n in (8, 16, 32, 64):
         blks = np.array([(x, f * H + y, int(fx), int(fy), n, n) for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)
                          for (fx, fy) in [rs.integers(0, 4, 2)]], dtype=np.int32)
         blks_d = torch.from_numpy(blks).to(dev)
@@ -129,7 +129,7 @@ def main():
 
     # whole-PU motion search (hexagon + fractional, with MV costs): every n x n PU of 4 frames
     me_prm = np.zeros(12, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
-    for n in (8, 16, 64):
+    for n in (8, 16, 32, 64):
         rows = [(x, f * H + y) for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)]
         pus = np.zeros((len(rows), 16), dtype=np.int32)
         pus[:, 0] = [r[0] for r in rows]; pus[:, 1] = [r[1] for r in rows]; pus[:, 2] = n; pus[:, 3] = n
