@@ -308,7 +308,9 @@ typedef struct {
   int32_t algorithm;             /* cfg.ime_algorithm: 0 hexbs (hexagon_search), 1 dia (diamond_search, :796-883), 2 tz (tz_search, :595-672),
                                     3 full (search_mv_full, :886-962; no early termination) */
   int32_t search_range;          /* algorithm 3 only: 8, 16, 32 or 64 (search_inter.c:1208-1215), any value 1..64 accepted */
-  int32_t reserved[2];
+  int32_t size_classes;          /* optional hint, 0 = unknown: OR of 1 (PUs up to 16x16), 2 (up to 32x32), 4 (larger) present in the
+                                    batch; the entry runs one kernel per size class and skips the launches for absent ones */
+  int32_t reserved;
 } kvz_hip_me_params;             /* 48 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */

@@ -550,13 +550,22 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
   hipStream_t st = ctx_stream(s);
   const refplane_t r = { ref, ref_stride, ref_w, ref_h };
-  hipLaunchKernelGGL(search_pu_big_kernel, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
-  KVZ_CHECK_LAUNCH("search_pu_big_kernel");
-  hipLaunchKernelGGL(search_pu_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
-                     *params, results);
-  KVZ_CHECK_LAUNCH("search_pu_small_kernel");
-  hipLaunchKernelGGL(search_pu_medium_kernel, dim3((unsigned)((count + 1) / 2)), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
-                     *params, results);
-  KVZ_CHECK_LAUNCH("search_pu_medium_kernel");
+  // one launch per size class over the same descriptor list; each kernel takes its class and skips the rest.  The big
+  // kernel also flags malformed descriptors, so it only goes when the caller vouches for the classes it names.
+  const int classes = (params->size_classes & 7) ? (params->size_classes & 7) : 7;
+  if (classes == 7 || (classes & 4)) {
+    hipLaunchKernelGGL(search_pu_big_kernel, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+    KVZ_CHECK_LAUNCH("search_pu_big_kernel");
+  }
+  if (classes & 1) {
+    hipLaunchKernelGGL(search_pu_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
+                       *params, results);
+    KVZ_CHECK_LAUNCH("search_pu_small_kernel");
+  }
+  if (classes & 2) {
+    hipLaunchKernelGGL(search_pu_medium_kernel, dim3((unsigned)((count + 1) / 2)), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
+                       *params, results);
+    KVZ_CHECK_LAUNCH("search_pu_medium_kernel");
+  }
   return KVZ_HIP_OK;
 }

@@ -1105,7 +1105,7 @@ void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, i
   in.mc.pu = pu; in.mc.prm = prm;
   if (prm->algorithm == 1) me_diamond(&in);
   else if (prm->algorithm == 2) me_tz(&in);
-  else if (prm->algorithm == 3) me_full(&in, prm->reserved[0]);
+  else if (prm->algorithm == 3) me_full(&in, prm->search_range);
   else me_hexagon(&in);
   if (prm->fme_level > 0 && in.best_cost < 0xffffffffu) {   /* inter_cost starts at its maximum (:1456) */
     int mv[2] = { in.best_mv[0] >> 2, in.best_mv[1] >> 2 };

@@ -200,8 +200,9 @@ typedef struct {
   int32_t ref_delay_px;          /* SAO_DELAY_PX (sao on), DEBLOCK_DELAY_PX (deblock only) or 0 */
   int32_t max_ref_lcu_down, max_ref_lcu_right;   /* ctrl->max_inter_ref_lcu */
   int32_t algorithm;             /* cfg.ime_algorithm: 0 hexbs (hexagon_search), 1 dia (diamond_search :796-883), 2 tz (tz_search :595-672),
-                                    3 full (search_mv_full :886-962) with search_range in reserved[0] (8, 16, 32 or 64) */
-  int32_t reserved[3];
+                                    3 full (search_mv_full :886-962) */
+  int32_t search_range;          /* algorithm 3: 8, 16, 32 or 64 (search_inter.c:1208-1215) */
+  int32_t size_classes, reserved;   /* launch hints of the GPU entry; unused here */
 } orc_me_params;                 /* 48 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */

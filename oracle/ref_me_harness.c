@@ -31,7 +31,7 @@ typedef struct {
   int32_t lambda_cost, early_termination;
   uint32_t max_steps;
   int32_t fme_level, wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right;
-  int32_t algorithm, reserved[3];
+  int32_t algorithm, search_range, size_classes, reserved;
 } me_params_t;
 typedef struct { int32_t mv[2]; uint32_t cost, bitcost; int32_t merged, merge_idx, mv_cand, reserved; } me_result_t;
 
@@ -92,7 +92,7 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   info.best_cost = UINT32_MAX;
   if (prm->algorithm == 1) diamond_search(&info, extra, prm->max_steps);
   else if (prm->algorithm == 2) tz_search(&info, extra);
-  else if (prm->algorithm == 3) search_mv_full(&info, prm->reserved[0], extra);
+  else if (prm->algorithm == 3) search_mv_full(&info, prm->search_range, extra);
   else hexagon_search(&info, extra, prm->max_steps);
   if (prm->fme_level > 0 && info.best_cost < UINT32_MAX) {
     search_frac(&info);

@@ -129,7 +129,7 @@ ME_PU = np.dtype([("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"
                   ("merge", [("mv", "<i2", (2,)), ("usable", "u1"), ("same_ref", "u1")], (5,)), ("pad", "<i2")])
 ME_PARAMS = np.dtype([("lambda_cost", "<i4"), ("early_termination", "<i4"), ("max_steps", "<u4"), ("fme_level", "<i4"),
                       ("wpp_owf", "<i4"), ("ref_delay_px", "<i4"), ("max_ref_lcu_down", "<i4"), ("max_ref_lcu_right", "<i4"),
-                      ("algorithm", "<i4"), ("reserved", "<i4", (3,))])
+                      ("algorithm", "<i4"), ("search_range", "<i4"), ("size_classes", "<i4"), ("reserved", "<i4")])
 ME_RESULT = np.dtype([("mv", "<i4", (2,)), ("cost", "<u4"), ("bitcost", "<u4"), ("merged", "<i4"), ("merge_idx", "<i4"),
                       ("mv_cand", "<i4"), ("reserved", "<i4")])
 assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 48 and ME_RESULT.itemsize == 32
@@ -141,7 +141,7 @@ def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_lev
     p["lambda_cost"], p["early_termination"], p["max_steps"], p["fme_level"] = lambda_cost, early_termination, max_steps, fme_level
     p["wpp_owf"], p["ref_delay_px"], p["max_ref_lcu_down"], p["max_ref_lcu_right"] = wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right
     p["algorithm"] = algorithm
-    p["reserved"][0, 0] = search_range
+    p["search_range"] = search_range
     return p
 
 

@@ -649,3 +649,14 @@ def test_bipred_candidate_cost(api):
         assert v == O.bipred_luma_satd(pic, ref0, ref1, c[0], c[1], c[2], c[3], c[4:6], c[6:8])[0], c
     bad = api.bipred_cost_batch(pic, ref0, ref1, [(0, 0, 12, 8, 0, 0, 0, 0), (190, 0, 8, 8, 0, 0, 0, 0)])
     assert (bad == 0xFFFFFFFF).all()
+
+
+def test_search_pu_size_class_hint(api):
+    """size_classes only prunes launches: with the hint naming the classes present the results are unchanged"""
+    pic, ref = me_frames(192, 128, 5, (4, 1))
+    for cls, sizes in ((1, ((8, 8), (16, 8), (16, 16))), (2, ((32, 32), (24, 16), (32, 8))), (4, ((64, 64), (64, 32), (48, 16))), (3, ((8, 8), (32, 32)))):
+        pus = me_random_pus(192, 128, 40, 50 + cls, sizes=sizes)
+        plain = api.search_pu_batch(pic, ref, pus, me_params())
+        prm = me_params()
+        prm["size_classes"] = cls
+        np.testing.assert_array_equal(api.search_pu_batch(pic, ref, pus, prm), plain)

@@ -135,10 +135,11 @@ def main():
         pus[:, 0] = [r[0] for r in rows]; pus[:, 1] = [r[1] for r in rows]; pus[:, 2] = n; pus[:, 3] = n
         pus_d = torch.from_numpy(pus).to(dev)
         res_d = torch.empty((len(rows), 8), dtype=torch.int32, device=dev)
+        cls_prm = me_prm.copy(); cls_prm[10] = 1 if n <= 16 else (2 if n <= 32 else 4)     # size_classes hint: one launch instead of three
         cases.append(("search_pu_%dx%d" % (n, n), len(rows), 2 * n * n + 96,
-                      lambda pus_d=pus_d, res_d=res_d, k=len(rows): L.kvz_hip_search_pu_batch(
+                      lambda pus_d=pus_d, res_d=res_d, k=len(rows), cls_prm=cls_prm: L.kvz_hip_search_pu_batch(
                           picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), k,
-                          me_prm.ctypes.data, res_d.data_ptr(), st)))
+                          cls_prm.ctypes.data, res_d.data_ptr(), st)))
         if n == 16:
             full_prm = me_prm.copy(); full_prm[8] = 3; full_prm[9] = 16        # --me full16: 1089 positions per PU
             kk = len(rows) // 8
