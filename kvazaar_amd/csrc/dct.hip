@@ -19,7 +19,7 @@ template <int N, int KIND>
 __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
 {
   constexpr int TPB = 256 / N;                       // blocks (TUs) per workgroup iteration
-  constexpr int LD = N >= 8 ? N + 8 : N;             // padded LDS row stride (int16), rows stay 16-byte aligned
+  constexpr int LD = lds_tile_ld(N);                 // LDS row stride (int16): an odd number of dwords, bank-conflict free
   constexpr int CPB = N * N / 8;                     // 16-byte chunks per block
   constexpr int CHUNKS = TPB * CPB;                  // per iteration
   __shared__ __attribute__((aligned(16))) i16 sa[TPB * N * LD];
@@ -37,8 +37,7 @@ __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ 
       const int t = c / CPB, e = (c % CPB) * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (first + t < count) v = ld_stream_u4(in + (first + t) * (size_t)(N * N) + e);
-      if (LD == N) *(uint4 *)(sa + t * N * LD + e) = v;
-      else *(uint4 *)(sa + t * N * LD + (e / N) * LD + (e % N)) = v;
+      lds_tile_store8<N, LD>(sa + t * N * LD, e, v);
     }
     __syncthreads();
     transform_2d_lds<N, KIND, LD>(sa + tu * N * LD, sb + tu * N * LD, row);
@@ -48,9 +47,7 @@ __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ 
     for (int c = tid; c < CHUNKS; c += 256) {
       const int t = c / CPB, e = (c % CPB) * 8;
       if (first + t < count) {
-        uint4 v;
-        if (LD == N) v = *(const uint4 *)(sa + t * N * LD + e);
-        else v = *(const uint4 *)(sa + t * N * LD + (e / N) * LD + (e % N));
+        const uint4 v = lds_tile_load8<N, LD>(sa + t * N * LD, e);
         st_stream_u4(out + (first + t) * (size_t)(N * N) + e, v);
       }
     }

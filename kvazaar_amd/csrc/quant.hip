@@ -253,19 +253,19 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
                                                                 u32 *__restrict__ ssd_out, u32 *__restrict__ abs_sum_out)
 {
   constexpr int TPB = 256 / N;
-  constexpr int LD = N >= 8 ? N + 8 : N;
+  constexpr int LD = lds_tile_ld(N);                 // odd number of dwords per row: bank-conflict free (transform_core.h)
   constexpr int LOG2N = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
   constexpr int TS_SHIFT = 15 - 8 - LOG2N;
   __shared__ __attribute__((aligned(16))) i16 sa[TPB * N * LD];     // residual / coefficients
   __shared__ __attribute__((aligned(16))) i16 sb[TPB * N * LD];     // transform scratch
-  __shared__ __attribute__((aligned(16))) i16 sq[TPB * N * N];      // quantized coefficients (row-major, unpadded)
+  __shared__ __attribute__((aligned(16))) i16 sq[TPB * N * LD];     // quantized coefficients (same padded rows)
   __shared__ int s_has[TPB];
 
   __shared__ __attribute__((aligned(16))) u8 sp[TPB * N * N];       // prediction, overwritten in place by the reconstruction
 
   const int tid = threadIdx.x, tu = tid / N, row = tid % N;
   const size_t ngroups = (count + TPB - 1) / TPB;
-  i16 *a = sa + tu * N * LD, *b = sb + tu * N * LD, *q = sq + tu * N * N;
+  i16 *a = sa + tu * N * LD, *b = sb + tu * N * LD, *q = sq + tu * N * LD;
   u8 *pp = sp + tu * N * N + row * N;
   constexpr int PCH = TPB * N * N / 16;              // 16-pixel chunks per group (64 .. 512)
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
         for (int i = 0; i < 8; ++i)
           o.s[i] = (i16)((int)((rr[2 * j + (i >> 2)] >> (8 * (i & 3))) & 255u) - (int)((pq[2 * j + (i >> 2)] >> (8 * (i & 3))) & 255u));
         const int ww = w + 8 * j;
-        *(uint4 *)(sa + t * N * LD + (ww / N) * LD + (ww % N)) = o.v;
+        lds_tile_store8<N, LD>(sa + t * N * LD, ww, o.v);
       }
     }
     if (row == 0) s_has[tu] = 0;
@@ -309,20 +309,20 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
     for (int x = 0; x < N; ++x) {
       const int n = row * N + x;
       const int v = quant_one(a[row * LD + x], k.qtable ? k.qtable[n] : k.flat_qc, k);
-      q[n] = (i16)v;
+      q[row * LD + x] = (i16)v;
       any |= v;
     }
     if (k.signhide) {
       __syncthreads();
       if (row == 0) {
-        struct lds_view { const i16 *p; int ld, n; __device__ int operator[](int i) const { return p[(i / n) * ld + (i % n)]; } };
-        lds_view cv = { a, LD, N };
-        sign_hide_block(cv, q, N, scan_order, k);
+        struct lds_view { i16 *p; int ld, n; __device__ i16 &operator[](int i) const { return p[(i / n) * ld + (i % n)]; } };
+        lds_view cv = { a, LD, N }, qv = { q, LD, N };
+        sign_hide_block(cv, qv, N, scan_order, k);
       }
       __syncthreads();
       any = 0;
 #pragma unroll
-      for (int x = 0; x < N; ++x) any |= q[row * N + x];
+      for (int x = 0; x < N; ++x) any |= q[row * LD + x];
     }
     if (any) atomicOr(&s_has[tu], 1);
     __syncthreads();
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
     // dequantize own row back into `a`, inverse transform (done for every TU so that
     // barriers stay uniform; the result is only used when has != 0)
 #pragma unroll
-    for (int x = 0; x < N; ++x) a[row * LD + x] = (i16)dequant_one(q[row * N + x], row * N + x, k);
+    for (int x = 0; x < N; ++x) a[row * LD + x] = (i16)dequant_one(q[row * LD + x], row * N + x, k);
     __syncthreads();
     if constexpr (TRK == 4) {
 #pragma unroll
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
 #pragma unroll
       for (int x = 0; x < N; ++x) {
         const int dd = (int)((rw[x >> 2] >> (8 * (x & 3))) & 255u) - (int)pp[x];
-        const int qq = q[row * N + x];
+        const int qq = q[row * LD + x];
         sq2 += (u32)(dd * dd);
         sab += (u32)(qq < 0 ? -qq : qq);
       }
@@ -377,9 +377,137 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
 #pragma unroll
     for (int c = tid; c < 2 * PCH; c += 256) {
       const int e = c * 8, t = e / (N * N);
-      if (first + t < count) *(uint4 *)(coeff_out + first * (size_t)(N * N) + e) = *(const uint4 *)(sq + e);
+      if (first + t < count) *(uint4 *)(coeff_out + first * (size_t)(N * N) + e) = lds_tile_load8<N, LD>(sq + t * N * LD, e % (N * N));
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 4x4 TUs: one lane per TU, the whole kvz_quantize_residual chain (quant-generic.c:180-273, rdoq off, no sign
+// hiding) in registers.  A TU is 16 bytes of ref and of pred: a lane's loads and stores are single 16-byte
+// accesses and a wave's are fully coalesced, so there is no LDS and no barrier.  (The LDS kernel below needed
+// nine barriers per 64 TUs and reached 2.2 TB/s.)
+// ---------------------------------------------------------------------------
+template <int TRK>     // 0 DCT, 2 DST (intra luma), 4 transform skip
+__global__ __launch_bounds__(256) void quantize_residual4_lane_kernel(const u8 *__restrict__ ref_in, const u8 *pred_in, u8 *rec_out,
+                                                                      i16 *__restrict__ coeff_out, i32 *__restrict__ has_coeffs,
+                                                                      size_t count, quant_consts k,
+                                                                      u32 *__restrict__ ssd_out, u32 *__restrict__ abs_sum_out)
+{
+  constexpr int TS_SHIFT = 15 - 8 - 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const uint4 rv = ld_stream_u4(ref_in + i * 16);
+    const uint4 pv = *(const uint4 *)(pred_in + i * 16);
+    const u32 rr[4] = { rv.x, rv.y, rv.z, rv.w }, pq[4] = { pv.x, pv.y, pv.z, pv.w };
+    int res[4][4], c[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) res[y][x] = (int)((rr[y] >> (8 * x)) & 255u) - (int)((pq[y] >> (8 * x)) & 255u);
+    if (TRK == 4) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) c[y][x] = (int)(i16)(res[y][x] << TS_SHIFT);
+    } else {
+      // dct-generic.c:567-576: two passes, each row -> transposed column (transform_core.h pass_1d)
+      int t1[4][4], w[4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        pass_1d<4, TRK>(res[y], w, 1);
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) t1[kx][y] = w[kx];
+      }
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        pass_1d<4, TRK>(t1[y], w, 8);
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) c[kx][y] = w[kx];
+      }
+    }
+    int q[4][4], any = 0;
+    u32 sab = 0;
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int n = y * 4 + x;
+        q[y][x] = quant_one(c[y][x], k.qtable ? k.qtable[n] : k.flat_qc, k);
+        any |= q[y][x];
+        sab += (u32)(q[y][x] < 0 ? -q[y][x] : q[y][x]);
+      }
+    const bool has = any != 0;
+    u32 out[4] = { pq[0], pq[1], pq[2], pq[3] };
+    if (has) {
+      int d[4][4], r2[4][4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) d[y][x] = (int)(i16)dequant_one(q[y][x], y * 4 + x, k);
+      if (TRK == 4) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) r2[y][x] = (int)(i16)((d[y][x] + (1 << (TS_SHIFT - 1))) >> TS_SHIFT);
+      } else {
+        // dct-generic.c:578-587: pass 1 columns of the input -> rows of tmp, pass 2 columns of tmp -> rows of out
+        int tmp[4][4], v[4], w[4];
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) v[kx] = d[kx][col];
+          pass_1d<4, TRK + 1>(v, w, 7);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) tmp[col][x] = w[x];
+        }
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+#pragma unroll
+          for (int kx = 0; kx < 4; ++kx) v[kx] = tmp[kx][col];
+          pass_1d<4, TRK + 1>(v, w, 12);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) r2[col][x] = w[x];
+        }
+      }
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        u32 wv = 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          int val = (int)(i16)(r2[y][x] + (int)((pq[y] >> (8 * x)) & 255u));             // quant-generic.c:255
+          // Keep the clamp away from the shift that produced r2: hipcc 7.2 fuses "(a >> 16) clamped to a byte, two at a
+          // time" into v_ashr_pk_u8_i32 and then ORs the next byte into the result assuming its upper half is zero,
+          // but gfx950 leaves the destination's upper 16 bits untouched -- every third pixel of a row came out
+          // OR-ed with the first (tests/test_abi.py keeps the instruction out of the build).
+          asm volatile("" : "+v"(val));
+          wv |= (u32)(val < 0 ? 0 : (val > 255 ? 255 : val)) << (8 * x);
+        }
+        out[y] = wv;
+      }
+    }
+    *(uint4 *)(rec_out + i * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+    uint4 c0, c1;
+    c0.x = (u32)(q[0][0] & 0xffff) | ((u32)q[0][1] << 16); c0.y = (u32)(q[0][2] & 0xffff) | ((u32)q[0][3] << 16);
+    c0.z = (u32)(q[1][0] & 0xffff) | ((u32)q[1][1] << 16); c0.w = (u32)(q[1][2] & 0xffff) | ((u32)q[1][3] << 16);
+    c1.x = (u32)(q[2][0] & 0xffff) | ((u32)q[2][1] << 16); c1.y = (u32)(q[2][2] & 0xffff) | ((u32)q[2][3] << 16);
+    c1.z = (u32)(q[3][0] & 0xffff) | ((u32)q[3][1] << 16); c1.w = (u32)(q[3][2] & 0xffff) | ((u32)q[3][3] << 16);
+    st_stream_u4(coeff_out + i * 16, c0);
+    st_stream_u4(coeff_out + i * 16 + 8, c1);
+    has_coeffs[i] = has ? 1 : 0;
+    if (ssd_out) {
+      u32 sq2 = 0;
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int dd = (int)((rr[y] >> (8 * x)) & 255u) - (int)((out[y] >> (8 * x)) & 255u);
+          sq2 += (u32)(dd * dd);
+        }
+      ssd_out[i] = sq2;
+      abs_sum_out[i] = sab;
+    }
   }
 }
 
@@ -471,6 +599,14 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   if (width == 16 && !use_trskip && !k.signhide && tuning("qr16_use_mfma", 1))
     return launch_quantize_residual16_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
                                            k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
+  if (width == 4 && !k.signhide && tuning("qr4_lane_kernel", 1)) {
+    const unsigned grid = stream_grid(count, 256, 16);
+    if (use_trskip) hipLaunchKernelGGL((quantize_residual4_lane_kernel<4>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
+    else if (dst) hipLaunchKernelGGL((quantize_residual4_lane_kernel<2>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
+    else hipLaunchKernelGGL((quantize_residual4_lane_kernel<0>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
+    KVZ_CHECK_LAUNCH("quantize_residual4_lane_kernel");
+    return KVZ_HIP_OK;
+  }
 #define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, 16)), dim3(256), 0, st, \
                                           ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, scan_order, k, ssd_out, abs_sum_out)
   switch (width) {

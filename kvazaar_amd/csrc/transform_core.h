@@ -142,6 +142,35 @@ __device__ __forceinline__ void pass_1d(const int (&in)[N], int (&out)[N], int s
   }
 }
 
+// Row stride (int16) of an N x N tile in LDS: N + 2 makes a row an ODD number of dwords, so the
+// row-per-thread accesses of transform_2d_lds (lane = row, consecutive lanes N + 2 int16 apart,
+// consecutive tiles N rows apart) fall on distinct banks.  With the power-of-two strides used at
+// first, rocprofv3 showed SQ_LDS_BANK_CONFLICT at 75 % of the LDS cycles of quantize_residual 8x8.
+constexpr int lds_tile_ld(int n) { return n + 2; }
+
+// 8 consecutive elements (e = multiple of 8) of a tile as four dwords; pairs never straddle a row
+template <int N, int LD>
+__device__ __forceinline__ void lds_tile_store8(i16 *tile, int e, uint4 v)
+{
+  const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = e + 2 * j;
+    *(u32 *)(tile + (idx / N) * LD + (idx % N)) = w[j];
+  }
+}
+template <int N, int LD>
+__device__ __forceinline__ uint4 lds_tile_load8(const i16 *tile, int e)
+{
+  u32 w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int idx = e + 2 * j;
+    w[j] = *(const u32 *)(tile + (idx / N) * LD + (idx % N));
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // 2-D transform of one N x N block by N cooperating threads (thread `row` owns
 // one row/column).  `a` holds the input block in LDS (row stride LD), `b` is an
 // LDS scratch of the same shape; the result is left in `a` (row-major).  The

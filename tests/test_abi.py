@@ -84,3 +84,31 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".c")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in text and "kvz_oracle" not in text and "libkvzref" not in text, f
+
+
+def test_build_is_free_of_v_ashr_pk_u8_i32():
+    """hipcc 7.2 selects v_ashr_pk_u8_i32 for "two (x >> 16) clamped to bytes" and consumes the result as if the upper half
+    of the destination were zero; on gfx950 it is left untouched, which corrupted a reconstruction kernel (quant.hip).
+    Guard: no translation unit of the product may contain the instruction."""
+    import concurrent.futures
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    srcs = sorted(glob.glob(os.path.join(ROOT, "kvazaar_amd", "csrc", "*.hip")))
+    tmp = tempfile.mkdtemp(prefix="kvz_isa_")
+
+    def compile_one(src):
+        out = os.path.join(tmp, os.path.basename(src) + ".s")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", out],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return src, open(out).read().count("v_ashr_pk_u8_i32")
+    try:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+            hits = [(s, n) for s, n in ex.map(compile_one, srcs) if n]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert not hits, hits

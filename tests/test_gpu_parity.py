@@ -308,6 +308,30 @@ def test_quantize_residual_16_both_kernels(api):
     L.kvz_hip_set_tuning(b"qr16_use_mfma", -1)
 
 
+def test_quantize_residual_4_both_kernels(api):
+    """4x4 TUs run one lane per TU in registers by default; the LDS kernel stays selectable (and serves sign hiding)"""
+    from kvazaar_amd import _lib
+    L = _lib.init(0)
+    g = rng(170)
+    for count in (1, 3, 257, 1000):
+        ref_in = g.integers(0, 256, (count, 16), dtype=np.uint8)
+        pred = np.clip(ref_in.astype(np.int32) + g.integers(-70, 71, ref_in.shape), 0, 255).astype(np.uint8)
+        pred[::3] = ref_in[::3]
+        for qp in (5, 27, 48):
+            for (color, intra, ts) in ((0, 1, 0), (0, 0, 0), (1, 1, 0), (0, 0, 1), (2, 1, 1)):
+                want = O.quantize_residual_batch(ref_in, pred, 4, qp, color, 0, intra, intra, 0, ts)
+                for use in (1, 0):
+                    _lib.check(L.kvz_hip_set_tuning(b"qr4_lane_kernel", use), "tuning")
+                    got = api.quantize_residual_batch(ref_in, pred, 4, qp, color, 0, intra, intra, 0, ts, with_costs=True)
+                    for a, b, nm in zip(got[:3], want, ("rec", "coeff", "has")):
+                        np.testing.assert_array_equal(a, b, err_msg="%s count=%d qp=%d color=%d intra=%d ts=%d lane=%d" % (nm, count, qp, color, intra, ts, use))
+                    if count <= 3:
+                        for i in range(count):
+                            assert got[3][i] == O.pixels_calc_ssd(ref_in[i], 0, want[0][i], 0, 4, 4, 4)
+                            assert got[4][i] == O.coeff_abs_sum(want[1][i])
+    L.kvz_hip_set_tuning(b"qr4_lane_kernel", -1)
+
+
 @pytest.mark.parametrize("w", [4, 8, 16, 32])
 def test_quantize_residual_fused_rd0_costs(api, w):
     """kvz_hip_quantize_residual_cost_batch: the SSD(ref, rec) and coeff_abs_sum the rd=0 TU cost is made of
