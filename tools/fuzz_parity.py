@@ -111,6 +111,85 @@ def main():
             x, y, fx, fy, w, h = b
             check("sample." + kind, np.array_equal(o, O.sample(kind, padded, x + PAD, y + PAD, w, h, fx, fy)), str(b))
     print("sample ok (%.0f s)" % (time.time() - t0))
+
+    # picture group: contiguous blocks of every size, frame-level descriptors incl. vectors that leave the frame
+    for n in (4, 8, 16, 32, 64):
+        cnt = int(g.integers(1, 40))
+        a8 = g.integers(0, 256, (cnt, n * n), dtype=np.uint8)
+        b8 = np.clip(a8.astype(np.int32) + g.integers(-30, 31, a8.shape), 0, 255).astype(np.uint8)
+        for kind in ("sad", "satd"):
+            check("%s_%d" % (kind, n), np.array_equal(api.cost_nxn_batch(kind, n, a8, b8), O.cost_nxn_batch(kind, n, a8, b8)))
+    picf = g.integers(0, 256, (96, 160), dtype=np.uint8)
+    reff = g.integers(0, 256, (96, 160), dtype=np.uint8)
+    pairs = []
+    for _ in range(150 * a.scale):
+        bw, bh = int(g.choice([4, 8, 12, 16, 24, 32, 64])), int(g.choice([4, 8, 12, 16, 32, 64]))
+        x1, y1 = int(g.integers(0, 160 - bw + 1)), int(g.integers(0, 96 - bh + 1))
+        pairs.append((x1, y1, x1 + int(g.integers(-200, 201)), y1 + int(g.integers(-120, 121)), bw, bh))
+    got_sad, got_satd = api.image_calc_sad_batch(picf, reff, pairs), api.image_calc_satd_batch(picf, reff, pairs)
+    for pr, s1, s2 in zip(pairs, got_sad, got_satd):
+        check("image_calc_sad", s1 == O.image_calc("sad", picf, reff, *pr), str(pr))
+        check("image_calc_satd", s2 == O.image_calc("satd", picf, reff, *pr), str(pr))
+    print("picture ok (%.0f s)" % (time.time() - t0))
+
+    # transforms / quant / dequant on full-range inputs
+    for n in (4, 8, 16, 32):
+        x = g.integers(-32768, 32768, (int(g.integers(1, 30)), n * n)).astype(np.int16)
+        r = g.integers(-255, 256, x.shape).astype(np.int16)
+        for kind, src in (("dct", r), ("idct", x)) + ((("dst", r), ("idst", x)) if n == 4 else ()):
+            check("%s_%d" % (kind, n), np.array_equal(api.transform_batch(kind, n, src), O.transform_batch(kind, n, src)))
+        qp, sh, intra = int(g.integers(0, 52)), int(g.integers(0, 2)), int(g.integers(0, 2))
+        tp = 0 if n == 32 else int(g.choice([0, 2]))
+        check("quant_%d" % n, np.array_equal(api.quant_batch(x, n, qp, tp, 0, intra, sh), O.quant_batch(x, n, qp, tp, 0, intra, sh)),
+              "qp %d sh %d intra %d type %d" % (qp, sh, intra, tp))
+        check("dequant_%d" % n, np.array_equal(api.dequant_batch(x, n, qp, tp), O.dequant_batch(x, n, qp, tp)))
+    print("transform / quant ok (%.0f s)" % (time.time() - t0))
+
+    # bi-prediction candidate costs and the fractional search, PUs inside an LCU
+    pic, ref0 = me_frames(192, 128, int(g.integers(0, 1 << 30)), (2, -1))
+    _, ref1 = me_frames(192, 128, int(g.integers(0, 1 << 30)), (-3, 2))
+    cands, sf = [], []
+    for _ in range(120 * a.scale):
+        w, h = int(g.choice([8, 16, 24, 32, 64])), int(g.choice([8, 16, 32, 64]))
+        x = int(g.integers(0, 3)) * 64 + int(g.integers(0, (64 - w) // 8 + 1)) * 8
+        y = int(g.integers(0, 2)) * 64 + int(g.integers(0, (64 - h) // 8 + 1)) * 8
+        big = int(g.choice([12, 60, 500]))
+        mv = g.integers(-big, big + 1, 4)
+        cands.append((x, y, w, h, int(mv[0]), int(mv[1]), int(mv[2]), int(mv[3])))
+        sf.append((x, y, x + int(mv[0]) // 4, y + int(mv[1]) // 4, w, h))
+    got = api.bipred_cost_batch(pic, ref0, ref1, cands)
+    for c, v in zip(cands, got):
+        check("bipred_cost", v == O.bipred_luma_satd(pic, ref0, ref1, c[0], c[1], c[2], c[3], c[4:6], c[6:8])[0], str(c))
+    costs, best = api.search_frac_batch(pic, ref0, sf)
+    for k, d in enumerate(sf):
+        oc, ob = O.search_frac_costs(pic, ref0, d[0], d[1], d[4], d[5], d[2] - d[0], d[3] - d[1])
+        check("search_frac.costs", np.array_equal(costs[k], oc), str(d))
+        check("search_frac.best", tuple(int(v) for v in best[k]) == tuple(ob), str(d))
+    print("bipred / search_frac ok (%.0f s)" % (time.time() - t0))
+
+    # SAO distortion deltas and reconstruction
+    for it in range(12 * a.scale):
+        bw, bh = int(g.integers(3, 65)), int(g.integers(3, 65))
+        orig, rec = sao_blocks(bw, bh, 5, int(g.integers(0, 1 << 30)))
+        offs = g.integers(-7, 8, (5, 4, 5)).astype(np.int32)
+        dd = api.sao_edge_ddistortion_batch(orig, rec, bw, bh, offs)
+        bp, bo = g.integers(0, 32, 5).astype(np.int32), g.integers(-7, 8, (5, 4)).astype(np.int32)
+        bd = api.sao_band_ddistortion_batch(orig, rec, bw, bh, bp, bo)
+        for i in range(5):
+            for eo in range(4):
+                check("sao_edge_dd", dd[i, eo] == O.sao_edge_ddistortion(orig[i], rec[i], bw, bh, eo, offs[i, eo]))
+            check("sao_band_dd", bd[i] == O.sao_band_ddistortion(orig[i], rec[i], bw, bh, int(bp[i]), bo[i]))
+    plane = g.integers(0, 256, (90, 130), dtype=np.uint8)
+    from patterns import sao_records
+    infos = sao_records(40, int(g.integers(0, 1 << 30)))
+    blocks = [(int(g.integers(1, 60)), int(g.integers(1, 40)), int(g.integers(1, 65)), int(g.integers(1, 45)), k) for k in range(40)]
+    for color in (0, 1, 2):
+        for b, info in zip(blocks, infos):
+            got = api.sao_reconstruct_color_batch(plane, [b[:4] + (0,)], info[None], color)
+            want = plane.copy()
+            want[b[1]:b[1] + b[3], b[0]:b[0] + b[2]] = O.sao_reconstruct_color(plane, b[0], b[1], b[2], b[3], info, color)
+            check("sao_reconstruct", np.array_equal(got, want), str(b))
+    print("sao dd / reconstruct ok (%.0f s)" % (time.time() - t0))
     print("FUZZ OK seed %d scale %d" % (a.seed, a.scale))
 
 
