@@ -42,18 +42,25 @@ struct call_ctx {
   u8 *d = nullptr;       // device staging (same layout)
   size_t cap = 0;
   bool ok = false;
+  bool zero_copy = false;
   call_ctx()
   {
     if (!ctx_enter() && (kvz_hip_init(-1) != KVZ_HIP_OK || !ctx_enter())) return;   // also binds this thread to the device
     cap = 1u << 20;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return;
     if (hipHostMalloc((void **)&h, cap, hipHostMallocDefault) != hipSuccess) return;
-    if (hipMalloc((void **)&d, cap) != hipSuccess) return;
+    // By default the kernels read and write the pinned staging buffer directly (no staging copies): a per-call operand
+    // set is a few hundred bytes, so the PCIe accesses are latency, not bandwidth -- 14 us per call against 20 us with
+    // explicit copies (tools/percall_latency.py).  KVZ_HIP_ZEROCOPY=0 restores the copies into device memory.
+    const char *zc = std::getenv("KVZ_HIP_ZEROCOPY");
+    zero_copy = !(zc && zc[0] == '0');
+    if (zero_copy) d = h;
+    else if (hipMalloc((void **)&d, cap) != hipSuccess) return;
     ok = true;
   }
   ~call_ctx()
   {
-    if (d) (void)hipFree(d);
+    if (d && !zero_copy) (void)hipFree(d);
     if (h) (void)hipHostFree(h);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -94,8 +101,8 @@ struct stage {
     if (off > c.cap) die("staging buffer overflow", KVZ_HIP_ERR_INVALID);
     return o;
   }
-  void h2d(size_t o, size_t bytes) { HMUST(hipMemcpyAsync(c.d + o, c.h + o, bytes, hipMemcpyHostToDevice, c.st)); }
-  void d2h(size_t o, size_t bytes) { HMUST(hipMemcpyAsync(c.h + o, c.d + o, bytes, hipMemcpyDeviceToHost, c.st)); }
+  void h2d(size_t o, size_t bytes) { if (!c.zero_copy) HMUST(hipMemcpyAsync(c.d + o, c.h + o, bytes, hipMemcpyHostToDevice, c.st)); }
+  void d2h(size_t o, size_t bytes) { if (!c.zero_copy) HMUST(hipMemcpyAsync(c.h + o, c.d + o, bytes, hipMemcpyDeviceToHost, c.st)); }
   void sync() { HMUST(hipStreamSynchronize(c.st)); }
 };
 
