@@ -272,3 +272,28 @@ def test_sao_group_through_registry(hip):
             for (x, y, bw, bh) in ((1, 1, 64, 64), (5, 3, 32, 32), (1, 7, 61, 13)):
                 np.testing.assert_array_equal(R.sao_reconstruct_color(plane, x, y, bw, bh, s, color, "hip"),
                                               R.sao_reconstruct_color(plane, x, y, bw, bh, s, color))
+
+
+def test_device_staging_mode_in_a_child_process():
+    """KVZ_HIP_ZEROCOPY=0 (explicit copies into device memory instead of kernels operating on the pinned staging buffer)
+    is read when a thread's context is created, so it gets its own process"""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np, ctypes as C\n"
+        "sys.path.insert(0, %r)\n"
+        "import ref_lib as R\n"
+        "L = R.lib(); L.ref_register_hip.restype = C.c_int; L.ref_register_hip.argtypes = [C.c_char_p]\n"
+        "assert L.ref_register_hip(%r.encode()) > 0\n"
+        "g = np.random.default_rng(4)\n"
+        "a = g.integers(0, 256, (6, 1024), dtype=np.uint8); b = g.integers(0, 256, (6, 1024), dtype=np.uint8)\n"
+        "assert (R.cost_nxn_batch('satd', 32, a, b, 'hip') == R.cost_nxn_batch('satd', 32, a, b, 'generic')).all()\n"
+        "x = g.integers(-255, 256, (5, 256)).astype(np.int16)\n"
+        "assert (R.transform_batch('dct', 16, x, 'hip') == R.transform_batch('dct', 16, x, 'generic')).all()\n"
+        "f = g.integers(0, 256, (64, 64), dtype=np.uint8)\n"
+        "assert (R.sample('luma', f, 20, 20, 16, 16, 1, 3, 'hip') == R.sample('luma', f, 20, 20, 16, 16, 1, 3, 'generic')).all()\n"
+        "print('child ok')\n"
+    ) % (os.path.join(ROOT, "tests"), os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"))
+    env = dict(os.environ, KVZ_HIP_ZEROCOPY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "child ok" in out.stdout, out.stderr[-2000:]
