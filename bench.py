@@ -211,7 +211,7 @@ def main():
         dom = max(ms, key=lambda k: ms[k])
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from a separate rocprofv3 --pmc pass
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and F == 128:                          # the PMC passes were taken at the default batch size
             try:
                 traffic = json.load(open(tfile)).get(dom)
             except Exception:
@@ -230,7 +230,9 @@ def main():
                        "frames_per_batch": F, "parallelism": "independent batches per GPU, no data-path collective"},
             "kernels": kern,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic},
+                         "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (bytes per launch)"
+                                           if traffic is not None else None},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
