@@ -51,6 +51,11 @@ void set_error(const char *what, hipError_t e)
   std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
 }
 void set_error_msg(const char *what) { std::snprintf(g_err, sizeof(g_err), "%s", what); }
+int invalid_arg(const char *entry)
+{
+  std::snprintf(g_err, sizeof(g_err), "%s: invalid argument (null or misaligned buffer, size or parameter out of range)", entry);
+  return KVZ_HIP_ERR_INVALID;
+}
 
 }  // namespace kvzhip
 
@@ -66,9 +71,9 @@ extern "C" {
 
 int kvz_hip_set_tuning(const char *key, int value)
 {
-  if (!key) return KVZ_HIP_ERR_INVALID;
+  if (!key) return kvzhip::invalid_arg(__func__);
   for (auto &e : g_tune) if (!std::strcmp(e.key, key)) { e.value = value; return KVZ_HIP_OK; }
-  return KVZ_HIP_ERR_INVALID;
+  return kvzhip::invalid_arg(__func__);
 }
 
 int kvz_hip_device_count(void)

@@ -80,7 +80,7 @@ static int launch_transform(const i16 *in, i16 *out, size_t count, hipStream_t s
 extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16_t *out, size_t count, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!in || !out || (((uintptr_t)in | (uintptr_t)out) & 15)) return KVZ_HIP_ERR_INVALID;
+  if (!in || !out || (((uintptr_t)in | (uintptr_t)out) & 15)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   switch (kind) {
@@ -108,5 +108,5 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
       if (n == 4) return launch_transform<4, 3>(in, out, count, st);
       break;
   }
-  return KVZ_HIP_ERR_INVALID;
+  return kvzhip::invalid_arg(__func__);
 }

@@ -389,7 +389,7 @@ int launch_rough(const kvz_hip_intra_ref *refs, const u8 *orig, size_t count, in
 {
   constexpr int N = 1 << LOG2, NB = N < 8 ? 4 : 8, S = (N / NB) * (N / NB), G = 64 / S;
   const size_t wgs = (count + G - 1) / G;
-  if (wgs > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (wgs > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   if (sad) hipLaunchKernelGGL((intra_rough_kernel<LOG2, true>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
   else hipLaunchKernelGGL((intra_rough_kernel<LOG2, false>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
   KVZ_CHECK_LAUNCH("intra_rough_kernel");

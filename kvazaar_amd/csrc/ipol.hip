@@ -344,7 +344,7 @@ namespace kvzhip {
 int launch_frac_step(const u8 *win, int w, int h, int step, int fme_level, int hx, int hy,
                      u8 *filtered, i16 *hor_out, i16 *cols_out, hipStream_t st)
 {
-  if (w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7) || step < 0 || step > 3) return KVZ_HIP_ERR_INVALID;
+  if (w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7) || step < 0 || step > 3) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL(frac_step_kernel, dim3(1), dim3(256), 0, st, win, w, h, step, fme_level, hx, hy, filtered, hor_out, cols_out);
   KVZ_CHECK_LAUNCH("frac_step_kernel");
   return KVZ_HIP_OK;
@@ -358,9 +358,9 @@ static int sample_launch(bool luma, const kvz_hip_pixel *ref, uint32_t ref_strid
                          int out_14bit, void *dst, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!ref || !blocks || !out_offsets || !dst || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (!ref || !blocks || !out_offsets || !dst || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   refplane_t r = { ref, ref_stride, ref_w, ref_h };
   hipStream_t st = ctx_stream(s);
   const unsigned long long *oo = (const unsigned long long *)out_offsets;
@@ -396,9 +396,9 @@ int kvz_hip_search_frac_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, con
                               uint32_t *costs, int32_t *best, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!pic || !ref || !pairs || !costs || !best || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (!pic || !ref || !pairs || !costs || !best || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   refplane_t r = { ref, ref_stride, ref_w, ref_h };
   // three passes over the same descriptor list: each kernel takes the size class it is built for and skips the rest
   hipLaunchKernelGGL(search_frac_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, ctx_stream(s), pic, pic_stride, r, pairs, count, costs, best);
@@ -415,9 +415,9 @@ int kvz_hip_bipred_cost_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int
                               int ref_w, int ref_h, const kvz_hip_bipred_cand *cands, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!pic || !ref0 || !ref1 || !cands || !costs || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (!pic || !ref0 || !ref1 || !cands || !costs || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   const refplane_t r0 = { ref0, ref0_stride, ref_w, ref_h }, r1 = { ref1, ref1_stride, ref_w, ref_h };
   hipLaunchKernelGGL(bipred_cost_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), pic, pic_stride, pic_w, pic_h, r0, r1, cands, costs);
   KVZ_CHECK_LAUNCH("bipred_cost_kernel");

@@ -21,6 +21,7 @@ bool ctx_enter();                               // ready, and the calling thread
 hipStream_t ctx_stream(kvz_hip_stream s);      // NULL -> library default stream
 void set_error(const char *what, hipError_t e);
 void set_error_msg(const char *what);
+int invalid_arg(const char *entry);             // records "<entry>: invalid argument" and returns KVZ_HIP_ERR_INVALID
 int num_cus();
 int tuning(const char *key, int dflt);     // kvz_hip_set_tuning override or dflt
 

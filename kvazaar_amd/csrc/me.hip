@@ -131,9 +131,9 @@ extern "C" int kvz_hip_ctu_sad_grid_batch(const kvz_hip_pixel *pic, uint32_t pic
                                           uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!pic || !ref || !ctus || !mv_offsets || !costs || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0 || n_mv < 0) return KVZ_HIP_ERR_INVALID;
+  if (!pic || !ref || !ctus || !mv_offsets || !costs || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0 || n_mv < 0) return kvzhip::invalid_arg(__func__);
   if (count == 0 || n_mv == 0) return KVZ_HIP_OK;
-  if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   me_plane p = { pic, pic_stride, pic_w, pic_h }, r = { ref, ref_stride, ref_w, ref_h };
   hipLaunchKernelGGL(ctu_sad_grid_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), p, r, ctus, mv_offsets, n_mv, costs);
   KVZ_CHECK_LAUNCH("ctu_sad_grid_kernel");

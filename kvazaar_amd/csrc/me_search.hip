@@ -547,7 +547,7 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     return KVZ_HIP_ERR_INVALID;
   }
   if (count == 0) return KVZ_HIP_OK;
-  if (count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   hipStream_t st = ctx_stream(s);
   const refplane_t r = { ref, ref_stride, ref_w, ref_h };
   // one launch per size class over the same descriptor list; each kernel takes its class and skips the rest.  The big

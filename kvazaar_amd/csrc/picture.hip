@@ -646,7 +646,7 @@ static int launch_sad(int n, const u8 *a, const u8 *b, size_t count, u32 *costs,
     KVZ_SAD_CASE(16, 4)
     KVZ_SAD_CASE(32, 4)
     KVZ_SAD_CASE(64, 4)
-    default: return KVZ_HIP_ERR_INVALID;
+    default: return kvzhip::invalid_arg(__func__);
   }
 #undef KVZ_SAD_CASE
   KVZ_CHECK_LAUNCH("sad_nxn_kernel");
@@ -672,7 +672,7 @@ static int launch_satd(int n, const u8 *a, const u8 *b, size_t count, u32 *costs
       break;
     case 32: hipLaunchKernelGGL((satd_nxn_kernel<32, DUAL>), dim3(stream_grid(count * 16, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
     case 64: hipLaunchKernelGGL((satd_nxn_kernel<64, DUAL>), dim3(stream_grid(count * 64, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
-    default: return KVZ_HIP_ERR_INVALID;
+    default: return kvzhip::invalid_arg(__func__);
   }
   KVZ_CHECK_LAUNCH("satd_nxn_kernel");
   return KVZ_HIP_OK;
@@ -683,7 +683,7 @@ extern "C" {
 int kvz_hip_sad_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel *blk2, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!blk1 || !blk2 || !costs || !aligned16(blk1) || !aligned16(blk2)) return KVZ_HIP_ERR_INVALID;
+  if (!blk1 || !blk2 || !costs || !aligned16(blk1) || !aligned16(blk2)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   return launch_sad<false>(n, blk1, blk2, count, costs, 0, 0, ctx_stream(s));
 }
@@ -691,7 +691,7 @@ int kvz_hip_sad_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel 
 int kvz_hip_satd_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel *blk2, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!blk1 || !blk2 || !costs || !aligned16(blk1) || !aligned16(blk2)) return KVZ_HIP_ERR_INVALID;
+  if (!blk1 || !blk2 || !costs || !aligned16(blk1) || !aligned16(blk2)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   return launch_satd<false>(n, blk1, blk2, count, costs, 0, 0, ctx_stream(s));
 }
@@ -700,7 +700,7 @@ int kvz_hip_sad_nxn_dual_batch(int n, const kvz_hip_pixel *preds, size_t pred_st
                                const kvz_hip_pixel *orig, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!preds || !orig || !costs || !aligned16(preds) || !aligned16(orig) || (pred_stride & 15) || (item_stride & 15)) return KVZ_HIP_ERR_INVALID;
+  if (!preds || !orig || !costs || !aligned16(preds) || !aligned16(orig) || (pred_stride & 15) || (item_stride & 15)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   return launch_sad<true>(n, preds, orig, count * 2, costs, pred_stride, item_stride, ctx_stream(s));
 }
@@ -709,7 +709,7 @@ int kvz_hip_satd_nxn_dual_batch(int n, const kvz_hip_pixel *preds, size_t pred_s
                                 const kvz_hip_pixel *orig, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!preds || !orig || !costs || !aligned16(preds) || !aligned16(orig) || (pred_stride & 15) || (item_stride & 15)) return KVZ_HIP_ERR_INVALID;
+  if (!preds || !orig || !costs || !aligned16(preds) || !aligned16(orig) || (pred_stride & 15) || (item_stride & 15)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   return launch_satd<true>(n, preds, orig, count * 2, costs, pred_stride, item_stride, ctx_stream(s));
 }
@@ -718,7 +718,7 @@ int kvz_hip_reg_sad_batch(const kvz_hip_pixel *plane1, uint32_t stride1, const k
                           const kvz_hip_block_pair *pairs, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!plane1 || !plane2 || !pairs || !costs) return KVZ_HIP_ERR_INVALID;
+  if (!plane1 || !plane2 || !pairs || !costs) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { plane1, stride1, 0, 0 }, p2 = { plane2, stride2, 0, 0 };
   hipLaunchKernelGGL((pair_sad_kernel<false>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
@@ -730,7 +730,7 @@ int kvz_hip_image_calc_sad_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, 
                                  int ref_w, int ref_h, const kvz_hip_block_pair *pairs, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { pic, pic_stride, 0, 0 }, p2 = { ref, ref_stride, ref_w, ref_h };
   hipLaunchKernelGGL((pair_sad_kernel<false>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
@@ -742,7 +742,7 @@ int kvz_hip_image_calc_satd_batch(const kvz_hip_pixel *pic, uint32_t pic_stride,
                                   int ref_w, int ref_h, const kvz_hip_block_pair *pairs, size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { pic, pic_stride, 0, 0 }, p2 = { ref, ref_stride, ref_w, ref_h };
   hipLaunchKernelGGL(pair_satd_kernel, dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
@@ -754,7 +754,7 @@ int kvz_hip_pixels_calc_ssd_batch(const kvz_hip_pixel *plane1, uint32_t stride1,
                                   const kvz_hip_block_pair *pairs, size_t count, uint32_t *ssd, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!plane1 || !plane2 || !pairs || !ssd) return KVZ_HIP_ERR_INVALID;
+  if (!plane1 || !plane2 || !pairs || !ssd) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { plane1, stride1, 0, 0 }, p2 = { plane2, stride2, 0, 0 };
   hipLaunchKernelGGL((pair_sad_kernel<true>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, ssd);
@@ -767,7 +767,7 @@ int kvz_hip_satd_any_size_quad_batch(const kvz_hip_pixel *preds, uint32_t pred_s
                                      size_t count, uint32_t *costs, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!preds || !orig || !pairs || !costs) return KVZ_HIP_ERR_INVALID;
+  if (!preds || !orig || !pairs || !costs) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t po = { orig, orig_stride, 0, 0 };
   hipLaunchKernelGGL(quad_satd_kernel, dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), preds, pred_stride, pred_item_stride, po, pairs, count, costs);
@@ -779,7 +779,7 @@ int kvz_hip_bipred_blend_batch(int w, int h, int hi_prec0, const void *src0, int
                                kvz_hip_pixel *dst, size_t count, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!src0 || !src1 || !dst || w <= 0 || h <= 0) return KVZ_HIP_ERR_INVALID;
+  if (!src0 || !src1 || !dst || w <= 0 || h <= 0) return kvzhip::invalid_arg(__func__);
   const size_t n = (size_t)w * h * count;
   if (n == 0) return KVZ_HIP_OK;
   const unsigned grid = stream_grid(n, 1024);

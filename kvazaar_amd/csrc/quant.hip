@@ -540,8 +540,8 @@ int kvz_hip_quant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *coef
 {
   KVZ_CHECK_CTX();
   quant_consts k;
-  if (!p || !coef || !q_coef || scan_idx < 0 || scan_idx > 2 || !make_consts(p, width, type, type, &k)) return KVZ_HIP_ERR_INVALID;
-  if ((((uintptr_t)coef | (uintptr_t)q_coef) & 15) != 0) return KVZ_HIP_ERR_INVALID;
+  if (!p || !coef || !q_coef || scan_idx < 0 || scan_idx > 2 || !make_consts(p, width, type, type, &k)) return kvzhip::invalid_arg(__func__);
+  if ((((uintptr_t)coef | (uintptr_t)q_coef) & 15) != 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   const size_t total = count * (size_t)(width * width);
@@ -559,8 +559,8 @@ int kvz_hip_dequant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *q_
 {
   KVZ_CHECK_CTX();
   quant_consts k;
-  if (!p || !coef || !q_coef || !make_consts(p, width, type, type, &k)) return KVZ_HIP_ERR_INVALID;
-  if ((((uintptr_t)coef | (uintptr_t)q_coef) & 15) != 0) return KVZ_HIP_ERR_INVALID;
+  if (!p || !coef || !q_coef || !make_consts(p, width, type, type, &k)) return kvzhip::invalid_arg(__func__);
+  if ((((uintptr_t)coef | (uintptr_t)q_coef) & 15) != 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   const size_t total = count * (size_t)(width * width);
   hipLaunchKernelGGL(dequant_kernel, dim3(stream_grid(total, 2048)), dim3(256), 0, ctx_stream(s), q_coef, coef, total, width * width, k);
@@ -571,7 +571,7 @@ int kvz_hip_dequant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *q_
 int kvz_hip_coeff_abs_sum_batch(const kvz_hip_coeff *coeffs, size_t length, size_t count, uint32_t *sums, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!coeffs || !sums) return KVZ_HIP_ERR_INVALID;
+  if (!coeffs || !sums) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   hipLaunchKernelGGL(coeff_abs_sum_kernel, dim3(stream_grid(count, 4)), dim3(256), 0, ctx_stream(s), coeffs, length, count, sums);
   KVZ_CHECK_LAUNCH("coeff_abs_sum_kernel");
@@ -588,8 +588,8 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   // quant uses type 0 / 2, dequant 0 / 2 / 3 (quant-generic.c:224, :244)
   const int tq = color == 0 ? 0 : 2, tdq = color == 0 ? 0 : (color == 1 ? 2 : 3);
   if (!p || !ref_in || !pred_in || !rec_out || !coeff_out || !has_coeffs || color < 0 || color > 2 ||
-      scan_order < 0 || scan_order > 2 || !make_consts(p, width, tq, tdq, &k)) return KVZ_HIP_ERR_INVALID;
-  if ((((uintptr_t)ref_in | (uintptr_t)pred_in | (uintptr_t)rec_out | (uintptr_t)coeff_out) & 15) != 0) return KVZ_HIP_ERR_INVALID;
+      scan_order < 0 || scan_order > 2 || !make_consts(p, width, tq, tdq, &k)) return kvzhip::invalid_arg(__func__);
+  if ((((uintptr_t)ref_in | (uintptr_t)pred_in | (uintptr_t)rec_out | (uintptr_t)coeff_out) & 15) != 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
@@ -614,7 +614,7 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
     case 8: if (use_trskip) KVZ_QR(8, 4); else KVZ_QR(8, 0); break;
     case 16: if (use_trskip) KVZ_QR(16, 4); else KVZ_QR(16, 0); break;
     case 32: if (use_trskip) KVZ_QR(32, 4); else KVZ_QR(32, 0); break;
-    default: return KVZ_HIP_ERR_INVALID;
+    default: return kvzhip::invalid_arg(__func__);
   }
 #undef KVZ_QR
   KVZ_CHECK_LAUNCH("quantize_residual_kernel");
@@ -625,7 +625,7 @@ int kvz_hip_residual_batch(const kvz_hip_pixel *ref_in, const kvz_hip_pixel *pre
 {
   KVZ_CHECK_CTX();
   if (n == 0) return KVZ_HIP_OK;
-  if (!ref_in || !pred_in || !residual) return KVZ_HIP_ERR_INVALID;
+  if (!ref_in || !pred_in || !residual) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL(residual_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, ctx_stream(s), ref_in, pred_in, residual, n);
   KVZ_CHECK_LAUNCH("residual_kernel");
   return KVZ_HIP_OK;
@@ -635,7 +635,7 @@ int kvz_hip_reconstruct_batch(const kvz_hip_coeff *residual, const kvz_hip_pixel
 {
   KVZ_CHECK_CTX();
   if (n == 0) return KVZ_HIP_OK;
-  if (!residual || !pred_in || !rec_out) return KVZ_HIP_ERR_INVALID;
+  if (!residual || !pred_in || !rec_out) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL(reconstruct_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, ctx_stream(s), residual, pred_in, rec_out, n);
   KVZ_CHECK_LAUNCH("reconstruct_kernel");
   return KVZ_HIP_OK;

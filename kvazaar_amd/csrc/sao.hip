@@ -217,9 +217,9 @@ int kvz_hip_sao_edge_stats_batch(const kvz_hip_pixel *orig, const kvz_hip_pixel 
                                  int32_t *cat_sum_cnt, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!block_dims_ok(block_width, block_height)) return KVZ_HIP_ERR_INVALID;
+  if (!block_dims_ok(block_width, block_height)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (!orig || !rec || !cat_sum_cnt || count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (!orig || !rec || !cat_sum_cnt || count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL((sao_edge_kernel<0>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
                      (const int *)nullptr, cat_sum_cnt);
   KVZ_CHECK_LAUNCH("sao_edge_kernel<stats>");
@@ -230,9 +230,9 @@ int kvz_hip_sao_edge_ddistortion_batch(const kvz_hip_pixel *orig, const kvz_hip_
                                        const int32_t *offsets, int32_t *ddistortion, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!block_dims_ok(block_width, block_height)) return KVZ_HIP_ERR_INVALID;
+  if (!block_dims_ok(block_width, block_height)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (!orig || !rec || !offsets || !ddistortion || count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (!orig || !rec || !offsets || !ddistortion || count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL((sao_edge_kernel<1>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
                      offsets, ddistortion);
   KVZ_CHECK_LAUNCH("sao_edge_kernel<ddistortion>");
@@ -243,9 +243,9 @@ int kvz_hip_sao_band_stats_batch(const kvz_hip_pixel *orig, const kvz_hip_pixel 
                                  int32_t *sao_bands, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!block_dims_ok(block_width, block_height)) return KVZ_HIP_ERR_INVALID;
+  if (!block_dims_ok(block_width, block_height)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (!orig || !rec || !sao_bands || count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (!orig || !rec || !sao_bands || count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL((sao_band_kernel<0>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
                      (const int *)nullptr, (const int *)nullptr, sao_bands);
   KVZ_CHECK_LAUNCH("sao_band_kernel<stats>");
@@ -256,9 +256,9 @@ int kvz_hip_sao_band_ddistortion_batch(const kvz_hip_pixel *orig, const kvz_hip_
                                        const int32_t *band_pos, const int32_t *sao_bands, int32_t *ddistortion, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!block_dims_ok(block_width, block_height)) return KVZ_HIP_ERR_INVALID;
+  if (!block_dims_ok(block_width, block_height)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (!orig || !rec || !band_pos || !sao_bands || !ddistortion || count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (!orig || !rec || !band_pos || !sao_bands || !ddistortion || count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL((sao_band_kernel<1>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
                      band_pos, sao_bands, ddistortion);
   KVZ_CHECK_LAUNCH("sao_band_kernel<ddistortion>");
@@ -271,9 +271,9 @@ int kvz_hip_sao_reconstruct_color_batch(const kvz_hip_pixel *rec, uint32_t strid
                                         kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (color < 0 || color > 2 || plane_w < 1 || plane_h < 1 || n_infos < 0) return KVZ_HIP_ERR_INVALID;
+  if (color < 0 || color > 2 || plane_w < 1 || plane_h < 1 || n_infos < 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
-  if (!rec || !new_rec || !blocks || !infos || count > 0x7fffffffu) return KVZ_HIP_ERR_INVALID;
+  if (!rec || !new_rec || !blocks || !infos || count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   hipLaunchKernelGGL(sao_reconstruct_kernel, dim3((unsigned)count), dim3(256), 0, ctx_stream(s), rec, stride, new_rec, new_stride, blocks, infos,
                      n_infos, plane_w, plane_h, color);
   KVZ_CHECK_LAUNCH("sao_reconstruct_kernel");

@@ -684,3 +684,13 @@ def test_search_pu_size_class_hint(api):
         prm = me_params()
         prm["size_classes"] = cls
         np.testing.assert_array_equal(api.search_pu_batch(pic, ref, pus, prm), plain)
+
+
+def test_invalid_arguments_leave_a_message(api):
+    """every KVZ_HIP_ERR_INVALID return records which entry refused its arguments"""
+    from kvazaar_amd import _lib
+    L = _lib.init(0)
+    assert L.kvz_hip_sad_nxn_batch(7, None, None, 1, None, None) != 0
+    assert b"kvz_hip_sad_nxn_batch" in L.kvz_hip_last_error()
+    assert L.kvz_hip_transform_batch(0, 5, None, None, 1, None) != 0
+    assert b"kvz_hip_transform_batch" in L.kvz_hip_last_error()
