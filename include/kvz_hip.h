@@ -84,6 +84,21 @@ KVZ_HIP_API void kvz_hip_event_destroy(void *ev);
 KVZ_HIP_API int kvz_hip_event_record(void *ev, kvz_hip_stream s);
 KVZ_HIP_API int kvz_hip_event_elapsed_ms(void *start, void *stop, float *ms);  /* syncs on stop */
 
+/* A frame's launch sequence as one hipGraph (the encoder issues the same batched entries, on
+ * the same buffers, for every frame: encoderstate.c:1330-1400 walks the same LCU grid per frame).
+ * Every batched entry above and below is capture-safe: it only enqueues kernels on `s`.
+ *   kvz_hip_graph_begin(s);  ...batched entries on s (and on streams forked from it with
+ *   kvz_hip_event_record + kvz_hip_stream_wait_event, joined back the same way)...
+ *   kvz_hip_graph_end(s, &g);  then per frame: kvz_hip_graph_launch(g, s).
+ * Independent stages (motion search, intra search, SAO statistics) put on forked streams become
+ * parallel branches of the graph and share the 256 CUs when one stage alone cannot fill them. */
+typedef void *kvz_hip_graph;         /* an instantiated graph (hipGraphExec_t) */
+KVZ_HIP_API int kvz_hip_stream_wait_event(kvz_hip_stream s, void *ev);
+KVZ_HIP_API int kvz_hip_graph_begin(kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_graph_end(kvz_hip_stream s, kvz_hip_graph *graph_out);
+KVZ_HIP_API int kvz_hip_graph_launch(kvz_hip_graph graph, kvz_hip_stream s);
+KVZ_HIP_API void kvz_hip_graph_destroy(kvz_hip_graph graph);
+
 /* ------------------------------------------------------------------ */
 /* (2) batched entries -- picture group                               */
 /*     reference typedefs: strategies/strategies-picture.h:102-130    */

@@ -59,6 +59,11 @@ SIGNATURES = {
     "kvz_hip_event_destroy": (None, [_P]),
     "kvz_hip_event_record": (_I, [_P, _P]),
     "kvz_hip_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
+    "kvz_hip_stream_wait_event": (_I, [_P, _P]),
+    "kvz_hip_graph_begin": (_I, [_P]),
+    "kvz_hip_graph_end": (_I, [_P, C.POINTER(_P)]),
+    "kvz_hip_graph_launch": (_I, [_P, _P]),
+    "kvz_hip_graph_destroy": (None, [_P]),
     "kvz_hip_sad_nxn_batch": (_I, [_I, _P, _P, _SZ, _P, _P]),
     "kvz_hip_satd_nxn_batch": (_I, [_I, _P, _P, _SZ, _P, _P]),
     "kvz_hip_sad_nxn_dual_batch": (_I, [_I, _P, _SZ, _SZ, _P, _SZ, _P, _P]),

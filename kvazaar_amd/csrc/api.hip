@@ -194,4 +194,44 @@ int kvz_hip_event_elapsed_ms(void *start, void *stop, float *ms)
   return KVZ_HIP_OK;
 }
 
+int kvz_hip_stream_wait_event(kvz_hip_stream s, void *ev)
+{
+  KVZ_CHECK_CTX();
+  if (!ev) return kvzhip::invalid_arg(__func__);
+  HIP_TRY(hipStreamWaitEvent(ctx_stream(s), (hipEvent_t)ev, 0), "hipStreamWaitEvent");
+  return KVZ_HIP_OK;
+}
+
+// Graph capture.  ThreadLocal mode: other threads of the host (the per-call strategies run on every threadqueue
+// worker) keep allocating / synchronising on their own streams while this thread captures.
+int kvz_hip_graph_begin(kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipStreamBeginCapture(ctx_stream(s), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+  return KVZ_HIP_OK;
+}
+int kvz_hip_graph_end(kvz_hip_stream s, kvz_hip_graph *graph_out)
+{
+  KVZ_CHECK_CTX();
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx_stream(s), &g);     // always called: it also ends a capture an entry invalidated
+  if (!graph_out) { if (g) (void)hipGraphDestroy(g); return kvzhip::invalid_arg(__func__); }
+  *graph_out = nullptr;
+  if (e != hipSuccess || !g) { set_error("hipStreamEndCapture", e); return KVZ_HIP_ERR_RUNTIME; }
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) { set_error("hipGraphInstantiate", e); return KVZ_HIP_ERR_RUNTIME; }
+  *graph_out = (kvz_hip_graph)ex;
+  return KVZ_HIP_OK;
+}
+int kvz_hip_graph_launch(kvz_hip_graph graph, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!graph) return kvzhip::invalid_arg(__func__);
+  HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph, ctx_stream(s)), "hipGraphLaunch");
+  return KVZ_HIP_OK;
+}
+void kvz_hip_graph_destroy(kvz_hip_graph graph) { if (graph) (void)hipGraphExecDestroy((hipGraphExec_t)graph); }
+
 }  // extern "C"

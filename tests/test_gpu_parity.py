@@ -694,3 +694,61 @@ def test_invalid_arguments_leave_a_message(api):
     assert b"kvz_hip_sad_nxn_batch" in L.kvz_hip_last_error()
     assert L.kvz_hip_transform_batch(0, 5, None, None, 1, None) != 0
     assert b"kvz_hip_transform_batch" in L.kvz_hip_last_error()
+
+
+def test_frame_graph_replay_matches_the_oracle(api):
+    """a frame's launch sequence captured once as a hipGraph (kvz_hip_graph_begin/_end) with the motion search on a
+    forked stream, replayed on NEW buffer contents: every replay must equal the oracle like an eager launch does"""
+    import ctypes as C
+    from kvazaar_amd import _lib
+    from kvazaar_amd.api import DeviceBuffer
+    L = _lib.init(0)
+    s, side = L.kvz_hip_stream_create(), L.kvz_hip_stream_create()
+    fork, join = L.kvz_hip_event_create(), L.kvz_hip_event_create()
+    count, n32 = 500, 40
+    prm = me_params()
+    pus = me_random_pus(192, 128, 48, 21)
+    d_a, d_b = DeviceBuffer(count * 64), DeviceBuffer(count * 64)
+    d_sad, d_satd = DeviceBuffer(4 * count), DeviceBuffer(4 * count)
+    d_res, d_coef = DeviceBuffer(2 * n32 * 1024), DeviceBuffer(2 * n32 * 1024)
+    d_pic, d_ref = DeviceBuffer(192 * 128), DeviceBuffer(192 * 128)
+    d_pus, d_out = DeviceBuffer.from_numpy(pus.view(np.uint8)), DeviceBuffer(32 * len(pus))
+
+    def enqueue():
+        _lib.check(L.kvz_hip_event_record(fork, s), "fork")
+        _lib.check(L.kvz_hip_stream_wait_event(side, fork), "fork wait")
+        _lib.check(L.kvz_hip_search_pu_batch(d_pic.ptr, 192, 192, 128, d_ref.ptr, 192, 192, 128, d_pus.ptr, len(pus),
+                                             prm.ctypes.data, d_out.ptr, side), "search_pu")
+        _lib.check(L.kvz_hip_sad_nxn_batch(8, d_a.ptr, d_b.ptr, count, d_sad.ptr, s), "sad")
+        _lib.check(L.kvz_hip_satd_nxn_batch(8, d_a.ptr, d_b.ptr, count, d_satd.ptr, s), "satd")
+        _lib.check(L.kvz_hip_transform_batch(0, 32, d_res.ptr, d_coef.ptr, n32, s), "dct")
+        _lib.check(L.kvz_hip_event_record(join, side), "join")
+        _lib.check(L.kvz_hip_stream_wait_event(s, join), "join wait")
+
+    graph = C.c_void_p()
+    _lib.check(L.kvz_hip_graph_begin(s), "graph_begin")
+    enqueue()
+    _lib.check(L.kvz_hip_graph_end(s, C.byref(graph)), "graph_end")
+    assert graph.value
+    try:
+        for frame in range(3):
+            a, b = _blocks(8, count, 4000 + frame, "random")
+            res = rng(4100 + frame).integers(-255, 256, (n32, 1024)).astype(np.int16)
+            pic, ref = me_frames(192, 128, 4200 + frame, (2 + frame, -1))
+            for buf, arr in ((d_a, a), (d_b, b), (d_res, res), (d_pic, pic), (d_ref, ref)):
+                arr = np.ascontiguousarray(arr)
+                _lib.check(L.kvz_hip_memcpy_h2d(buf.ptr, arr.ctypes.data, arr.nbytes, s), "h2d")
+            _lib.check(L.kvz_hip_stream_sync(s), "sync")
+            _lib.check(L.kvz_hip_graph_launch(graph, s), "graph_launch")
+            np.testing.assert_array_equal(d_sad.to_numpy(np.uint32, (count,), s), O.cost_nxn_batch("sad", 8, a, b))
+            np.testing.assert_array_equal(d_satd.to_numpy(np.uint32, (count,), s), O.cost_nxn_batch("satd", 8, a, b))
+            np.testing.assert_array_equal(d_coef.to_numpy(np.int16, (n32, 1024), s), O.transform_batch("dct", 32, res))
+            got = d_out.to_numpy(np.int32, (len(pus), 8), s).view(ME_RESULT).reshape(-1)
+            want = O.search_pu_batch(pic, ref, pus, prm)
+            for f in ("mv", "cost", "bitcost"):
+                np.testing.assert_array_equal(got[f], want[f], err_msg="%s frame %d" % (f, frame))
+    finally:
+        L.kvz_hip_graph_destroy(graph)
+        L.kvz_hip_event_destroy(fork); L.kvz_hip_event_destroy(join)
+        L.kvz_hip_stream_destroy(s); L.kvz_hip_stream_destroy(side)
+    assert L.kvz_hip_graph_launch(None, None) != 0 and b"kvz_hip_graph_launch" in L.kvz_hip_last_error()
