@@ -6,7 +6,7 @@
 
 namespace kvzhip {
 
-static __constant__ signed char c_luma_filter[4][8] = {       // filter.c:54-60
+static __constant__ __attribute__((aligned(8))) signed char c_luma_filter[4][8] = {       // filter.c:54-60
   { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
 
 struct refplane_t { const u8 *p; u32 stride; int w, h; };
@@ -33,7 +33,6 @@ __device__ __forceinline__ u8 round_clip16(i16 sample) { return fast_clip16((i16
 // ---------------------------------------------------------------------------
 #define FR_HS 65                 /* H plane row stride of the per-call filter step kernel */
 
-struct frac_cand { int fx, fy, ry, cx; };
 // square[] of search_inter.c:972-976
 static __constant__ signed char c_sq_x[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 };
 static __constant__ signed char c_sq_y[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
@@ -41,15 +40,44 @@ static __constant__ signed char c_sq_y[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
 // LDS geometry of one block's working set.  BIG: blocks up to 64x64, the whole 256-thread workgroup
 // cooperates (barriers).  SMALL: blocks up to 16x16, ONE WAVE per block, four blocks per workgroup,
 // wave-private LDS slices and no barrier (DS operations of a wave execute in order).
+//
+// The horizontal planes are kept TRANSPOSED (column-major): the vertical 8-tap filter then finds the samples it
+// multiplies next to each other, two int16 per dword = one operand of v_dot2_i32_i16, and a lane that produces
+// two rows x eight columns of a candidate reads each column's ten samples as five dwords instead of sixteen
+// 2-byte reads.  Four planes: fx = 0 (64 P), fx = 2 and the two odd filters of the quarter-pel steps.
 template <int MAXW>
 struct frac_geom {
   static constexpr int PS = MAXW + 8;                 // P window stride: cols -4 .. w+3
   static constexpr int PR = MAXW + 8;                 // P rows -4 .. h+3
-  static constexpr int HS = MAXW + 1;                 // H plane stride: cols -1 .. w-1
-  static constexpr int CS = MAXW;                     // cur / candidate stride
-  static constexpr int P_BYTES = PS * PR, CUR_BYTES = CS * MAXW, H_ELEMS = PR * HS, CAND_BYTES = CS * MAXW;
-  static constexpr int TOTAL = ((P_BYTES + CUR_BYTES + 4 * CAND_BYTES + 15) & ~15) + 3 * H_ELEMS * 2 + 32;
+  static constexpr int CS = MAXW;                     // cur stride
+  static constexpr int HT = MAXW + 10;                // int16 per H column: rows -4 .. h+3 at index r+4; HT/2 is odd, so
+                                                      // neighbouring columns start in different LDS banks
+  static constexpr int HC = MAXW + 4;                 // H columns: c = -1 .. w-1 at index c+1, filled in groups of 4
+  static constexpr int P_BYTES = PS * PR + 16;        // + the dwords the last column group reads past the last row
+  static constexpr int CUR_BYTES = CS * MAXW, H_ELEMS = HC * HT;
+  static constexpr int H_OFF = (P_BYTES + CUR_BYTES + 15) & ~15;
+  static constexpr int TOTAL = H_OFF + 4 * H_ELEMS * 2 + 32;
 };
+
+// Coefficient pairs of the vertical filter for v_dot2: a lane owns output rows (y0, y0+1), y0 even, and reads the five
+// row pairs that start at the even row b - parity, b = first tap row of y0.  [fy][parity][output row][pair]
+struct frac_vcoef { u32 c[4][2][2][5]; };
+__host__ __device__ constexpr u32 frac_pack16(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }
+__host__ __device__ constexpr frac_vcoef frac_make_vcoef()
+{
+  constexpr int f[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+  frac_vcoef t = {};
+  for (int fy = 0; fy < 4; ++fy)
+    for (int i = 0; i < 5; ++i) {
+      const u32 aligned = i < 4 ? frac_pack16(f[fy][2 * i], f[fy][2 * i + 1]) : 0u;                        // taps (2i, 2i+1) on pair i
+      const u32 shifted = frac_pack16(i > 0 ? f[fy][2 * i - 1] : 0, i < 4 ? f[fy][2 * i] : 0);             // taps (2i-1, 2i) on pair i
+      const u32 late = i > 0 ? frac_pack16(f[fy][2 * i - 2], f[fy][2 * i - 1]) : 0u;                       // taps (2i-2, 2i-1) on pair i
+      t.c[fy][0][0][i] = aligned; t.c[fy][0][1][i] = shifted;      // b even: row y0 starts on pair 0, row y0+1 half a pair later
+      t.c[fy][1][0][i] = shifted; t.c[fy][1][1][i] = late;         // b odd: pairs start one row early
+    }
+  return t;
+}
+static __constant__ const frac_vcoef c_frac_vcoef = frac_make_vcoef();
 
 // MV cost policy of the search: cost() = calc_mvd_cost (search_inter.c:373-412) of the vector (x, y) << shift,
 // within() = fracmv_within_tile (:87-176) of a quarter-pel vector.  frac_no_cost gives the bare SATD search.
@@ -69,79 +97,159 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
                                                         u32 *__restrict__ out, i32 *__restrict__ best)
 {
   typedef frac_geom<MAXW> G;
-  u8 *s_p = lds, *s_cur = s_p + G::P_BYTES, *s_cand = s_cur + G::CUR_BYTES;
-  i16 *s_h = (i16 *)(lds + ((G::P_BYTES + G::CUR_BYTES + 4 * G::CAND_BYTES + 15) & ~15));
-  u32 *s_cost = (u32 *)(s_h + 3 * G::H_ELEMS);
+  u8 *s_p = lds, *s_cur = s_p + G::P_BYTES;
+  u32 *s_h = (u32 *)(lds + G::H_OFF);                  // plane k at dword k * H_ELEMS / 2
+  u32 *s_cost = s_h + 4 * (G::H_ELEMS / 2);
   int *s_sel = (int *)(s_cost + 4);
   auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
 
   const int w = FW ? FW : d.width, h = FH ? FH : d.height;
   const int pw = w + 8, ph = h + 8;
-  for (int i = tid; i < pw * ph; i += T) {
-    const int y = i / pw, x = i - y * pw;
-    s_p[y * G::PS + x] = ref_px(ref, d.x2 - 4 + x, d.y2 - 4 + y);
+  // P window: dword loads when it lies inside the frame, clamped bytes otherwise (ipol-generic.c:731-784)
+  if (d.x2 - 4 >= 0 && d.x2 + w + 4 <= ref.w && d.y2 - 4 >= 0 && d.y2 + h + 4 <= ref.h) {
+    const int pw4 = pw >> 2;
+    const u8 *src = ref.p + (size_t)(d.y2 - 4) * ref.stride + (d.x2 - 4);
+    for (int i = tid; i < pw4 * ph; i += T) {
+      const int y = i / pw4, x = (i - y * pw4) * 4;
+      u32 v;
+      __builtin_memcpy(&v, src + (size_t)y * ref.stride + x, 4);
+      *(u32 *)(s_p + y * G::PS + x) = v;
+    }
+  } else {
+    for (int i = tid; i < pw * ph; i += T) {
+      const int y = i / pw, x = i - y * pw;
+      s_p[y * G::PS + x] = ref_px(ref, d.x2 - 4 + x, d.y2 - 4 + y);
+    }
   }
-  for (int i = tid; i < w * h; i += T) {
-    const int y = i / w, x = i - y * w;
-    s_cur[y * G::CS + x] = pic[(size_t)(d.y1 + y) * pic_stride + d.x1 + x];
+  {
+    const int w8 = w >> 3;
+    for (int i = tid; i < w8 * h; i += T) {
+      const int y = i / w8, x = (i - y * w8) * 8;
+      uint2 v;
+      __builtin_memcpy(&v, pic + (size_t)(d.y1 + y) * pic_stride + d.x1 + x, 8);
+      *(uint2 *)(s_cur + y * G::CS + x) = v;
+    }
   }
   sync();
 
-  // H plane for filter f: rows r = -4 .. h+3 (index r+4), cols c = -1 .. w-1 (index c+1)
-  auto hor_plane = [&](int f, i16 *dst) {
-    const signed char *fl = c_luma_filter[f];
-    for (int i = tid; i < ph * (w + 1); i += T) {
-      const int y = i / (w + 1), x = i - y * (w + 1);     // c = x - 1 -> P cols c-3 .. c+4 -> window index x .. x+7
-      int acc = 0;
+  // Two horizontal planes in one pass over the window.  Work item = 2 rows x 4 columns: three aligned dwords of each row,
+  // the byte windows of the four columns cut out with v_alignbyte, each sample two v_dot4_i32_i8 on pixels - 128
+  // (sum of the taps = 64, so + 128 * 64 restores the offset; exact in int32, the result fits int16 like the reference's).
+  // H(r, c): plane rows r = -4 .. h+3 (index r+4), columns c = -1 .. w-1 (index c+1), stored column-major.
+  auto hor_planes = [&](int fa, int slot_a, int fb, int slot_b) {
+    const u32 *fl = (const u32 *)&c_luma_filter[0][0];
+    const u32 fa0 = fl[2 * fa], fa1 = fl[2 * fa + 1], fb0 = fl[2 * fb], fb1 = fl[2 * fb + 1];
+    u32 *pa = s_h + slot_a * (G::H_ELEMS / 2), *pb = s_h + slot_b * (G::H_ELEMS / 2);
+    const int npair = ph >> 1, ngrp = (w >> 2) + 1;
+    for (int i = tid; i < npair * ngrp; i += T) {
+      const int g = i / npair, yp = i - g * npair, x0 = 4 * g;       // consecutive lanes: consecutive dwords of one column
+      int ha[4][2], hb[4][2];
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc += fl[t] * (int)s_p[y * G::PS + x + t];
-      dst[y * G::HS + x] = (i16)acc;
-    }
-  };
-  // candidate: S(fx, fy; y + ry, x + cx) for the whole block
-  auto filter_cand = [&](const frac_cand &c, int plane, u8 *dst) {
-    const signed char *vf = c_luma_filter[c.fy];
-    for (int i = tid; i < w * h; i += T) {
-      const int y = i / w, x = i - y * w;
-      const int r = y + c.ry, cc = x + c.cx;              // H row index of (r-3+j) is r+1+j, col index cc+1
-      int acc = 0;
-      if (plane < 0) {                                    // fx == 0: H_0 = 64 * P
+      for (int rr = 0; rr < 2; ++rr) {
+        const u32 *q = (const u32 *)(s_p + (2 * yp + rr) * G::PS + x0);
+        const u32 d0 = q[0] ^ 0x80808080u, d1 = q[1] ^ 0x80808080u, d2 = q[2] ^ 0x80808080u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += vf[j] * 64 * (int)s_p[(r + 1 + j) * G::PS + cc + 4];
-      } else {
-        const i16 *pl = s_h + plane * G::H_ELEMS;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += vf[j] * (int)pl[(r + 1 + j) * G::HS + cc + 1];
+        for (int k = 0; k < 4; ++k) {
+          const u32 lo = k ? __builtin_amdgcn_alignbyte(d1, d0, (u32)k) : d0, hi = k ? __builtin_amdgcn_alignbyte(d2, d1, (u32)k) : d1;
+          ha[k][rr] = __builtin_amdgcn_sdot4((int)fa0, (int)lo, __builtin_amdgcn_sdot4((int)fa1, (int)hi, 8192, false), false);
+          hb[k][rr] = __builtin_amdgcn_sdot4((int)fb0, (int)lo, __builtin_amdgcn_sdot4((int)fb1, (int)hi, 8192, false), false);
+        }
       }
-      dst[y * G::CS + x] = round_clip16((i16)(acc >> 6));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pa[((x0 + k) * G::HT >> 1) + yp] = ((u32)ha[k][0] & 0xffffu) | ((u32)ha[k][1] << 16);
+        pb[((x0 + k) * G::HT >> 1) + yp] = ((u32)hb[k][0] & 0xffffu) | ((u32)hb[k][1] << 16);
+      }
     }
   };
-  // SATD of candidates 0..ncand-1 against s_cur -> s_cost.  Four lanes per (candidate, 8x8 sub-block): lane p takes rows
-  // 2p, 2p+1 and the last two vertical Hadamard stages cross the quad with DPP (satd8_quad_part), a quarter of the
-  // instructions of one lane per sub-block -- the scoring rounds are the largest part of a small block's search.
-  auto score = [&](int ncand, const u8 *cand0, int cand_stride, int cand_pitch) {
+
+  // SATD of one candidate given as bytes (the integer position: P itself) against s_cur -> s_cost[0].  Four lanes per
+  // 8x8 sub-block: lane p takes rows 2p, 2p+1 and the last two vertical Hadamard stages cross the quad with DPP.
+  const int p = tid & 3;
+  const short sg1 = (p & 1) ? (short)-1 : (short)1, sg2 = (p & 2) ? (short)-1 : (short)1;
+  const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 };
+  const int w8 = w >> 3, n8 = w8 * (h >> 3);
+  // lanes that share a candidate form aligned runs of min(4 n8, 64) lanes when n8 is a power of two: their SATDs are
+  // added in registers first (many lanes on one LDS address with an atomic serialise)
+  const int run = 4 * n8 < 64 ? 4 * n8 : 64;
+  const bool run_pow2 = (n8 & (n8 - 1)) == 0;
+  auto add_cost = [&](int k, u32 m) {
+    m = group_sum<4>(m);
+    u32 v = p == 0 ? (m + 2) >> 2 : 0u;
+    if (run_pow2) {
+      v = run == 4 ? v : run == 8 ? group_sum<8>(v) : run == 16 ? group_sum<16>(v) : run == 32 ? group_sum<32>(v) : group_sum<64>(v);
+      if (((tid & 63) & (run - 1)) == 0) atomicAdd(&s_cost[k], v);
+    } else if (p == 0) {
+      atomicAdd(&s_cost[k], v);
+    }
+  };
+  auto score_integer = [&]() {
     if (tid < 4) s_cost[tid] = 0;
     sync();
-    const int w8 = w >> 3, n8 = w8 * (h >> 3);
-    const int p = tid & 3;
-    const short sg1 = (p & 1) ? (short)-1 : (short)1, sg2 = (p & 2) ? (short)-1 : (short)1;
-    const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 };
-    for (int i = tid; i < ncand * n8 * 4; i += T) {        // whole quads are active or idle together: counts are multiples of 4
-      const int q = i >> 2, k = q / n8, sb = q - k * n8, by = sb / w8, bx = sb - by * w8;
+    for (int i = tid; i < n8 * 4; i += T) {
+      const int sb = i >> 2, by = sb / w8, bx = sb - by * w8;
       const u8 *a = s_cur + (by * 8 + 2 * p) * G::CS + bx * 8;
-      const u8 *b = cand0 + (size_t)k * cand_pitch + (by * 8 + 2 * p) * cand_stride + bx * 8;
+      const u8 *b = s_p + (4 + by * 8 + 2 * p) * G::PS + 4 + bx * 8;
       uint4 x, y;
       __builtin_memcpy(&x.x, a, 4); __builtin_memcpy(&x.y, a + 4, 4); __builtin_memcpy(&x.z, a + G::CS, 4); __builtin_memcpy(&x.w, a + G::CS + 4, 4);
-      __builtin_memcpy(&y.x, b, 4); __builtin_memcpy(&y.y, b + 4, 4); __builtin_memcpy(&y.z, b + cand_stride, 4); __builtin_memcpy(&y.w, b + cand_stride + 4, 4);
-      u32 m = satd8_quad_part(x, y, m1, m2);
-      m = group_sum<4>(m);
-      if (p == 0) atomicAdd(&s_cost[k], (m + 2) >> 2);
+      __builtin_memcpy(&y.x, b, 4); __builtin_memcpy(&y.y, b + 4, 4); __builtin_memcpy(&y.z, b + G::PS, 4); __builtin_memcpy(&y.w, b + G::PS + 4, 4);
+      add_cost(0, satd8_quad_part(x, y, m1, m2));
+    }
+    sync();
+  };
+
+  // The four candidates of a step, filtered and scored without leaving registers.  Candidate k of the step sits at the
+  // quarter-pel offset (qx, qy) = (ox, oy) + scale * square[pat + k]: S(qx & 3, qy & 3; y + (qy >> 2), x + (qx >> 2)).
+  // Work item = (candidate, 8x8 sub-block, quad lane p): the lane filters rows 2p, 2p+1 x 8 columns -- per column five
+  // dwords of the transposed plane and ten v_dot2_i32_i16 -- and feeds the differences straight into the quad SATD.
+  auto score_step = [&](int pat, int ox, int oy, int scale) {
+    if (tid < 4) s_cost[tid] = 0;
+    sync();
+    for (int i = tid; i < 4 * n8 * 4; i += T) {            // whole quads are active or idle together
+      const int q = i >> 2, k = q / n8, sb = q - k * n8, by = sb / w8, bx = sb - by * w8;
+      // square[] (search_inter.c:972-976) entries 1..8 as 2-bit fields of (value + 1)
+      const int sx = (int)((0x8858u >> (2 * (pat + k - 1))) & 3u) - 1;       // -1, 1, 0, 0, -1, 1, -1, 1
+      const int sy = (int)((0xa085u >> (2 * (pat + k - 1))) & 3u) - 1;       //  0, 0,-1, 1, -1,-1,  1, 1
+      const int qx = ox + scale * sx, qy = oy + scale * sy;
+      const int fx = qx & 3, fy = qy & 3, cx = qx >> 2, ry = qy >> 2;
+      const int slot = fx == 0 ? 0 : fx == 2 ? 1 : (sx > 0 ? 3 : 2);
+      const int y0 = by * 8 + 2 * p, b = y0 + ry + 1, par = b & 1;          // first tap row of output row y0 is plane row b
+      u32 c0[5], c1[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) { c0[t] = c_frac_vcoef.c[fy][par][0][t]; c1[t] = c_frac_vcoef.c[fy][par][1][t]; }
+      const u8 *a = s_cur + y0 * G::CS + bx * 8;
+      u32 cur[4];
+      __builtin_memcpy(&cur[0], a, 4); __builtin_memcpy(&cur[1], a + 4, 4); __builtin_memcpy(&cur[2], a + G::CS, 4); __builtin_memcpy(&cur[3], a + G::CS + 4, 4);
+      const u32 *col = s_h + slot * (G::H_ELEMS / 2) + ((bx * 8 + cx + 1) * G::HT >> 1) + (b >> 1);
+      int t0[8], t1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const u32 *cj = col + j * (G::HT >> 1);
+        int a0 = 0, a1 = 0;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          const v2s pr = as_v2s(cj[t]);
+          a0 = __builtin_amdgcn_sdot2(pr, as_v2s(c0[t]), a0, false);
+          a1 = __builtin_amdgcn_sdot2(pr, as_v2s(c1[t]), a1, false);
+        }
+        // round_clip16((int16)(acc >> 6)): the clip's argument is within +-512, where it is a plain clamp
+        t0[j] = clampi(((int)(i16)(a0 >> 6) + 32) >> 6, 0, 255);
+        t1[j] = clampi(((int)(i16)(a1 >> 6) + 32) >> 6, 0, 255);
+      }
+      v2s dd[2][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const u32 cw0 = cur[jj >> 1], cw1 = cur[2 + (jj >> 1)];
+        dd[0][jj] = ((jj & 1) ? unpack_hi(cw0) : unpack_lo(cw0)) - as_v2s((u32)t0[2 * jj] | ((u32)t0[2 * jj + 1] << 16));
+        dd[1][jj] = ((jj & 1) ? unpack_hi(cw1) : unpack_lo(cw1)) - as_v2s((u32)t1[2 * jj] | ((u32)t1[2 * jj + 1] << 16));
+      }
+      add_cost(k, satd8_quad_part_diff(dd, m1, m2));
     }
     sync();
   };
 
   // integer position: candidate = P[y][x]
-  score(1, s_p + 4 * G::PS + 4, G::PS, 0);
+  score_integer();
   int mx = d.x2 - d.x1, my = d.y2 - d.y1;              // pixel precision
   u32 best_bitcost = 0;
   u32 best_cost = s_cost[0];
@@ -149,46 +257,21 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   best_cost += mvc.cost(mx, my, 2, best_bitcost);
   mx *= 2; my *= 2;                                    // half-pel precision (search_inter.c:1031-1032)
 
-  hor_plane(2, s_h);
+  if (fme_level > 0) hor_planes(0, 0, 2, 1);
   sync();
 
   int best_index = 0, pat = 1;                         // pat: first index of the step's 4 positions in square[]
   for (int step = 0; step < fme_level; ++step) {
-    frac_cand c[4];
-    int plane[4];
     if (step < 2) {
-      if (step == 0) {
-        c[0] = { 2, 0, 0, -1 }; c[1] = { 2, 0, 0, 0 }; c[2] = { 0, 2, -1, 0 }; c[3] = { 0, 2, 0, 0 };
-        plane[0] = 0; plane[1] = 0; plane[2] = -1; plane[3] = -1;
-      } else {
-        c[0] = { 2, 2, -1, -1 }; c[1] = { 2, 2, -1, 0 }; c[2] = { 2, 2, 0, -1 }; c[3] = { 2, 2, 0, 0 };
-        plane[0] = plane[1] = plane[2] = plane[3] = 0;
-      }
+      score_step(pat, 0, 0, 2);                        // half-pel ring: offsets +-2 quarter-pels
     } else {
-      const int hx = s_sel[0], hy = s_sel[1];              // best half-pel offset in {-1,0,1}^2
-      const int bx = 2 * hx, by = 2 * hy;
-      const int hp = (bx & 3) ? 0 : -1;                    // plane of the half-pel column itself: fx 2 -> plane 0, fx 0 -> P
+      const int hx = s_sel[0], hy = s_sel[1];          // best half-pel offset in {-1,0,1}^2
       if (step == 2) {
-        c[0] = { (bx - 1) & 3, by & 3, by >> 2, (bx - 1) >> 2 };
-        c[1] = { (bx + 1) & 3, by & 3, by >> 2, (bx + 1) >> 2 };
-        c[2] = { bx & 3, (by - 1) & 3, (by - 1) >> 2, bx >> 2 };
-        c[3] = { bx & 3, (by + 1) & 3, (by + 1) >> 2, bx >> 2 };
-        plane[0] = 1; plane[1] = 2; plane[2] = hp; plane[3] = hp;
-        hor_plane((bx - 1) & 3, s_h + G::H_ELEMS);
-        hor_plane((bx + 1) & 3, s_h + 2 * G::H_ELEMS);
+        hor_planes((2 * hx - 1) & 3, 2, (2 * hx + 1) & 3, 3);
         sync();
-      } else {
-        c[0] = { (bx - 1) & 3, (by - 1) & 3, (by - 1) >> 2, (bx - 1) >> 2 };
-        c[1] = { (bx + 1) & 3, (by - 1) & 3, (by - 1) >> 2, (bx + 1) >> 2 };
-        c[2] = { (bx - 1) & 3, (by + 1) & 3, (by + 1) >> 2, (bx - 1) >> 2 };
-        c[3] = { (bx + 1) & 3, (by + 1) & 3, (by + 1) >> 2, (bx + 1) >> 2 };
-        plane[0] = 1; plane[1] = 2; plane[2] = 1; plane[3] = 2;
       }
+      score_step(pat, 2 * hx, 2 * hy, 1);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) filter_cand(c[k], plane[k], s_cand + k * G::CAND_BYTES);
-    sync();
-    score(4, s_cand, G::CS, G::CAND_BYTES);
     // decision: same order and strict '<' as search_inter.c:1069-1102
     const int mv_shift = step < 2 ? 1 : 0;
 #pragma unroll

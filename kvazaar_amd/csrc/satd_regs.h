@@ -118,15 +118,10 @@ __device__ __forceinline__ v2s dpp_v2s(v2s v)
   return as_v2s((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(v), CTRL, 0xF, 0xF, true));
 }
 
-// x, y: the lane's 16-byte chunk of each block (rows 2p and 2p+1).  Returns the lane's share of the
+// d[j][q]: the lane's differences, row 2p+j, columns (2q, 2q+1) packed.  Returns the lane's share of the
 // block's absolute Hadamard sum; the block's SATD is (sum over the quad + 2) >> 2.
-__device__ __forceinline__ u32 satd8_quad_part(uint4 x, uint4 y, v2s m1, v2s m2)
+__device__ __forceinline__ u32 satd8_quad_part_diff(v2s (&d)[2][4], v2s m1, v2s m2)
 {
-  v2s d[2][4];
-  d[0][0] = unpack_lo(x.x) - unpack_lo(y.x); d[0][1] = unpack_hi(x.x) - unpack_hi(y.x);
-  d[0][2] = unpack_lo(x.y) - unpack_lo(y.y); d[0][3] = unpack_hi(x.y) - unpack_hi(y.y);
-  d[1][0] = unpack_lo(x.z) - unpack_lo(y.z); d[1][1] = unpack_hi(x.z) - unpack_hi(y.z);
-  d[1][2] = unpack_lo(x.w) - unpack_lo(y.w); d[1][3] = unpack_hi(x.w) - unpack_hi(y.w);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {          // column bits 2 and 1
     v2s s0 = d[j][0] + d[j][2], s1 = d[j][1] + d[j][3], e0 = d[j][0] - d[j][2], e1 = d[j][1] - d[j][3];
@@ -145,6 +140,17 @@ __device__ __forceinline__ u32 satd8_quad_part(uint4 x, uint4 y, v2s m1, v2s m2)
     m = abs_last_stage(u, m);            // column bit 0 and the absolute sum
   }
   return m;
+}
+
+// x, y: the lane's 16-byte chunk of each block (rows 2p and 2p+1).
+__device__ __forceinline__ u32 satd8_quad_part(uint4 x, uint4 y, v2s m1, v2s m2)
+{
+  v2s d[2][4];
+  d[0][0] = unpack_lo(x.x) - unpack_lo(y.x); d[0][1] = unpack_hi(x.x) - unpack_hi(y.x);
+  d[0][2] = unpack_lo(x.y) - unpack_lo(y.y); d[0][3] = unpack_hi(x.y) - unpack_hi(y.y);
+  d[1][0] = unpack_lo(x.z) - unpack_lo(y.z); d[1][1] = unpack_hi(x.z) - unpack_hi(y.z);
+  d[1][2] = unpack_lo(x.w) - unpack_lo(y.w); d[1][3] = unpack_hi(x.w) - unpack_hi(y.w);
+  return satd8_quad_part_diff(d, m1, m2);
 }
 
 }  // namespace kvzhip
