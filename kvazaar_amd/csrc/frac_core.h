@@ -248,6 +248,62 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
     sync();
   };
 
+  // The same step for an 8x8 block owned by one wave: with one sub-block the scheme above keeps 16 lanes busy, so the
+  // work is cut finer -- lane = (candidate k, row pair p, column pair g) filters 2 x 2 samples, and the Hadamard crosses
+  // the 16 lanes of a candidate with DPP (quad_perm for g, row_shl/shr:4 and row_ror:8 for p).
+  auto score_step8 = [&](int pat, int ox, int oy, int scale) {
+    const int g = tid & 3, pp = (tid >> 2) & 3, k = tid >> 4;
+    const int sx = (int)((0x8858u >> (2 * (pat + k - 1))) & 3u) - 1, sy = (int)((0xa085u >> (2 * (pat + k - 1))) & 3u) - 1;
+    const int qx = ox + scale * sx, qy = oy + scale * sy;
+    const int fx = qx & 3, fy = qy & 3, cx = qx >> 2, ry = qy >> 2;
+    const int slot = fx == 0 ? 0 : fx == 2 ? 1 : (sx > 0 ? 3 : 2);
+    const int y0 = 2 * pp, b = y0 + ry + 1, par = b & 1;
+    u32 c0[5], c1[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) { c0[t] = c_frac_vcoef.c[fy][par][0][t]; c1[t] = c_frac_vcoef.c[fy][par][1][t]; }
+    const u32 *col = s_h + slot * (G::H_ELEMS / 2) + ((2 * g + cx + 1) * G::HT >> 1) + (b >> 1);
+    int t0[2], t1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32 *cj = col + j * (G::HT >> 1);
+      int a0 = 0, a1 = 0;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const v2s pr = as_v2s(cj[t]);
+        a0 = __builtin_amdgcn_sdot2(pr, as_v2s(c0[t]), a0, false);
+        a1 = __builtin_amdgcn_sdot2(pr, as_v2s(c1[t]), a1, false);
+      }
+      t0[j] = clampi(((int)(i16)(a0 >> 6) + 32) >> 6, 0, 255);
+      t1[j] = clampi(((int)(i16)(a1 >> 6) + 32) >> 6, 0, 255);
+    }
+    const u8 *a = s_cur + y0 * G::CS + 2 * g;
+    const u32 cw0 = *(const unsigned short *)a, cw1 = *(const unsigned short *)(a + G::CS);
+    const v2s r0 = unpack_lo(cw0) - as_v2s((u32)t0[0] | ((u32)t0[1] << 16)), r1 = unpack_lo(cw1) - as_v2s((u32)t1[0] | ((u32)t1[1] << 16));
+    const short s4 = (tid & 4) ? (short)-1 : (short)1, s8 = (tid & 8) ? (short)-1 : (short)1;
+    const v2s m4 = { s4, s4 }, m8 = { s8, s8 };
+    v2s v[2] = { r0 + r1, r0 - r1 };                    // row bit 0
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v2s t = dpp_v2s<0xB1>(v[i]);                      // column bit 1
+      v2s u = v[i] * m1 + t;
+      t = dpp_v2s<0x4E>(u);                             // column bit 2
+      u = u * m2 + t;
+      t = dpp_xor4_v2s(u);                              // row bit 1
+      u = u * m4 + t;
+      t = dpp_v2s<0x128>(u);                            // row bit 2 (row_ror:8)
+      u = u * m8 + t;
+      acc = abs_last_stage(u, acc);                     // column bit 0 and the absolute sum
+    }
+    acc = group_sum<16>(acc);
+    if ((tid & 15) == 0) s_cost[k] = (acc + 2) >> 2;
+    sync();
+  };
+  constexpr bool SPLIT8 = WAVE && T == 64 && FW == 8 && FH == 8;
+  auto score_any = [&](int pat, int ox, int oy, int scale) {
+    if constexpr (SPLIT8) score_step8(pat, ox, oy, scale); else score_step(pat, ox, oy, scale);
+  };
+
   // integer position: candidate = P[y][x]
   score_integer();
   int mx = d.x2 - d.x1, my = d.y2 - d.y1;              // pixel precision
@@ -263,14 +319,14 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   int best_index = 0, pat = 1;                         // pat: first index of the step's 4 positions in square[]
   for (int step = 0; step < fme_level; ++step) {
     if (step < 2) {
-      score_step(pat, 0, 0, 2);                        // half-pel ring: offsets +-2 quarter-pels
+      score_any(pat, 0, 0, 2);                         // half-pel ring: offsets +-2 quarter-pels
     } else {
       const int hx = s_sel[0], hy = s_sel[1];          // best half-pel offset in {-1,0,1}^2
       if (step == 2) {
         hor_planes((2 * hx - 1) & 3, 2, (2 * hx + 1) & 3, 3);
         sync();
       }
-      score_step(pat, 2 * hx, 2 * hy, 1);
+      score_any(pat, 2 * hx, 2 * hy, 1);
     }
     // decision: same order and strict '<' as search_inter.c:1069-1102
     const int mv_shift = step < 2 ? 1 : 0;

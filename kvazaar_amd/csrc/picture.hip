@@ -245,19 +245,6 @@ __global__ __launch_bounds__(256) void satd8_kernel(const u8 *__restrict__ a, co
 // for row bit 2.  Per-sub-block rounding (sum+2)>>2 is applied before the four
 // sub-blocks are added (strategies-picture.h:40-56).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ v2s dpp_xor4_v2s(v2s v)
-{
-  int t = __builtin_amdgcn_update_dpp(0, (int)as_u32(v), 0x104, 0xF, 0x5, false);      // row_shl:4 into banks 0, 2
-  t = __builtin_amdgcn_update_dpp(t, (int)as_u32(v), 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1, 3
-  return as_v2s((u32)t);
-}
-__device__ __forceinline__ u32 dpp_xor4_u32(u32 v)
-{
-  int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
-  t = __builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
-  return (u32)t;
-}
-
 // x, y: row `lane & 15` of the block in each array.  Returns the block's SATD in every lane of its 16-lane row.
 __device__ __forceinline__ u32 satd16_row_part(uint4 x, uint4 y, v2s m1, v2s m2, v2s m4)
 {

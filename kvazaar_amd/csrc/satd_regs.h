@@ -118,6 +118,20 @@ __device__ __forceinline__ v2s dpp_v2s(v2s v)
   return as_v2s((u32)__builtin_amdgcn_update_dpp(0, (int)as_u32(v), CTRL, 0xF, 0xF, true));
 }
 
+// lane ^ 4 within a row of 16 lanes: a bank-masked row_shl:4 / row_shr:4 pair
+__device__ __forceinline__ v2s dpp_xor4_v2s(v2s v)
+{
+  int t = __builtin_amdgcn_update_dpp(0, (int)as_u32(v), 0x104, 0xF, 0x5, false);      // row_shl:4 into banks 0, 2
+  t = __builtin_amdgcn_update_dpp(t, (int)as_u32(v), 0x114, 0xF, 0xA, false);          // row_shr:4 into banks 1, 3
+  return as_v2s((u32)t);
+}
+__device__ __forceinline__ u32 dpp_xor4_u32(u32 v)
+{
+  int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
+  t = __builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+  return (u32)t;
+}
+
 // d[j][q]: the lane's differences, row 2p+j, columns (2q, 2q+1) packed.  Returns the lane's share of the
 // block's absolute Hadamard sum; the block's SATD is (sum over the quad + 2) >> 2.
 __device__ __forceinline__ u32 satd8_quad_part_diff(v2s (&d)[2][4], v2s m1, v2s m2)
