@@ -328,15 +328,21 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
       }
       score_any(pat, 2 * hx, 2 * hy, 1);
     }
-    // decision: same order and strict '<' as search_inter.c:1069-1102
+    // decision: same order and strict '<' as search_inter.c:1069-1102.  calc_mvd_cost is ~100 instructions: lane j of
+    // every wave prices candidate j and the four results are read back with v_readlane (all lanes pricing all four
+    // candidates was a third of a small block's search).
     const int mv_shift = step < 2 ? 1 : 0;
+    const int lj = tid & 3;
+    const int lpx = mx + (int)((0x8858u >> (2 * (pat + lj - 1))) & 3u) - 1, lpy = my + (int)((0xa085u >> (2 * (pat + lj - 1))) & 3u) - 1;
+    u32 lbits = 0;
+    const u32 lraw = s_cost[lj];
+    const int lok = mvc.within(lpx * (1 << mv_shift), lpy * (1 << mv_shift)) ? 1 : 0;
+    const u32 lcost = lraw + mvc.cost(lpx, lpy, mv_shift, lbits);
+    if (out && tid < 4) out[(step >= 2 ? 8 : 0) + pat + tid] = lraw;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      u32 cj = s_cost[j], bj = 0;
-      if (out && tid == 0) out[(step >= 2 ? 8 : 0) + pat + j] = cj;
-      const int px = mx + c_sq_x[pat + j], py = my + c_sq_y[pat + j];
-      if (!mvc.within(px * (1 << mv_shift), py * (1 << mv_shift))) continue;
-      cj += mvc.cost(px, py, mv_shift, bj);
+      const u32 cj = (u32)__builtin_amdgcn_readlane((int)lcost, j), bj = (u32)__builtin_amdgcn_readlane((int)lbits, j);
+      if (!__builtin_amdgcn_readlane(lok, j)) continue;
       if (cj < best_cost) { best_cost = cj; best_bitcost = bj; best_index = pat + j; }
     }
     pat += 4;

@@ -66,8 +66,11 @@ struct me_cost_model {
   // get_ep_ex_golomb_bitcost (:235-254)
   static __device__ __forceinline__ u32 golomb(u32 symbol)
   {
-    u32 bins = 0;
     symbol += 2;
+    // the reference's four range tests add up to 2 * floor(log2(symbol)) while symbol < 2^16 (they test bits 8, 4, 2, 1
+    // of the exponent once each); vectors are int16, so only a difference of two extreme vectors gets past that
+    if (__builtin_expect(symbol < (1u << 16), 1)) return 2u * (31u - (u32)__builtin_clz(symbol));
+    u32 bins = 0;
     if (symbol >= 1u << 8) { bins += 16; symbol >>= 8; }
     if (symbol >= 1u << 4) { bins += 8; symbol >>= 4; }
     if (symbol >= 1u << 2) { bins += 4; symbol >>= 2; }
