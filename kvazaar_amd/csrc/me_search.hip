@@ -478,8 +478,9 @@ __device__ __forceinline__ void flag_bad(kvz_hip_me_result *out)
   *out = r;
 }
 
-// PUs larger than 32x32 in either direction (and malformed descriptors, which are flagged): one workgroup per PU
-__global__ __launch_bounds__(256) void search_pu_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
+// PUs larger than 32x32 in either direction (and malformed descriptors, which are flagged): one workgroup (T threads) per PU
+template <int T>
+__global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                             const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
                                                             kvz_hip_me_result *__restrict__ out)
 {
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(256) void search_pu_big_kernel(const u8 *__restrict
   const kvz_hip_me_pu &pu = pus[blockIdx.x];            // uniform address: the compiler reads it with scalar loads
   if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   if (pu.width <= 32 && pu.height <= 32) return;       // the one-wave-per-PU kernels'
-  search_pu_core<64, 256, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  search_pu_core<64, T, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
 
 // PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier
@@ -557,7 +558,10 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   // kernel also flags malformed descriptors, so it only goes when the caller vouches for the classes it names.
   const int classes = (params->size_classes & 7) ? (params->size_classes & 7) : 7;
   if (classes == 7 || (classes & 4)) {
-    hipLaunchKernelGGL(search_pu_big_kernel, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+    const int bt = tuning("me_big_threads", 512);      // measured at 480 and 1920 PUs of 64x64: 512 threads 10.5 M/s, 256: 9.5, 1024: 6.5
+    if (bt == 1024) hipLaunchKernelGGL(search_pu_big_kernel<1024>, dim3((unsigned)count), dim3(1024), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+    else if (bt == 512) hipLaunchKernelGGL(search_pu_big_kernel<512>, dim3((unsigned)count), dim3(512), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+    else hipLaunchKernelGGL(search_pu_big_kernel<256>, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
     KVZ_CHECK_LAUNCH("search_pu_big_kernel");
   }
   if (classes & 1) {

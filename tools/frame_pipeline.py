@@ -142,9 +142,13 @@ def run(L, s, frames, per_frame):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--tune", default="", help="key=value[,key=value...] passed to kvz_hip_set_tuning")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     L = _lib.init(0)
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        chk(L.kvz_hip_set_tuning(k.encode(), int(v)), "set_tuning " + k)
     s = L.kvz_hip_stream_create()
     side = [L.kvz_hip_stream_create() for _ in range(7)]
     events = [L.kvz_hip_event_create() for _ in range(8)]
