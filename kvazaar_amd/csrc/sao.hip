@@ -118,6 +118,102 @@ __global__ __launch_bounds__(256) void sao_edge_kernel(const u8 *__restrict__ or
   }
 }
 
+// The same two entries for the shapes sao.c really blits (width a multiple of 4, dword-aligned arrays).
+// ONE WAVE per block.  A work item is one dword of rec = 4 pixels with the 3 x 3 dwords around it, so a pixel's eight
+// neighbours come from registers.  Per (class, pixel) the category index sgn(c-a) + sgn(c-b) is two v_sub + two v_med3,
+// and instead of selecting it into 5 sums + 5 counts, the pixel is added into PACKED accumulators at a bit position
+// looked up with v_perm: counts in 7-bit fields of a dword, (orig - rec + 255) in 15-bit fields of a 64-bit register
+// (a lane sees at most 64 pixels).  The middle category (index 0) and the excluded border columns go to a scratch
+// field: its sum and count are what is left of the totals.  One wave per block keeps the unpack + cross-lane reduction
+// (34 values) to once per block -- with four waves it was a third of the kernel.  ddistortion is evaluated from the
+// statistics: the sum over a category of (diff - off)^2 - diff^2 is cnt * off^2 - 2 * off * sum (sao-generic.c:67-71).
+template <int MODE>
+__global__ __launch_bounds__(64) void sao_edge_fast_kernel(const u8 *__restrict__ orig, const u8 *__restrict__ rec, int bw, int bh,
+                                                          const int *__restrict__ offsets, int *__restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) u32 s_o[MAX_PX / 4], s_r[MAX_PX / 4];
+  __shared__ int s_stat[4][2][5];
+  const int tid = threadIdx.x, n4 = (bw * bh) >> 2, g4 = bw >> 2;
+  const size_t blk = blockIdx.x;
+  {
+    const u32 *go = (const u32 *)(orig + blk * (size_t)(bw * bh)), *gr = (const u32 *)(rec + blk * (size_t)(bw * bh));
+    for (int i = tid; i < n4; i += 64) { s_o[i] = go[i]; s_r[i] = gr[i]; }
+  }
+  wave_lds_fence();
+
+  unsigned long long sum[4] = { 0, 0, 0, 0 };
+  u32 cnt[4] = { 0, 0, 0, 0 };
+  int tot = 0, npx = 0;
+  const int items = (bh - 2) * g4;
+  const u32 recip = (65536u + (u32)g4 - 1u) / (u32)g4;        // it / g4 == (it * recip) >> 16 for it < 1024, g4 <= 16
+  for (int it = tid; it < items; it += 64) {
+    const int yy = (int)(((u32)it * recip) >> 16), xg = it - yy * g4, at = (yy + 1) * g4 + xg;
+    // rows y-1, y, y+1 as 6-pixel windows: [last byte of the left dword, the dword, first byte of the right dword]
+    int win[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      // the first / last item's outer neighbour dword lies just outside the block: those pixels are excluded border
+      // columns, any value will do, but the read stays inside the array
+      const int il = at + (r - 1) * g4 - 1, ir = at + (r - 1) * g4 + 1;
+      const u32 l = s_r[r == 0 ? (il < 0 ? 0 : il) : il], c = s_r[at + (r - 1) * g4], rt = s_r[r == 2 ? (ir < n4 ? ir : n4 - 1) : ir];
+      win[r][0] = (int)(l >> 24);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) win[r][1 + k] = (int)((c >> (8 * k)) & 255u);
+      win[r][5] = (int)(rt & 255u);
+    }
+    const u32 od = s_o[at];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool valid = !((k == 0 && xg == 0) || (k == 3 && xg == g4 - 1));
+      const int c = win[1][1 + k];
+      const int diff = (int)((od >> (8 * k)) & 255u) - c;
+      tot += valid ? diff : 0;
+      npx += valid ? 1 : 0;
+      const u32 v = (u32)(diff + 255);
+      // neighbour pairs of the four classes (g_sao_edge_offsets, sao.h:58-63)
+      const int na[4] = { win[1][k], win[0][1 + k], win[0][k], win[0][2 + k] };
+      const int nb[4] = { win[1][2 + k], win[2][1 + k], win[2][2 + k], win[2][k] };
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s1 = clampi(c - na[e], -1, 1), s2 = clampi(c - nb[e], -1, 1);
+        u32 sel = (u32)(s1 + s2) + 0x0c0c0c02u;                         // byte 0 = index + 2, other selector bytes = constant zero
+        if (k == 0 || k == 3) sel = valid ? sel : 0x0c0c0c02u;
+        const u32 shs = __builtin_amdgcn_perm(0x0000002Du, 0x1E3C0F00u, sel);    // index -2, -1, 0, 1, 2 -> bit 0, 15, 60, 30, 45
+        const u32 shc = __builtin_amdgcn_perm(0x00000015u, 0x0E1C0700u, sel);    //                        -> bit 0, 7, 28, 14, 21
+        sum[e] += (unsigned long long)v << shs;
+        cnt[e] += 1u << shc;
+      }
+    }
+  }
+  // unpack and reduce over the wave: slots -2, -1, +1, +2 are categories 1, 2, 3, 4 (sao_calc_eo_cat, sao-generic.c:34-43)
+  const int wt = wave_sum(tot), wn = wave_sum(npx);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int rest_s = wt, rest_c = wn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = (int)((cnt[e] >> (7 * k)) & 127u);
+      const int sm = (int)((sum[e] >> (15 * k)) & 32767u) - 255 * c;
+      const int ws = wave_sum(sm), wc = wave_sum(c);
+      rest_s -= ws; rest_c -= wc;
+      if (tid == 0) { s_stat[e][0][1 + k] = ws; s_stat[e][1][1 + k] = wc; }
+    }
+    if (tid == 0) { s_stat[e][0][0] = rest_s; s_stat[e][1][0] = rest_c; }      // category 0 is the rest
+  }
+  wave_lds_fence();
+  if (MODE == 0) {
+    if (tid < 40) out[blk * 40 + tid] = (&s_stat[0][0][0])[tid];
+  } else if (tid < 4) {
+    int dd = 0;
+#pragma unroll
+    for (int cat = 0; cat < 5; ++cat) {
+      const int off = offsets[blk * 20 + tid * 5 + cat];
+      dd += s_stat[tid][1][cat] * off * off - 2 * off * s_stat[tid][0][cat];
+    }
+    out[blk * 4 + tid] = dd;
+  }
+}
+
 // MODE 0: calc_sao_bands (sao.c:247-261) -> out[blk][2][32]
 // MODE 1: sao_band_ddistortion (sao-generic.c:157-183) with band_pos[blk], bands[blk][4] -> out[blk]
 template <int MODE>
@@ -200,6 +296,12 @@ __global__ __launch_bounds__(256) void sao_reconstruct_kernel(const u8 *__restri
   }
 }
 
+// the packed-accumulator kernel: whole dwords per row, dword-aligned arrays, an interior to work on
+bool edge_fast_ok(const void *orig, const void *rec, int bw, int bh)
+{
+  return tuning("sao_edge_fast", 1) && (bw & 3) == 0 && bh >= 3 && (((uintptr_t)orig | (uintptr_t)rec) & 3) == 0;
+}
+
 bool block_dims_ok(int bw, int bh)
 {
   if (bw < 1 || bh < 1 || bw > 64 || bh > 64) {
@@ -220,8 +322,12 @@ int kvz_hip_sao_edge_stats_batch(const kvz_hip_pixel *orig, const kvz_hip_pixel 
   if (!block_dims_ok(block_width, block_height)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   if (!orig || !rec || !cat_sum_cnt || count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
-  hipLaunchKernelGGL((sao_edge_kernel<0>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
-                     (const int *)nullptr, cat_sum_cnt);
+  if (edge_fast_ok(orig, rec, block_width, block_height))
+    hipLaunchKernelGGL((sao_edge_fast_kernel<0>), dim3((unsigned)count), dim3(64), 0, ctx_stream(s), orig, rec, block_width, block_height,
+                       (const int *)nullptr, cat_sum_cnt);
+  else
+    hipLaunchKernelGGL((sao_edge_kernel<0>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
+                       (const int *)nullptr, cat_sum_cnt);
   KVZ_CHECK_LAUNCH("sao_edge_kernel<stats>");
   return KVZ_HIP_OK;
 }
@@ -233,8 +339,12 @@ int kvz_hip_sao_edge_ddistortion_batch(const kvz_hip_pixel *orig, const kvz_hip_
   if (!block_dims_ok(block_width, block_height)) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   if (!orig || !rec || !offsets || !ddistortion || count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
-  hipLaunchKernelGGL((sao_edge_kernel<1>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
-                     offsets, ddistortion);
+  if (edge_fast_ok(orig, rec, block_width, block_height))
+    hipLaunchKernelGGL((sao_edge_fast_kernel<1>), dim3((unsigned)count), dim3(64), 0, ctx_stream(s), orig, rec, block_width, block_height,
+                       offsets, ddistortion);
+  else
+    hipLaunchKernelGGL((sao_edge_kernel<1>), dim3((unsigned)count), dim3(256), 0, ctx_stream(s), orig, rec, block_width, block_height,
+                       offsets, ddistortion);
   KVZ_CHECK_LAUNCH("sao_edge_kernel<ddistortion>");
   return KVZ_HIP_OK;
 }

@@ -602,7 +602,8 @@ def test_search_pu_frame_of_ctus_and_bad_descriptors(api):
 from patterns import sao_blocks, sao_records  # noqa: E402
 
 
-@pytest.mark.parametrize("bw,bh", [(64, 64), (32, 32), (64, 56), (16, 24), (8, 8), (3, 3), (40, 2), (1, 1)])
+# widths that are multiples of 4 take the packed-accumulator edge kernel (one dword column when bw == 4), the others the generic one
+@pytest.mark.parametrize("bw,bh", [(64, 64), (32, 32), (64, 56), (16, 24), (8, 8), (3, 3), (40, 2), (1, 1), (4, 4), (4, 3), (60, 64), (12, 5), (62, 64)])
 def test_sao_statistics_and_ddistortion(api, bw, bh):
     orig, rec = sao_blocks(bw, bh, 21, 40 + bw + bh)
     g = rng(5)
@@ -620,6 +621,16 @@ def test_sao_statistics_and_ddistortion(api, bw, bh):
             assert dd[i, eo] == O.sao_edge_ddistortion(orig[i], rec[i], bw, bh, eo, offs[i, eo])
         np.testing.assert_array_equal(bands[i], O.calc_sao_bands(orig[i], rec[i], bw, bh))
         assert bdd[i] == O.sao_band_ddistortion(orig[i], rec[i], bw, bh, int(bp[i]), bo[i])
+    if bw % 4 == 0 and bh >= 3:
+        # the generic kernel on the same shape (tuning knob): both implementations stay covered
+        from kvazaar_amd import _lib
+        L = _lib.init(0)
+        assert L.kvz_hip_set_tuning(b"sao_edge_fast", 0) == 0
+        try:
+            np.testing.assert_array_equal(api.sao_edge_stats_batch(orig, rec, bw, bh), stats)
+            np.testing.assert_array_equal(api.sao_edge_ddistortion_batch(orig, rec, bw, bh, offs), dd)
+        finally:
+            L.kvz_hip_set_tuning(b"sao_edge_fast", -1)
 
 
 @pytest.mark.parametrize("color", [0, 1, 2])
