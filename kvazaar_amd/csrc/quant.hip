@@ -68,6 +68,10 @@ static bool make_consts(const kvz_hip_quant_params *p, int width, int type_q, in
 __device__ __forceinline__ int quant_level(int c, int qc, const quant_consts &k)
 {
   const int a = c < 0 ? -c : c;
+  // flat quantisation: |c| <= 2^15 and quant_scales < 2^15, so the product is a full-rate 24-bit multiply and the sum
+  // stays below 2^31 (add < 2^26); only scaling lists need the reference's 64-bit product (v_mul_lo_u32 and the 64-bit
+  // multiply-add run at a quarter of the rate)
+  if (!k.qtable) return (int)((__umul24((unsigned)a, (unsigned)qc) + (unsigned)k.add) >> k.q_bits);
   return (int)(((long long)a * qc + k.add) >> k.q_bits);
 }
 __device__ __forceinline__ int quant_one(int c, int qc, const quant_consts &k)
@@ -79,7 +83,7 @@ __device__ __forceinline__ int quant_one(int c, int qc, const quant_consts &k)
 // quant-generic.c:290-320
 __device__ __forceinline__ int dequant_one(int q, int n, const quant_consts &k)
 {
-  if (k.dq_mode == 0) return clip16((int)((unsigned)(q * k.dq_scale) + (unsigned)k.dq_add) >> k.dq_shift);
+  if (k.dq_mode == 0) return clip16((int)((unsigned)__mul24(q, k.dq_scale) + (unsigned)k.dq_add) >> k.dq_shift);   // |q| <= 2^15, scale <= 72 << 8
   const int d = k.dqtable[n];
   if (k.dq_mode == 1) return clip16((q * d + k.dq_add) >> k.dq_shift);
   int v = clip16(q * d);

@@ -45,13 +45,13 @@ __device__ __forceinline__ int q32_quant(int c, int n, const q32_consts &k)
   const int a = c < 0 ? -c : c;
   int level;
   if (k.qtable) level = (int)(((long long)a * k.qtable[n] + k.add) >> k.q_bits);
-  else level = (int)(((u32)a * (u32)k.flat_qc + (u32)k.add) >> k.q_bits);      // < 2^31: |c| <= 2^15, qc < 2^15, add < 2^23
+  else level = (int)((__umul24((u32)a, (u32)k.flat_qc) + (u32)k.add) >> k.q_bits);      // < 2^31: |c| <= 2^15, qc < 2^15, add < 2^23
   level = c < 0 ? -level : level;
   return clip16(level);
 }
 __device__ __forceinline__ int q32_dequant(int q, int n, const q32_consts &k)
 {
-  if (k.dq_mode == 0) return clip16((int)((u32)(q * k.dq_scale) + (u32)k.dq_add) >> k.dq_shift);
+  if (k.dq_mode == 0) return clip16((int)((u32)__mul24(q, k.dq_scale) + (u32)k.dq_add) >> k.dq_shift);
   const int d = k.dqtable[n];
   if (k.dq_mode == 1) return clip16((q * d + k.dq_add) >> k.dq_shift);
   return clip16((int)((u32)clip16(q * d) << k.dq_shift));
