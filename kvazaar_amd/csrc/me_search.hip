@@ -528,6 +528,21 @@ __global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restr
   else search_pu_core<32, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
 }
 
+// The same class with one workgroup of T threads per PU: lower latency per search (more lanes on each step, barriers
+// instead of wave-local fences), lower throughput -- for batches too small to fill the chip with one wave per PU.
+template <int T>
+__global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
+                                                                const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
+                                                                kvz_hip_me_result *__restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[(frac_geom<32>::TOTAL + 15) & ~15];
+  __shared__ me_shared sh;
+  const kvz_hip_me_pu &pu = pus[blockIdx.x];
+  if (!pu_ok(pu, pic_w, pic_h) || pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
+  if (pu.width == 32 && pu.height == 32) search_pu_core<32, T, false, 32, 32>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  else search_pu_core<32, T, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+}
+
 }  // namespace
 
 extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
@@ -570,8 +585,14 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     KVZ_CHECK_LAUNCH("search_pu_small_kernel");
   }
   if (classes & 2) {
-    hipLaunchKernelGGL(search_pu_medium_kernel, dim3((unsigned)((count + 1) / 2)), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
-                       *params, results);
+    const int mt = tuning("me_medium_threads", 128);   // measured (1980 and 7920 PUs of 32x32): 128 threads per PU 48.9 M/s, 256: 46.6, one wave: 42.6
+    if (mt == 256)
+      hipLaunchKernelGGL(search_pu_medium_wg_kernel<256>, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+    else if (mt != 64)
+      hipLaunchKernelGGL(search_pu_medium_wg_kernel<128>, dim3((unsigned)count), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+    else
+      hipLaunchKernelGGL(search_pu_medium_kernel, dim3((unsigned)((count + 1) / 2)), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
+                         *params, results);
     KVZ_CHECK_LAUNCH("search_pu_medium_kernel");
   }
   return KVZ_HIP_OK;

@@ -763,3 +763,23 @@ def test_frame_graph_replay_matches_the_oracle(api):
         L.kvz_hip_event_destroy(fork); L.kvz_hip_event_destroy(join)
         L.kvz_hip_stream_destroy(s); L.kvz_hip_stream_destroy(side)
     assert L.kvz_hip_graph_launch(None, None) != 0 and b"kvz_hip_graph_launch" in L.kvz_hip_last_error()
+
+
+def test_search_pu_kernel_variants(api):
+    """the thread-count variants behind the tuning knobs (one wave / 128 / 256 threads per medium PU, 256 / 512 / 1024 per
+    big PU) walk the same search: identical results, so the non-default kernels stay covered"""
+    from kvazaar_amd import _lib
+    L = _lib.init(0)
+    pic, ref = me_frames(192, 128, 77, (5, -3))
+    pus = me_random_pus(192, 128, 50, 91, sizes=((32, 32), (32, 16), (24, 32), (64, 64), (64, 32), (48, 64), (16, 16)))
+    prm = me_params()
+    want = O.search_pu_batch(pic, ref, pus, prm)
+    for key, values in ((b"me_medium_threads", (64, 128, 256)), (b"me_big_threads", (256, 512, 1024))):
+        for v in values:
+            assert L.kvz_hip_set_tuning(key, v) == 0
+            try:
+                got = api.search_pu_batch(pic, ref, pus, prm).view(ME_RESULT).reshape(-1)
+            finally:
+                L.kvz_hip_set_tuning(key, -1)
+            for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+                np.testing.assert_array_equal(got[f], want[f], err_msg="%s=%d %s" % (key.decode(), v, f))
