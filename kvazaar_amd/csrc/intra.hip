@@ -245,8 +245,9 @@ __device__ __forceinline__ u32 sad_of(const sub_block<NB> &b)
   return (u32)acc.x + (u32)acc.y;
 }
 
-template <int LOG2, bool WITH_SAD>
-__global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_ref *__restrict__ refs, const u8 *__restrict__ orig,
+// NW waves per workgroup walk the 35 modes NW apart
+template <int LOG2, bool WITH_SAD, int NW>
+__global__ __launch_bounds__(64 * NW) void intra_rough_kernel(const kvz_hip_intra_ref *__restrict__ refs, const u8 *__restrict__ orig,
                                                          size_t count, int flags, u32 *__restrict__ satd_out, u32 *__restrict__ sad_out)
 {
   constexpr int N = 1 << LOG2, NB = N < 8 ? 4 : 8, SB = N / NB, S = SB * SB, G = 64 / S;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_re
   constexpr int NQ = NB / 2;             // packed pairs per sub-block row
   __shared__ __align__(16) u8 s_ref[G][4][RS];
   __shared__ __align__(16) u8 s_orig[G][OS];
-  __shared__ __align__(16) u8 s_ext[4][G][ES];
+  __shared__ __align__(16) u8 s_ext[NW][G][ES];
   __shared__ int s_dc[G];
   __shared__ u32 s_cost[WITH_SAD ? 2 : 1][G][35];
 
@@ -263,12 +264,12 @@ __global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_re
   // look-ups are compiled per lane
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t pu0 = (size_t)blockIdx.x * G;
-  stage_refs<N>(s_ref, G, refs, pu0, count, tid, 256);
+  stage_refs<N>(s_ref, G, refs, pu0, count, tid, 64 * NW);
   {
     const size_t left = count - pu0;
     const int avail = (int)(left < (size_t)G ? left : (size_t)G);
     const uint2 *g = (const uint2 *)(orig + pu0 * (size_t)(N * N));
-    for (int i = tid; i < G * N * N / 8; i += 256) {
+    for (int i = tid; i < G * N * N / 8; i += 64 * NW) {
       const int p = i / (N * N / 8), o = (i - p * (N * N / 8)) * 8;
       uint2 v = { 0u, 0u };
       if (p < avail) v = g[i];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_re
   const bool edge = luma_edge_filters(LOG2, flags);
   const u8 (*ref)[RS] = s_ref[p];
 
-  for (int mode = w; mode < 35; mode += 4) {
+  for (int mode = w; mode < 35; mode += NW) {
     sub_block<NB> b;
     const bool fil = use_filtered(mode, LOG2, flags);
     if (mode >= 2) {
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void intra_rough_kernel(const kvz_hip_intra_re
   }
   __syncthreads();
   const size_t total = count * 35, base = pu0 * 35;
-  for (int i = tid; i < G * 35; i += 256)
+  for (int i = tid; i < G * 35; i += 64 * NW)
     if (base + i < total) {
       satd_out[base + i] = (&s_cost[0][0][0])[i];
       if (WITH_SAD) sad_out[base + i] = (&s_cost[WITH_SAD ? 1 : 0][0][0])[i];
@@ -390,8 +391,16 @@ int launch_rough(const kvz_hip_intra_ref *refs, const u8 *orig, size_t count, in
   constexpr int N = 1 << LOG2, NB = N < 8 ? 4 : 8, S = (N / NB) * (N / NB), G = 64 / S;
   const size_t wgs = (count + G - 1) / G;
   if (wgs > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
-  if (sad) hipLaunchKernelGGL((intra_rough_kernel<LOG2, true>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
-  else hipLaunchKernelGGL((intra_rough_kernel<LOG2, false>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
+  // 4x4 PUs: 64 PUs per workgroup make it LDS-limited (31 KB), eight waves per workgroup fill the CU's wave slots
+  // (3.4 against 2.7 G PUs/s); the larger sizes are register-limited and lose a third with eight (measured)
+  const int nw = tuning("intra_rough_waves", LOG2 == 2 ? 8 : 4);
+  if (nw == 8) {
+    if (sad) hipLaunchKernelGGL((intra_rough_kernel<LOG2, true, 8>), dim3((unsigned)wgs), dim3(512), 0, st, refs, orig, count, flags, satd, sad);
+    else hipLaunchKernelGGL((intra_rough_kernel<LOG2, false, 8>), dim3((unsigned)wgs), dim3(512), 0, st, refs, orig, count, flags, satd, sad);
+  } else {
+    if (sad) hipLaunchKernelGGL((intra_rough_kernel<LOG2, true, 4>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
+    else hipLaunchKernelGGL((intra_rough_kernel<LOG2, false, 4>), dim3((unsigned)wgs), dim3(256), 0, st, refs, orig, count, flags, satd, sad);
+  }
   KVZ_CHECK_LAUNCH("intra_rough_kernel");
   return KVZ_HIP_OK;
 }
