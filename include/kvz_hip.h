@@ -445,6 +445,45 @@ KVZ_HIP_API int kvz_hip_sao_reconstruct_color_batch(const kvz_hip_pixel *rec, ui
                                                     const kvz_hip_sao_info *infos, int n_infos, int color, kvz_hip_stream s);
 
 /* ------------------------------------------------------------------ */
+/* deblocking of a reconstructed frame                                 */
+/*   reference: kvz_filter_deblock_lcu (filter.c:770-779) called for   */
+/*   every LCU (encoderstate.c:579-616), with filter.c:83-768 below it */
+/*   SURVEY.md section 8(f) row 4                                      */
+/* ------------------------------------------------------------------ */
+/* One record per 4x4 SCU, row-major, ceil(width / 4) records per row: the fields
+ * of cu_info_t (cu.h:117-153) the filter reads.  Inter CUs carry mv_dir 1..3. */
+typedef struct {
+  uint8_t type;                 /* cu_type_t: CU_INTRA 1, CU_INTER 2 (cu.h:38-43) */
+  uint8_t depth, part_size, tr_depth;
+  uint8_t cbf_y;                /* cbf_is_set(cu->cbf, cu->tr_depth, COLOR_Y) (cu.h:504-507) */
+  uint8_t mv_dir;               /* inter.mv_dir */
+  uint8_t qp;                   /* cu->qp */
+  uint8_t reserved;
+  int16_t mv[2][2];             /* inter.mv */
+  uint8_t mv_ref[2];            /* inter.mv_ref */
+  uint8_t pad[2];
+} kvz_hip_cu_info;              /* 20 bytes */
+typedef struct {
+  int32_t beta_offset_div2;     /* cfg.deblock_beta */
+  int32_t tc_offset_div2;       /* cfg.deblock_tc */
+  int32_t qp;                   /* state->qp, used when per_cu_qp == 0 (get_qp_y_pred, filter.c:263-282) */
+  int32_t frame_qp;             /* state->frame->QP */
+  int32_t per_cu_qp;            /* encoder_control->max_qp_delta_depth >= 0 */
+  int32_t slice_is_b;           /* state->frame->slicetype == KVZ_SLICE_B */
+  int32_t chroma;               /* 0: 4:0:0 (rec_u / rec_v unused), 1: 4:2:0 */
+  int32_t reserved;
+  uint8_t ref_LX[2][16];        /* state->frame->ref_LX (encoderstate.h:100) */
+} kvz_hip_deblock_params;       /* 64 bytes */
+/* Filters the planes in place: every vertical edge of the frame, then every
+ * horizontal edge (two launches) -- the order the reference's LCU walk with its
+ * deferred rightmost 4 pixels (filter.c:711-779) implements.  width / height
+ * multiples of 8, planes / strides / cus 4-byte aligned; bitdepth 8, lossless
+ * and PCM blocks are not handled (kvz_filter_deblock_lcu asserts !lossless). */
+KVZ_HIP_API int kvz_hip_deblock_frame(kvz_hip_pixel *rec_y, uint32_t stride_y, kvz_hip_pixel *rec_u, kvz_hip_pixel *rec_v,
+                                      uint32_t stride_c, int width, int height, const kvz_hip_cu_info *cus,
+                                      const kvz_hip_deblock_params *params, kvz_hip_stream s);
+
+/* ------------------------------------------------------------------ */
 /* (1) strategy registration -- the drop-in boundary                   */
 /* ------------------------------------------------------------------ */
 /* kvz_strategyselector_register (strategyselector.h:87, strategyselector.c:216-256) */

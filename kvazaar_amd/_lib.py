@@ -95,6 +95,7 @@ SIGNATURES = {
     "kvz_hip_sao_band_stats_batch": (_I, [_P, _P, _I, _I, _SZ, _P, _P]),
     "kvz_hip_sao_band_ddistortion_batch": (_I, [_P, _P, _I, _I, _SZ, _P, _P, _P, _P]),
     "kvz_hip_sao_reconstruct_color_batch": (_I, [_P, _U, _I, _I, _P, _U, _P, _SZ, _P, _I, _I, _P]),
+    "kvz_hip_deblock_frame": (_I, [_P, _U, _P, _P, _U, _I, _I, _P, _P, _P]),
     "kvz_hip_set_registrar": (None, [_P]),
     "kvz_hip_dropin_calls": (C.c_ulonglong, []),
     "kvz_hip_set_state_accessors": (None, [_P]),

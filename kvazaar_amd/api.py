@@ -399,3 +399,20 @@ def bipred_cost_batch(pic, ref0, ref1, cands):
     check(L.kvz_hip_bipred_cost_batch(a.ptr, pic.shape[1], pic.shape[1], pic.shape[0], b.ptr, ref0.shape[1], d.ptr, ref1.shape[1],
                                       ref0.shape[1], ref0.shape[0], e.ptr, len(rec), out.ptr, None), "bipred_cost batch")
     return out.to_numpy(np.uint32, (len(rec),))
+
+
+# ---- deblocking ----
+def deblock_frame(y, u, v, cus, prm):
+    """y, u, v: uint8 planes (u, v None with prm['chroma'] == 0); cus: kvz_hip_cu_info records [h/4, w/4] (20 bytes each);
+    prm: one kvz_hip_deblock_params record (64 bytes).  Returns the filtered planes."""
+    L = _lib.init()
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    cus = np.ascontiguousarray(cus)
+    prm = np.ascontiguousarray(prm)
+    assert cus.dtype.itemsize == 20 and prm.nbytes == 64
+    dy, dc = DeviceBuffer.from_numpy(y), DeviceBuffer.from_numpy(cus.view(np.uint8))
+    du = DeviceBuffer.from_numpy(np.ascontiguousarray(u, dtype=np.uint8)) if u is not None else None
+    dv = DeviceBuffer.from_numpy(np.ascontiguousarray(v, dtype=np.uint8)) if v is not None else None
+    check(L.kvz_hip_deblock_frame(dy.ptr, y.shape[1], du.ptr if du else None, dv.ptr if dv else None, u.shape[1] if u is not None else 0,
+                                  y.shape[1], y.shape[0], dc.ptr, prm.ctypes.data, None), "deblock_frame")
+    return (dy.to_numpy(np.uint8, y.shape), du.to_numpy(np.uint8, u.shape) if du else None, dv.to_numpy(np.uint8, v.shape) if dv else None)

@@ -187,10 +187,28 @@ def me():
     np.savez_compressed(os.path.join(OUT, "me.npz"), **d)
 
 
+def deblock():
+    """kvz_filter_deblock_lcu over every LCU (oracle/ref_harness.c: ref_deblock_frame) on three fabricated frames"""
+    from patterns import deblock_case, deblock_params
+    d = {}
+    cfgs = [dict(w=192, h=128, qp=34), dict(w=136, h=72, qp=40, beta=2, tc=-1, per_cu_qp=1, slice_is_b=1), dict(w=128, h=64, qp=28, chroma=0)]
+    for i, c in enumerate(cfgs):
+        c = dict(c)
+        w, h = c.pop("w"), c.pop("h")
+        prm = deblock_params(**c)
+        y, u, v, cus = deblock_case(w, h, SEED + 20 + i, slice_is_b=int(prm["slice_is_b"][0]), qp=int(prm["qp"][0]))
+        oy, ou, ov = R.deblock_frame(y, u, v, cus, prm)
+        d["y%d" % i], d["u%d" % i], d["v%d" % i] = y, u, v
+        d["cus%d" % i] = cus.view(np.uint8).reshape(cus.shape[0], cus.shape[1], 20)
+        d["params%d" % i] = prm.view(np.uint8).reshape(64)
+        d["out_y%d" % i], d["out_u%d" % i], d["out_v%d" % i] = oy, ou, ov
+    np.savez_compressed(os.path.join(OUT, "deblock.npz"), **d)
+
+
 if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    picture(); dct(); quant(); ipol(); intra(); sao(); me()
+    picture(); dct(); quant(); ipol(); intra(); sao(); me(); deblock()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

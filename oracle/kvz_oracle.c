@@ -1419,3 +1419,173 @@ unsigned orc_bipred_luma_satd(const orc_pixel *pic, int pic_stride, const orc_pi
   free(hp0); free(hp1); free(px0); free(px1); free(pred);
   return cost;
 }
+
+
+/* ======================================================================== */
+/* deblocking -- src/filter.c                                               */
+/* ======================================================================== */
+static const uint8_t db_tc_table[54] = {       /* kvz_g_tc_table_8x8, filter.c:34-42 */
+  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5,
+  6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+static const uint8_t db_beta_table[52] = {     /* kvz_g_beta_table_8x8, filter.c:44-52 */
+  0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28, 30, 32,
+  34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+static const uint8_t db_chroma_scale[58] = {   /* kvz_g_chroma_scale, transform.c:44-50 */
+  0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32,
+  33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+/* kvz_part_mode_num_parts / kvz_part_mode_offsets, cu.c:33-60 */
+static const uint8_t db_num_parts[8] = { 1, 2, 2, 4, 2, 2, 2, 2 };
+static const uint8_t db_part_off[8][4][2] = {
+  { { 0, 0 } }, { { 0, 0 }, { 0, 2 } }, { { 0, 0 }, { 2, 0 } }, { { 0, 0 }, { 2, 0 }, { 0, 2 }, { 2, 2 } },
+  { { 0, 0 }, { 0, 1 } }, { { 0, 0 }, { 0, 3 } }, { { 0, 0 }, { 1, 0 } }, { { 0, 0 }, { 3, 0 } } };
+
+typedef struct { const orc_cu_info *cus; int w4, width, height; const orc_deblock_params *prm; } db_ctx;
+static const orc_cu_info *db_cu(const db_ctx *c, int x, int y) { return &c->cus[(y >> 2) * c->w4 + (x >> 2)]; }
+static int db_clip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* is_tu_boundary (filter.c:190-206) || is_pu_boundary (:216-243); dir 0 = vertical edge, 1 = horizontal edge */
+static int db_boundary(const db_ctx *c, int x, int y, int dir, int *tu_boundary)
+{
+  const orc_cu_info *scu = db_cu(c, x, y);
+  const int tu_width = 64 >> scu->tr_depth;
+  *tu_boundary = ((dir ? y : x) & (tu_width - 1)) == 0;
+  if (*tu_boundary) return 1;
+  const int cu_width = 64 >> scu->depth, x_cu = x & ~(cu_width - 1), y_cu = y & ~(cu_width - 1);
+  const orc_cu_info *cu = db_cu(c, x_cu, y_cu);
+  for (int i = 0; i < db_num_parts[cu->part_size & 7]; ++i) {
+    if (dir) { if (y_cu + db_part_off[cu->part_size & 7][i][1] * cu_width / 4 == y) return 1; }
+    else if (x_cu + db_part_off[cu->part_size & 7][i][0] * cu_width / 4 == x) return 1;
+  }
+  return 0;
+}
+/* get_qp_y_pred (:263-282) */
+static int db_qp(const db_ctx *c, int x, int y, int dir)
+{
+  if (!c->prm->per_cu_qp) return c->prm->qp;
+  int qp_p;
+  if (dir && y > 0) qp_p = db_cu(c, x, y - 1)->qp;
+  else if (!dir && x > 0) qp_p = db_cu(c, x - 1, y)->qp;
+  else qp_p = c->prm->frame_qp;
+  return (qp_p + db_cu(c, x, y)->qp + 1) >> 1;
+}
+/* the boundary strength of filter_deblock_edge_luma (:379-460) */
+static int db_strength(const db_ctx *c, const orc_cu_info *p, const orc_cu_info *q, int tu_boundary)
+{
+  if (q->type == 1 || p->type == 1) return 2;
+  if (tu_boundary && (q->cbf_y || p->cbf_y)) return 1;
+  if (p->mv_dir != 3 && q->mv_dir != 3) {
+    const int lp = (p->mv_dir - 1) & 1, lq = (q->mv_dir - 1) & 1;
+    if (abs(q->mv[lq][0] - p->mv[lp][0]) >= 4 || abs(q->mv[lq][1] - p->mv[lp][1]) >= 4) return 1;
+    if (q->mv_ref[lq] != p->mv_ref[lp]) return 1;
+  }
+  if (!c->prm->slice_is_b) return 0;
+  /* B slices: undefined vectors count as zero (:400-417) */
+  int mvp[2][2], mvq[2][2];
+  for (int l = 0; l < 2; ++l)
+    for (int k = 0; k < 2; ++k) {
+      mvp[l][k] = (p->mv_dir & (1 << l)) ? p->mv[l][k] : 0;
+      mvq[l][k] = (q->mv_dir & (1 << l)) ? q->mv[l][k] : 0;
+    }
+  const int refP0 = (p->mv_dir & 1) ? c->prm->ref_LX[0][p->mv_ref[0] & 15] : -1, refP1 = (p->mv_dir & 2) ? c->prm->ref_LX[1][p->mv_ref[1] & 15] : -1;
+  const int refQ0 = (q->mv_dir & 1) ? c->prm->ref_LX[0][q->mv_ref[0] & 15] : -1, refQ1 = (q->mv_dir & 2) ? c->prm->ref_LX[1][q->mv_ref[1] & 15] : -1;
+#define DB_FAR(a, b) (abs((a)[0] - (b)[0]) >= 4 || abs((a)[1] - (b)[1]) >= 4)
+  if ((refP0 == refQ0 && refP1 == refQ1) || (refP0 == refQ1 && refP1 == refQ0)) {
+    if (refP0 != refP1) {
+      if (refP0 == refQ0) return (DB_FAR(mvq[0], mvp[0]) || DB_FAR(mvq[1], mvp[1])) ? 1 : 0;
+      return (DB_FAR(mvq[1], mvp[0]) || DB_FAR(mvq[0], mvp[1])) ? 1 : 0;
+    }
+    return ((DB_FAR(mvq[0], mvp[0]) || DB_FAR(mvq[1], mvp[1])) && (DB_FAR(mvq[1], mvp[0]) || DB_FAR(mvq[0], mvp[1]))) ? 1 : 0;
+  }
+#undef DB_FAR
+  return 1;
+}
+/* one 4-line luma segment: src = q0 of line 0, xs = step across the edge, ys = step along it (:462-520, :83-153) */
+static void db_luma_segment(orc_pixel *src, int xs, int ys, int beta, int tc)
+{
+  int b[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int k = -4; k < 4; ++k) b[i][k + 4] = src[k * xs + i * ys];
+  const int dp0 = abs(b[0][1] - 2 * b[0][2] + b[0][3]), dq0 = abs(b[0][4] - 2 * b[0][5] + b[0][6]);
+  const int dp3 = abs(b[3][1] - 2 * b[3][2] + b[3][3]), dq3 = abs(b[3][4] - 2 * b[3][5] + b[3][6]);
+  const int dp = dp0 + dp3, dq = dq0 + dq3;
+  if (dp + dq >= beta) return;
+  const int sw = 2 * (dp0 + dq0) < (beta >> 2) && 2 * (dp3 + dq3) < (beta >> 2) &&
+                 abs(b[0][3] - b[0][4]) < ((5 * tc + 1) >> 1) && abs(b[3][3] - b[3][4]) < ((5 * tc + 1) >> 1) &&
+                 abs(b[0][0] - b[0][3]) + abs(b[0][4] - b[0][7]) < (beta >> 3) && abs(b[3][0] - b[3][3]) + abs(b[3][4] - b[3][7]) < (beta >> 3);
+  const int side = (beta + (beta >> 1)) >> 3;
+  for (int i = 0; i < 4; ++i) {
+    const int *m = b[i];
+    int o[8];
+    for (int k = 0; k < 8; ++k) o[k] = m[k];
+    if (sw) {
+      o[1] = db_clip(m[1] - 2 * tc, m[1] + 2 * tc, (2 * m[0] + 3 * m[1] + m[2] + m[3] + m[4] + 4) >> 3);
+      o[2] = db_clip(m[2] - 2 * tc, m[2] + 2 * tc, (m[1] + m[2] + m[3] + m[4] + 2) >> 2);
+      o[3] = db_clip(m[3] - 2 * tc, m[3] + 2 * tc, (m[1] + 2 * m[2] + 2 * m[3] + 2 * m[4] + m[5] + 4) >> 3);
+      o[4] = db_clip(m[4] - 2 * tc, m[4] + 2 * tc, (m[2] + 2 * m[3] + 2 * m[4] + 2 * m[5] + m[6] + 4) >> 3);
+      o[5] = db_clip(m[5] - 2 * tc, m[5] + 2 * tc, (m[3] + m[4] + m[5] + m[6] + 2) >> 2);
+      o[6] = db_clip(m[6] - 2 * tc, m[6] + 2 * tc, (m[3] + m[4] + m[5] + 3 * m[6] + 2 * m[7] + 4) >> 3);
+    } else {
+      int delta = (9 * (m[4] - m[3]) - 3 * (m[5] - m[2]) + 8) >> 4;
+      if (abs(delta) < tc * 10) {
+        const int tc2 = tc >> 1;
+        delta = db_clip(-tc, tc, delta);
+        o[3] = db_clip(0, 255, m[3] + delta);
+        o[4] = db_clip(0, 255, m[4] - delta);
+        if (dp < side) o[2] = db_clip(0, 255, m[2] + db_clip(-tc2, tc2, (((m[1] + m[3] + 1) >> 1) - m[2] + delta) >> 1));
+        if (dq < side) o[5] = db_clip(0, 255, m[5] + db_clip(-tc2, tc2, (((m[6] + m[4] + 1) >> 1) - m[5] - delta) >> 1));
+      }
+    }
+    /* the strong filter's clip bounds can leave 0..255 only on paper: m +- 2 tc brackets a mean of pixels */
+    for (int k = 1; k < 7; ++k) src[(k - 4) * xs + i * ys] = (orc_pixel)o[k];
+  }
+}
+/* kvz_filter_deblock_chroma (:158-180) on the 4 lines of a segment */
+static void db_chroma_segment(orc_pixel *src, int xs, int ys, int tc)
+{
+  for (int i = 0; i < 4; ++i) {
+    orc_pixel *s = src + i * ys;
+    const int m2 = s[-2 * xs], m3 = s[-xs], m4 = s[0], m5 = s[xs];
+    const int delta = db_clip(-tc, tc, (((m4 - m3) * 4) + m2 - m5 + 4) >> 3);
+    s[-xs] = (orc_pixel)db_clip(0, 255, m3 + delta);
+    s[0] = (orc_pixel)db_clip(0, 255, m4 - delta);
+  }
+}
+
+void orc_deblock_frame(orc_pixel *y, int stride_y, orc_pixel *u, orc_pixel *v, int stride_c, int width, int height,
+                       const orc_cu_info *cus, const orc_deblock_params *prm)
+{
+  const db_ctx c = { cus, (width + 3) >> 2, width, height, prm };
+  for (int dir = 0; dir < 2; ++dir)
+    for (int uy = 0; uy < height; uy += 8)
+      for (int ux = 0; ux < width; ux += 8) {
+        if ((dir == 0 && ux == 0) || (dir == 1 && uy == 0)) continue;            /* filter_deblock_unit, :635-636 */
+        /* the second half of a horizontal edge at the right border of an LCU is filtered with the next LCU
+         * (filter_deblock_lcu_rightmost, :711-731), its boundary flags and QP taken at that half's own SCU */
+        const int deferred = dir == 1 && (ux + 8) % 64 == 0 && ux + 8 != width;
+        for (int s = 0; s < 2; ++s) {
+          const int fx = (deferred && s == 1) ? ux + 4 : ux;
+          int tu_b;
+          if (!db_boundary(&c, fx, uy, dir, &tu_b)) continue;
+          const int qp = db_qp(&c, fx, uy, dir);
+          const int sx = dir ? ux + 4 * s : ux, sy = dir ? uy : uy + 4 * s;
+          const orc_cu_info *cp = dir ? db_cu(&c, sx, sy - 1) : db_cu(&c, sx - 1, sy), *cq = db_cu(&c, sx, sy);
+          const int bs = db_strength(&c, cp, cq, tu_b);
+          if (!bs) continue;
+          const int beta = db_beta_table[db_clip(0, 51, qp + (prm->beta_offset_div2 << 1))];
+          const int tc = db_tc_table[db_clip(0, 53, qp + 2 * (bs - 1) + (prm->tc_offset_div2 << 1))];
+          db_luma_segment(y + (size_t)sy * stride_y + sx, dir ? stride_y : 1, dir ? 1 : stride_y, beta, tc);
+        }
+        /* chroma: edges on the 8x8 chroma grid, only next to intra CUs (:554-615); one 4-pixel segment per unit */
+        if (prm->chroma && ((dir ? uy : ux) & 15) == 0) {
+          int tu_b;
+          if (!db_boundary(&c, ux, uy, dir, &tu_b)) continue;
+          const orc_cu_info *cp = dir ? db_cu(&c, ux, uy - 2) : db_cu(&c, ux - 2, uy), *cq = db_cu(&c, ux, uy);
+          if (cq->type != 1 && cp->type != 1) continue;
+          const int qpc = db_chroma_scale[db_clip(0, 57, db_qp(&c, ux, uy, dir))];
+          const int tc = db_tc_table[db_clip(0, 53, qpc + 2 + (prm->tc_offset_div2 << 1))];
+          const int xc = ux >> 1, yc = uy >> 1;
+          db_chroma_segment(u + (size_t)yc * stride_c + xc, dir ? stride_c : 1, dir ? 1 : stride_c, tc);
+          db_chroma_segment(v + (size_t)yc * stride_c + xc, dir ? stride_c : 1, dir ? 1 : stride_c, tc);
+        }
+      }
+}

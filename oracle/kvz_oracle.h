@@ -243,6 +243,34 @@ void orc_calc_sao_bands(const orc_pixel *orig, const orc_pixel *rec, int bw, int
 unsigned orc_bipred_luma_satd(const orc_pixel *pic, int pic_stride, const orc_pixel *ref0, const orc_pixel *ref1, int ref_w, int ref_h,
                               int x, int y, int w, int h, const int16_t mv0[2], const int16_t mv1[2], orc_pixel *out);
 
+/* ---- deblocking: src/filter.c:83-779 (kvz_filter_deblock_lcu over every LCU of a frame).  SURVEY.md section 8(f) row 4.
+ * The frame is filtered the way the HEVC process is specified -- every vertical edge, then every horizontal edge --
+ * which is what the reference's LCU-by-LCU order with its deferred "rightmost 4 pixels" (filter.c:711-779) computes.
+ * cus: one record per 4x4 SCU, row-major, ceil(width/4) per row: the cu_info_t fields (cu.h:117-153) the filter reads. */
+typedef struct {
+  uint8_t type;                  /* cu_type_t: 1 intra, 2 inter */
+  uint8_t depth, part_size, tr_depth;
+  uint8_t cbf_y;                 /* cbf_is_set(cbf, tr_depth, COLOR_Y) */
+  uint8_t mv_dir;                /* inter: 1 L0, 2 L1, 3 both */
+  uint8_t qp;
+  uint8_t reserved;
+  int16_t mv[2][2];
+  uint8_t mv_ref[2];
+  uint8_t pad[2];
+} orc_cu_info;
+typedef struct {
+  int32_t beta_offset_div2, tc_offset_div2;   /* cfg.deblock_beta, cfg.deblock_tc */
+  int32_t qp;                    /* state->qp (used when per_cu_qp == 0) */
+  int32_t frame_qp;              /* state->frame->QP */
+  int32_t per_cu_qp;             /* encoder_control->max_qp_delta_depth >= 0 */
+  int32_t slice_is_b;            /* state->frame->slicetype == KVZ_SLICE_B */
+  int32_t chroma;                /* 0: 4:0:0, luma only; 1: 4:2:0 */
+  int32_t reserved;
+  uint8_t ref_LX[2][16];         /* state->frame->ref_LX */
+} orc_deblock_params;
+void orc_deblock_frame(orc_pixel *y, int stride_y, orc_pixel *u, orc_pixel *v, int stride_c, int width, int height,
+                       const orc_cu_info *cus, const orc_deblock_params *prm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -323,6 +323,61 @@ double ref_bench_reg_sad(const char *name, const kvz_pixel *a, const kvz_pixel *
  * strategies-*.c of INTEGRATION.md do.  The accessors below are the glue a
  * Kvazaar maintainer compiles inside the encoder (they need encoderstate.h).
  * ------------------------------------------------------------------------ */
+/* ---- deblocking: kvz_filter_deblock_lcu (filter.c:770-779) for every LCU in raster order, on an encoder state
+ * fabricated from the flat SCU map the oracle / the GPU entry take (same layout as orc_cu_info / orc_deblock_params) ---- */
+#include "filter.h"
+#include "videoframe.h"
+typedef struct { uint8_t type, depth, part_size, tr_depth, cbf_y, mv_dir, qp, reserved; int16_t mv[2][2]; uint8_t mv_ref[2]; uint8_t pad[2]; } ref_cu_flat;
+typedef struct { int32_t beta_offset_div2, tc_offset_div2, qp, frame_qp, per_cu_qp, slice_is_b, chroma, reserved; uint8_t ref_LX[2][16]; } ref_deblock_prm;
+
+void ref_deblock_frame(kvz_pixel *y, int stride_y, kvz_pixel *u, kvz_pixel *v, int stride_c, int width, int height,
+                       const ref_cu_flat *cus, const ref_deblock_prm *prm)
+{
+  static encoder_control_t ctrl;
+  static encoder_state_t state;
+  static encoder_state_config_frame_t frame;
+  static encoder_state_config_tile_t tile;
+  static videoframe_t vframe;
+  memset(&ctrl, 0, sizeof(ctrl)); memset(&state, 0, sizeof(state)); memset(&frame, 0, sizeof(frame));
+  memset(&tile, 0, sizeof(tile)); memset(&vframe, 0, sizeof(vframe));
+  ctrl.bitdepth = 8;
+  ctrl.cfg.deblock_beta = prm->beta_offset_div2;
+  ctrl.cfg.deblock_tc = prm->tc_offset_div2;
+  ctrl.max_qp_delta_depth = prm->per_cu_qp ? 0 : -1;
+  ctrl.chroma_format = prm->chroma ? KVZ_CSP_420 : KVZ_CSP_400;
+  kvz_picture rec;
+  memset(&rec, 0, sizeof(rec));
+  rec.y = y; rec.u = u; rec.v = v; rec.width = width; rec.height = height; rec.stride = stride_y;
+  (void)stride_c;                                           /* the reference derives it: rec->stride >> 1 */
+  vframe.rec = &rec; vframe.width = width; vframe.height = height;
+  vframe.width_in_lcu = (width + 63) / 64; vframe.height_in_lcu = (height + 63) / 64;
+  vframe.cu_array = kvz_cu_array_alloc(width, height);
+  const int w4 = (width + 3) >> 2;
+  for (int sy = 0; sy < height; sy += 4)
+    for (int sx = 0; sx < width; sx += 4) {
+      const ref_cu_flat *f = &cus[(sy >> 2) * w4 + (sx >> 2)];
+      cu_info_t *cu = kvz_cu_array_at(vframe.cu_array, sx, sy);
+      cu->type = f->type; cu->depth = f->depth; cu->part_size = f->part_size; cu->tr_depth = f->tr_depth;
+      cu->cbf = 0;
+      if (f->cbf_y) cbf_set(&cu->cbf, f->tr_depth, COLOR_Y);
+      cu->qp = f->qp;
+      if (f->type != CU_INTRA) {
+        memcpy(cu->inter.mv, f->mv, sizeof(cu->inter.mv));
+        cu->inter.mv_ref[0] = f->mv_ref[0]; cu->inter.mv_ref[1] = f->mv_ref[1];
+        cu->inter.mv_dir = f->mv_dir;
+      }
+    }
+  tile.frame = &vframe;
+  frame.QP = prm->frame_qp;
+  frame.slicetype = prm->slice_is_b ? KVZ_SLICE_B : KVZ_SLICE_P;
+  memcpy(frame.ref_LX, prm->ref_LX, sizeof(frame.ref_LX));
+  state.encoder_control = &ctrl; state.tile = &tile; state.frame = &frame;
+  state.qp = prm->qp;
+  for (int ly = 0; ly < height; ly += 64)
+    for (int lx = 0; lx < width; lx += 64) kvz_filter_deblock_lcu(&state, lx, ly);
+  kvz_cu_array_free(&vframe.cu_array);
+}
+
 #include <dlfcn.h>
 #include "../include/kvz_hip.h"
 

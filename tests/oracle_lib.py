@@ -460,3 +460,20 @@ def bipred_luma_satd(pic, ref0, ref1, x, y, w, h, mv0, mv1):
     c = L.orc_bipred_luma_satd(_p(pic, u8p), pic.shape[1], _p(ref0, u8p), _p(ref1, u8p), ref0.shape[1], ref0.shape[0], x, y, w, h,
                                _p(a, i16p), _p(b, i16p), _p(out, u8p))
     return c, out
+
+
+# ---- deblocking ----
+def deblock_frame(y, u, v, cus, prm):
+    """-> filtered copies of the three planes (u, v may be None with prm['chroma'] == 0)"""
+    L = lib()
+    L.orc_deblock_frame.restype = None
+    L.orc_deblock_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    y = np.array(y, dtype=np.uint8, order="C")
+    u = np.array(u, dtype=np.uint8, order="C") if u is not None else None
+    v = np.array(v, dtype=np.uint8, order="C") if v is not None else None
+    cus = np.ascontiguousarray(cus)
+    prm = np.ascontiguousarray(prm)
+    assert cus.dtype.itemsize == 20 and prm.nbytes == 64 and cus.shape == (y.shape[0] // 4, (y.shape[1] + 3) // 4)
+    L.orc_deblock_frame(y.ctypes.data, y.shape[1], u.ctypes.data if u is not None else None, v.ctypes.data if v is not None else None,
+                        u.shape[1] if u is not None else 0, y.shape[1], y.shape[0], cus.ctypes.data, prm.ctypes.data)
+    return y, u, v

@@ -221,3 +221,90 @@ def sao_records(count, seed):
     s[:, 4] = 0
     s[:, 9] = 0
     return s
+
+
+# ---- deblocking (filter.c): a frame with a random CU / PU / TU quadtree and blocky content ----
+CU_INFO = np.dtype([("type", "u1"), ("depth", "u1"), ("part_size", "u1"), ("tr_depth", "u1"), ("cbf_y", "u1"), ("mv_dir", "u1"),
+                    ("qp", "u1"), ("reserved", "u1"), ("mv", "<i2", (2, 2)), ("mv_ref", "u1", (2,)), ("pad", "u1", (2,))])
+DEBLOCK_PARAMS = np.dtype([("beta_offset_div2", "<i4"), ("tc_offset_div2", "<i4"), ("qp", "<i4"), ("frame_qp", "<i4"),
+                           ("per_cu_qp", "<i4"), ("slice_is_b", "<i4"), ("chroma", "<i4"), ("reserved", "<i4"), ("ref_LX", "u1", (2, 16))])
+assert CU_INFO.itemsize == 20 and DEBLOCK_PARAMS.itemsize == 64
+
+
+def deblock_params(qp=34, beta=0, tc=0, per_cu_qp=0, slice_is_b=0, chroma=1):
+    p = np.zeros(1, dtype=DEBLOCK_PARAMS)
+    p["beta_offset_div2"], p["tc_offset_div2"], p["qp"], p["frame_qp"] = beta, tc, qp, qp
+    p["per_cu_qp"], p["slice_is_b"], p["chroma"] = per_cu_qp, slice_is_b, chroma
+    p["ref_LX"][0, 0, :4] = (0, 1, 2, 3)
+    p["ref_LX"][0, 1, :4] = (1, 0, 3, 2)          # L1 index i is L0's picture i ^ 1: the same picture under two names
+    return p
+
+
+def deblock_case(w, h, seed, intra_share=0.35, slice_is_b=0, qp=34):
+    """-> (y, u, v planes, cus [h/4, w/4] CU_INFO): random quadtree (CU 64..8, all part modes, TU down to 4x4), vectors from a
+    small pool so that neighbours often differ by less than one pixel, blocky pictures with little noise so that the
+    on/off decisions, the strong and the weak filter all occur"""
+    g = np.random.default_rng(seed)
+    cus = np.zeros((h // 4, w // 4), dtype=CU_INFO)
+    pool = [(0, 0), (1, 0), (3, -2), (4, 0), (-5, 7), (12, -9), (2, 2), (-3, 1)]
+
+    def leaf(x, y, size, depth):
+        intra = g.random() < intra_share
+        if intra:
+            part = 3 if (size == 8 and g.random() < 0.4) else 0
+        else:
+            opts = [0, 0, 1, 2] + ([4, 5, 6, 7] if size >= 16 else [])
+            part = int(opts[int(g.integers(0, len(opts)))])
+        lo = max(depth, 1)
+        trd = 4 if (intra and part == 3) else int(g.integers(lo, min(depth + 2, 4 if size == 8 else 3) + 1))
+        cu_qp = int(np.clip(qp + g.integers(-6, 7), 10, 51))
+        n_parts = (1, 2, 2, 4, 2, 2, 2, 2)[part]
+        offs = (((0, 0),), ((0, 0), (0, 2)), ((0, 0), (2, 0)), ((0, 0), (2, 0), (0, 2), (2, 2)), ((0, 0), (0, 1)), ((0, 0), (0, 3)),
+                ((0, 0), (1, 0)), ((0, 0), (3, 0)))[part]
+        sizes = (((4, 4),), ((4, 2), (4, 2)), ((2, 4), (2, 4)), ((2, 2),) * 4, ((4, 1), (4, 3)), ((4, 3), (4, 1)), ((1, 4), (3, 4)),
+                 ((3, 4), (1, 4)))[part]
+        for i in range(n_parts):
+            px, py = x + offs[i][0] * size // 4, y + offs[i][1] * size // 4
+            pw, ph = sizes[i][0] * size // 4, sizes[i][1] * size // 4
+            blk = cus[py // 4:min(py + ph, h) // 4, px // 4:min(px + pw, w) // 4]
+            blk["type"] = 1 if intra else 2
+            blk["depth"], blk["part_size"], blk["tr_depth"], blk["qp"] = depth, part, trd, cu_qp
+            if not intra:
+                d = int(g.integers(1, 4)) if slice_is_b else 1
+                blk["mv_dir"] = d
+                blk["mv"][..., 0, :] = pool[int(g.integers(0, len(pool)))]
+                blk["mv"][..., 1, :] = pool[int(g.integers(0, len(pool)))]
+                blk["mv_ref"][..., 0] = int(g.integers(0, 2))
+                blk["mv_ref"][..., 1] = int(g.integers(0, 2))
+        # coded-block flags per TU
+        tu = 64 >> trd
+        for ty in range(y, min(y + size, h), max(tu, 4)):
+            for tx in range(x, min(x + size, w), max(tu, 4)):
+                cus[ty // 4:min(ty + tu, h) // 4, tx // 4:min(tx + tu, w) // 4]["cbf_y"] = int(g.random() < 0.5)
+
+    def split(x, y, size, depth):
+        if x >= w or y >= h:
+            return
+        must = x + size > w or y + size > h
+        if size > 8 and (must or g.random() < (0.85, 0.6, 0.4)[depth]):
+            half = size // 2
+            for dy in (0, half):
+                for dx in (0, half):
+                    split(x + dx, y + dy, half, depth + 1)
+        else:
+            leaf(x, y, size, depth)
+
+    for ly in range(0, h, 64):
+        for lx in range(0, w, 64):
+            split(lx, ly, 64, 0)
+
+    def plane(pw, ph, cell):
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        base = 90 + 0.3 * xx + 0.2 * yy
+        steps = g.integers(-7, 8, (ph // cell + 1, pw // cell + 1))
+        img = base + steps[yy // cell, xx // cell] + g.integers(-1, 2, (ph, pw))
+        rough = g.random((ph // cell + 1, pw // cell + 1)) < 0.15               # some busy cells: the filter must stay off there
+        img = np.where(rough[yy // cell, xx // cell], g.integers(0, 256, (ph, pw)), img)
+        return np.clip(img, 0, 255).astype(np.uint8)
+
+    return plane(w, h, 8), plane(w // 2, h // 2, 4), plane(w // 2, h // 2, 4), cus

@@ -446,3 +446,18 @@ def bipred_luma_satd(pic, ref0, ref1, x, y, w, h, mv0, mv1):
     c = L.ref_bipred_luma_satd(_p(pic, u8p), _p(ref0, u8p), _p(ref1, u8p), pic.shape[1], pic.shape[0], x, y, w, h,
                                _p(a, i16p), _p(b, i16p), _p(out, u8p))
     return c, out
+
+
+# ---- deblocking: kvz_filter_deblock_lcu over every LCU (oracle/ref_harness.c: ref_deblock_frame) ----
+def deblock_frame(y, u, v, cus, prm):
+    L = lib()
+    L.ref_deblock_frame.restype = None
+    L.ref_deblock_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    y = np.array(y, dtype=np.uint8, order="C")
+    u = np.array(u, dtype=np.uint8, order="C") if u is not None else None
+    v = np.array(v, dtype=np.uint8, order="C") if v is not None else None
+    cus = np.ascontiguousarray(cus)
+    prm = np.ascontiguousarray(prm)
+    L.ref_deblock_frame(y.ctypes.data, y.shape[1], u.ctypes.data if u is not None else None, v.ctypes.data if v is not None else None,
+                        u.shape[1] if u is not None else 0, y.shape[1], y.shape[0], cus.ctypes.data, prm.ctypes.data)
+    return y, u, v

@@ -114,3 +114,17 @@ def test_golden_motion_search(api):
         got = api.search_pu_batch(d["pic"], d["ref"], np.ascontiguousarray(d["pus"]).view(np.dtype(("V", 64))).reshape(-1),
                                   np.ascontiguousarray(d["params%d" % i]))
         np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])
+
+
+def test_golden_deblock(api):
+    from patterns import CU_INFO, DEBLOCK_PARAMS
+    d = gold("deblock.npz")
+    for i in range(3):
+        cus = np.ascontiguousarray(d["cus%d" % i]).view(CU_INFO).reshape(d["cus%d" % i].shape[:2])
+        prm = np.ascontiguousarray(d["params%d" % i]).view(DEBLOCK_PARAMS)
+        chroma = bool(prm["chroma"][0])
+        got = api.deblock_frame(d["y%d" % i], d["u%d" % i] if chroma else None, d["v%d" % i] if chroma else None, cus, prm)
+        np.testing.assert_array_equal(got[0], d["out_y%d" % i])
+        if chroma:
+            np.testing.assert_array_equal(got[1], d["out_u%d" % i])
+            np.testing.assert_array_equal(got[2], d["out_v%d" % i])

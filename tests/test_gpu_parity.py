@@ -783,3 +783,37 @@ def test_search_pu_kernel_variants(api):
                 L.kvz_hip_set_tuning(key, -1)
             for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
                 np.testing.assert_array_equal(got[f], want[f], err_msg="%s=%d %s" % (key.decode(), v, f))
+
+
+# ---- deblocking ----
+from patterns import deblock_case, deblock_params  # noqa: E402
+
+DEBLOCK_CONFIGS = [dict(w=192, h=128, qp=34), dict(w=200, h=136, qp=38, beta=2, tc=-1), dict(w=128, h=64, qp=30, per_cu_qp=1),
+                   dict(w=192, h=128, qp=36, slice_is_b=1), dict(w=136, h=72, qp=45, tc=3, per_cu_qp=1, slice_is_b=1),
+                   dict(w=64, h=64, qp=22, beta=-3), dict(w=192, h=64, qp=40, chroma=0), dict(w=72, h=200, qp=51, beta=6, tc=6),
+                   dict(w=8, h=8, qp=40), dict(w=640, h=360, qp=37, per_cu_qp=1, slice_is_b=1)]
+
+
+@pytest.mark.parametrize("cfg", range(len(DEBLOCK_CONFIGS)))
+def test_deblock_frame(api, cfg):
+    c = dict(DEBLOCK_CONFIGS[cfg])
+    w, h = c.pop("w"), c.pop("h")
+    prm = deblock_params(**c)
+    chroma = bool(prm["chroma"][0])
+    for seed in range(3):
+        y, u, v, cus = deblock_case(w, h, 300 * cfg + seed, slice_is_b=int(prm["slice_is_b"][0]), qp=int(prm["qp"][0]),
+                                    intra_share=(0.35, 0.0, 1.0)[seed])
+        want = O.deblock_frame(y, u if chroma else None, v if chroma else None, cus, prm)
+        got = api.deblock_frame(y, u if chroma else None, v if chroma else None, cus, prm)
+        np.testing.assert_array_equal(got[0], want[0], err_msg="luma cfg %d seed %d" % (cfg, seed))
+        if chroma:
+            np.testing.assert_array_equal(got[1], want[1], err_msg="u cfg %d seed %d" % (cfg, seed))
+            np.testing.assert_array_equal(got[2], want[2], err_msg="v cfg %d seed %d" % (cfg, seed))
+
+
+def test_deblock_argument_errors(api):
+    from kvazaar_amd import _lib
+    L = _lib.init(0)
+    prm = deblock_params()
+    assert L.kvz_hip_deblock_frame(None, 64, None, None, 32, 64, 64, None, prm.ctypes.data, None) != 0
+    assert b"kvz_hip_deblock_frame" in L.kvz_hip_last_error()

@@ -172,3 +172,17 @@ def test_golden_motion_search():
         prm = np.ascontiguousarray(d["params%d" % i]).view(ME_PARAMS)
         got = O.search_pu_batch(d["pic"], d["ref"], pus, prm).view(np.int32).reshape(len(pus), 8)
         np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])
+
+
+def test_golden_deblock():
+    from patterns import CU_INFO, DEBLOCK_PARAMS
+    d = gold("deblock.npz")
+    for i in range(3):
+        cus = np.ascontiguousarray(d["cus%d" % i]).view(CU_INFO).reshape(d["cus%d" % i].shape[:2])
+        prm = np.ascontiguousarray(d["params%d" % i]).view(DEBLOCK_PARAMS)
+        chroma = bool(prm["chroma"][0])
+        got = O.deblock_frame(d["y%d" % i], d["u%d" % i] if chroma else None, d["v%d" % i] if chroma else None, cus, prm)
+        np.testing.assert_array_equal(got[0], d["out_y%d" % i])
+        if chroma:
+            np.testing.assert_array_equal(got[1], d["out_u%d" % i])
+            np.testing.assert_array_equal(got[2], d["out_v%d" % i])

@@ -408,3 +408,31 @@ def test_bipred_candidate_cost():
             b = R.bipred_luma_satd(pic, ref0, ref1, x, y, w, h, mv0, mv1)
             assert a[0] == b[0], (w, h, x, y, mv0, mv1)
             np.testing.assert_array_equal(a[1], b[1])
+
+
+# ---- deblocking: the oracle filters every vertical edge of the frame, then every horizontal one; the
+# reference goes LCU by LCU with its deferred rightmost 4 pixels -- the planes must come out identical ----
+from patterns import deblock_case, deblock_params  # noqa: E402
+
+DEBLOCK_CONFIGS = [dict(w=192, h=128, qp=34), dict(w=200, h=136, qp=38, beta=2, tc=-1), dict(w=128, h=64, qp=30, per_cu_qp=1),
+                   dict(w=192, h=128, qp=36, slice_is_b=1), dict(w=136, h=72, qp=45, tc=3, per_cu_qp=1, slice_is_b=1),
+                   dict(w=64, h=64, qp=22, beta=-3), dict(w=192, h=64, qp=40, chroma=0), dict(w=72, h=200, qp=51, beta=6, tc=6)]
+
+
+@pytest.mark.parametrize("cfg", range(len(DEBLOCK_CONFIGS)))
+def test_deblock_frame(cfg):
+    c = dict(DEBLOCK_CONFIGS[cfg])
+    w, h = c.pop("w"), c.pop("h")
+    prm = deblock_params(**c)
+    changed = 0
+    for seed in range(3):
+        y, u, v, cus = deblock_case(w, h, 100 * cfg + seed, slice_is_b=int(prm["slice_is_b"][0]), qp=int(prm["qp"][0]),
+                                    intra_share=(0.35, 0.0, 1.0)[seed])
+        want = R.deblock_frame(y, u, v, cus, prm)
+        got = O.deblock_frame(y, u, v, cus, prm)
+        for a, b, name in zip(got, want, "yuv"):
+            np.testing.assert_array_equal(a, b, err_msg="plane %s cfg %d seed %d" % (name, cfg, seed))
+        changed += int((want[0] != y).sum())
+        if not int(prm["chroma"][0]):
+            np.testing.assert_array_equal(want[1], u)
+    assert changed > 0                      # the filter did something
