@@ -156,6 +156,22 @@ def main():
     cases.append(("sao_band_stats_64x64", sao_cnt, 2 * 4096 + 256,
                   lambda: L.kvz_hip_sao_band_stats_batch(a8.data_ptr(), b8.data_ptr(), 64, 64, sao_cnt, sao_stats.data_ptr(), st)))
 
+    # deblocking of a whole 1080p (1920x1080 -> 1080 is not a multiple of 8 in the reference either: 1088 coded rows) frame
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patterns import deblock_case, deblock_params
+    DW, DH = 1920, 1088
+    ty, tu, tv, tcus = deblock_case(256, 128, 11, qp=36)
+    reps = (DH // 128 + 1, DW // 256 + 1)
+    dby = torch.from_numpy(np.tile(ty, reps)[:DH, :DW].copy()).to(dev)
+    dbu = torch.from_numpy(np.tile(tu, reps)[:DH // 2, :DW // 2].copy()).to(dev)
+    dbv = torch.from_numpy(np.tile(tv, reps)[:DH // 2, :DW // 2].copy()).to(dev)
+    dbc = torch.from_numpy(np.tile(tcus, reps)[:DH // 4, :DW // 4].copy().view(np.uint8)).to(dev)
+    dbp = deblock_params(qp=36)
+    # bytes per frame: luma + chroma read and written once per pass at most + the SCU map
+    cases.append(("deblock_frame_1080p(frames)", 1, 2 * 2 * (DW * DH * 3 // 2) + DW * DH // 16 * 20 * 2,
+                  lambda: L.kvz_hip_deblock_frame(dby.data_ptr(), DW, dbu.data_ptr(), dbv.data_ptr(), DW // 2, DW, DH, dbc.data_ptr(),
+                                                  dbp.ctypes.data, st)))
+
     # intra rough search: all 35 modes per PU; bytes per PU = refs 130 + orig N^2 + 35 costs
     for lg in (2, 3, 4, 5):
         n = 1 << lg

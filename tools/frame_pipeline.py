@@ -41,7 +41,7 @@ def build_stages(L, dev):
     noise = torch.randint(-6, 7, (H, W), dtype=torch.int16, device=dev, generator=g)
     pred = (cur.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
     keep += [cur, ref, pred]
-    stages = {"me": [], "intra": [], "tu": [], "sao": []}
+    stages = {"me": [], "intra": [], "tu": [], "sao": []}      # "sao": the in-loop filter stage, deblocking + SAO statistics
 
     me_prm = np.zeros(12, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
     for n in (8, 16, 32, 64):
@@ -93,6 +93,20 @@ def build_stages(L, dev):
         stages["sao"].append(("sao_band_stats_%s" % label, cnt,
                               lambda s, n=n, cnt=cnt, band=band: L.kvz_hip_sao_band_stats_batch(
                                   flat_cur.data_ptr(), flat_pred.data_ptr(), n, n, cnt, band.data_ptr(), s)))
+    # deblocking of the reconstructed frame (1088 coded rows), both passes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patterns import deblock_case, deblock_params
+    DH = 1088
+    ty, tu, tv, tcus = deblock_case(256, 128, 11, qp=36)
+    reps = (DH // 128 + 1, W // 256 + 1)
+    dby = torch.from_numpy(np.tile(ty, reps)[:DH, :W].copy()).to(dev)
+    dbu = torch.from_numpy(np.tile(tu, reps)[:DH // 2, :W // 2].copy()).to(dev)
+    dbv = torch.from_numpy(np.tile(tv, reps)[:DH // 2, :W // 2].copy()).to(dev)
+    dbc = torch.from_numpy(np.tile(tcus, reps)[:DH // 4, :W // 4].copy().view(np.uint8)).to(dev)
+    dbp = deblock_params(qp=36)
+    keep += [dby, dbu, dbv, dbc, dbp]
+    stages["sao"].insert(0, ("deblock_frame", 1, lambda s: L.kvz_hip_deblock_frame(
+        dby.data_ptr(), W, dbu.data_ptr(), dbv.data_ptr(), W // 2, W, DH, dbc.data_ptr(), dbp.ctypes.data, s)))
     return stages, keep
 
 

@@ -190,6 +190,22 @@ def main():
             want[b[1]:b[1] + b[3], b[0]:b[0] + b[2]] = O.sao_reconstruct_color(plane, b[0], b[1], b[2], b[3], info, color)
             check("sao_reconstruct", np.array_equal(got, want), str(b))
     print("sao dd / reconstruct ok (%.0f s)" % (time.time() - t0))
+
+    # ---- deblocking: random frame sizes, QPs, offsets, slice types ----
+    t0 = time.time()
+    from patterns import deblock_case, deblock_params
+    for _ in range(6 * a.scale):
+        w, h = int(g.integers(1, 40)) * 8, int(g.integers(1, 30)) * 8
+        prm = deblock_params(qp=int(g.integers(18, 52)), beta=int(g.integers(-6, 7)), tc=int(g.integers(-6, 7)), per_cu_qp=int(g.integers(0, 2)),
+                             slice_is_b=int(g.integers(0, 2)), chroma=int(g.integers(0, 4) > 0))
+        chroma = bool(prm["chroma"][0])
+        y, u, v, cus = deblock_case(w, h, int(g.integers(0, 1 << 30)), intra_share=float(g.random()), slice_is_b=int(prm["slice_is_b"][0]),
+                                    qp=int(prm["qp"][0]))
+        want = O.deblock_frame(y, u if chroma else None, v if chroma else None, cus, prm)
+        got = api.deblock_frame(y, u if chroma else None, v if chroma else None, cus, prm)
+        for k in range(3 if chroma else 1):
+            check("deblock_frame", np.array_equal(got[k], want[k]), "%dx%d plane %d" % (w, h, k))
+    print("deblock ok (%.0f s)" % (time.time() - t0))
     print("FUZZ OK seed %d scale %d" % (a.seed, a.scale))
 
 
