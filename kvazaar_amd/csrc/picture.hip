@@ -420,9 +420,48 @@ __device__ __forceinline__ uint2 load_seg8(const plane_t &pl, int x, int y, int 
 }
 
 // reg_sad (picture-generic.c:86-99) / kvz_image_calc_sad (image.c:455-486) and
-// pixels_calc_ssd (picture-generic.c:521-536).  8 lanes share one block pair;
-// a lane takes 8-pixel row segments round robin, so the 8 lanes of a group read
-// up to 64 contiguous bytes of a row.
+// pixels_calc_ssd (picture-generic.c:521-536).  `lanes` lanes (8, or the whole wave) share one block pair; a lane takes
+// 8-pixel row segments round robin, so 8 neighbouring lanes read up to 64 contiguous bytes of a row.  Four segments
+// per lane are in flight (issued one at a time their latencies add up); segments past the end load nothing.
+template <bool SSD>
+__device__ __forceinline__ u32 pair_sad_accum(const plane_t &p1, const plane_t &p2, const kvz_hip_block_pair &d, int sub, int lanes)
+{
+  const int w = d.width, h = SSD ? d.width : d.height;
+  const int spr = (w + 7) >> 3;
+  const int nseg = spr * h;
+  u32 acc = 0;
+  for (int t0 = sub; t0 < nseg; t0 += 4 * lanes) {
+    uint2 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int t = t0 + lanes * k;
+      a[k] = make_uint2(0u, 0u); b[k] = a[k];
+      if (t < nseg) {
+        const int y = t / spr, sx = (t - y * spr) << 3;
+        const int n = (w - sx) < 8 ? (w - sx) : 8;
+        a[k] = load_seg8(p1, d.x1 + sx, d.y1 + y, n);
+        b[k] = load_seg8(p2, d.x2 + sx, d.y2 + y, n);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (SSD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int e0 = (int)((a[k].x >> (8 * q)) & 255) - (int)((b[k].x >> (8 * q)) & 255);
+          int e1 = (int)((a[k].y >> (8 * q)) & 255) - (int)((b[k].y >> (8 * q)) & 255);
+          acc += (u32)(e0 * e0 + e1 * e1);
+        }
+      } else {
+        acc = sad_dword(a[k].x, b[k].x, acc);
+        acc = sad_dword(a[k].y, b[k].y, acc);
+      }
+    }
+  }
+  return acc;
+}
+
+// Large batches: 8 lanes per pair, grid-stride.
 template <bool SSD>
 __global__ __launch_bounds__(256) void pair_sad_kernel(plane_t p1, plane_t p2, const kvz_hip_block_pair *__restrict__ pairs,
                                                        size_t count, u32 *__restrict__ out)
@@ -433,46 +472,46 @@ __global__ __launch_bounds__(256) void pair_sad_kernel(plane_t p1, plane_t p2, c
   const size_t count_up = (count + 7) & ~(size_t)7;
   for (size_t i = tid >> 3; i < count_up; i += ngroups) {
     u32 acc = 0;
-    if (i < count) {
-      const kvz_hip_block_pair d = pairs[i];
-      const int w = d.width, h = SSD ? d.width : d.height;
-      const int spr = (w + 7) >> 3;
-      const int nseg = spr * h;
-      // four segments per lane in flight (a 64x64 pair is 64 segments per lane; issued one at a time their latencies
-      // add up); segments past the end load nothing and contribute zeros.  Measured alternative: a second launch
-      // that gives large pairs a whole wave is 1.5-3x faster on them but its fixed cost doubles the time of the
-      // (far more common) small-pair batches, which are launch bound at a few microseconds.
-      for (int t0 = sub; t0 < nseg; t0 += 32) {
-        uint2 a[4], b[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int t = t0 + 8 * k;
-          a[k] = make_uint2(0u, 0u); b[k] = a[k];
-          if (t < nseg) {
-            const int y = t / spr, sx = (t - y * spr) << 3;
-            const int n = (w - sx) < 8 ? (w - sx) : 8;
-            a[k] = load_seg8(p1, d.x1 + sx, d.y1 + y, n);
-            b[k] = load_seg8(p2, d.x2 + sx, d.y2 + y, n);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (SSD) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              int e0 = (int)((a[k].x >> (8 * q)) & 255) - (int)((b[k].x >> (8 * q)) & 255);
-              int e1 = (int)((a[k].y >> (8 * q)) & 255) - (int)((b[k].y >> (8 * q)) & 255);
-              acc += (u32)(e0 * e0 + e1 * e1);
-            }
-          } else {
-            acc = sad_dword(a[k].x, b[k].x, acc);
-            acc = sad_dword(a[k].y, b[k].y, acc);
-          }
-        }
-      }
-    }
+    if (i < count) acc = pair_sad_accum<SSD>(p1, p2, pairs[i], sub, 8);
     acc = group_sum<8>(acc);
     if (i < count && sub == 0) out[i] = acc;
+  }
+}
+
+// Frame-sized batches (one launch per frame: a few hundred 64x64 pairs cannot fill the chip 8 lanes at a time): ONE WAVE
+// PER DESCRIPTOR is launched, and each group of 8 consecutive descriptors decides from its sizes how to use its 8 waves --
+// all pairs of at least 1024 pixels: every wave takes one pair with all 64 lanes; otherwise the group's first wave takes
+// the 8 pairs 8 lanes each and the other seven exit at once.  One launch, no size hint from the host: a second launch
+// for the large pairs costs more than it saves on small-pair batches, which are launch bound at a few microseconds.
+__device__ __forceinline__ bool pair_group_is_large(const kvz_hip_block_pair *__restrict__ pairs, size_t base, size_t count)
+{
+  bool large = true;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (base + k < count) large = large && (pairs[base + k].width * pairs[base + k].height >= 1024);   // uniform address: scalar loads
+  return large;
+}
+template <bool SSD>
+__global__ __launch_bounds__(256) void pair_sad_wave_kernel(plane_t p1, plane_t p2, const kvz_hip_block_pair *__restrict__ pairs,
+                                                            size_t count, u32 *__restrict__ out)
+{
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t base = wave & ~(size_t)7;
+  const int j = (int)(wave & 7), lane = threadIdx.x & 63;
+  if (base >= count) return;
+  if (pair_group_is_large(pairs, base, count)) {
+    const size_t i = base + j;
+    if (i >= count) return;
+    const kvz_hip_block_pair d = pairs[i];
+    const u32 acc = group_sum<64>(pair_sad_accum<SSD>(p1, p2, d, lane, 64));
+    if (lane == 0) out[i] = acc;
+  } else {
+    if (j != 0) return;
+    const size_t i = base + (lane >> 3);
+    u32 acc = 0;
+    if (i < count) acc = pair_sad_accum<SSD>(p1, p2, pairs[i], lane & 7, 8);
+    acc = group_sum<8>(acc);
+    if (i < count && (lane & 7) == 0) out[i] = acc;
   }
 }
 
@@ -500,9 +539,28 @@ __device__ __forceinline__ u32 satd4x4_planes(const plane_t &p1, const plane_t &
 }
 
 // SATD_ANY_SIZE (strategies-picture.h:62-100) / kvz_image_calc_satd
-// (image.c:488-545).  8 lanes share a pair and split its 8x8 sub-blocks (and
+// (image.c:488-545).  `lanes` lanes share a pair and split its 8x8 sub-blocks (and
 // the 4x4 ones of a leading 4-pixel column / row when w or h is not a multiple
 // of 8).
+__device__ __forceinline__ u32 pair_satd_accum(const plane_t &p1, const plane_t &p2, const kvz_hip_block_pair &d, int sub, int lanes)
+{
+  u32 acc = 0;
+  int w = d.width, h = d.height, ox = 0, oy = 0;
+  if (w & 7) {                                   // first 4-px column, full height
+    for (int y = sub * 4; y < h; y += 4 * lanes) acc += satd4x4_planes(p1, p2, d, 0, y);
+    ox = 4; w -= 4;
+  }
+  if (h & 7) {                                   // first 4-px row of the rest
+    for (int x = sub * 4; x < w; x += 4 * lanes) acc += satd4x4_planes(p1, p2, d, ox + x, 0);
+    oy = 4; h -= 4;
+  }
+  const int w8 = w >> 3, n8 = w8 * (h >> 3);
+  for (int t = sub; t < n8; t += lanes) {
+    const int by = t / w8, bx = t - by * w8;
+    acc += satd8x8_planes(p1, p2, d, ox + bx * 8, oy + by * 8);
+  }
+  return acc;
+}
 __global__ __launch_bounds__(256) void pair_satd_kernel(plane_t p1, plane_t p2, const kvz_hip_block_pair *__restrict__ pairs,
                                                         size_t count, u32 *__restrict__ out)
 {
@@ -512,25 +570,32 @@ __global__ __launch_bounds__(256) void pair_satd_kernel(plane_t p1, plane_t p2, 
   const size_t count_up = (count + 7) & ~(size_t)7;
   for (size_t i = tid >> 3; i < count_up; i += ngroups) {
     u32 acc = 0;
-    if (i < count) {
-      const kvz_hip_block_pair d = pairs[i];
-      int w = d.width, h = d.height, ox = 0, oy = 0;
-      if (w & 7) {                                   // first 4-px column, full height
-        for (int y = sub * 4; y < h; y += 32) acc += satd4x4_planes(p1, p2, d, 0, y);
-        ox = 4; w -= 4;
-      }
-      if (h & 7) {                                   // first 4-px row of the rest
-        for (int x = sub * 4; x < w; x += 32) acc += satd4x4_planes(p1, p2, d, ox + x, 0);
-        oy = 4; h -= 4;
-      }
-      const int w8 = w >> 3, n8 = w8 * (h >> 3);
-      for (int t = sub; t < n8; t += 8) {
-        const int by = t / w8, bx = t - by * w8;
-        acc += satd8x8_planes(p1, p2, d, ox + bx * 8, oy + by * 8);
-      }
-    }
+    if (i < count) acc = pair_satd_accum(p1, p2, pairs[i], sub, 8);
     acc = group_sum<8>(acc);
     if (i < count && sub == 0) out[i] = acc;
+  }
+}
+// one wave per descriptor, see pair_sad_wave_kernel
+__global__ __launch_bounds__(256) void pair_satd_wave_kernel(plane_t p1, plane_t p2, const kvz_hip_block_pair *__restrict__ pairs,
+                                                             size_t count, u32 *__restrict__ out)
+{
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t base = wave & ~(size_t)7;
+  const int j = (int)(wave & 7), lane = threadIdx.x & 63;
+  if (base >= count) return;
+  if (pair_group_is_large(pairs, base, count)) {
+    const size_t i = base + j;
+    if (i >= count) return;
+    const kvz_hip_block_pair d = pairs[i];
+    const u32 acc = group_sum<64>(pair_satd_accum(p1, p2, d, lane, 64));
+    if (lane == 0) out[i] = acc;
+  } else {
+    if (j != 0) return;
+    const size_t i = base + (lane >> 3);
+    u32 acc = 0;
+    if (i < count) acc = pair_satd_accum(p1, p2, pairs[i], lane & 7, 8);
+    acc = group_sum<8>(acc);
+    if (i < count && (lane & 7) == 0) out[i] = acc;
   }
 }
 
@@ -665,6 +730,17 @@ static int launch_satd(int n, const u8 *a, const u8 *b, size_t count, u32 *costs
   return KVZ_HIP_OK;
 }
 
+// batches up to PAIR_WAVE_MAX descriptors (the large blocks of a frame) get one wave per descriptor; larger ones fill the chip anyway
+constexpr size_t PAIR_WAVE_MAX = 4096;      // measured: at 32 400 16x16 pairs the seven idle waves per group double the time; at 1 920 64x64 pairs a wave each is 3.5x faster
+template <bool SSD>
+static void launch_pair_sad(const plane_t &p1, const plane_t &p2, const kvz_hip_block_pair *pairs, size_t count, u32 *out, hipStream_t st)
+{
+  if (count <= PAIR_WAVE_MAX && tuning("pair_wave_kernel", 1))
+    hipLaunchKernelGGL((pair_sad_wave_kernel<SSD>), dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, p1, p2, pairs, count, out);
+  else
+    hipLaunchKernelGGL((pair_sad_kernel<SSD>), dim3(stream_grid(count, 32)), dim3(256), 0, st, p1, p2, pairs, count, out);
+}
+
 extern "C" {
 
 int kvz_hip_sad_nxn_batch(int n, const kvz_hip_pixel *blk1, const kvz_hip_pixel *blk2, size_t count, uint32_t *costs, kvz_hip_stream s)
@@ -708,7 +784,7 @@ int kvz_hip_reg_sad_batch(const kvz_hip_pixel *plane1, uint32_t stride1, const k
   if (!plane1 || !plane2 || !pairs || !costs) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { plane1, stride1, 0, 0 }, p2 = { plane2, stride2, 0, 0 };
-  hipLaunchKernelGGL((pair_sad_kernel<false>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
+  launch_pair_sad<false>(p1, p2, pairs, count, costs, ctx_stream(s));
   KVZ_CHECK_LAUNCH("pair_sad_kernel");
   return KVZ_HIP_OK;
 }
@@ -720,7 +796,7 @@ int kvz_hip_image_calc_sad_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, 
   if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { pic, pic_stride, 0, 0 }, p2 = { ref, ref_stride, ref_w, ref_h };
-  hipLaunchKernelGGL((pair_sad_kernel<false>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
+  launch_pair_sad<false>(p1, p2, pairs, count, costs, ctx_stream(s));
   KVZ_CHECK_LAUNCH("pair_sad_kernel");
   return KVZ_HIP_OK;
 }
@@ -732,7 +808,10 @@ int kvz_hip_image_calc_satd_batch(const kvz_hip_pixel *pic, uint32_t pic_stride,
   if (!pic || !ref || !pairs || !costs || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { pic, pic_stride, 0, 0 }, p2 = { ref, ref_stride, ref_w, ref_h };
-  hipLaunchKernelGGL(pair_satd_kernel, dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
+  if (count <= PAIR_WAVE_MAX && tuning("pair_wave_kernel", 1))
+    hipLaunchKernelGGL(pair_satd_wave_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
+  else
+    hipLaunchKernelGGL(pair_satd_kernel, dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, costs);
   KVZ_CHECK_LAUNCH("pair_satd_kernel");
   return KVZ_HIP_OK;
 }
@@ -744,7 +823,7 @@ int kvz_hip_pixels_calc_ssd_batch(const kvz_hip_pixel *plane1, uint32_t stride1,
   if (!plane1 || !plane2 || !pairs || !ssd) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   plane_t p1 = { plane1, stride1, 0, 0 }, p2 = { plane2, stride2, 0, 0 };
-  hipLaunchKernelGGL((pair_sad_kernel<true>), dim3(stream_grid(count, 32)), dim3(256), 0, ctx_stream(s), p1, p2, pairs, count, ssd);
+  launch_pair_sad<true>(p1, p2, pairs, count, ssd, ctx_stream(s));
   KVZ_CHECK_LAUNCH("pair_sad_kernel<ssd>");
   return KVZ_HIP_OK;
 }

@@ -817,3 +817,36 @@ def test_deblock_argument_errors(api):
     prm = deblock_params()
     assert L.kvz_hip_deblock_frame(None, 64, None, None, 32, 64, 64, None, prm.ctypes.data, None) != 0
     assert b"kvz_hip_deblock_frame" in L.kvz_hip_last_error()
+
+
+def test_pair_kernels_wave_and_lane_groups(api):
+    """frame-sized batches launch one wave per descriptor and every group of 8 descriptors picks its own mode: groups of
+    large pairs (a wave each), groups of small ones (8 lanes each), mixed groups, a ragged last group -- and the grid-stride
+    kernel for large batches (forced through the tuning knob) must agree with all of them"""
+    from kvazaar_amd import _lib
+    L = _lib.init(0)
+    g = rng(77)
+    pic = g.integers(0, 256, (160, 256), dtype=np.uint8)
+    ref = g.integers(0, 256, (160, 256), dtype=np.uint8)
+    pairs = []
+    def add(n, sizes):
+        for _ in range(n):
+            w, h = sizes[int(g.integers(0, len(sizes)))]
+            x1, y1 = int(g.integers(0, 256 - w + 1)), int(g.integers(0, 160 - h + 1))
+            pairs.append((x1, y1, x1 + int(g.integers(-9, 10)), y1 + int(g.integers(-9, 10)), w, h))
+    add(16, ((64, 64), (32, 32), (64, 32), (48, 40)))          # two all-large groups
+    add(16, ((8, 8), (16, 16), (4, 4), (12, 8)))               # two all-small groups
+    add(24, ((64, 64), (8, 8), (32, 32), (16, 8), (24, 24)))   # mixed groups
+    add(5, ((64, 64), (32, 64)))                               # ragged, large
+    want_sad = [O.image_calc("sad", pic, ref, *p) for p in pairs]
+    want_satd = [O.image_calc("satd", pic, ref, *p) for p in pairs]
+    inside = [p for p in pairs if 0 <= p[2] and p[2] + p[4] <= 256 and 0 <= p[3] and p[3] + p[5] <= 160 and p[4] == p[5]]
+    want_ssd = [O.pixels_calc_ssd(pic, p[1] * 256 + p[0], ref, p[3] * 256 + p[2], 256, 256, p[4]) for p in inside]
+    for knob in (1, 0):
+        assert L.kvz_hip_set_tuning(b"pair_wave_kernel", knob) == 0
+        try:
+            np.testing.assert_array_equal(api.image_calc_sad_batch(pic, ref, pairs), want_sad, err_msg="sad knob %d" % knob)
+            np.testing.assert_array_equal(api.image_calc_satd_batch(pic, ref, pairs), want_satd, err_msg="satd knob %d" % knob)
+            np.testing.assert_array_equal(api.pixels_calc_ssd_batch(pic, ref, inside), want_ssd, err_msg="ssd knob %d" % knob)
+        finally:
+            L.kvz_hip_set_tuning(b"pair_wave_kernel", -1)
