@@ -18,6 +18,96 @@ __constant__ signed char c_chroma_filter[8][4] = {     // filter.c:62-72
   { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
 
+// The same two passes for the shapes motion compensation really asks for (width a multiple of 4, even height), with the
+// arithmetic of frac_core.h: the horizontal pass cuts the byte windows of 4 neighbouring samples out of aligned dwords
+// (v_alignbyte) and takes each sample as one (chroma) or two (luma) v_dot4_i32_i8 on pixels - 128 (the taps sum to 64, so
+// + 128 * 64 restores the offset; exact); its int16 plane is stored TRANSPOSED, two vertically adjacent samples per dword,
+// so the vertical pass is v_dot2_i32_i16 on consecutive dwords -- a lane produces 2 rows x 4 columns from 3 (chroma) or
+// 5 (luma) dwords per column instead of TAPS 16-bit reads per sample.
+template <int TAPS, int MAXW> struct sample_geom {
+  static constexpr int WS = MAXW + TAPS;                       // window row stride (a multiple of 4)
+  static constexpr int WIN_BYTES = (MAXW + TAPS) * WS;         // one row more than the window: the last row pair may be half
+  static constexpr int HP = (MAXW + TAPS) / 2 + 1;             // dwords per transposed column (odd: columns start in different banks)
+  static constexpr int HOR_DWORDS = MAXW * HP > (MAXW + TAPS - 1) * MAXW / 2 ? MAXW * HP : (MAXW + TAPS - 1) * MAXW / 2 + 1;
+};
+template <int TAPS, bool OUT14, int MAXW, int T, bool WAVE>
+__device__ __forceinline__ void sample_core_fast(int tid, u8 *s_win, u32 *s_hor, const kvz_hip_ipol_block &b, size_t o, void *__restrict__ dst)
+{
+  typedef sample_geom<TAPS, MAXW> G;
+  constexpr int HALF = TAPS / 2;
+  const int w = b.width, h = b.height, wh = h + TAPS - 1;
+  const signed char *hf = TAPS == 8 ? c_luma_filter[b.mv_frac_x & 3] : c_chroma_filter[b.mv_frac_x & 7];
+  const signed char *vf = TAPS == 8 ? c_luma_filter[b.mv_frac_y & 3] : c_chroma_filter[b.mv_frac_y & 7];
+  u32 h0 = 0, h1 = 0;                                          // horizontal taps as bytes
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    h0 |= (u32)(u8)hf[t] << (8 * t);
+    if (TAPS == 8) h1 |= (u32)(u8)hf[4 + t] << (8 * t);
+  }
+  // vertical taps as int16 pairs: va[t] = (f[2t], f[2t+1]) prices the row pair t for the even output row, vb[t] =
+  // (f[2t-1], f[2t]) for the odd one, which starts half a pair later
+  u32 va[HALF + 1], vb[HALF + 1];
+#pragma unroll
+  for (int t = 0; t <= HALF; ++t) {
+    va[t] = t < HALF ? frac_pack16(vf[2 * t], vf[2 * t + 1]) : 0u;
+    vb[t] = frac_pack16(t > 0 ? vf[2 * t - 1] : 0, t < HALF ? vf[2 * t] : 0);
+  }
+  const int npair = (wh + 1) >> 1, w4 = w >> 2;
+  for (int i = tid; i < npair * w4; i += T) {
+    const int g = i / npair, yp = i - g * npair, x0 = 4 * g;
+    int hv[4][2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const u32 *q = (const u32 *)(s_win + (2 * yp + rr) * G::WS + x0);
+      const u32 d0 = q[0] ^ 0x80808080u, d1 = q[1] ^ 0x80808080u, d2 = TAPS == 8 ? q[2] ^ 0x80808080u : 0u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u32 lo = k ? __builtin_amdgcn_alignbyte(d1, d0, (u32)k) : d0;
+        if (TAPS == 8) {
+          const u32 hi = k ? __builtin_amdgcn_alignbyte(d2, d1, (u32)k) : d1;
+          hv[k][rr] = __builtin_amdgcn_sdot4((int)h0, (int)lo, __builtin_amdgcn_sdot4((int)h1, (int)hi, 8192, false), false);
+        } else {
+          hv[k][rr] = __builtin_amdgcn_sdot4((int)h0, (int)lo, 8192, false);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_hor[(x0 + k) * G::HP + yp] = ((u32)hv[k][0] & 0xffffu) | ((u32)hv[k][1] << 16);
+  }
+  if (WAVE) wave_lds_fence(); else __syncthreads();
+  const int h2 = h >> 1;
+  for (int i = tid; i < h2 * w4; i += T) {
+    const int g = i / h2, yo = i - g * h2, x0 = 4 * g;
+    int v0[4], v1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32 *col = s_hor + (x0 + k) * G::HP + yo;
+      int a0 = 0, a1 = 0;
+#pragma unroll
+      for (int t = 0; t <= HALF; ++t) {
+        const v2s pr = as_v2s(col[t]);
+        if (t < HALF) a0 = __builtin_amdgcn_sdot2(pr, as_v2s(va[t]), a0, false);
+        a1 = __builtin_amdgcn_sdot2(pr, as_v2s(vb[t]), a1, false);
+      }
+      v0[k] = a0 >> 6; v1[k] = a1 >> 6;
+    }
+    const size_t at = o + (size_t)(2 * yo) * w + x0;
+    if (OUT14) {
+      const uint2 p0 = make_uint2((u32)(v0[0] & 0xffff) | ((u32)v0[1] << 16), (u32)(v0[2] & 0xffff) | ((u32)v0[3] << 16));
+      const uint2 p1 = make_uint2((u32)(v1[0] & 0xffff) | ((u32)v1[1] << 16), (u32)(v1[2] & 0xffff) | ((u32)v1[3] << 16));
+      __builtin_memcpy((i16 *)dst + at, &p0, 8);
+      __builtin_memcpy((i16 *)dst + at + w, &p1, 8);
+    } else {
+      const u32 p0 = (u32)fast_clip32((v0[0] + 32) >> 6) | ((u32)fast_clip32((v0[1] + 32) >> 6) << 8) |
+                     ((u32)fast_clip32((v0[2] + 32) >> 6) << 16) | ((u32)fast_clip32((v0[3] + 32) >> 6) << 24);
+      const u32 p1 = (u32)fast_clip32((v1[0] + 32) >> 6) | ((u32)fast_clip32((v1[1] + 32) >> 6) << 8) |
+                     ((u32)fast_clip32((v1[2] + 32) >> 6) << 16) | ((u32)fast_clip32((v1[3] + 32) >> 6) << 24);
+      __builtin_memcpy((u8 *)dst + at, &p0, 4);
+      __builtin_memcpy((u8 *)dst + at + w, &p1, 4);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // kvz_sample_quarterpel_luma / kvz_sample_octpel_chroma (+14-bit variants),
 // ipol-generic.c:122-190, :660-728: horizontal pass over h+TAPS-1 rows into
@@ -53,6 +143,10 @@ __device__ __forceinline__ void sample_core(int tid, u8 *s_win, i16 *s_hor, cons
     }
   }
   if (WAVE) wave_lds_fence(); else __syncthreads();
+  if ((w & 3) == 0 && (h & 1) == 0) {                  // every PU shape of motion compensation
+    sample_core_fast<TAPS, OUT14, MAXW, T, WAVE>(tid, s_win, (u32 *)s_hor, b, o, dst);
+    return;
+  }
   for (int i = tid; i < w * wh; i += T) {
     const int y = i / w, x = i - y * w;
     int acc = 0;
@@ -101,8 +195,8 @@ __global__ __launch_bounds__(256) void sample_big_kernel(refplane_t ref, const k
                                                          const unsigned long long *__restrict__ out_offsets, void *__restrict__ dst)
 {
   constexpr int MAXW = TAPS == 8 ? 64 : 32;
-  __shared__ u8 s_win[(MAXW + TAPS - 1) * (MAXW + TAPS)];
-  __shared__ i16 s_hor[(MAXW + TAPS - 1) * MAXW];
+  __shared__ __attribute__((aligned(16))) u8 s_win[sample_geom<TAPS, MAXW>::WIN_BYTES];
+  __shared__ __attribute__((aligned(16))) i16 s_hor[2 * sample_geom<TAPS, MAXW>::HOR_DWORDS];
   const kvz_hip_ipol_block b = blocks[blockIdx.x];
   if (b.width < 1 || b.height < 1 || b.width > MAXW || b.height > MAXW) return;     // unsupported shape: nothing written
   if (b.width <= 16 && b.height <= 16) return;                                      // sample_small_kernel's
@@ -114,8 +208,8 @@ template <int TAPS, bool OUT14>
 __global__ __launch_bounds__(256) void sample_small_kernel(refplane_t ref, const kvz_hip_ipol_block *__restrict__ blocks, size_t count,
                                                            const unsigned long long *__restrict__ out_offsets, void *__restrict__ dst)
 {
-  __shared__ u8 s_win[4][(16 + TAPS - 1) * (16 + TAPS)];
-  __shared__ i16 s_hor[4][(16 + TAPS - 1) * 16];
+  __shared__ __attribute__((aligned(16))) u8 s_win[4][sample_geom<TAPS, 16>::WIN_BYTES];
+  __shared__ __attribute__((aligned(16))) i16 s_hor[4][2 * sample_geom<TAPS, 16>::HOR_DWORDS];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: descriptor loads and block geometry go scalar
   const size_t i = (size_t)blockIdx.x * 4 + wv;
   if (i >= count) return;
@@ -192,8 +286,8 @@ __global__ __launch_bounds__(256) void bipred_cost_kernel(const u8 *__restrict__
                                                          refplane_t ref0, refplane_t ref1, const kvz_hip_bipred_cand *__restrict__ cands,
                                                          u32 *__restrict__ costs)
 {
-  __shared__ u8 s_win[(64 + 7) * (64 + 8)];
-  __shared__ i16 s_hor[(64 + 7) * 64];
+  __shared__ __attribute__((aligned(16))) u8 s_win[sample_geom<8, 64>::WIN_BYTES];
+  __shared__ __attribute__((aligned(16))) i16 s_hor[2 * sample_geom<8, 64>::HOR_DWORDS];
   __shared__ __attribute__((aligned(16))) i16 s_s[2][64 * 64];
   __shared__ __attribute__((aligned(16))) u8 s_pred[64 * 64], s_cur[64 * 64];
   __shared__ u32 s_cost;
