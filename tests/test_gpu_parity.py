@@ -850,3 +850,24 @@ def test_pair_kernels_wave_and_lane_groups(api):
             np.testing.assert_array_equal(api.pixels_calc_ssd_batch(pic, ref, inside), want_ssd, err_msg="ssd knob %d" % knob)
         finally:
             L.kvz_hip_set_tuning(b"pair_wave_kernel", -1)
+
+
+@pytest.mark.parametrize("kind", ["luma", "luma14", "chroma", "chroma14"])
+def test_sample_filters_small_and_odd_blocks(api, kind):
+    """many blocks of at most 8x8 (the dot-product path), odd shapes that take the generic path, windows that leave the
+    frame, mixed with 16-pixel blocks, a ragged tail"""
+    g = rng(62)
+    frame = g.integers(0, 256, (48, 64), dtype=np.uint8)
+    pad = 40
+    padded = np.pad(frame, pad, mode="edge")
+    nfrac = 4 if kind.startswith("luma") else 8
+    blocks = []
+    for k in range(43):
+        w, h = ((8, 8), (4, 4), (8, 4), (4, 8), (8, 8), (2, 2), (6, 6), (8, 2))[k % 8]
+        if 16 <= k < 24:
+            w, h = ((16, 16), (8, 8), (16, 8), (8, 8), (8, 8), (8, 16), (8, 8), (12, 8))[k - 16]      # mixed runs
+        blocks.append((int(g.integers(-6, 64)), int(g.integers(-6, 48)), int(g.integers(0, nfrac)), int(g.integers(0, nfrac)), w, h))
+    got = api.sample_batch(kind, frame, blocks)
+    for b, o in zip(blocks, got):
+        x, y, fx, fy, w, h = b
+        np.testing.assert_array_equal(o, O.sample(kind, padded, x + pad, y + pad, w, h, fx, fy), err_msg=str(b))
