@@ -30,6 +30,7 @@ struct me_cost_model {
   int n_merge;
   int mx[5], my[5];
   u32 usable, same_ref;                                // bit i = merge[i].usable / .same_ref
+  u32 mkey[5];                                         // merge vector i as (x & 0xffff) | y << 16, for merge_match
   int lambda_cost, wpp_owf, ref_delay_px, max_down, max_right;
 
   __device__ __forceinline__ me_cost_model(const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm)
@@ -41,6 +42,7 @@ struct me_cost_model {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       mx[i] = pu.merge[i].mv[0]; my[i] = pu.merge[i].mv[1];
+      mkey[i] = ((u32)mx[i] & 0xffffu) | ((u32)my[i] << 16);
       if (i < n_merge && pu.merge[i].usable) usable |= 1u << i;
       if (pu.merge[i].same_ref) same_ref |= 1u << i;
     }
@@ -93,11 +95,13 @@ struct me_cost_model {
   // index of the first merge candidate that codes (x, y) (quarter-pel) for this reference, or -1
   __device__ __forceinline__ int merge_match(int x, int y) const
   {
+    // one compare per candidate on the packed vector; a vector outside int16 matches nothing (the candidates are int16)
+    const u32 key = ((u32)x & 0xffffu) | ((u32)y << 16), live = usable & same_ref;
     int m = -1;
 #pragma unroll
     for (int i = 4; i >= 0; --i)
-      if (((usable & same_ref) >> i & 1u) && mx[i] == x && my[i] == y) m = i;
-    return m;
+      if ((live >> i & 1u) && mkey[i] == key) m = i;
+    return ((u32)(x + 32768) < 65536u && (u32)(y + 32768) < 65536u) ? m : -1;
   }
   // calc_mvd_cost (:373-412)
   __device__ __forceinline__ u32 cost(int x, int y, int mv_shift, u32 &bits) const
@@ -107,7 +111,7 @@ struct me_cost_model {
     const int m = merge_match(x, y);
     if (m >= 0) bits = (u32)m;
     else select_cand(x, y, bits);
-    return bits * (u32)lambda_cost;
+    return __umul24(bits, (u32)lambda_cost);            // bits < 2^7, lambda_cost <= 2^20 (checked by the entry): a full-rate multiply
   }
   // mv_in_merge (:260-273), integer-pel vector
   __device__ __forceinline__ bool in_merge(int x, int y) const
