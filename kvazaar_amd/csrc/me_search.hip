@@ -84,13 +84,28 @@ struct me_cost_model {
   {
     return golomb((u32)(dx < 0 ? -dx : dx)) + golomb((u32)(dy < 0 ? -dy : dy));
   }
-  // select_mv_cand (:326-370)
+  // select_mv_cand (:326-370).  |d| + 2 of each vector component is one v_sad_u32 on operands moved into the unsigned
+  // range, the exp-Golomb length of a component 2 * (31 - clz(|d| + 2)) (see golomb), so a candidate costs
+  // 124 - 2 * (clz + clz) bits and the cheaper of the two is the one with the larger clz sum.
   __device__ __forceinline__ int select_cand(int mvx, int mvy, u32 &cost) const
   {
-    const u32 c1 = mvd_bits(mvx - cand[0][0], mvy - cand[0][1]);
-    const u32 c2 = mvd_bits(mvx - cand[1][0], mvy - cand[1][1]);
-    cost = c1 < c2 ? c1 : c2;
-    return c2 < c1 ? 1 : 0;
+    constexpr u32 BIAS = 1u << 20;                       // |mv|, |candidate| < 2^18: sums stay positive
+    const u32 xb = (u32)mvx + BIAS, yb = (u32)mvy + BIAS;
+    u32 s[4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const u32 cx = (u32)cand[c][0] + BIAS, cy = (u32)cand[c][1] + BIAS;
+      s[2 * c] = (xb > cx ? xb - cx : cx - xb) + 2u;     // v_sad_u32
+      s[2 * c + 1] = (yb > cy ? yb - cy : cy - yb) + 2u;
+    }
+    if (__builtin_expect(((s[0] | s[1] | s[2] | s[3]) >> 16) != 0, 0)) {        // a difference of two extreme vectors
+      const u32 c1 = mvd_bits(mvx - cand[0][0], mvy - cand[0][1]), c2 = mvd_bits(mvx - cand[1][0], mvy - cand[1][1]);
+      cost = c1 < c2 ? c1 : c2;
+      return c2 < c1 ? 1 : 0;
+    }
+    const u32 z1 = (u32)__builtin_clz(s[0]) + (u32)__builtin_clz(s[1]), z2 = (u32)__builtin_clz(s[2]) + (u32)__builtin_clz(s[3]);
+    cost = 124u - 2u * (z1 > z2 ? z1 : z2);
+    return z2 > z1 ? 1 : 0;
   }
   // index of the first merge candidate that codes (x, y) (quarter-pel) for this reference, or -1
   __device__ __forceinline__ int merge_match(int x, int y) const
