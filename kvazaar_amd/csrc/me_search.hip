@@ -235,10 +235,21 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
       if (mvc.within(x * 4, y * 4)) cost = sh->sad[k] + mvc.cost(x, y, 2, bits);   // < 2^32: lambda_cost is bounded by the entry
     }
     u32 m = cost;
+    if (n <= 16) {
+      // every pattern but the exhaustive search: the candidates sit in lanes 0..15, one DPP row -- four v_min with
+      // DPP operands instead of six LDS-crossbar exchanges
+      u32 o;
+      o = dpp_mov<0xB1>(m); m = o < m ? o : m;             // quad_perm [1,0,3,2]
+      o = dpp_mov<0x4E>(m); m = o < m ? o : m;             // quad_perm [2,3,0,1]
+      o = dpp_mov<0x141>(m); m = o < m ? o : m;            // row_half_mirror
+      o = dpp_mov<0x140>(m); m = o < m ? o : m;            // row_mirror
+      m = (u32)__builtin_amdgcn_readfirstlane((int)m);
+    } else {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const u32 o = (u32)__shfl_xor((int)m, off, 64);
-      m = o < m ? o : m;
+      for (int off = 1; off < 64; off <<= 1) {
+        const u32 o = (u32)__shfl_xor((int)m, off, 64);
+        m = o < m ? o : m;
+      }
     }
     if (m >= best_cost) return -1;
     const int win = __builtin_ctzll(__ballot(cost == m));
