@@ -305,7 +305,36 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   };
 
   // integer position: candidate = P[y][x]
-  score_integer();
+  if constexpr (SPLIT8) {
+    // the 8x8 block of one wave again cut into 2 x 2 samples per lane: lanes 0..15 hold the block, the Hadamard crosses
+    // them with DPP -- a quarter of the instructions of the quad scheme, which keeps 4 lanes busy here
+    const int g = tid & 3, pp = (tid >> 2) & 3;
+    const u8 *a = s_cur + 2 * pp * G::CS + 2 * g, *bq = s_p + (4 + 2 * pp) * G::PS + 4 + 2 * g;
+    const u32 cw0 = *(const unsigned short *)a, cw1 = *(const unsigned short *)(a + G::CS);
+    const u32 pw0 = *(const unsigned short *)bq, pw1 = *(const unsigned short *)(bq + G::PS);
+    const v2s r0 = unpack_lo(cw0) - unpack_lo(pw0), r1 = unpack_lo(cw1) - unpack_lo(pw1);
+    const short s4 = (tid & 4) ? (short)-1 : (short)1, s8 = (tid & 8) ? (short)-1 : (short)1;
+    const v2s m4 = { s4, s4 }, m8 = { s8, s8 };
+    v2s v[2] = { r0 + r1, r0 - r1 };
+    u32 acc = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      v2s t = dpp_v2s<0xB1>(v[i]);
+      v2s u = v[i] * m1 + t;
+      t = dpp_v2s<0x4E>(u);
+      u = u * m2 + t;
+      t = dpp_xor4_v2s(u);
+      u = u * m4 + t;
+      t = dpp_v2s<0x128>(u);
+      u = u * m8 + t;
+      acc = abs_last_stage(u, acc);
+    }
+    acc = group_sum<16>(acc);
+    if (tid == 0) s_cost[0] = (acc + 2) >> 2;
+    sync();
+  } else {
+    score_integer();
+  }
   int mx = d.x2 - d.x1, my = d.y2 - d.y1;              // pixel precision
   u32 best_bitcost = 0;
   u32 best_cost = s_cost[0];
