@@ -300,16 +300,18 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
     sync();
   };
   constexpr bool SPLIT8 = WAVE && T == 64 && FW == 8 && FH == 8;
+  constexpr bool SPLIT16 = WAVE && T == 64 && FW == 16 && FH == 16;
   auto score_any = [&](int pat, int ox, int oy, int scale) {
     if constexpr (SPLIT8) score_step8(pat, ox, oy, scale); else score_step(pat, ox, oy, scale);
   };
 
   // integer position: candidate = P[y][x]
-  if constexpr (SPLIT8) {
-    // the 8x8 block of one wave again cut into 2 x 2 samples per lane: lanes 0..15 hold the block, the Hadamard crosses
-    // them with DPP -- a quarter of the instructions of the quad scheme, which keeps 4 lanes busy here
-    const int g = tid & 3, pp = (tid >> 2) & 3;
-    const u8 *a = s_cur + 2 * pp * G::CS + 2 * g, *bq = s_p + (4 + 2 * pp) * G::PS + 4 + 2 * g;
+  if constexpr (SPLIT8 || SPLIT16) {
+    // blocks owned by one wave, cut into 2 x 2 samples per lane: 16 lanes per 8x8 sub-block (an 8x8 block fills lanes
+    // 0..15, a 16x16 block the wave), the Hadamard crosses them with DPP -- a quarter of the instructions of the quad
+    // scheme, which keeps 4 lanes per sub-block busy here
+    const int g = tid & 3, pp = (tid >> 2) & 3, sb = SPLIT16 ? tid >> 4 : 0, y0 = (sb >> 1) * 8 + 2 * pp, x0 = (sb & 1) * 8 + 2 * g;
+    const u8 *a = s_cur + y0 * G::CS + x0, *bq = s_p + (4 + y0) * G::PS + 4 + x0;
     const u32 cw0 = *(const unsigned short *)a, cw1 = *(const unsigned short *)(a + G::CS);
     const u32 pw0 = *(const unsigned short *)bq, pw1 = *(const unsigned short *)(bq + G::PS);
     const v2s r0 = unpack_lo(cw0) - unpack_lo(pw0), r1 = unpack_lo(cw1) - unpack_lo(pw1);
@@ -329,8 +331,9 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
       u = u * m8 + t;
       acc = abs_last_stage(u, acc);
     }
-    acc = group_sum<16>(acc);
-    if (tid == 0) s_cost[0] = (acc + 2) >> 2;
+    acc = (group_sum<16>(acc) + 2) >> 2;                 // the sub-block's SATD, in each of its 16 lanes
+    if (SPLIT16) acc = group_sum<64>((tid & 15) == 0 ? acc : 0u);
+    if (tid == 0) s_cost[0] = acc;
     sync();
   } else {
     score_integer();
