@@ -390,7 +390,7 @@ int launch_rough(const kvz_hip_intra_ref *refs, const u8 *orig, size_t count, in
 {
   constexpr int N = 1 << LOG2, NB = N < 8 ? 4 : 8, S = (N / NB) * (N / NB), G = 64 / S;
   const size_t wgs = (count + G - 1) / G;
-  if (wgs > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
+  if (wgs > 0x7fffffffu) return kvzhip::invalid_arg("kvz_hip_intra_rough_batch");
   // 4x4 PUs: 64 PUs per workgroup make it LDS-limited (31 KB), eight waves per workgroup fill the CU's wave slots
   // (3.4 against 2.7 G PUs/s); the larger sizes are register-limited and lose a third with eight (measured)
   const int nw = tuning("intra_rough_waves", LOG2 == 2 ? 8 : 4);

@@ -452,9 +452,9 @@ static int sample_launch(bool luma, const kvz_hip_pixel *ref, uint32_t ref_strid
                          int out_14bit, void *dst, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
-  if (!ref || !blocks || !out_offsets || !dst || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg(__func__);
+  if (!ref || !blocks || !out_offsets || !dst || ref_w <= 0 || ref_h <= 0) return kvzhip::invalid_arg("kvz_hip_sample_luma_batch / kvz_hip_sample_chroma_batch");
   if (count == 0) return KVZ_HIP_OK;
-  if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
+  if (count > 0x7fffffffu) return kvzhip::invalid_arg("kvz_hip_sample_luma_batch / kvz_hip_sample_chroma_batch");
   refplane_t r = { ref, ref_stride, ref_w, ref_h };
   hipStream_t st = ctx_stream(s);
   const unsigned long long *oo = (const unsigned long long *)out_offsets;

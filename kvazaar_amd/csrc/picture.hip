@@ -698,7 +698,7 @@ static int launch_sad(int n, const u8 *a, const u8 *b, size_t count, u32 *costs,
     KVZ_SAD_CASE(16, 4)
     KVZ_SAD_CASE(32, 4)
     KVZ_SAD_CASE(64, 4)
-    default: return kvzhip::invalid_arg(__func__);
+    default: return kvzhip::invalid_arg("kvz_hip_sad_nxn_batch / kvz_hip_sad_nxn_dual_batch (n must be 4, 8, 16, 32 or 64)");
   }
 #undef KVZ_SAD_CASE
   KVZ_CHECK_LAUNCH("sad_nxn_kernel");
@@ -724,7 +724,7 @@ static int launch_satd(int n, const u8 *a, const u8 *b, size_t count, u32 *costs
       break;
     case 32: hipLaunchKernelGGL((satd_nxn_kernel<32, DUAL>), dim3(stream_grid(count * 16, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
     case 64: hipLaunchKernelGGL((satd_nxn_kernel<64, DUAL>), dim3(stream_grid(count * 64, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is); break;
-    default: return kvzhip::invalid_arg(__func__);
+    default: return kvzhip::invalid_arg("kvz_hip_satd_nxn_batch / kvz_hip_satd_nxn_dual_batch (n must be 4, 8, 16, 32 or 64)");
   }
   KVZ_CHECK_LAUNCH("satd_nxn_kernel");
   return KVZ_HIP_OK;

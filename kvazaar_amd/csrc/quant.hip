@@ -592,8 +592,8 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   // quant uses type 0 / 2, dequant 0 / 2 / 3 (quant-generic.c:224, :244)
   const int tq = color == 0 ? 0 : 2, tdq = color == 0 ? 0 : (color == 1 ? 2 : 3);
   if (!p || !ref_in || !pred_in || !rec_out || !coeff_out || !has_coeffs || color < 0 || color > 2 ||
-      scan_order < 0 || scan_order > 2 || !make_consts(p, width, tq, tdq, &k)) return kvzhip::invalid_arg(__func__);
-  if ((((uintptr_t)ref_in | (uintptr_t)pred_in | (uintptr_t)rec_out | (uintptr_t)coeff_out) & 15) != 0) return kvzhip::invalid_arg(__func__);
+      scan_order < 0 || scan_order > 2 || !make_consts(p, width, tq, tdq, &k)) return kvzhip::invalid_arg("kvz_hip_quantize_residual_batch / kvz_hip_quantize_residual_cost_batch");
+  if ((((uintptr_t)ref_in | (uintptr_t)pred_in | (uintptr_t)rec_out | (uintptr_t)coeff_out) & 15) != 0) return kvzhip::invalid_arg("kvz_hip_quantize_residual_batch / kvz_hip_quantize_residual_cost_batch");
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
@@ -618,7 +618,7 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
     case 8: if (use_trskip) KVZ_QR(8, 4); else KVZ_QR(8, 0); break;
     case 16: if (use_trskip) KVZ_QR(16, 4); else KVZ_QR(16, 0); break;
     case 32: if (use_trskip) KVZ_QR(32, 4); else KVZ_QR(32, 0); break;
-    default: return kvzhip::invalid_arg(__func__);
+    default: return kvzhip::invalid_arg("kvz_hip_quantize_residual_batch / kvz_hip_quantize_residual_cost_batch");
   }
 #undef KVZ_QR
   KVZ_CHECK_LAUNCH("quantize_residual_kernel");
