@@ -18,6 +18,8 @@
 
 using namespace kvzhip;
 
+static_assert(sizeof(kvz_hip_cu_info) == 20 && sizeof(kvz_hip_deblock_params) == 64, "layouts of include/kvz_hip.h");
+
 namespace {
 
 __constant__ u8 c_tc_table[54] = {       // kvz_g_tc_table_8x8, filter.c:34-42
