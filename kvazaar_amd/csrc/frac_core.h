@@ -65,7 +65,10 @@ struct frac_vcoef { u32 c[4][2][2][5]; };
 __host__ __device__ constexpr u32 frac_pack16(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }
 __host__ __device__ constexpr frac_vcoef frac_make_vcoef()
 {
-  constexpr int f[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+  // the taps times 4: the vertical sums then carry the reference's (int16)(sum >> 6) in bytes 1..2 of the accumulator,
+  // where one v_perm_b32 picks it up for two neighbouring samples at once (4 sum >> 8 == sum >> 6, exactly)
+  constexpr int f[4][8] = { { 0, 0, 0, 256, 0, 0, 0, 0 }, { -4, 16, -40, 232, 68, -20, 4, 0 }, { -4, 16, -44, 160, 160, -44, 16, -4 },
+                            { 0, 4, -20, 68, 232, -40, 16, -4 } };
   frac_vcoef t = {};
   for (int fy = 0; fy < 4; ++fy)
     for (int i = 0; i < 5; ++i) {
@@ -78,6 +81,18 @@ __host__ __device__ constexpr frac_vcoef frac_make_vcoef()
   return t;
 }
 static __constant__ const frac_vcoef c_frac_vcoef = frac_make_vcoef();
+
+// Two neighbouring samples from their vertical sums (taps x 4, see frac_make_vcoef): the int16 truncation of sum >> 6 is
+// the byte pick, then (s + 32) >> 6 and the 0..255 clamp in packed int16 -- the addition saturates, which is where the
+// reference's int arithmetic and a wrapping 16-bit add would part (s >= 32736 clips to 255 either way).
+__device__ __forceinline__ v2s frac_round_clip_pair(int acc_even, int acc_odd)
+{
+  const v2s sft = as_v2s(__builtin_amdgcn_perm((u32)acc_odd, (u32)acc_even, 0x06050201u));
+  const v2s r32 = { 32, 32 }, six = { 6, 6 }, zero = { 0, 0 }, top = { 255, 255 };
+  v2s t = __builtin_elementwise_add_sat(sft, r32) >> six;
+  t = __builtin_elementwise_max(t, zero);
+  return __builtin_elementwise_min(t, top);
+}
 
 // MV cost policy of the search: cost() = calc_mvd_cost (search_inter.c:373-412) of the vector (x, y) << shift,
 // within() = fracmv_within_tile (:87-176) of a quarter-pel vector.  frac_no_cost gives the bare SATD search.
@@ -221,27 +236,24 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
       u32 cur[4];
       __builtin_memcpy(&cur[0], a, 4); __builtin_memcpy(&cur[1], a + 4, 4); __builtin_memcpy(&cur[2], a + G::CS, 4); __builtin_memcpy(&cur[3], a + G::CS + 4, 4);
       const u32 *col = s_h + slot * (G::H_ELEMS / 2) + ((bx * 8 + cx + 1) * G::HT >> 1) + (b >> 1);
-      int t0[8], t1[8];
+      int a0[8], a1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const u32 *cj = col + j * (G::HT >> 1);
-        int a0 = 0, a1 = 0;
+        a0[j] = 0; a1[j] = 0;
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
           const v2s pr = as_v2s(cj[t]);
-          a0 = __builtin_amdgcn_sdot2(pr, as_v2s(c0[t]), a0, false);
-          a1 = __builtin_amdgcn_sdot2(pr, as_v2s(c1[t]), a1, false);
+          a0[j] = __builtin_amdgcn_sdot2(pr, as_v2s(c0[t]), a0[j], false);
+          a1[j] = __builtin_amdgcn_sdot2(pr, as_v2s(c1[t]), a1[j], false);
         }
-        // round_clip16((int16)(acc >> 6)): the clip's argument is within +-512, where it is a plain clamp
-        t0[j] = clampi(((int)(i16)(a0 >> 6) + 32) >> 6, 0, 255);
-        t1[j] = clampi(((int)(i16)(a1 >> 6) + 32) >> 6, 0, 255);
       }
       v2s dd[2][4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const u32 cw0 = cur[jj >> 1], cw1 = cur[2 + (jj >> 1)];
-        dd[0][jj] = ((jj & 1) ? unpack_hi(cw0) : unpack_lo(cw0)) - as_v2s((u32)t0[2 * jj] | ((u32)t0[2 * jj + 1] << 16));
-        dd[1][jj] = ((jj & 1) ? unpack_hi(cw1) : unpack_lo(cw1)) - as_v2s((u32)t1[2 * jj] | ((u32)t1[2 * jj + 1] << 16));
+        dd[0][jj] = ((jj & 1) ? unpack_hi(cw0) : unpack_lo(cw0)) - frac_round_clip_pair(a0[2 * jj], a0[2 * jj + 1]);
+        dd[1][jj] = ((jj & 1) ? unpack_hi(cw1) : unpack_lo(cw1)) - frac_round_clip_pair(a1[2 * jj], a1[2 * jj + 1]);
       }
       add_cost(k, satd8_quad_part_diff(dd, m1, m2));
     }
@@ -262,23 +274,21 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
 #pragma unroll
     for (int t = 0; t < 5; ++t) { c0[t] = c_frac_vcoef.c[fy][par][0][t]; c1[t] = c_frac_vcoef.c[fy][par][1][t]; }
     const u32 *col = s_h + slot * (G::H_ELEMS / 2) + ((2 * g + cx + 1) * G::HT >> 1) + (b >> 1);
-    int t0[2], t1[2];
+    int a0[2], a1[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const u32 *cj = col + j * (G::HT >> 1);
-      int a0 = 0, a1 = 0;
+      a0[j] = 0; a1[j] = 0;
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
         const v2s pr = as_v2s(cj[t]);
-        a0 = __builtin_amdgcn_sdot2(pr, as_v2s(c0[t]), a0, false);
-        a1 = __builtin_amdgcn_sdot2(pr, as_v2s(c1[t]), a1, false);
+        a0[j] = __builtin_amdgcn_sdot2(pr, as_v2s(c0[t]), a0[j], false);
+        a1[j] = __builtin_amdgcn_sdot2(pr, as_v2s(c1[t]), a1[j], false);
       }
-      t0[j] = clampi(((int)(i16)(a0 >> 6) + 32) >> 6, 0, 255);
-      t1[j] = clampi(((int)(i16)(a1 >> 6) + 32) >> 6, 0, 255);
     }
     const u8 *a = s_cur + y0 * G::CS + 2 * g;
     const u32 cw0 = *(const unsigned short *)a, cw1 = *(const unsigned short *)(a + G::CS);
-    const v2s r0 = unpack_lo(cw0) - as_v2s((u32)t0[0] | ((u32)t0[1] << 16)), r1 = unpack_lo(cw1) - as_v2s((u32)t1[0] | ((u32)t1[1] << 16));
+    const v2s r0 = unpack_lo(cw0) - frac_round_clip_pair(a0[0], a0[1]), r1 = unpack_lo(cw1) - frac_round_clip_pair(a1[0], a1[1]);
     const short s4 = (tid & 4) ? (short)-1 : (short)1, s8 = (tid & 8) ? (short)-1 : (short)1;
     const v2s m4 = { s4, s4 }, m8 = { s8, s8 };
     v2s v[2] = { r0 + r1, r0 - r1 };                    // row bit 0

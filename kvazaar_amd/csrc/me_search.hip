@@ -522,8 +522,9 @@ __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__
   search_pu_core<64, T, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
 
-// PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier
-__global__ __launch_bounds__(256) void search_pu_small_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
+// PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier.  The register budget is held at
+// 6 waves per SIMD (80 VGPRs): at 82 the kernel dropped to 5 and lost 8 % (measured A/B on one box).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void search_pu_small_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                               const kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_me_params prm,
                                                               kvz_hip_me_result *__restrict__ out)
 {
