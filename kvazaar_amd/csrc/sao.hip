@@ -131,13 +131,16 @@ template <int MODE>
 __global__ __launch_bounds__(64) void sao_edge_fast_kernel(const u8 *__restrict__ orig, const u8 *__restrict__ rec, int bw, int bh,
                                                           const int *__restrict__ offsets, int *__restrict__ out)
 {
-  __shared__ __attribute__((aligned(16))) u32 s_o[MAX_PX / 4], s_r[MAX_PX / 4];
+  // only rec is staged (its pixels are read nine times); orig is read once per item, straight from memory -- with both
+  // blocks in LDS a CU held 19 of its 32 waves
+  __shared__ __attribute__((aligned(16))) u32 s_r[MAX_PX / 4];
   __shared__ int s_stat[4][2][5];
   const int tid = threadIdx.x, n4 = (bw * bh) >> 2, g4 = bw >> 2;
   const size_t blk = blockIdx.x;
+  const u32 *go = (const u32 *)(orig + blk * (size_t)(bw * bh));
   {
-    const u32 *go = (const u32 *)(orig + blk * (size_t)(bw * bh)), *gr = (const u32 *)(rec + blk * (size_t)(bw * bh));
-    for (int i = tid; i < n4; i += 64) { s_o[i] = go[i]; s_r[i] = gr[i]; }
+    const u32 *gr = (const u32 *)(rec + blk * (size_t)(bw * bh));
+    for (int i = tid; i < n4; i += 64) s_r[i] = gr[i];
   }
   wave_lds_fence();
 
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(64) void sao_edge_fast_kernel(const u8 *__restrict_
       for (int k = 0; k < 4; ++k) win[r][1 + k] = (int)((c >> (8 * k)) & 255u);
       win[r][5] = (int)(rt & 255u);
     }
-    const u32 od = s_o[at];
+    const u32 od = go[at];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const bool valid = !((k == 0 && xg == 0) || (k == 3 && xg == g4 - 1));
