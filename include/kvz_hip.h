@@ -283,7 +283,9 @@ KVZ_HIP_API int kvz_hip_sample_chroma_batch(const kvz_hip_pixel *ref, uint32_t r
 
 /* Fractional motion search of search_frac (search_inter.c:965-1128): for block
  * pair i (x1,y1 in pic; x2,y2 = integer-pel position in ref; w,h multiples of
- * 8 up to 64) the four filter steps (filter_hpel/qpel_blocks_*_luma,
+ * 4 up to 64, not both 4 mod 8 -- for the SMP / AMP shapes the integer position
+ * is scored by satd_any_size and the candidates by satd_any_size_quad, whose
+ * 4x4 stages add nothing, exactly as the reference does) the four filter steps (filter_hpel/qpel_blocks_*_luma,
  * ipol-generic.c:192-658) fused with satd_any_size(_quad); filtered candidates
  * stay in LDS, only costs leave the CU.  costs[17*i + 0] integer position,
  * [1..8] half-pel neighbours, [9..16] quarter-pel neighbours of the best
@@ -307,7 +309,8 @@ typedef struct {
 } kvz_hip_me_merge;
 /* inter_search_info_t (search_inter.c:40-76) of one PU for one reference picture */
 typedef struct {
-  int32_t x, y, width, height;   /* PU inside the picture; width, height multiples of 8 in 8..64 */
+  int32_t x, y, width, height;   /* PU inside the picture; width, height multiples of 4 in 4..64, not both 4 mod 8:
+                                  * every shape of the inter search incl. the SMP / AMP ones (8x4, 4x8, 16x4, 4x16, 16x12, 12x16) */
   int16_t mv_cand[2][2];         /* AMVP candidates (kvz_inter_get_mv_cand), quarter-pel */
   int16_t extra_mv[2];           /* start vector from the co-located CU (search_inter.c:1190-1206), quarter-pel */
   int16_t num_merge_cand;        /* 0..5 */

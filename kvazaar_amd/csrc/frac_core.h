@@ -136,7 +136,15 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
       s_p[y * G::PS + x] = ref_px(ref, d.x2 - 4 + x, d.y2 - 4 + y);
     }
   }
-  {
+  if (w & 4) {                                          // 4, 12: dword segments
+    const int w4 = w >> 2;
+    for (int i = tid; i < w4 * h; i += T) {
+      const int y = i / w4, x = (i - y * w4) * 4;
+      u32 v;
+      __builtin_memcpy(&v, pic + (size_t)(d.y1 + y) * pic_stride + d.x1 + x, 4);
+      *(u32 *)(s_cur + y * G::CS + x) = v;
+    }
+  } else {
     const int w8 = w >> 3;
     for (int i = tid; i < w8 * h; i += T) {
       const int y = i / w8, x = (i - y * w8) * 8;
@@ -183,7 +191,13 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   const int p = tid & 3;
   const short sg1 = (p & 1) ? (short)-1 : (short)1, sg2 = (p & 2) ? (short)-1 : (short)1;
   const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 };
-  const int w8 = w >> 3, n8 = w8 * (h >> 3);
+  // The 8x8 grid of the scores.  For a dimension that is 4 mod 8 the reference's two SATD helpers differ: satd_any_size
+  // (the integer position, strategies-picture.h:62-100) scores the first 4-pixel column / row in 4x4 blocks and puts the
+  // 8x8 grid behind them; satd_any_size_quad (the fractional candidates, picture-generic.c:392-456) only shrinks the
+  // size by 4 -- its 4x4 stages add nothing -- and keeps the grid at the block origin.  Both are reproduced: ox / oy
+  // below is the grid origin of the integer position, the candidates use (0, 0).
+  const int ox = w & 4, oy = h & 4;
+  const int w8 = (w - ox) >> 3, n8 = w8 * ((h - oy) >> 3);
   // lanes that share a candidate form aligned runs of min(4 n8, 64) lanes when n8 is a power of two: their SATDs are
   // added in registers first (many lanes on one LDS address with an atomic serialise)
   const int run = 4 * n8 < 64 ? 4 * n8 : 64;
@@ -201,10 +215,24 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   auto score_integer = [&]() {
     if (tid < 4) s_cost[tid] = 0;
     sync();
+    if (ox | oy) {
+      // 4x4 blocks: the first 4-pixel column over the full height, or the first 4-pixel row (one lane per block)
+      const int nb = ox ? h >> 2 : w >> 2;
+      for (int i = tid; i < nb; i += T) {
+        const int bx4 = ox ? 0 : 4 * i, by4 = ox ? 4 * i : 0;
+        u32 ra[4], rb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          __builtin_memcpy(&ra[r], s_cur + (by4 + r) * G::CS + bx4, 4);
+          __builtin_memcpy(&rb[r], s_p + (4 + by4 + r) * G::PS + 4 + bx4, 4);
+        }
+        atomicAdd(&s_cost[0], satd4x4_regs(ra, rb));
+      }
+    }
     for (int i = tid; i < n8 * 4; i += T) {
       const int sb = i >> 2, by = sb / w8, bx = sb - by * w8;
-      const u8 *a = s_cur + (by * 8 + 2 * p) * G::CS + bx * 8;
-      const u8 *b = s_p + (4 + by * 8 + 2 * p) * G::PS + 4 + bx * 8;
+      const u8 *a = s_cur + (oy + by * 8 + 2 * p) * G::CS + ox + bx * 8;
+      const u8 *b = s_p + (4 + oy + by * 8 + 2 * p) * G::PS + 4 + ox + bx * 8;
       uint4 x, y;
       __builtin_memcpy(&x.x, a, 4); __builtin_memcpy(&x.y, a + 4, 4); __builtin_memcpy(&x.z, a + G::CS, 4); __builtin_memcpy(&x.w, a + G::CS + 4, 4);
       __builtin_memcpy(&y.x, b, 4); __builtin_memcpy(&y.y, b + 4, 4); __builtin_memcpy(&y.z, b + G::PS, 4); __builtin_memcpy(&y.w, b + G::PS + 4, 4);
@@ -405,6 +433,11 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   return res;
 }
 
-__device__ __forceinline__ bool frac_shape_ok(int w, int h) { return !(w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7)); }
+// every PU shape of the inter search: multiples of 4 up to 64 (the AMP / SMP shapes 8x4, 4x8, 16x4, 4x16, 16x12, 12x16
+// have one dimension that is 4 mod 8; never both)
+__device__ __forceinline__ bool frac_shape_ok(int w, int h)
+{
+  return !(w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || ((w & 4) && (h & 4)));
+}
 
 }  // namespace kvzhip

@@ -158,13 +158,22 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   u8 *s_cur = lds + G::P_BYTES;                        // same place search_frac_core keeps the current block
   auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
   const me_cost_model mvc(pu, prm);
-  const int w = FW ? FW : pu.width, h = FH ? FH : pu.height, w8 = w >> 3, segs = w8 * h;   // FW, FH: compile-time size (0 = runtime)
+  const int w = FW ? FW : pu.width, h = FH ? FH : pu.height;                       // FW, FH: compile-time size (0 = runtime)
+  // a row is cut into 8-pixel segments, or 4-pixel ones when the width is 4 or 12 (AMP / SMP shapes)
+  const bool seg4 = !FW && (w & 4);
+  const int segw = seg4 ? 4 : 8, w8 = seg4 ? w >> 2 : w >> 3, segs = w8 * h;       // w8: segments per row
 
   for (int i = tid; i < segs; i += T) {
-    const int y = i / w8, x = (i - y * w8) * 8;
-    uint2 v;
-    __builtin_memcpy(&v, pic + (size_t)(pu.y + y) * pic_stride + pu.x + x, 8);
-    *(uint2 *)(s_cur + y * G::CS + x) = v;
+    const int y = i / w8, x = (i - y * w8) * segw;
+    if (seg4) {
+      u32 v;
+      __builtin_memcpy(&v, pic + (size_t)(pu.y + y) * pic_stride + pu.x + x, 4);
+      *(u32 *)(s_cur + y * G::CS + x) = v;
+    } else {
+      uint2 v;
+      __builtin_memcpy(&v, pic + (size_t)(pu.y + y) * pic_stride + pu.x + x, 8);
+      *(uint2 *)(s_cur + y * G::CS + x) = v;
+    }
   }
 
   int best_x = 0, best_y = 0;                          // info->best_mv, integer-pel here
@@ -185,9 +194,25 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     if (tid < ME_GROUP) sh->sad[tid] = 0;
     sync();
     for (int it = tid; it < n * segs; it += T) {
-      const int k = it / segs, s = it - k * segs, y = s / w8, x = (s - y * w8) * 8;
-      const uint2 c = *(const uint2 *)(s_cur + y * G::CS + x);
-      uint2 r;
+      const int k = it / segs, s = it - k * segs, y = s / w8, x = (s - y * w8) * segw;
+      uint2 c, r;
+      if (seg4) {
+        c.x = *(const u32 *)(s_cur + y * G::CS + x); c.y = 0u; r.y = 0u;
+        if (win_on) {
+          const int col = sh->cx[k] - win_cx + win_R + x, row = sh->cy[k] - win_cy + win_R + y;
+          const u32 *q = (const u32 *)(s_win + row * win_stride + (col & ~3));
+          r.x = __builtin_amdgcn_alignbyte(q[1], q[0], (u32)col & 3u);
+        } else {
+          const int rx = pu.x + sh->cx[k] + x, ry = pu.y + sh->cy[k] + y;
+          if (rx >= 0 && rx + 4 <= ref.w && ry >= 0 && ry < ref.h) {
+            __builtin_memcpy(&r.x, ref.p + (size_t)ry * ref.stride + rx, 4);
+          } else {
+            r.x = (u32)ref_px(ref, rx, ry) | ((u32)ref_px(ref, rx + 1, ry) << 8) | ((u32)ref_px(ref, rx + 2, ry) << 16) |
+                  ((u32)ref_px(ref, rx + 3, ry) << 24);
+          }
+        }
+      } else {
+      c = *(const uint2 *)(s_cur + y * G::CS + x);
       if (win_on) {
         // 8 bytes at a byte-granular column of the window: aligned dwords + v_alignbyte (unaligned wide DS reads replay)
         const int col = sh->cx[k] - win_cx + win_R + x, row = sh->cy[k] - win_cy + win_R + y;
@@ -207,6 +232,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
           r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
           r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
         }
+      }
       }
       u32 v = __builtin_amdgcn_sad_u8(c.y, r.y, __builtin_amdgcn_sad_u8(c.x, r.x, 0u));
       if (seg_pow2) {

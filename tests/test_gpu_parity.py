@@ -389,7 +389,7 @@ def test_search_frac(api):
     ref = g.integers(0, 256, (72, 96), dtype=np.uint8)
     pic = ((ref.astype(np.int32) + np.roll(ref, 1, axis=1)) // 2).astype(np.uint8)
     pairs, meta = [], []
-    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 32)):
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 32), (8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16)):
         for (x, y) in ((0, 0), (32 - w // 2, 24 - h // 4), (96 - w, 72 - h)):
             for (mvx, mvy) in ((0, 0), (-2, 1), (5, -3), (-40, -40), (90, 70)):
                 pairs.append((x, y, x + mvx, y + mvy, w, h))
@@ -592,8 +592,9 @@ def test_search_pu_frame_of_ctus_and_bad_descriptors(api):
     want = O.search_pu_batch(pic, ref, pus[sel], prm)
     for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
         np.testing.assert_array_equal(got[sel][f], want[f], err_msg=f)
-    bad = pus[:4].copy()
-    bad[0]["width"] = 12; bad[1]["x"] = 380; bad[2]["num_merge_cand"] = 9; bad[3]["height"] = 0
+    bad = pus[:5].copy()
+    bad[0]["width"] = 10; bad[1]["x"] = 380; bad[2]["num_merge_cand"] = 9; bad[3]["height"] = 0
+    bad[4]["width"] = 12; bad[4]["height"] = 12          # both dimensions 4 mod 8: no such PU
     r = api.search_pu_batch(pic, ref, bad, prm).view(ME_RESULT).reshape(-1)
     assert (r["cost"] == 0xFFFFFFFF).all() and (r["reserved"] == -1).all()
 
@@ -871,3 +872,26 @@ def test_sample_filters_small_and_odd_blocks(api, kind):
     for b, o in zip(blocks, got):
         x, y, fx, fy, w, h = b
         np.testing.assert_array_equal(o, O.sample(kind, padded, x + pad, y + pad, w, h, fx, fy), err_msg=str(b))
+
+
+AMP_SMP_SHAPES = ((8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16), (8, 8), (16, 16), (32, 8), (24, 32))
+
+
+@pytest.mark.parametrize("cfg", [0, 3, 4, 6, 8, 11, 14])
+def test_search_pu_amp_smp_shapes(api, cfg):
+    """PU shapes with a dimension that is 4 mod 8 (--smp, --amp): dword row segments in the SAD rounds, satd_any_size's
+    4x4 blocks for the integer position, satd_any_size_quad's origin-anchored 8x8 grid (possibly empty) for the candidates"""
+    prm = me_params(**ME_CONFIGS[cfg])
+    for k, motion in enumerate(((3, -2), (-6, 5), (0, 0))):
+        pic, ref = me_frames(192, 128, 950 + k, motion)
+        pus = me_random_pus(192, 128, 64, 31 + 10 * cfg + k, hint=(-4 * motion[0] + 1, -4 * motion[1]), sizes=AMP_SMP_SHAPES)
+        pus["x"] = (pus["x"] // 4) * 4 + 4 * (np.arange(len(pus)) % 2)
+        pus["x"] = np.minimum(pus["x"], 192 - pus["width"])
+        _me_compare(api, pic, ref, pus, prm, "amp/smp cfg %d motion %s" % (cfg, motion))
+    # vectors that leave the frame with a 4-wide block
+    pic, ref = me_frames(192, 128, 33, (18, -15))
+    pus = me_random_pus(192, 128, 40, 8, sizes=((4, 8), (4, 16), (12, 16), (8, 4), (16, 4), (16, 12)))
+    pus["x"] = np.where(np.arange(40) % 2 == 0, 0, 192 - pus["width"])
+    pus["y"] = np.where(np.arange(40) % 3 == 0, 0, 128 - pus["height"])
+    pus["extra_mv"] = np.array([[-130, 90], [150, -120]] * 20, dtype=np.int16)
+    _me_compare(api, pic, ref, pus, prm, "amp/smp borders cfg %d" % cfg)

@@ -235,7 +235,8 @@ def test_search_frac_costs():
     ref = g.integers(0, 256, (72, 96), dtype=np.uint8)
     # pic = ref shifted by a sub-pel-ish blend so that fractional positions matter
     pic = ((ref.astype(np.int32) + np.roll(ref, 1, axis=1)) // 2).astype(np.uint8)
-    for (w, h) in ((8, 8), (16, 16), (32, 32)):
+    # incl. the AMP / SMP shapes, whose candidates satd_any_size_quad scores on an origin-anchored (possibly empty) 8x8 grid
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16)):
         for (x, y) in ((0, 0), (32, 24), (96 - w, 72 - h)):
             for (mvx, mvy) in ((0, 0), (-2, 1), (5, -3), (-40, -40), (90, 70)):
                 o = O.search_frac_costs(pic, ref, x, y, w, h, mvx, mvy)
@@ -335,6 +336,25 @@ def test_search_pu(cfg):
     pus = me_random_pus(192, 128, 12, 5)
     a, b = O.search_pu_batch(flat, flat, pus, prm), R.search_pu_batch(flat, flat, pus, prm)
     np.testing.assert_array_equal(a.view(np.int32), b.view(np.int32))
+
+
+AMP_SMP_SHAPES = ((8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16), (8, 8), (16, 16))
+
+
+@pytest.mark.parametrize("cfg", [0, 3, 4, 6, 8, 11, 14])
+def test_search_pu_amp_smp_shapes(cfg):
+    """PU shapes with a dimension that is 4 mod 8 (--smp at 8x8 CUs, --amp at 16x16): the integer position is scored by
+    satd_any_size (4x4 blocks on the first 4-pixel column / row), the fractional candidates by satd_any_size_quad, whose
+    4x4 stages add nothing -- the oracle must follow the reference through both"""
+    prm = me_params(**ME_CONFIGS[cfg])
+    for k, motion in enumerate(((3, -2), (-6, 5), (0, 0))):
+        pic, ref = me_frames(192, 128, 950 + k, motion)
+        pus = me_random_pus(192, 128, 48, 31 + 10 * cfg + k, hint=(-4 * motion[0] + 1, -4 * motion[1]), sizes=AMP_SMP_SHAPES)
+        pus["x"] = (pus["x"] // 4) * 4 + 4 * (np.arange(len(pus)) % 2)            # 4-aligned origins, as the part offsets give
+        pus["x"] = np.minimum(pus["x"], 192 - pus["width"])
+        a, b = O.search_pu_batch(pic, ref, pus, prm), R.search_pu_batch(pic, ref, pus, prm)
+        for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+            np.testing.assert_array_equal(a[f], b[f], err_msg="%s cfg %d motion %s" % (f, cfg, motion))
 
 
 # ---- SAO group (SURVEY 8(f) row 4) ----

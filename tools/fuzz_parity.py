@@ -43,6 +43,7 @@ def main():
         motion = (int(g.integers(-20, 21)), int(g.integers(-20, 21)))
         pic, ref = me_frames(w, h, int(g.integers(0, 1 << 30)), motion)
         sizes = tuple((bw, bh) for bw in (8, 16, 24, 32, 48, 64) for bh in (8, 16, 24, 32, 48, 64) if bw <= w and bh <= h)
+        sizes += ((8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16)) * 2          # the AMP / SMP shapes
         pus = me_random_pus(w, h, 150, int(g.integers(0, 1 << 30)), hint=(-4 * motion[0] + 2, -4 * motion[1]), sizes=sizes)
         got = api.search_pu_batch(pic, ref, pus, prm).view(ME_RESULT).reshape(-1)
         want = O.search_pu_batch(pic, ref, pus, prm)
