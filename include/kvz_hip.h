@@ -358,7 +358,8 @@ KVZ_HIP_API int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_s
  * kvz_inter_recon_bipred (inter.c:430-477; a 14-bit quarter-pel sample per reference when its vector is fractional,
  * else the edge-clamped pixels << 6, blended and clipped) scored with kvz_satd_any_size against the source block
  * (:1359-1362).  The caller adds the MV bit costs (:1366-1389).  Quarter-pel vectors; both reference planes have
- * ref_w x ref_h pixels; width, height multiples of 8 in 8..64, block inside the picture (else cost 0xFFFFFFFF). */
+ * ref_w x ref_h pixels; width, height multiples of 4 in 4..64 and not both 4 mod 8 (every PU shape), block inside the
+ * picture (else cost 0xFFFFFFFF). */
 typedef struct {
   int32_t x, y, width, height;
   int16_t mv0[2], mv1[2];

@@ -320,15 +320,33 @@ __global__ __launch_bounds__(256) void bipred_cost_kernel(const u8 *__restrict__
   }
   __syncthreads();
   {
-    const int w8 = w >> 3, n8 = w8 * (h >> 3), p = tid & 3;
+    // satd_any_size (strategies-picture.h:62-100): 4x4 blocks on the first 4-pixel column / row of an SMP / AMP shape,
+    // the 8x8 grid behind them
+    const int ox = w & 4, oy = h & 4;
+    const int w8 = (w - ox) >> 3, n8 = w8 * ((h - oy) >> 3), p = tid & 3;
     const short sg1 = (p & 1) ? (short)-1 : (short)1, sg2 = (p & 2) ? (short)-1 : (short)1;
     const v2s m1 = { sg1, sg1 }, m2 = { sg2, sg2 };
     u32 acc = 0;
+    if (ox | oy) {
+      const int nb = ox ? h >> 2 : w >> 2;
+      for (int i = tid; i < nb; i += 256) {
+        const int bx4 = ox ? 0 : 4 * i, by4 = ox ? 4 * i : 0;
+        u32 ra[4], rb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          __builtin_memcpy(&ra[r], s_pred + (by4 + r) * w + bx4, 4);
+          __builtin_memcpy(&rb[r], s_cur + (by4 + r) * w + bx4, 4);
+        }
+        acc += satd4x4_regs(ra, rb);
+      }
+    }
     for (int i = tid; i < n8 * 4; i += 256) {
       const int sb = i >> 2, by = sb / w8, bx = sb - by * w8;
-      const u8 *a = s_pred + (by * 8 + 2 * p) * w + bx * 8, *b = s_cur + (by * 8 + 2 * p) * w + bx * 8;
-      const uint2 a0 = *(const uint2 *)a, a1 = *(const uint2 *)(a + w), b0 = *(const uint2 *)b, b1 = *(const uint2 *)(b + w);
-      u32 m = satd8_quad_part(make_uint4(a0.x, a0.y, a1.x, a1.y), make_uint4(b0.x, b0.y, b1.x, b1.y), m1, m2);
+      const u8 *a = s_pred + (oy + by * 8 + 2 * p) * w + ox + bx * 8, *b = s_cur + (oy + by * 8 + 2 * p) * w + ox + bx * 8;
+      uint4 x, y;                                        // rows are 4-byte aligned (w is a multiple of 4)
+      __builtin_memcpy(&x.x, a, 4); __builtin_memcpy(&x.y, a + 4, 4); __builtin_memcpy(&x.z, a + w, 4); __builtin_memcpy(&x.w, a + w + 4, 4);
+      __builtin_memcpy(&y.x, b, 4); __builtin_memcpy(&y.y, b + 4, 4); __builtin_memcpy(&y.z, b + w, 4); __builtin_memcpy(&y.w, b + w + 4, 4);
+      u32 m = satd8_quad_part(x, y, m1, m2);
       m = group_sum<4>(m);
       if (p == 0) acc += (m + 2) >> 2;
     }

@@ -669,10 +669,10 @@ def test_bipred_candidate_cost(api):
     _, ref1 = me_frames(192, 128, 13, (-3, 2))
     ref1 = np.where(g.integers(0, 40, ref1.shape) == 0, 255, ref1).astype(np.uint8)
     cands = []
-    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (32, 64), (24, 8)):
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (32, 64), (24, 8), (8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16)):
         for k in range(14):
-            x = int(g.integers(0, 3)) * 64 + int(g.integers(0, (64 - w) // 8 + 1)) * 8
-            y = int(g.integers(0, 2)) * 64 + int(g.integers(0, (64 - h) // 8 + 1)) * 8
+            x = int(g.integers(0, 3)) * 64 + int(g.integers(0, (64 - w) // 4 + 1)) * 4
+            y = int(g.integers(0, 2)) * 64 + int(g.integers(0, (64 - h) // 4 + 1)) * 4
             big = 400 if k % 5 == 4 else 24
             mv0, mv1 = g.integers(-big, big + 1, 2), g.integers(-big, big + 1, 2)
             if k % 3 == 0:
@@ -683,7 +683,7 @@ def test_bipred_candidate_cost(api):
     got = api.bipred_cost_batch(pic, ref0, ref1, cands)
     for c, v in zip(cands, got):
         assert v == O.bipred_luma_satd(pic, ref0, ref1, c[0], c[1], c[2], c[3], c[4:6], c[6:8])[0], c
-    bad = api.bipred_cost_batch(pic, ref0, ref1, [(0, 0, 12, 8, 0, 0, 0, 0), (190, 0, 8, 8, 0, 0, 0, 0)])
+    bad = api.bipred_cost_batch(pic, ref0, ref1, [(0, 0, 10, 8, 0, 0, 0, 0), (190, 0, 8, 8, 0, 0, 0, 0), (0, 0, 12, 12, 0, 0, 0, 0)])
     assert (bad == 0xFFFFFFFF).all()
 
 
