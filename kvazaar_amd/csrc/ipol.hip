@@ -456,7 +456,7 @@ namespace kvzhip {
 int launch_frac_step(const u8 *win, int w, int h, int step, int fme_level, int hx, int hy,
                      u8 *filtered, i16 *hor_out, i16 *cols_out, hipStream_t st)
 {
-  if (w < 8 || h < 8 || w > 64 || h > 64 || ((w | h) & 7) || step < 0 || step > 3) return kvzhip::invalid_arg(__func__);
+  if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || step < 0 || step > 3) return kvzhip::invalid_arg(__func__);   // any PU shape incl. SMP / AMP
   hipLaunchKernelGGL(frac_step_kernel, dim3(1), dim3(256), 0, st, win, w, h, step, fme_level, hx, hy, filtered, hor_out, cols_out);
   KVZ_CHECK_LAUNCH("frac_step_kernel");
   return KVZ_HIP_OK;

@@ -170,7 +170,7 @@ def test_frac_filter_steps_write_the_callers_scratch_like_generic(hip, pattern):
     frame = g.integers(0, 256, (96, 96), dtype=np.uint8)
     if pattern == "extreme":
         frame = np.where(g.integers(0, 2, (96, 96)) > 0, 255, 0).astype(np.uint8)
-    for (w, h) in ((8, 8), (16, 16), (64, 64), (16, 8)):
+    for (w, h) in ((8, 8), (16, 16), (64, 64), (16, 8), (8, 4), (4, 8), (16, 12), (12, 16)):       # incl. SMP / AMP shapes
         for off in ((0, 0), (-1, 1), (1, -1), (1, 1), (-1, -1), (0, 1)):
             hipr = R.filter_frac_steps(frame, 10, 9, w, h, off, 4, "hip")
             gen = R.filter_frac_steps(frame, 10, 9, w, h, off, 4, "generic")
