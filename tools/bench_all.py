@@ -141,6 +141,12 @@ def main():
                           picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), k,
                           cls_prm.ctypes.data, res_d.data_ptr(), st)))
         if n == 16:
+            for alg_name, alg in (("dia", 1), ("tz", 2)):                      # --me dia / --me tz
+                alg_prm = cls_prm.copy(); alg_prm[8] = alg
+                cases.append(("search_pu_16x16_%s" % alg_name, len(rows), 2 * n * n + 96,
+                              lambda pus_d=pus_d, res_d=res_d, k=len(rows), alg_prm=alg_prm: L.kvz_hip_search_pu_batch(
+                                  picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), k,
+                                  alg_prm.ctypes.data, res_d.data_ptr(), st)))
             full_prm = me_prm.copy(); full_prm[8] = 3; full_prm[9] = 16        # --me full16: 1089 positions per PU
             kk = len(rows) // 8
             cases.append(("search_pu_16x16_full16", kk, 2 * n * n + 96,
