@@ -62,6 +62,10 @@ KVZ_HIP_API void kvz_hip_shutdown(void);
 KVZ_HIP_API int kvz_hip_device_count(void);
 KVZ_HIP_API const char *kvz_hip_last_error(void);    /* text of the calling thread's last failure */
 KVZ_HIP_API const char *kvz_hip_device_name(void);
+/* Version of this header's ABI as the library was built (layouts of the kvz_hip_* structs, entry signatures); a host
+ * compares it with the KVZ_HIP_ABI_VERSION it was compiled against before it registers the strategies. */
+#define KVZ_HIP_ABI_VERSION 1
+KVZ_HIP_API int kvz_hip_abi_version(void);
 
 /* Launch-geometry / kernel-selection knobs for A/B runs (tools/bench_all.py --tune key=v1,v2);
  * value < 0 restores the built-in default.  Keys: "{sad,satd8,dct,dct16,idct16,dct32,idct32,qr,qr16,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "kvz_hip_device_count": (_I, []),
     "kvz_hip_last_error": (C.c_char_p, []),
     "kvz_hip_device_name": (C.c_char_p, []),
+    "kvz_hip_abi_version": (_I, []),
     "kvz_hip_set_tuning": (_I, [C.c_char_p, _I]),
     "kvz_hip_malloc": (_P, [_SZ]),
     "kvz_hip_free": (None, [_P]),

@@ -128,6 +128,7 @@ void kvz_hip_shutdown(void)
 
 const char *kvz_hip_last_error(void) { return g_err; }
 const char *kvz_hip_device_name(void) { return g_name; }
+int kvz_hip_abi_version(void) { return KVZ_HIP_ABI_VERSION; }
 
 void *kvz_hip_malloc(size_t bytes)
 {

@@ -14,6 +14,7 @@
 
 int main(void)
 {
+  CHECK(kvz_hip_abi_version() == KVZ_HIP_ABI_VERSION, "library ABI %d, header %d", kvz_hip_abi_version(), KVZ_HIP_ABI_VERSION);
   CHECK(kvz_hip_init(-1) == KVZ_HIP_OK, "kvz_hip_init");
   printf("device: %s\n", kvz_hip_device_name());
   kvz_hip_stream st = kvz_hip_stream_create();
