@@ -193,35 +193,48 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   auto group_sads = [&](int n) {
     if (tid < ME_GROUP) sh->sad[tid] = 0;
     sync();
+    if (win_on) {
+      // Exhaustive search, window in LDS: ONE LANE PER POSITION walks the block's row segments (the current block's
+      // segment is the same address for every lane: an LDS broadcast), so a position's SAD never leaves its lane -- no
+      // per-item index arithmetic, no cross-lane reduction, no atomics for a one-wave PU.  Wider workgroups split the
+      // segments between their waves.
+      const int k = tid & (ME_GROUP - 1), part = tid / ME_GROUP, nparts = T / ME_GROUP;
+      if (k < n) {
+        const int col0 = sh->cx[k] - win_cx + win_R, row0 = sh->cy[k] - win_cy + win_R;
+        u32 acc = 0;
+        for (int s = part; s < segs; s += nparts) {
+          const int y = s / w8, x = (s - y * w8) * segw;
+          const int col = col0 + x;
+          const u32 *q = (const u32 *)(s_win + (row0 + y) * win_stride + (col & ~3));
+          const u32 sh8 = (u32)col & 3u;
+          if (seg4) {
+            acc = __builtin_amdgcn_sad_u8(*(const u32 *)(s_cur + y * G::CS + x), __builtin_amdgcn_alignbyte(q[1], q[0], sh8), acc);
+          } else {
+            const uint2 c = *(const uint2 *)(s_cur + y * G::CS + x);
+            const u32 d0 = q[0], d1 = q[1], d2 = q[2];
+            acc = __builtin_amdgcn_sad_u8(c.x, __builtin_amdgcn_alignbyte(d1, d0, sh8), acc);
+            acc = __builtin_amdgcn_sad_u8(c.y, __builtin_amdgcn_alignbyte(d2, d1, sh8), acc);
+          }
+        }
+        if (nparts == 1) sh->sad[k] = acc; else atomicAdd(&sh->sad[k], acc);
+      }
+      sync();
+      return;
+    }
     for (int it = tid; it < n * segs; it += T) {
       const int k = it / segs, s = it - k * segs, y = s / w8, x = (s - y * w8) * segw;
       uint2 c, r;
       if (seg4) {
         c.x = *(const u32 *)(s_cur + y * G::CS + x); c.y = 0u; r.y = 0u;
-        if (win_on) {
-          const int col = sh->cx[k] - win_cx + win_R + x, row = sh->cy[k] - win_cy + win_R + y;
-          const u32 *q = (const u32 *)(s_win + row * win_stride + (col & ~3));
-          r.x = __builtin_amdgcn_alignbyte(q[1], q[0], (u32)col & 3u);
+        const int rx = pu.x + sh->cx[k] + x, ry = pu.y + sh->cy[k] + y;
+        if (rx >= 0 && rx + 4 <= ref.w && ry >= 0 && ry < ref.h) {
+          __builtin_memcpy(&r.x, ref.p + (size_t)ry * ref.stride + rx, 4);
         } else {
-          const int rx = pu.x + sh->cx[k] + x, ry = pu.y + sh->cy[k] + y;
-          if (rx >= 0 && rx + 4 <= ref.w && ry >= 0 && ry < ref.h) {
-            __builtin_memcpy(&r.x, ref.p + (size_t)ry * ref.stride + rx, 4);
-          } else {
-            r.x = (u32)ref_px(ref, rx, ry) | ((u32)ref_px(ref, rx + 1, ry) << 8) | ((u32)ref_px(ref, rx + 2, ry) << 16) |
-                  ((u32)ref_px(ref, rx + 3, ry) << 24);
-          }
+          r.x = (u32)ref_px(ref, rx, ry) | ((u32)ref_px(ref, rx + 1, ry) << 8) | ((u32)ref_px(ref, rx + 2, ry) << 16) |
+                ((u32)ref_px(ref, rx + 3, ry) << 24);
         }
       } else {
-      c = *(const uint2 *)(s_cur + y * G::CS + x);
-      if (win_on) {
-        // 8 bytes at a byte-granular column of the window: aligned dwords + v_alignbyte (unaligned wide DS reads replay)
-        const int col = sh->cx[k] - win_cx + win_R + x, row = sh->cy[k] - win_cy + win_R + y;
-        const u32 *q = (const u32 *)(s_win + row * win_stride + (col & ~3));
-        const u32 sh8 = (u32)col & 3u;
-        const u32 d0 = q[0], d1 = q[1], d2 = q[2];
-        r.x = __builtin_amdgcn_alignbyte(d1, d0, sh8);
-        r.y = __builtin_amdgcn_alignbyte(d2, d1, sh8);
-      } else {
+        c = *(const uint2 *)(s_cur + y * G::CS + x);
         const int rx = pu.x + sh->cx[k] + x, ry = pu.y + sh->cy[k] + y;
         if (rx >= 0 && rx + 8 <= ref.w && ry >= 0 && ry < ref.h) {
           __builtin_memcpy(&r, ref.p + (size_t)ry * ref.stride + rx, 8);
@@ -233,11 +246,10 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
           r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
         }
       }
-      }
       u32 v = __builtin_amdgcn_sad_u8(c.y, r.y, __builtin_amdgcn_sad_u8(c.x, r.x, 0u));
       if (seg_pow2) {
         // the lanes that share a candidate are an aligned run of min(segs, 64): add them up in registers first --
-        // 32 lanes hitting one LDS address with an atomic serialise (this was the cost of the exhaustive search)
+        // 32 lanes hitting one LDS address with an atomic serialise
         v = run == 8 ? group_sum<8>(v) : run == 16 ? group_sum<16>(v) : run == 32 ? group_sum<32>(v) : group_sum<64>(v);   // DPP up to 16 lanes
         if (((tid & 63) & (run - 1)) == 0) atomicAdd(&sh->sad[k], v);
       } else {
