@@ -87,3 +87,95 @@ def test_dct_32x32_full_batch(env):
     x = res[idx].cpu().numpy()
     np.testing.assert_array_equal(coef[idx].cpu().numpy(), O.transform_batch("dct", 32, x))
     np.testing.assert_array_equal(back[idx].cpu().numpy(), O.transform_batch("idct", 32, coef[idx].cpu().numpy()))
+
+
+@pytest.mark.parametrize("width", [4, 8, 16, 32])
+def test_quantize_residual_frame_is_consistent_with_the_separate_entries(env, width):
+    """every TU of 8 1080p frames through the fused entry; the same result must come out of the chain of separate entries
+    (residual -> dct -> quant -> dequant -> idct -> reconstruct), TUs without coefficients must keep their prediction, and a
+    strided sample must equal the oracle"""
+    torch, _lib, L, dev, g = env
+    from kvazaar_amd._lib import QuantParams
+    n = (1920 // width) * (1080 // width) * 8
+    px = n * width * width
+    ref = torch.randint(0, 256, (px,), dtype=torch.uint8, device=dev, generator=g)
+    noise = torch.randint(-20, 21, (px,), dtype=torch.int16, device=dev, generator=g)
+    noise.view(n, -1)[::3] //= 8                              # a third of the TUs almost predicted: many all-zero TUs
+    pred = (ref.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+    qp = QuantParams(); qp.qp = 32
+    rec = torch.empty_like(ref); coef = torch.empty(px, dtype=torch.int16, device=dev); has = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(L.kvz_hip_quantize_residual_batch(C.byref(qp), 0, width, 0, 0, 0, ref.data_ptr(), pred.data_ptr(), rec.data_ptr(),
+                                                 coef.data_ptr(), has.data_ptr(), n, None), "quantize_residual")
+    res = torch.empty(px, dtype=torch.int16, device=dev); t1 = torch.empty_like(res); q = torch.empty_like(res)
+    dq = torch.empty_like(res); back = torch.empty_like(res); rec2 = torch.empty_like(ref)
+    _lib.check(L.kvz_hip_residual_batch(ref.data_ptr(), pred.data_ptr(), res.data_ptr(), px, None), "residual")
+    _lib.check(L.kvz_hip_transform_batch(0, width, res.data_ptr(), t1.data_ptr(), n, None), "dct")
+    _lib.check(L.kvz_hip_quant_batch(C.byref(qp), t1.data_ptr(), q.data_ptr(), width, 0, 0, n, None), "quant")
+    _lib.check(L.kvz_hip_dequant_batch(C.byref(qp), q.data_ptr(), dq.data_ptr(), width, 0, n, None), "dequant")
+    _lib.check(L.kvz_hip_transform_batch(1, width, dq.data_ptr(), back.data_ptr(), n, None), "idct")
+    _lib.check(L.kvz_hip_reconstruct_batch(back.data_ptr(), pred.data_ptr(), rec2.data_ptr(), px, None), "reconstruct")
+    _lib.check(L.kvz_hip_stream_sync(None), "sync")
+    assert bool((coef == q).all())
+    nz = q.view(n, -1).ne(0).any(dim=1)
+    assert bool((has.ne(0) == nz).all()) and 0 < int(nz.sum()) < n
+    # with coefficients: the chain's reconstruction; without: the prediction (quant-generic.c:262-271)
+    want = torch.where(nz[:, None], rec2.view(n, -1), pred.view(n, -1))
+    assert bool((rec.view(n, -1) == want).all())
+    idx = list(range(0, n, max(1, n // 60))) + [n - 1]
+    w2 = width * width
+    sel = torch.tensor(idx, device=dev)
+    r, c, h = O.quantize_residual_batch(ref.view(n, w2)[sel].cpu().numpy(), pred.view(n, w2)[sel].cpu().numpy(), width, 32, 0, 0, 0)
+    np.testing.assert_array_equal(rec.view(n, w2)[sel].cpu().numpy(), r)
+    np.testing.assert_array_equal(coef.view(n, w2)[sel].cpu().numpy(), c)
+    np.testing.assert_array_equal(has[sel].cpu().numpy() != 0, h != 0)
+
+
+def test_sample_luma_integer_position_is_the_identity_over_a_frame(env):
+    """fractional offset (0, 0) runs both filter passes with the taps {0,0,0,64,...}: every 8x8 and 16x16 block of a 1080p
+    frame -- incl. windows clamped at the frame border -- must come back unchanged, 8-bit and (<< 6) 14-bit"""
+    torch, _lib, L, dev, g = env
+    W, H = 1920, 1080
+    frame = torch.randint(0, 256, (H, W), dtype=torch.uint8, device=dev, generator=g)
+    for n in (8, 16):
+        blocks = np.array([(x, y, 0, 0, n, n) for y in range(0, H - n + 1, n) for x in range(0, W, n)], dtype=np.int32)
+        bd = torch.from_numpy(blocks).to(dev)
+        offs = torch.arange(len(blocks), dtype=torch.int64, device=dev) * (n * n)
+        out8 = torch.empty(len(blocks) * n * n, dtype=torch.uint8, device=dev)
+        out14 = torch.empty(len(blocks) * n * n, dtype=torch.int16, device=dev)
+        _lib.check(L.kvz_hip_sample_luma_batch(frame.data_ptr(), W, W, H, bd.data_ptr(), offs.data_ptr(), len(blocks), 0, out8.data_ptr(), None), "sample")
+        _lib.check(L.kvz_hip_sample_luma_batch(frame.data_ptr(), W, W, H, bd.data_ptr(), offs.data_ptr(), len(blocks), 1, out14.data_ptr(), None), "sample14")
+        _lib.check(L.kvz_hip_stream_sync(None), "sync")
+        rows = (H // n) * n
+        want = frame[:rows].view(rows // n, n, W // n, n).permute(0, 2, 1, 3).reshape(-1)
+        assert bool((out8 == want).all())
+        assert bool((out14 == want.to(torch.int16) * 64).all())
+
+
+def test_search_pu_results_do_not_depend_on_the_batch(env):
+    """every 16x16 PU of a 1080p frame in one launch, and the same PUs in three launches of shuffled thirds: a PU's result
+    depends on nothing but its descriptor"""
+    torch, _lib, L, dev, g = env
+    from patterns import me_frames, me_params
+    W, H = 1920, 1080
+    pic_np, ref_np = me_frames(W, H, 99, (3, -2))
+    pic, ref = torch.from_numpy(pic_np).to(dev), torch.from_numpy(ref_np).to(dev)
+    xy = [(x, y) for y in range(0, H - 15, 16) for x in range(0, W, 16)]
+    pus = np.zeros((len(xy), 16), dtype=np.int32)
+    pus[:, 0] = [p[0] for p in xy]; pus[:, 1] = [p[1] for p in xy]; pus[:, 2] = 16; pus[:, 3] = 16
+    prm = me_params()
+    pd = torch.from_numpy(pus).to(dev)
+    whole = torch.empty((len(xy), 8), dtype=torch.int32, device=dev)
+    _lib.check(L.kvz_hip_search_pu_batch(pic.data_ptr(), W, W, H, ref.data_ptr(), W, W, H, pd.data_ptr(), len(xy), prm.ctypes.data,
+                                         whole.data_ptr(), None), "search_pu")
+    perm = torch.randperm(len(xy), device=dev, generator=g)
+    parts = torch.empty_like(whole)
+    for part in perm.chunk(3):
+        sub = pd[part].contiguous()
+        out = torch.empty((len(part), 8), dtype=torch.int32, device=dev)
+        _lib.check(L.kvz_hip_search_pu_batch(pic.data_ptr(), W, W, H, ref.data_ptr(), W, W, H, sub.data_ptr(), len(part), prm.ctypes.data,
+                                             out.data_ptr(), None), "search_pu part")
+        _lib.check(L.kvz_hip_stream_sync(None), "sync")
+        parts[part] = out
+    _lib.check(L.kvz_hip_stream_sync(None), "sync")
+    assert bool((whole == parts).all())
+    assert int((whole[:, 2] != -1).sum()) == len(xy)          # every PU was searched (cost field set)
