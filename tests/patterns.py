@@ -300,7 +300,7 @@ def deblock_case(w, h, seed, intra_share=0.35, slice_is_b=0, qp=34):
 
     def plane(pw, ph, cell):
         yy, xx = np.mgrid[0:ph, 0:pw]
-        base = 90 + 0.3 * xx + 0.2 * yy
+        base = 90 + (0.3 * xx + 0.2 * yy) % 100            # a ramp that wraps, so that large frames do not saturate at 255
         steps = g.integers(-7, 8, (ph // cell + 1, pw // cell + 1))
         img = base + steps[yy // cell, xx // cell] + g.integers(-1, 2, (ph, pw))
         rough = g.random((ph // cell + 1, pw // cell + 1)) < 0.15               # some busy cells: the filter must stay off there

@@ -179,3 +179,37 @@ def test_search_pu_results_do_not_depend_on_the_batch(env):
     _lib.check(L.kvz_hip_stream_sync(None), "sync")
     assert bool((whole == parts).all())
     assert int((whole[:, 2] != -1).sum()) == len(xy)          # every PU was searched (cost field set)
+
+
+def test_sao_edge_statistics_add_up_over_a_frame(env):
+    """every 64x64 luma LCU of a 1080p frame: per class the five category counts add up to the interior pixel count and
+    the five sums to the interior's sum of (orig - rec), both computed independently with torch; a sample equals the oracle"""
+    torch, _lib, L, dev, g = env
+    n = 30 * 16
+    orig = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev, generator=g)
+    rec = (orig.to(torch.int16) + torch.randint(-6, 7, orig.shape, dtype=torch.int16, device=dev, generator=g)).clamp_(0, 255).to(torch.uint8)
+    stats = torch.empty((n, 4, 2, 5), dtype=torch.int32, device=dev)
+    _lib.check(L.kvz_hip_sao_edge_stats_batch(orig.data_ptr(), rec.data_ptr(), 64, 64, n, stats.data_ptr(), None), "sao_edge_stats")
+    _lib.check(L.kvz_hip_stream_sync(None), "sync")
+    diff = (orig.to(torch.int32) - rec.to(torch.int32))[:, 1:-1, 1:-1].sum(dim=(1, 2))
+    assert bool((stats[:, :, 1, :].sum(dim=2) == 62 * 62).all())
+    assert bool((stats[:, :, 0, :].sum(dim=2) == diff[:, None]).all())
+    for i in (0, 7, n - 1):
+        for eo in range(4):
+            np.testing.assert_array_equal(stats[i, eo].cpu().numpy(),
+                                          O.calc_sao_edge_dir(orig[i].cpu().numpy().ravel(), rec[i].cpu().numpy().ravel(), eo, 64, 64))
+
+
+@pytest.mark.parametrize("slice_is_b", [0, 1])
+def test_deblock_a_1080p_frame(env, slice_is_b):
+    """a whole 1920 x 1088 4:2:0 frame with a random CU / PU / TU quadtree against the oracle"""
+    torch, _lib, L, dev, g = env
+    from kvazaar_amd import api
+    from patterns import deblock_case, deblock_params
+    prm = deblock_params(qp=35, per_cu_qp=1, slice_is_b=slice_is_b, beta=1, tc=-1)
+    y, u, v, cus = deblock_case(1920, 1088, 2024 + slice_is_b, slice_is_b=slice_is_b, qp=35)
+    want = O.deblock_frame(y, u, v, cus, prm)
+    got = api.deblock_frame(y, u, v, cus, prm)
+    for a, b, name in zip(got, want, "yuv"):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    assert int((want[0] != y).sum()) > 100000
