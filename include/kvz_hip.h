@@ -42,7 +42,10 @@ extern "C" {
 
 typedef uint8_t kvz_hip_pixel;
 typedef int16_t kvz_hip_coeff;
-typedef void *kvz_hip_stream;        /* hipStream_t; NULL = the library's default stream */
+typedef void *kvz_hip_stream;        /* hipStream_t; NULL = the library's default stream.  That stream is created non-blocking:
+                                      * it does not wait for work queued on any other stream (a framework's, the legacy
+                                      * default stream).  Inputs produced elsewhere must be complete before an entry is called,
+                                      * or the entry is given the producer's own hipStream_t (any HIP stream is accepted). */
 
 enum {
   KVZ_HIP_OK = 0,

@@ -33,6 +33,7 @@ def test_sad_satd_8x8_full_batch(env):
     ref = (cur.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
     del noise
     out = [torch.empty(N8, dtype=torch.int32, device=dev) for _ in range(4)]
+    torch.cuda.synchronize()                                  # the library's stream does not wait for torch's: inputs must be complete
     _lib.check(L.kvz_hip_sad_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), N8, out[0].data_ptr(), None), "sad")
     _lib.check(L.kvz_hip_sad_nxn_batch(8, ref.data_ptr(), cur.data_ptr(), N8, out[1].data_ptr(), None), "sad swapped")
     _lib.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), N8, out[2].data_ptr(), None), "satd")
@@ -70,6 +71,7 @@ def test_dct_32x32_full_batch(env):
     res[1::7] = res[1::7, :1].expand(-1, 1024)                # flat blocks: only the DC coefficient, 128 * value
     coef = torch.empty_like(res)
     back = torch.empty_like(res)
+    torch.cuda.synchronize()                                  # the library's stream does not wait for torch's: inputs must be complete
     _lib.check(L.kvz_hip_transform_batch(0, 32, res.data_ptr(), coef.data_ptr(), N32, None), "dct")
     _lib.check(L.kvz_hip_transform_batch(1, 32, coef.data_ptr(), back.data_ptr(), N32, None), "idct")
     _lib.check(L.kvz_hip_stream_sync(None), "sync")
@@ -104,6 +106,7 @@ def test_quantize_residual_frame_is_consistent_with_the_separate_entries(env, wi
     pred = (ref.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
     qp = QuantParams(); qp.qp = 32
     rec = torch.empty_like(ref); coef = torch.empty(px, dtype=torch.int16, device=dev); has = torch.empty(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()                                  # the library's stream does not wait for torch's: inputs must be complete
     _lib.check(L.kvz_hip_quantize_residual_batch(C.byref(qp), 0, width, 0, 0, 0, ref.data_ptr(), pred.data_ptr(), rec.data_ptr(),
                                                  coef.data_ptr(), has.data_ptr(), n, None), "quantize_residual")
     res = torch.empty(px, dtype=torch.int16, device=dev); t1 = torch.empty_like(res); q = torch.empty_like(res)
@@ -142,6 +145,7 @@ def test_sample_luma_integer_position_is_the_identity_over_a_frame(env):
         offs = torch.arange(len(blocks), dtype=torch.int64, device=dev) * (n * n)
         out8 = torch.empty(len(blocks) * n * n, dtype=torch.uint8, device=dev)
         out14 = torch.empty(len(blocks) * n * n, dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()                              # the library's stream does not wait for torch's: inputs must be complete
         _lib.check(L.kvz_hip_sample_luma_batch(frame.data_ptr(), W, W, H, bd.data_ptr(), offs.data_ptr(), len(blocks), 0, out8.data_ptr(), None), "sample")
         _lib.check(L.kvz_hip_sample_luma_batch(frame.data_ptr(), W, W, H, bd.data_ptr(), offs.data_ptr(), len(blocks), 1, out14.data_ptr(), None), "sample14")
         _lib.check(L.kvz_hip_stream_sync(None), "sync")
@@ -165,6 +169,7 @@ def test_search_pu_results_do_not_depend_on_the_batch(env):
     prm = me_params()
     pd = torch.from_numpy(pus).to(dev)
     whole = torch.empty((len(xy), 8), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()                                  # the library's stream does not wait for torch's: inputs must be complete
     _lib.check(L.kvz_hip_search_pu_batch(pic.data_ptr(), W, W, H, ref.data_ptr(), W, W, H, pd.data_ptr(), len(xy), prm.ctypes.data,
                                          whole.data_ptr(), None), "search_pu")
     perm = torch.randperm(len(xy), device=dev, generator=g)
@@ -172,6 +177,7 @@ def test_search_pu_results_do_not_depend_on_the_batch(env):
     for part in perm.chunk(3):
         sub = pd[part].contiguous()
         out = torch.empty((len(part), 8), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
         _lib.check(L.kvz_hip_search_pu_batch(pic.data_ptr(), W, W, H, ref.data_ptr(), W, W, H, sub.data_ptr(), len(part), prm.ctypes.data,
                                              out.data_ptr(), None), "search_pu part")
         _lib.check(L.kvz_hip_stream_sync(None), "sync")
@@ -189,6 +195,7 @@ def test_sao_edge_statistics_add_up_over_a_frame(env):
     orig = torch.randint(0, 256, (n, 64, 64), dtype=torch.uint8, device=dev, generator=g)
     rec = (orig.to(torch.int16) + torch.randint(-6, 7, orig.shape, dtype=torch.int16, device=dev, generator=g)).clamp_(0, 255).to(torch.uint8)
     stats = torch.empty((n, 4, 2, 5), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()                                  # the library's stream does not wait for torch's: inputs must be complete
     _lib.check(L.kvz_hip_sao_edge_stats_batch(orig.data_ptr(), rec.data_ptr(), 64, 64, n, stats.data_ptr(), None), "sao_edge_stats")
     _lib.check(L.kvz_hip_stream_sync(None), "sync")
     diff = (orig.to(torch.int32) - rec.to(torch.int32))[:, 1:-1, 1:-1].sum(dim=(1, 2))
@@ -209,6 +216,7 @@ def test_deblock_a_1080p_frame(env, slice_is_b):
     prm = deblock_params(qp=35, per_cu_qp=1, slice_is_b=slice_is_b, beta=1, tc=-1)
     y, u, v, cus = deblock_case(1920, 1088, 2024 + slice_is_b, slice_is_b=slice_is_b, qp=35)
     want = O.deblock_frame(y, u, v, cus, prm)
+    torch.cuda.synchronize()                                  # the library's stream does not wait for torch's: inputs must be complete
     got = api.deblock_frame(y, u, v, cus, prm)
     for a, b, name in zip(got, want, "yuv"):
         np.testing.assert_array_equal(a, b, err_msg=name)
