@@ -192,6 +192,7 @@ def main():
     if args.tune:
         tune_key, vals = args.tune.split("=")
         tune_vals = [int(v) for v in vals.split(",")]
+    torch.cuda.synchronize()         # the operands above were written on torch's stream; the library's stream does not wait for it
     print("%-26s %10s %12s %10s %8s" % ("kernel", "tune", "Mblocks/s", "GB/s", "ms"))
     for name, blocks, bpb, fn in cases:
         if args.only and args.only not in name:

@@ -13,6 +13,7 @@ for n in (8, 16):
     pus = np.zeros((len(rows), 16), dtype=np.int32)
     pus[:, 0] = [r[0] for r in rows]; pus[:, 1] = [r[1] for r in rows]; pus[:, 2] = n; pus[:, 3] = n
     pus_d = torch.from_numpy(pus).to(dev); res_d = torch.empty((len(rows), 8), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     for label, prm in (("default", (20, 1, -1, 4, 0, 0, 1, 1, 0, 0, 1, 0)), ("fme0", (20, 1, -1, 0, 0, 0, 1, 1, 0, 0, 1, 0)),
                        ("no early term", (20, 0, -1, 4, 0, 0, 1, 1, 0, 0, 1, 0)), ("fme0 + no ET", (20, 0, -1, 0, 0, 0, 1, 1, 0, 0, 1, 0)),
                        ("max_steps 0, fme0, no ET", (20, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 0)), ("dia", (20, 1, -1, 4, 0, 0, 1, 1, 1, 0, 1, 0)),
