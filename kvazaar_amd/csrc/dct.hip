@@ -71,7 +71,9 @@ template <int N, int KIND>
 static int launch_transform(const i16 *in, i16 *out, size_t count, hipStream_t st)
 {
   constexpr int TPB = 256 / N;
-  const unsigned grid = stream_grid(count, TPB, (unsigned)tuning("dct_wgs_per_cu", 16));
+  // workgroups per CU of the grid-stride launch, measured per size (0.5 GiB arrays): 4x4 is best at <= 48 (5.8 TB/s, 5.2 at 96),
+  // 8x8 keeps gaining up to ~192 (6.5 TB/s against 5.8 at 16), the 16x16 inverse peaks around 48
+  const unsigned grid = stream_grid(count, TPB, (unsigned)tuning("dct_wgs_per_cu", N == 8 ? 160 : N == 16 ? 48 : 16));
   hipLaunchKernelGGL((transform_kernel<N, KIND>), dim3(grid), dim3(256), 0, st, in, out, count);
   KVZ_CHECK_LAUNCH("transform_kernel");
   return KVZ_HIP_OK;

@@ -87,10 +87,11 @@ int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipSt
 {
   // 4 waves per workgroup, each wave strides over blocks; enough workgroups for ~4 waves per SIMD
   size_t wgs = (count + 3) / 4;
-  // Workgroups per CU, measured on three boxes of the pool (they differ: on one, 2 per CU ran the forward transform at 5.28 TB/s
-  // and 8 at 5.87; on another 2 gave 5.73 and 8 gave 5.60).  4 (forward: 5.64 / 5.80 / 5.81 TB/s) and 8 (inverse) are
-  // within 4 % of the best on each of them.
-  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 8) : tuning("dct32_wgs_per_cu", 4));
+  // Workgroups per CU.  Few persistent workgroups (2 .. 12 per CU, long grid-stride loops) gave 5.3 - 5.9 TB/s depending on the
+  // box and on how the count divided over them; many short-lived ones -- two to three blocks per wave, handed out by the
+  // dispatcher as waves retire -- are faster and steadier: forward 4: 5.81, 32: 5.94, 64: 6.24, 96: 6.35, 128: 6.33, 160: 6.00 TB/s;
+  // inverse 8: 5.53, 32: 5.84, 64: 5.69, 128: 5.48 (0.5 GiB arrays, tools/bench_all.py --tune).
+  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 32) : tuning("dct32_wgs_per_cu", 96));
   if (wgs > cap) wgs = cap;
   if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   else hipLaunchKernelGGL((dct32_mfma_kernel<false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);

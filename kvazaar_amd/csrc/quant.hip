@@ -549,7 +549,7 @@ int kvz_hip_quant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *coef
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   const size_t total = count * (size_t)(width * width);
-  hipLaunchKernelGGL(quant_kernel, dim3(stream_grid(total, 2048)), dim3(256), 0, st, coef, q_coef, total, width * width, k);
+  hipLaunchKernelGGL(quant_kernel, dim3(stream_grid(total, 2048, (unsigned)tuning("quant_wgs_per_cu", 256))), dim3(256), 0, st, coef, q_coef, total, width * width, k);
   KVZ_CHECK_LAUNCH("quant_kernel");
   if (k.signhide) {
     hipLaunchKernelGGL(sign_hide_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, coef, q_coef, count, width, scan_idx, k);
@@ -567,7 +567,7 @@ int kvz_hip_dequant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *q_
   if ((((uintptr_t)coef | (uintptr_t)q_coef) & 15) != 0) return kvzhip::invalid_arg(__func__);
   if (count == 0) return KVZ_HIP_OK;
   const size_t total = count * (size_t)(width * width);
-  hipLaunchKernelGGL(dequant_kernel, dim3(stream_grid(total, 2048)), dim3(256), 0, ctx_stream(s), q_coef, coef, total, width * width, k);
+  hipLaunchKernelGGL(dequant_kernel, dim3(stream_grid(total, 2048, (unsigned)tuning("quant_wgs_per_cu", 256))), dim3(256), 0, ctx_stream(s), q_coef, coef, total, width * width, k);
   KVZ_CHECK_LAUNCH("dequant_kernel");
   return KVZ_HIP_OK;
 }
@@ -604,14 +604,14 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
     return launch_quantize_residual16_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
                                            k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
   if (width == 4 && !k.signhide && tuning("qr4_lane_kernel", 1)) {
-    const unsigned grid = stream_grid(count, 256, 16);
+    const unsigned grid = stream_grid(count, 256, (unsigned)tuning("qr4_wgs_per_cu", 96)       /* measured: 16: 4.8 TB/s, 64: 5.4, 128: 5.4 */);
     if (use_trskip) hipLaunchKernelGGL((quantize_residual4_lane_kernel<4>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
     else if (dst) hipLaunchKernelGGL((quantize_residual4_lane_kernel<2>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
     else hipLaunchKernelGGL((quantize_residual4_lane_kernel<0>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
     KVZ_CHECK_LAUNCH("quantize_residual4_lane_kernel");
     return KVZ_HIP_OK;
   }
-#define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, 16)), dim3(256), 0, st, \
+#define KVZ_QR(N, TRK) hipLaunchKernelGGL((quantize_residual_kernel<N, TRK>), dim3(stream_grid(count, 256 / N, (unsigned)tuning("qr_wgs_per_cu", N == 8 ? 64 : 16))), dim3(256), 0, st, \
                                           ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, scan_order, k, ssd_out, abs_sum_out)
   switch (width) {
     case 4: if (use_trskip) KVZ_QR(4, 4); else if (dst) KVZ_QR(4, 2); else KVZ_QR(4, 0); break;
