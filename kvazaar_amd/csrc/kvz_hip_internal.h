@@ -43,7 +43,7 @@ int tuning(const char *key, int dflt);     // kvz_hip_set_tuning override or dfl
 
 // Grid sizing for streaming kernels: enough workgroups to fill 256 CUs several
 // times over, capped so that grid-stride loops amortise the launch.
-static inline unsigned stream_grid(size_t work_items, unsigned items_per_block, unsigned max_blocks_per_cu = 8)
+static inline unsigned stream_grid(size_t work_items, unsigned items_per_block, unsigned max_blocks_per_cu = 128)
 {
   size_t need = (work_items + items_per_block - 1) / items_per_block;
   size_t cap = (size_t)num_cus() * max_blocks_per_cu;

@@ -689,7 +689,7 @@ static int launch_sad(int n, const u8 *a, const u8 *b, size_t count, u32 *costs,
 #define KVZ_SAD_CASE(N, U)                                                                        \
   case N: {                                                                                       \
     size_t chunks = count * (N * N / 16);                                                         \
-    unsigned grid = stream_grid(chunks, (threads / 64) * 64 * U, (unsigned)tuning("sad_wgs_per_cu", 8)); \
+    unsigned grid = stream_grid(chunks, (threads / 64) * 64 * U, (unsigned)tuning("sad_wgs_per_cu", 256)); \
     hipLaunchKernelGGL((sad_nxn_kernel<N, U, DUAL>), dim3(grid), dim3(threads), 0, st, a, b, costs, count, ps, is); \
   } break;
   switch (n) {
@@ -715,7 +715,7 @@ static int launch_satd(int n, const u8 *a, const u8 *b, size_t count, u32 *costs
       else hipLaunchKernelGGL((satd_4x4_kernel<DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is);
       break;
     case 8:
-      if (!DUAL) hipLaunchKernelGGL((satd8_kernel<4>), dim3(stream_grid(count * 4, threads * 4, (unsigned)tuning("satd8_wgs_per_cu", 8))), dim3(threads), 0, st, a, b, costs, count);
+      if (!DUAL) hipLaunchKernelGGL((satd8_kernel<4>), dim3(stream_grid(count * 4, threads * 4, (unsigned)tuning("satd8_wgs_per_cu", 256))), dim3(threads), 0, st, a, b, costs, count);
       else hipLaunchKernelGGL((satd_nxn_kernel<8, DUAL>), dim3(stream_grid(count, threads)), dim3(threads), 0, st, a, b, costs, count, ps, is);
       break;
     case 16:
