@@ -76,7 +76,8 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * "qr4_lane_kernel", "sao_edge_fast" (0/1), "me_big_threads" (256/512/1024 threads per PU larger than 32x32), "me_medium_threads" (64/128/256 per PU up to 32x32),
  * "intra_rough_waves" (4/8 waves per workgroup of the rough search), "pair_wave_kernel" (0/1: one wave per
  * descriptor for frame-level pair batches of up to 4096 descriptors).
- * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key). */
+ * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
+ * knobs at kvz_hip_init() for A/B runs of an unmodified host. */
 KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);
 
 /* Thin device-memory helpers so a C host needs no HIP headers. */

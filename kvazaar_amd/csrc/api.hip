@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <mutex>
 
 namespace kvzhip {
@@ -112,6 +113,22 @@ int kvz_hip_init(int device)
   g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if ((e = hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking)) != hipSuccess) { set_error("hipStreamCreate", e); return KVZ_HIP_ERR_RUNTIME; }
   g_device = device;
+  // A/B runs of unmodified hosts: KVZ_HIP_TUNE="key=value,key=value" presets kvz_hip_set_tuning knobs
+  if (const char *env = std::getenv("KVZ_HIP_TUNE")) {
+    std::string all(env);
+    size_t pos = 0;
+    while (pos < all.size()) {
+      size_t end = all.find(',', pos);
+      if (end == std::string::npos) end = all.size();
+      const std::string kv = all.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos) {
+        const std::string key = kv.substr(0, eq);
+        for (auto &e : g_tune) if (key == e.key) e.value = std::atoi(kv.c_str() + eq + 1);
+      }
+      pos = end + 1;
+    }
+  }
   g_ready.store(true, std::memory_order_release);
   return KVZ_HIP_OK;
 }

@@ -39,19 +39,12 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
-  const signed char *M = c_m32.v;
-
-  // constant operands (built once per wave)
+  // constant operands: one precomputed record per lane (dct32_mfma_core.h)
   op16 t_nat, t_kap, t_col, t_id;
-  int rowsum = 0, colsum = 0;
+  const dct32_lane_consts &lc = c_dct32_lanes.l[lane];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    t_nat.b[e] = M[r * 32 + 16 * h + e];            // M[r][16h+e]
-    t_kap.b[e] = M[r * 32 + kappa(h, e)];           // M[r][kappa(h,e)]
-    t_col.b[e] = M[kappa(h, e) * 32 + r];           // M[kappa(h,e)][r]
-    t_id.b[e] = (16 * h + e == r) ? 1 : 0;          // identity, natural K order
-  }
-  for (int n = 0; n < 32; ++n) { rowsum += M[r * 32 + n]; colsum += M[n * 32 + r]; }
+  for (int q = 0; q < 4; ++q) { t_nat.w[q] = lc.t_nat[q]; t_kap.w[q] = lc.t_kap[q]; t_col.w[q] = lc.t_col[q]; t_id.w[q] = lc.t_id[q]; }
+  const int rowsum = lc.rowsum, colsum = lc.colsum;
   __shared__ __attribute__((aligned(16))) u8 s_tile[4][2048];
   u8 *tile = s_tile[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];               // wave-private: DS ops of one wave execute in order, no barrier
 
@@ -90,8 +83,10 @@ int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipSt
   // Workgroups per CU.  Few persistent workgroups (2 .. 12 per CU, long grid-stride loops) gave 5.3 - 5.9 TB/s depending on the
   // box and on how the count divided over them; many short-lived ones -- two to three blocks per wave, handed out by the
   // dispatcher as waves retire -- are faster and steadier: forward 4: 5.81, 32: 5.94, 64: 6.24, 96: 6.35, 128: 6.33, 160: 6.00 TB/s;
-  // inverse 8: 5.53, 32: 5.84, 64: 5.69, 128: 5.48 (0.5 GiB arrays, tools/bench_all.py --tune).
-  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 32) : tuning("dct32_wgs_per_cu", 96));
+  // inverse 8: 5.53, 32: 5.84, 64: 5.69, 128: 5.48 (0.5 GiB arrays, tools/bench_all.py --tune).  With the per-lane constants
+  // precomputed (five vector loads per wave) the optimum moved out further: forward 96: 6.27, 192: 6.39, 256: 6.41 (one block
+  // per wave at this size); inverse 32: 5.87, 64: 6.11, 128: 6.04.
+  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 64) : tuning("dct32_wgs_per_cu", 192));
   if (wgs > cap) wgs = cap;
   if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   else hipLaunchKernelGGL((dct32_mfma_kernel<false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);

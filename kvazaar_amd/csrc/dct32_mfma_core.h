@@ -27,6 +27,41 @@ __device__ __forceinline__ int kappa(int h, int e) { return (e & 3) + 8 * (e >> 
 
 union op16 { i32x4 v; signed char b[16]; u32 w[4]; };
 
+// The constant MFMA operands of a lane (r = lane & 31, h = lane >> 5) and the plane-offset sums, built at compile time:
+// a wave fetches them with five vector loads instead of ~100 byte loads and two 32-step sums -- the kernels are launched
+// as many short-lived workgroups, so the per-wave set-up is paid once per two or three blocks.
+struct dct32_lane_consts {
+  u32 t_nat[4];      // M[r][16h + e]
+  u32 t_kap[4];      // M[r][kappa(h, e)]
+  u32 t_col[4];      // M[kappa(h, e)][r]
+  u32 t_id[4];       // identity, natural K order
+  int rowsum, colsum, pad0, pad1;
+};
+struct dct32_lane_table {
+  dct32_lane_consts l[64];
+  constexpr dct32_lane_table() : l()
+  {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int r = lane & 31, h = lane >> 5;
+      int rs = 0, cs = 0;
+      for (int n = 0; n < 32; ++n) { rs += dct_coef(32, r, n); cs += dct_coef(32, n, r); }
+      l[lane].rowsum = rs; l[lane].colsum = cs; l[lane].pad0 = 0; l[lane].pad1 = 0;
+      for (int q = 0; q < 4; ++q) {
+        u32 a = 0, b = 0, c = 0, d = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * q + k, kap = (e & 3) + 8 * (e >> 2) + 4 * h;
+          a |= ((u32)dct_coef(32, r, 16 * h + e) & 255u) << (8 * k);
+          b |= ((u32)dct_coef(32, r, kap) & 255u) << (8 * k);
+          c |= ((u32)dct_coef(32, kap, r) & 255u) << (8 * k);
+          d |= (u32)(16 * h + e == r ? 1 : 0) << (8 * k);
+        }
+        l[lane].t_nat[q] = a; l[lane].t_kap[q] = b; l[lane].t_col[q] = c; l[lane].t_id[q] = d;
+      }
+    }
+  }
+};
+static __constant__ dct32_lane_table c_dct32_lanes = dct32_lane_table();
+
 // byte planes of 16 int16 held as 8 dwords (element pairs): hi = X >> 8, lo' = (X & 255) - 128
 __device__ __forceinline__ void planes_from_rows(const u32 (&d)[8], op16 &hi, op16 &lo)
 {
