@@ -85,8 +85,8 @@ int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipSt
   // dispatcher as waves retire -- are faster and steadier: forward 4: 5.81, 32: 5.94, 64: 6.24, 96: 6.35, 128: 6.33, 160: 6.00 TB/s;
   // inverse 8: 5.53, 32: 5.84, 64: 5.69, 128: 5.48 (0.5 GiB arrays, tools/bench_all.py --tune).  With the per-lane constants
   // precomputed (five vector loads per wave) the optimum moved out further: forward 96: 6.27, 192: 6.39, 256: 6.41 (one block
-  // per wave at this size); inverse 32: 5.87, 64: 6.11, 128: 6.04.
-  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 64) : tuning("dct32_wgs_per_cu", 192));
+  // per wave at this size); inverse 32: 5.83, 64: 6.07, 128: 6.17, 256: 5.29.
+  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 96) : tuning("dct32_wgs_per_cu", 192));
   if (wgs > cap) wgs = cap;
   if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   else hipLaunchKernelGGL((dct32_mfma_kernel<false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);

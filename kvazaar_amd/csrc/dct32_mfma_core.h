@@ -35,6 +35,7 @@ struct dct32_lane_consts {
   u32 t_kap[4];      // M[r][kappa(h, e)]
   u32 t_col[4];      // M[kappa(h, e)][r]
   u32 t_id[4];       // identity, natural K order
+  u32 t_idk[4];      // identity in kappa K order
   int rowsum, colsum, pad0, pad1;
 };
 struct dct32_lane_table {
@@ -47,15 +48,16 @@ struct dct32_lane_table {
       for (int n = 0; n < 32; ++n) { rs += dct_coef(32, r, n); cs += dct_coef(32, n, r); }
       l[lane].rowsum = rs; l[lane].colsum = cs; l[lane].pad0 = 0; l[lane].pad1 = 0;
       for (int q = 0; q < 4; ++q) {
-        u32 a = 0, b = 0, c = 0, d = 0;
+        u32 a = 0, b = 0, c = 0, d = 0, dk = 0;
         for (int k = 0; k < 4; ++k) {
           const int e = 4 * q + k, kap = (e & 3) + 8 * (e >> 2) + 4 * h;
           a |= ((u32)dct_coef(32, r, 16 * h + e) & 255u) << (8 * k);
           b |= ((u32)dct_coef(32, r, kap) & 255u) << (8 * k);
           c |= ((u32)dct_coef(32, kap, r) & 255u) << (8 * k);
           d |= (u32)(16 * h + e == r ? 1 : 0) << (8 * k);
+          dk |= (u32)(kap == r ? 1 : 0) << (8 * k);
         }
-        l[lane].t_nat[q] = a; l[lane].t_kap[q] = b; l[lane].t_col[q] = c; l[lane].t_id[q] = d;
+        l[lane].t_nat[q] = a; l[lane].t_kap[q] = b; l[lane].t_col[q] = c; l[lane].t_id[q] = d; l[lane].t_idk[q] = dk;
       }
     }
   }
@@ -180,14 +182,22 @@ __device__ __forceinline__ void inv32_core(const op16 &hi, const op16 &lo, const
 }
 
 // fills the 2 x 16 table of inverse pass-2 constants (call with all threads, then __syncthreads())
+struct dct32_c2_table {
+  int v[32];         // [half][register]: 128 * colsum(M)[kappa(h, g)] + 2048
+  constexpr dct32_c2_table() : v()
+  {
+    for (int i = 0; i < 32; ++i) {
+      const int h = i >> 4, g = i & 15, row = (g & 3) + 8 * (g >> 2) + 4 * h;
+      int cs = 0;
+      for (int n = 0; n < 32; ++n) cs += dct_coef(32, n, row);
+      v[i] = 128 * cs + (1 << 11);
+    }
+  }
+};
+static __constant__ dct32_c2_table c_dct32_c2 = dct32_c2_table();
 __device__ __forceinline__ void fill_inv_c2(int (*s_c2)[16])
 {
-  if (threadIdx.x < 32) {
-    const int row = kappa(threadIdx.x >> 4, threadIdx.x & 15);
-    int cs = 0;
-    for (int n = 0; n < 32; ++n) cs += c_m32.v[n * 32 + row];
-    s_c2[threadIdx.x >> 4][threadIdx.x & 15] = 128 * cs + (1 << 11);
-  }
+  if (threadIdx.x < 32) s_c2[threadIdx.x >> 4][threadIdx.x & 15] = c_dct32_c2.v[threadIdx.x];
 }
 
 }  // namespace kvzhip

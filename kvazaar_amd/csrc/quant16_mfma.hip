@@ -145,7 +145,7 @@ int launch_quantize_residual16_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec
   q16_consts k = { q_bits, add, flat_qc, qtable, dq_mode, dq_shift, dq_add, dq_scale, dqtable };
   const size_t npairs = (count + 1) / 2;
   size_t wgs = (npairs + 3) / 4;
-  const size_t cap = (size_t)num_cus() * (size_t)tuning("qr16_wgs_per_cu", 8);
+  const size_t cap = (size_t)num_cus() * (size_t)tuning("qr16_wgs_per_cu", 16)       /* 4: 2.71, 8: 2.88, 16: 2.97, 32: 2.95, 64: 2.87 TB/s */;
   if (wgs > cap) wgs = cap;
   hipLaunchKernelGGL(quantize_residual16_mfma_kernel, dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs,
                      count, k, ssd_out, abs_sum_out);
