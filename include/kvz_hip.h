@@ -42,10 +42,13 @@ extern "C" {
 
 typedef uint8_t kvz_hip_pixel;
 typedef int16_t kvz_hip_coeff;
-typedef void *kvz_hip_stream;        /* hipStream_t; NULL = the library's default stream.  That stream is created non-blocking:
-                                      * it does not wait for work queued on any other stream (a framework's, the legacy
-                                      * default stream).  Inputs produced elsewhere must be complete before an entry is called,
-                                      * or the entry is given the producer's own hipStream_t (any HIP stream is accepted). */
+typedef void *kvz_hip_stream;        /* hipStream_t; any HIP stream of the current device is accepted.  NULL = the library's
+                                      * default stream of the calling thread's current device: a BLOCKING stream, i.e. ordered
+                                      * like the legacy default stream -- work enqueued with NULL starts after everything the host
+                                      * queued on the legacy default stream before the call (hipMemcpy, a framework's default
+                                      * stream) and is waited for by what the host queues there afterwards.  Streams made by
+                                      * kvz_hip_stream_create() are non-blocking: inputs produced on another stream must be
+                                      * complete (or ordered by an event, kvz_hip_stream_wait_event) before the entry is called. */
 
 enum {
   KVZ_HIP_OK = 0,
@@ -57,17 +60,25 @@ enum {
 /* ------------------------------------------------------------------ */
 /* context                                                            */
 /* ------------------------------------------------------------------ */
-/* Select the device and create the library context.  Idempotent.  Called
- * implicitly (device 0 or $KVZ_HIP_DEVICE) by the registration hooks -- the
- * analogue of set_hardware_flags(), strategyselector.c:452. */
+/* One context per device, all reachable from ONE process (the reference is a single process whose strategy
+ * pointers are process-global, strategies/strategies-picture.c:33-64, and whose workers are pthreads,
+ * threadqueue.c:263).  Every host thread has a current device, as with hipSetDevice: kvz_hip_init(device) creates
+ * that device's context if needed (idempotent) and makes it the calling thread's current device; kvz_hip_set_device
+ * switches the calling thread; a thread that never chose uses the process default = the first device initialised.
+ * Every entry below runs on the calling thread's current device, so its pointer arguments and its stream must
+ * belong to that device.  kvz_hip_init(-1): keep the thread's current device / the process default if there is one,
+ * else $KVZ_HIP_DEVICE, else device 0 -- what the registration hooks call, the analogue of set_hardware_flags(),
+ * strategyselector.c:452.  An index >= kvz_hip_device_count() fails with KVZ_HIP_ERR_INVALID. */
 KVZ_HIP_API int kvz_hip_init(int device);
-KVZ_HIP_API void kvz_hip_shutdown(void);
+KVZ_HIP_API int kvz_hip_set_device(int device);      /* binds the calling thread; initialises the device on first use */
+KVZ_HIP_API int kvz_hip_get_device(void);            /* the calling thread's current device, -1 before any kvz_hip_init */
+KVZ_HIP_API void kvz_hip_shutdown(void);             /* destroys every context */
 KVZ_HIP_API int kvz_hip_device_count(void);
 KVZ_HIP_API const char *kvz_hip_last_error(void);    /* text of the calling thread's last failure */
-KVZ_HIP_API const char *kvz_hip_device_name(void);
+KVZ_HIP_API const char *kvz_hip_device_name(void);   /* of the calling thread's current device */
 /* Version of this header's ABI as the library was built (layouts of the kvz_hip_* structs, entry signatures); a host
  * compares it with the KVZ_HIP_ABI_VERSION it was compiled against before it registers the strategies. */
-#define KVZ_HIP_ABI_VERSION 1
+#define KVZ_HIP_ABI_VERSION 2   /* 2: per-device contexts, kvz_hip_me_params with tile / mv-constraint fields */
 KVZ_HIP_API int kvz_hip_abi_version(void);
 
 /* Launch-geometry / kernel-selection knobs for A/B runs (tools/bench_all.py --tune key=v1,v2);
@@ -86,6 +97,14 @@ KVZ_HIP_API void kvz_hip_free(void *dptr);
 KVZ_HIP_API int kvz_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, kvz_hip_stream s);
 KVZ_HIP_API int kvz_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, kvz_hip_stream s);
 KVZ_HIP_API int kvz_hip_memset(void *dst, int value, size_t bytes, kvz_hip_stream s);
+KVZ_HIP_API int kvz_hip_memcpy_d2d(void *dst, const void *src, size_t bytes, kvz_hip_stream s);
+/* The reconstructed-pixel exchange at a shard boundary (the reference's analogue is the bounded
+ * cross-row read of WPP / tiles, encoderstate.c:777-828, encoder.c:240-241) for a host that drives several devices
+ * from one process: an asynchronous peer copy (xGMI) of `bytes` from src on src_device to dst on dst_device, on a
+ * stream of the calling thread's current device.  Both devices must have been initialised.  A CTU-row shard sends
+ * the `margin` rows at its top / bottom edge into the halo rows of the shard above / below: with stride == width
+ * those rows are one contiguous range, i.e. one call per direction per plane. */
+KVZ_HIP_API int kvz_hip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, kvz_hip_stream s);
 KVZ_HIP_API kvz_hip_stream kvz_hip_stream_create(void);
 KVZ_HIP_API void kvz_hip_stream_destroy(kvz_hip_stream s);
 KVZ_HIP_API int kvz_hip_stream_sync(kvz_hip_stream s);
@@ -326,7 +345,7 @@ typedef struct {
   kvz_hip_me_merge merge[5];
   int16_t pad;
 } kvz_hip_me_pu;                 /* 64 bytes */
-/* the encoder settings the search reads (no tiles, mv_constraint none, mv_rdo off) */
+/* the encoder settings the search reads (mv_rdo off) */
 typedef struct {
   int32_t lambda_cost;           /* (int32_t)(state->lambda_sqrt + 0.5), search_inter.c:411 */
   int32_t early_termination;     /* cfg.me_early_termination: 0 off, 1 on, 2 sensitive */
@@ -340,8 +359,16 @@ typedef struct {
   int32_t search_range;          /* algorithm 3 only: 8, 16, 32 or 64 (search_inter.c:1208-1215), any value 1..64 accepted */
   int32_t size_classes;          /* optional hint, 0 = unknown: OR of 1 (PUs up to 16x16), 2 (up to 32x32), 4 (larger) present in the
                                     batch; the entry runs one kernel per size class and skips the launches for absent ones */
-  int32_t reserved;
-} kvz_hip_me_params;             /* 48 bytes */
+  int32_t mv_constraint;         /* cfg.mv_constraint (enum kvz_mv_constraint, kvazaar.h:113-119): 0 none, 1 frame, 2 tile, 3 frame and tile,
+                                    4 frame and tile with the interpolation margin -- the five branches of fracmv_within_tile
+                                    (search_inter.c:142-171; the reference treats 1..3 alike) */
+  int32_t tile_x, tile_y;        /* state->tile->offset_x / offset_y: top-left of the tile (multiples of 64) in the picture */
+  int32_t tile_w, tile_h;        /* state->tile->frame->width / height; 0 x 0 = the whole picture is one tile.  PU coordinates stay
+                                    picture coordinates; the entry derives the tile-relative info->origin the reference tests.
+                                    A CTU-row shard of a frame is a tile of full width: with mv_constraint 3 or 4 its
+                                    search reads nothing outside its own rows (+ nothing at all beyond them), with wpp_owf and
+                                    max_ref_lcu_down = 1 nothing beyond one CTU row + ref_delay_px + 4 rows below them. */
+} kvz_hip_me_params;             /* 64 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */
   uint32_t cost, bitcost;        /* info->best_cost, info->best_bitcost; cost 0xFFFFFFFF: nothing allowed / bad descriptor */

@@ -42,6 +42,8 @@ _U = C.c_uint32
 # name -> (restype, argtypes); every symbol include/kvz_hip.h declares
 SIGNATURES = {
     "kvz_hip_init": (_I, [_I]),
+    "kvz_hip_set_device": (_I, [_I]),
+    "kvz_hip_get_device": (_I, []),
     "kvz_hip_shutdown": (None, []),
     "kvz_hip_device_count": (_I, []),
     "kvz_hip_last_error": (C.c_char_p, []),
@@ -53,6 +55,8 @@ SIGNATURES = {
     "kvz_hip_memcpy_h2d": (_I, [_P, _P, _SZ, _P]),
     "kvz_hip_memcpy_d2h": (_I, [_P, _P, _SZ, _P]),
     "kvz_hip_memset": (_I, [_P, _I, _SZ, _P]),
+    "kvz_hip_memcpy_d2d": (_I, [_P, _P, _SZ, _P]),
+    "kvz_hip_memcpy_peer": (_I, [_P, _I, _P, _I, _SZ, _P]),
     "kvz_hip_stream_create": (_P, []),
     "kvz_hip_stream_destroy": (None, [_P]),
     "kvz_hip_stream_sync": (_I, [_P]),

@@ -306,14 +306,14 @@ def intra_rough_batch(refs, log2_width, orig, flags=INTRA_LUMA | INTRA_FILTER_BO
 
 # ---- motion search of whole PUs ----
 def search_pu_batch(pic, ref, pus, params):
-    """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (48 bytes).
+    """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (64 bytes).
     Returns the raw results as int32 [count, 8] (= kvz_hip_me_result)."""
     L = _lib.init()
     pic = np.ascontiguousarray(pic, dtype=np.uint8)
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     pus = np.ascontiguousarray(pus)
     params = np.ascontiguousarray(params)
-    assert pus.dtype.itemsize == 64 and params.nbytes == 48
+    assert pus.dtype.itemsize == 64 and params.nbytes == 64
     count = pus.shape[0]
     a, b, d = DeviceBuffer.from_numpy(pic), DeviceBuffer.from_numpy(ref), DeviceBuffer.from_numpy(pus.view(np.uint8))
     out = DeviceBuffer(max(1, 32 * count))

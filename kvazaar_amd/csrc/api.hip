@@ -1,5 +1,11 @@
-// api.hip -- library context, device-memory helpers and HIP-event timing of the
-// C ABI declared in include/kvz_hip.h.
+// api.hip -- library contexts (one per device, all reachable from one process), device-memory helpers and
+// HIP-event timing of the C ABI declared in include/kvz_hip.h.
+//
+// Device model (the reference is ONE process whose strategy pointers are process-global,
+// strategies/strategies-picture.c:33-64, and whose workers are pthreads, threadqueue.c:263): a context per device;
+// every host thread has a current device (kvz_hip_init / kvz_hip_set_device bind it, exactly like hipSetDevice);
+// a thread that never chose one uses the process default = the first device initialised.  Every entry runs on the
+// calling thread's current device: its default stream, its CU count, its staging buffers.
 #include "kvz_hip_internal.h"
 
 #include <atomic>
@@ -11,43 +17,54 @@
 
 namespace kvzhip {
 
+constexpr int KVZ_MAX_DEVICES = 64;
+struct dev_ctx {
+  std::atomic<bool> ready{false};
+  int num_cus = 256;
+  hipStream_t stream = nullptr;      // the device's default stream of this library (what a NULL kvz_hip_stream means)
+  char name[256] = "";
+};
 static std::mutex g_mu;
-static std::atomic<bool> g_ready{false};
-static int g_device = -1;
-static int g_num_cus = 256;
-static hipStream_t g_stream = nullptr;
+static dev_ctx g_ctx[KVZ_MAX_DEVICES];
+static std::atomic<int> g_default_dev{-1};    // first device initialised: the current device of threads that never chose one
+static thread_local int t_dev = -1;           // the calling thread's current device (kvz_hip_init / kvz_hip_set_device)
 static thread_local char g_err[512] = "";     // last error of the calling thread
-static char g_name[256] = "";
 
-struct tune_entry { const char *key; int value; };
-static tune_entry g_tune[] = { { "sad_wgs_per_cu", -1 }, { "satd8_wgs_per_cu", -1 }, { "dct32_wgs_per_cu", -1 },
-                               { "idct32_wgs_per_cu", -1 }, { "dct_wgs_per_cu", -1 }, { "qr32_wgs_per_cu", -1 },
-                               { "qr_wgs_per_cu", -1 }, { "dct16_wgs_per_cu", -1 }, { "idct16_wgs_per_cu", -1 }, { "idct16_use_mfma", -1 },
-                               { "qr16_wgs_per_cu", -1 }, { "qr16_use_mfma", -1 }, { "qr4_lane_kernel", -1 },
-                               { "me_big_threads", -1 }, { "sao_edge_fast", -1 }, { "me_medium_threads", -1 },
-                               { "intra_rough_waves", -1 }, { "pair_wave_kernel", -1 }, { "qr4_wgs_per_cu", -1 }, { "quant_wgs_per_cu", -1 } };
+struct tune_entry { const char *key; std::atomic<int> value; };
+static tune_entry g_tune[] = { { "sad_wgs_per_cu", {-1} }, { "satd8_wgs_per_cu", {-1} }, { "dct32_wgs_per_cu", {-1} },
+                               { "idct32_wgs_per_cu", {-1} }, { "dct_wgs_per_cu", {-1} }, { "qr32_wgs_per_cu", {-1} },
+                               { "qr_wgs_per_cu", {-1} }, { "dct16_wgs_per_cu", {-1} }, { "idct16_wgs_per_cu", {-1} }, { "idct16_use_mfma", {-1} },
+                               { "qr16_wgs_per_cu", {-1} }, { "qr16_use_mfma", {-1} }, { "qr4_lane_kernel", {-1} },
+                               { "me_big_threads", {-1} }, { "sao_edge_fast", {-1} }, { "me_medium_threads", {-1} },
+                               { "intra_rough_waves", {-1} }, { "pair_wave_kernel", {-1} }, { "qr4_wgs_per_cu", {-1} }, { "quant_wgs_per_cu", {-1} },
+                               { "qr8_reg_kernel", {-1} }, { "qr8_wgs_per_cu", {-1} } };
 int tuning(const char *key, int dflt)
 {
-  for (auto &e : g_tune) if (!std::strcmp(e.key, key)) return e.value >= 0 ? e.value : dflt;
+  for (auto &e : g_tune) if (!std::strcmp(e.key, key)) { const int v = e.value.load(std::memory_order_relaxed); return v >= 0 ? v : dflt; }
   return dflt;
 }
 
-bool ctx_ready() { return g_ready.load(std::memory_order_acquire); }
+int ctx_device() { return t_dev >= 0 ? t_dev : g_default_dev.load(std::memory_order_acquire); }
+bool ctx_ready()
+{
+  const int d = ctx_device();
+  return d >= 0 && g_ctx[d].ready.load(std::memory_order_acquire);
+}
 
-// HIP's current device is a per-thread setting that starts at device 0: every thread that enters the library
-// (encoder worker threads call the strategy functions directly) is bound to the context's device once.
+// HIP's current device is a per-thread setting that starts at device 0 and that the host may change behind our back
+// (a framework's set_device): every entry makes the HIP device of the calling thread the thread's kvz_hip device.
 bool ctx_enter()
 {
-  if (!ctx_ready()) return false;
-  static thread_local int bound = -1;
-  if (bound != g_device) {
-    if (hipSetDevice(g_device) != hipSuccess) return false;
-    bound = g_device;
+  const int d = ctx_device();
+  if (d < 0 || !g_ctx[d].ready.load(std::memory_order_acquire)) return false;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != d) {
+    if (hipSetDevice(d) != hipSuccess) return false;
   }
   return true;
 }
-hipStream_t ctx_stream(kvz_hip_stream s) { return s ? (hipStream_t)s : g_stream; }
-int num_cus() { return g_num_cus; }
+hipStream_t ctx_stream(kvz_hip_stream s) { return s ? (hipStream_t)s : g_ctx[ctx_device()].stream; }
+int num_cus() { const int d = ctx_device(); return d >= 0 ? g_ctx[d].num_cus : 256; }
 
 void set_error(const char *what, hipError_t e)
 {
@@ -58,6 +75,29 @@ int invalid_arg(const char *entry)
 {
   std::snprintf(g_err, sizeof(g_err), "%s: invalid argument (null or misaligned buffer, size or parameter out of range)", entry);
   return KVZ_HIP_ERR_INVALID;
+}
+
+// brings up the context of one device (idempotent); g_mu held by the caller
+static int ctx_create_locked(int device)
+{
+  dev_ctx &c = g_ctx[device];
+  if (c.ready.load(std::memory_order_acquire)) return KVZ_HIP_OK;
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e); return KVZ_HIP_ERR_NO_DEVICE; }
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { set_error("hipGetDeviceProperties", e); return KVZ_HIP_ERR_NO_DEVICE; }
+  std::snprintf(c.name, sizeof(c.name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    std::snprintf(g_err, sizeof(g_err), "kvz_hip_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return KVZ_HIP_ERR_NO_DEVICE;
+  }
+  c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  // A BLOCKING stream: work enqueued with a NULL kvz_hip_stream is ordered after everything the host put on the legacy
+  // default stream before the call (hipMemcpy, a framework's default stream) and before what it puts there afterwards --
+  // what a host that passes NULL expects from a HIP API.  Streams from kvz_hip_stream_create() are non-blocking.
+  if ((e = hipStreamCreateWithFlags(&c.stream, hipStreamDefault)) != hipSuccess) { set_error("hipStreamCreate", e); return KVZ_HIP_ERR_RUNTIME; }
+  c.ready.store(true, std::memory_order_release);
+  return KVZ_HIP_OK;
 }
 
 }  // namespace kvzhip
@@ -75,7 +115,7 @@ extern "C" {
 int kvz_hip_set_tuning(const char *key, int value)
 {
   if (!key) return kvzhip::invalid_arg(__func__);
-  for (auto &e : g_tune) if (!std::strcmp(e.key, key)) { e.value = value; return KVZ_HIP_OK; }
+  for (auto &e : g_tune) if (!std::strcmp(e.key, key)) { e.value.store(value, std::memory_order_relaxed); return KVZ_HIP_OK; }
   return kvzhip::invalid_arg(__func__);
 }
 
@@ -88,63 +128,85 @@ int kvz_hip_device_count(void)
 
 int kvz_hip_init(int device)
 {
-  if (ctx_ready()) return KVZ_HIP_OK;
+  if (device < 0) {
+    // "whatever the process uses": the calling thread's current device if it has one, else the process default,
+    // else $KVZ_HIP_DEVICE, else device 0
+    if (ctx_ready()) return KVZ_HIP_OK;
+    const int dflt = g_default_dev.load(std::memory_order_acquire);
+    const char *env = std::getenv("KVZ_HIP_DEVICE");
+    device = dflt >= 0 ? dflt : (env ? std::atoi(env) : 0);
+  }
   std::lock_guard<std::mutex> lk(g_mu);
-  if (ctx_ready()) return KVZ_HIP_OK;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {
     set_error_msg("kvz_hip_init: no HIP device visible (this library has no CPU fallback)");
     return KVZ_HIP_ERR_NO_DEVICE;
   }
-  if (device < 0) {
-    const char *env = std::getenv("KVZ_HIP_DEVICE");
-    device = env ? std::atoi(env) : 0;
+  if (device >= n || device >= KVZ_MAX_DEVICES) {
+    std::snprintf(g_err, sizeof(g_err), "kvz_hip_init: device index %d out of range (%d device(s) visible)", device, n);
+    return KVZ_HIP_ERR_INVALID;
   }
-  if (device >= n) { set_error_msg("kvz_hip_init: device index out of range"); return KVZ_HIP_ERR_INVALID; }
-  if ((e = hipSetDevice(device)) != hipSuccess) { set_error("hipSetDevice", e); return KVZ_HIP_ERR_NO_DEVICE; }
-  hipDeviceProp_t prop;
-  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { set_error("hipGetDeviceProperties", e); return KVZ_HIP_ERR_NO_DEVICE; }
-  std::snprintf(g_name, sizeof(g_name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    std::snprintf(g_err, sizeof(g_err), "kvz_hip_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
-    return KVZ_HIP_ERR_NO_DEVICE;
-  }
-  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if ((e = hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking)) != hipSuccess) { set_error("hipStreamCreate", e); return KVZ_HIP_ERR_RUNTIME; }
-  g_device = device;
-  // A/B runs of unmodified hosts: KVZ_HIP_TUNE="key=value,key=value" presets kvz_hip_set_tuning knobs
-  if (const char *env = std::getenv("KVZ_HIP_TUNE")) {
-    std::string all(env);
-    size_t pos = 0;
-    while (pos < all.size()) {
-      size_t end = all.find(',', pos);
-      if (end == std::string::npos) end = all.size();
-      const std::string kv = all.substr(pos, end - pos);
-      const size_t eq = kv.find('=');
-      if (eq != std::string::npos) {
-        const std::string key = kv.substr(0, eq);
-        for (auto &e : g_tune) if (key == e.key) e.value = std::atoi(kv.c_str() + eq + 1);
+  const bool first = g_default_dev.load(std::memory_order_acquire) < 0;
+  const int rc = ctx_create_locked(device);
+  if (rc != KVZ_HIP_OK) return rc;
+  if (first) {
+    // A/B runs of unmodified hosts: KVZ_HIP_TUNE="key=value,key=value" presets kvz_hip_set_tuning knobs
+    if (const char *env = std::getenv("KVZ_HIP_TUNE")) {
+      std::string all(env);
+      size_t pos = 0;
+      while (pos < all.size()) {
+        size_t end = all.find(',', pos);
+        if (end == std::string::npos) end = all.size();
+        const std::string kv = all.substr(pos, end - pos);
+        const size_t eq = kv.find('=');
+        if (eq != std::string::npos) {
+          const std::string key = kv.substr(0, eq);
+          for (auto &t : g_tune) if (key == t.key) t.value.store(std::atoi(kv.c_str() + eq + 1), std::memory_order_relaxed);
+        }
+        pos = end + 1;
       }
-      pos = end + 1;
     }
+    g_default_dev.store(device, std::memory_order_release);
   }
-  g_ready.store(true, std::memory_order_release);
+  t_dev = device;             // like hipSetDevice: the initialising thread now works on this device
   return KVZ_HIP_OK;
 }
+
+int kvz_hip_set_device(int device)
+{
+  if (device < 0) return kvzhip::invalid_arg(__func__);
+  if (device >= KVZ_MAX_DEVICES || !g_ctx[device].ready.load(std::memory_order_acquire)) {
+    const int saved = t_dev;
+    const int rc = kvz_hip_init(device);          // binds on success
+    if (rc != KVZ_HIP_OK) { t_dev = saved; return rc; }
+  }
+  t_dev = device;
+  if (hipSetDevice(device) != hipSuccess) { set_error_msg("kvz_hip_set_device: hipSetDevice failed"); return KVZ_HIP_ERR_RUNTIME; }
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_get_device(void) { return ctx_device(); }
 
 void kvz_hip_shutdown(void)
 {
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!ctx_ready()) return;
-  (void)hipStreamSynchronize(g_stream);
-  (void)hipStreamDestroy(g_stream);
-  g_stream = nullptr;
-  g_ready.store(false, std::memory_order_release);
+  for (int d = 0; d < KVZ_MAX_DEVICES; ++d) {
+    dev_ctx &c = g_ctx[d];
+    if (!c.ready.load(std::memory_order_acquire)) continue;
+    c.ready.store(false, std::memory_order_release);
+    if (hipSetDevice(d) == hipSuccess) {
+      (void)hipStreamSynchronize(c.stream);
+      (void)hipStreamDestroy(c.stream);
+    }
+    c.stream = nullptr;
+  }
+  g_default_dev.store(-1, std::memory_order_release);
+  t_dev = -1;
 }
 
 const char *kvz_hip_last_error(void) { return g_err; }
-const char *kvz_hip_device_name(void) { return g_name; }
+const char *kvz_hip_device_name(void) { const int d = ctx_device(); return d >= 0 ? g_ctx[d].name : ""; }
 int kvz_hip_abi_version(void) { return KVZ_HIP_ABI_VERSION; }
 
 void *kvz_hip_malloc(size_t bytes)
@@ -174,6 +236,24 @@ int kvz_hip_memset(void *dst, int value, size_t bytes, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
   HIP_TRY(hipMemsetAsync(dst, value, bytes, ctx_stream(s)), "hipMemsetAsync");
+  return KVZ_HIP_OK;
+}
+int kvz_hip_memcpy_d2d(void *dst, const void *src, size_t bytes, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx_stream(s)), "hipMemcpyAsync(D2D)");
+  return KVZ_HIP_OK;
+}
+// Rows of a reconstructed plane from one device's shard into a neighbour's halo, inside one process:
+// an asynchronous peer copy over xGMI on a stream of the calling thread's current device.
+int kvz_hip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!dst || !src || dst_device < 0 || src_device < 0 || dst_device >= KVZ_MAX_DEVICES || src_device >= KVZ_MAX_DEVICES ||
+      !g_ctx[dst_device].ready.load(std::memory_order_acquire) || !g_ctx[src_device].ready.load(std::memory_order_acquire))
+    return kvzhip::invalid_arg(__func__);
+  if (bytes == 0) return KVZ_HIP_OK;
+  HIP_TRY(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, ctx_stream(s)), "hipMemcpyPeerAsync");
   return KVZ_HIP_OK;
 }
 kvz_hip_stream kvz_hip_stream_create(void)

@@ -16,8 +16,9 @@ typedef int32_t i32;
 namespace kvzhip {
 
 // ---- context (api.hip) ----
+int ctx_device();                               // the calling thread's current device (-1: none initialised)
 bool ctx_ready();
-bool ctx_enter();                               // ready, and the calling thread bound to the context's device
+bool ctx_enter();                               // ready, and the calling thread's HIP device = its kvz_hip device
 hipStream_t ctx_stream(kvz_hip_stream s);      // NULL -> library default stream
 void set_error(const char *what, hipError_t e);
 void set_error_msg(const char *what);

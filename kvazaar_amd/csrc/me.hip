@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void ctu_sad_grid_kernel(me_plane pic, me_plan
     const int r = i >> 4, q = (i & 15) << 2;
     const int yy = clampi(c.y + r, 0, pic.h - 1);
     u32 v;
-    if (c.x + q + 4 <= pic.w) __builtin_memcpy(&v, pic.p + (size_t)yy * pic.stride + c.x + q, 4);
+    if (c.x + q >= 0 && c.x + q + 4 <= pic.w) __builtin_memcpy(&v, pic.p + (size_t)yy * pic.stride + c.x + q, 4);
     else {
       u8 b[4];
       for (int k = 0; k < 4; ++k) b[k] = pic.p[(size_t)yy * pic.stride + clampi(c.x + q + k, 0, pic.w - 1)];

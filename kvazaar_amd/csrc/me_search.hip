@@ -32,6 +32,7 @@ struct me_cost_model {
   u32 usable, same_ref;                                // bit i = merge[i].usable / .same_ref
   u32 mkey[5];                                         // merge vector i as (x & 0xffff) | y << 16, for merge_match
   int lambda_cost, wpp_owf, ref_delay_px, max_down, max_right;
+  int constraint, ox, oy, tw, th;                      // cfg.mv_constraint, tile-relative origin of the PU, tile size
 
   __device__ __forceinline__ me_cost_model(const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm)
   {
@@ -48,22 +49,29 @@ struct me_cost_model {
     }
     lambda_cost = prm.lambda_cost; wpp_owf = prm.wpp_owf; ref_delay_px = prm.ref_delay_px;
     max_down = prm.max_ref_lcu_down; max_right = prm.max_ref_lcu_right;
+    constraint = prm.mv_constraint;
+    ox = pu.x - prm.tile_x; oy = pu.y - prm.tile_y; tw = prm.tile_w; th = prm.tile_h;
   }
 
-  // fracmv_within_tile (search_inter.c:87-176) for mv_constraint == NONE; quarter-pel vector
+  // fracmv_within_tile (search_inter.c:87-176), all mv_constraint branches; quarter-pel vector.  info->origin is
+  // relative to the tile, and so are the LCU indices of the availability rule (C division: truncation toward zero).
   __device__ __forceinline__ bool within(int x, int y) const
   {
-    if (!wpp_owf) return true;
-    int margin = 0;
-    if (x % 4 != 0 || y % 4 != 0) margin = 4;
-    else if (x % 8 != 0 || y % 8 != 0) margin = 2;
-    margin += ref_delay_px;
-    const int lcu_x = px / 64, lcu_y = py / 64;
-    const int mv_lcu_x = ((px + pw + margin) * 4 + x) / (64 << 2) - lcu_x;
-    const int mv_lcu_y = ((py + ph + margin) * 4 + y) / (64 << 2) - lcu_y;
-    if (mv_lcu_y > max_down) return false;
-    if (mv_lcu_x + mv_lcu_y > max_down + max_right) return false;
-    return true;
+    const bool frac_luma = x % 4 != 0 || y % 4 != 0, frac_chroma = x % 8 != 0 || y % 8 != 0;
+    if (wpp_owf) {
+      int margin = frac_luma ? 4 : (frac_chroma ? 2 : 0);
+      margin += ref_delay_px;
+      const int lcu_x = ox / 64, lcu_y = oy / 64;
+      const int mv_lcu_x = ((ox + pw + margin) * 4 + x) / (64 << 2) - lcu_x;
+      const int mv_lcu_y = ((oy + ph + margin) * 4 + y) / (64 << 2) - lcu_y;
+      if (mv_lcu_y > max_down) return false;
+      if (mv_lcu_x + mv_lcu_y > max_down + max_right) return false;
+    }
+    if (constraint == 0) return true;
+    const int margin = constraint == 4 ? (frac_luma ? 4 << 2 : (frac_chroma ? 2 << 2 : 0)) : 0;
+    const int ax = ox * 4 + x, ay = oy * 4 + y;
+    const int from_right = (tw << 2) - (ax + (pw << 2)), from_bottom = (th << 2) - (ay + (ph << 2));
+    return ax >= margin && ay >= margin && from_right >= margin && from_bottom >= margin;
   }
   // get_ep_ex_golomb_bitcost (:235-254)
   static __device__ __forceinline__ u32 golomb(u32 symbol)
@@ -572,8 +580,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const size_t i = (size_t)blockIdx.x * 4 + wv;
   if (i >= count) return;
   const kvz_hip_me_pu &pu = pus[i];
-  if (!pu_ok(pu, pic_w, pic_h) || pu.width > 16 || pu.height > 16) return;
   const int lane = threadIdx.x & 63;
+  if (!pu_ok(pu, pic_w, pic_h)) { if (lane == 0) flag_bad(out + i); return; }
+  if (pu.width > 16 || pu.height > 16) return;
   if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else search_pu_core<16, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
@@ -591,8 +600,9 @@ __global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restr
   const size_t i = (size_t)blockIdx.x * 2 + wv;
   if (i >= count) return;
   const kvz_hip_me_pu &pu = pus[i];
-  if (!pu_ok(pu, pic_w, pic_h) || pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
   const int lane = threadIdx.x & 63;
+  if (!pu_ok(pu, pic_w, pic_h)) { if (lane == 0) flag_bad(out + i); return; }
+  if (pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
   if (pu.width == 32 && pu.height == 32) search_pu_core<32, 64, true, 32, 32>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else search_pu_core<32, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
 }
@@ -607,7 +617,8 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
   __shared__ __attribute__((aligned(16))) u8 lds[(frac_geom<32>::TOTAL + 15) & ~15];
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];
-  if (!pu_ok(pu, pic_w, pic_h) || pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
+  if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  if (pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
   if (pu.width == 32 && pu.height == 32) search_pu_core<32, T, false, 32, 32>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
   else search_pu_core<32, T, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
@@ -634,6 +645,14 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     set_error_msg("kvz_hip_search_pu_batch: fme_level must be 0..4, early_termination 0..2, algorithm 0 (hexbs), 1 (dia), 2 (tz) or 3 (full, search_range 1..64)");
     return KVZ_HIP_ERR_INVALID;
   }
+  kvz_hip_me_params prm_v = *params;
+  if (prm_v.tile_w == 0 && prm_v.tile_h == 0) { prm_v.tile_x = 0; prm_v.tile_y = 0; prm_v.tile_w = pic_w; prm_v.tile_h = pic_h; }
+  if (prm_v.mv_constraint < 0 || prm_v.mv_constraint > 4 || prm_v.tile_x < 0 || prm_v.tile_y < 0 || prm_v.tile_w <= 0 || prm_v.tile_h <= 0 ||
+      prm_v.tile_x + prm_v.tile_w > pic_w || prm_v.tile_y + prm_v.tile_h > pic_h || (prm_v.tile_x & 63) || (prm_v.tile_y & 63)) {
+    set_error_msg("kvz_hip_search_pu_batch: mv_constraint must be 0..4 and the tile (origin a multiple of 64) must lie inside the picture");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  params = &prm_v;
   if (count == 0) return KVZ_HIP_OK;
   if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
   hipStream_t st = ctx_stream(s);
@@ -641,6 +660,11 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   // one launch per size class over the same descriptor list; each kernel takes its class and skips the rest.  The big
   // kernel also flags malformed descriptors, so it only goes when the caller vouches for the classes it names.
   const int classes = (params->size_classes & 7) ? (params->size_classes & 7) : 7;
+  if (classes != 7) {
+    // with a hint, PUs of a class it does not name are searched by no kernel: they read cost 0xFFFFFFFF, reserved -1
+    hipError_t e = hipMemsetAsync(results, 0xFF, count * sizeof(kvz_hip_me_result), st);
+    if (e != hipSuccess) { set_error("hipMemsetAsync(results)", e); return KVZ_HIP_ERR_RUNTIME; }
+  }
   if (classes == 7 || (classes & 4)) {
     const int bt = tuning("me_big_threads", 512);      // measured at 480 and 1920 PUs of 64x64: 512 threads 10.5 M/s, 256: 9.5, 1024: 6.5
     if (bt == 1024) hipLaunchKernelGGL(search_pu_big_kernel<1024>, dim3((unsigned)count), dim3(1024), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);

@@ -66,9 +66,20 @@ struct call_ctx {
   }
 };
 
+// one staging context per (host thread, device): a worker that switches devices with kvz_hip_set_device keeps both
 call_ctx &tls()
 {
-  static thread_local call_ctx c;
+  static thread_local call_ctx *per_dev[64] = { nullptr };
+  struct reaper { call_ctx **v; ~reaper() { for (int i = 0; i < 64; ++i) delete v[i]; } };
+  static thread_local reaper r{ per_dev };
+  if (!ctx_enter()) (void)kvz_hip_init(-1);
+  const int d = ctx_device();
+  if (d < 0 || d >= 64) {
+    std::fprintf(stderr, "kvzhip: no GPU context in a strategy call: %s\n", kvz_hip_last_error());
+    std::abort();
+  }
+  if (!per_dev[d]) per_dev[d] = new call_ctx();
+  call_ctx &c = *per_dev[d];
   if (!c.ok) {
     // A strategy function has no error channel: never return garbage.
     std::fprintf(stderr, "kvzhip: GPU context unavailable in a strategy call: %s\n", kvz_hip_last_error());

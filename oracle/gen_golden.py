@@ -15,7 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_lib as R  # noqa: E402
-from patterns import (dct_test_input, intra_ref_cases, me_frames, me_params, me_random_pus, rng, sao_blocks,  # noqa: E402
+from patterns import (dct_test_input, intra_ref_cases, me_frames, me_params, me_pus_in_tile, me_random_pus, rng, sao_blocks,  # noqa: E402
                       sao_records)
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -176,14 +176,18 @@ def me():
     d = {}
     cfgs = [dict(), dict(early_termination=2, fme_level=2, lambda_cost=35), dict(wpp_owf=1, ref_delay_px=10, lambda_cost=9, early_termination=0),
             dict(algorithm=1, lambda_cost=25), dict(algorithm=2, lambda_cost=15),
-            dict(algorithm=3, search_range=8, lambda_cost=30)]
+            dict(algorithm=3, search_range=8, lambda_cost=30),
+            # the mv_constraint branches of fracmv_within_tile (search_inter.c:142-171), frame = one tile and a real tile
+            dict(mv_constraint=1, lambda_cost=12), dict(mv_constraint=4, lambda_cost=12, early_termination=0),
+            dict(mv_constraint=3, tile=(64, 0, 128, 128), lambda_cost=18),
+            dict(mv_constraint=4, tile=(0, 64, 192, 64), wpp_owf=1, ref_delay_px=10, lambda_cost=9, algorithm=1)]
     pic, ref = me_frames(192, 128, SEED + 7, (5, -3))
     pus = me_random_pus(192, 128, 48, SEED + 8, hint=(-18, 12))
     d["pic"], d["ref"], d["pus"] = pic, ref, pus.view(np.uint8).reshape(len(pus), 64)
     for i, c in enumerate(cfgs):
         prm = me_params(**c)
-        d["params%d" % i] = prm.view(np.int32).reshape(12)
-        d["results%d" % i] = R.search_pu_batch(pic, ref, pus, prm).view(np.int32).reshape(len(pus), 8)
+        d["params%d" % i] = prm.view(np.int32).reshape(16)
+        d["results%d" % i] = R.search_pu_batch(pic, ref, me_pus_in_tile(pus, prm), prm).view(np.int32).reshape(len(pus), 8)
     np.savez_compressed(os.path.join(OUT, "me.npz"), **d)
 
 
@@ -209,6 +213,8 @@ if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    picture(); dct(); quant(); ipol(); intra(); sao(); me(); deblock()
+    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, sao=sao, me=me, deblock=deblock)
+    for name in (sys.argv[1:] or list(groups)):          # python oracle/gen_golden.py [group ...]
+        groups[name]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -765,21 +765,31 @@ int orc_get_extended_block(int xpos, int ypos, int mv_x, int mv_y, int off_x, in
 /* ---- MV cost model: search_inter.c:87-176, :235-412 ---- */
 typedef struct { const orc_me_pu *pu; const orc_me_params *prm; } me_ctx;
 
-/* fracmv_within_tile (:87-176) for mv_constraint == NONE; x, y in quarter-pel */
+/* fracmv_within_tile (:87-176); x, y in quarter-pel.  The reference's info->origin is relative to the tile
+ * (the search runs on the tile's sub-frame), ours is a picture position: subtract the tile offset first. */
 static int me_within(const me_ctx *mc, int x, int y)
 {
-  if (!mc || !mc->prm->wpp_owf) return 1;
+  if (!mc) return 1;
   const orc_me_pu *pu = mc->pu;
-  int margin = 0;
-  if (x % 4 != 0 || y % 4 != 0) margin = 4;
-  else if (x % 8 != 0 || y % 8 != 0) margin = 2;
-  margin += mc->prm->ref_delay_px;
-  const int lcu_x = pu->x / 64, lcu_y = pu->y / 64;
-  const int mv_lcu_x = ((pu->x + pu->width + margin) * 4 + x) / (64 << 2) - lcu_x;
-  const int mv_lcu_y = ((pu->y + pu->height + margin) * 4 + y) / (64 << 2) - lcu_y;
-  if (mv_lcu_y > mc->prm->max_ref_lcu_down) return 0;
-  if (mv_lcu_x + mv_lcu_y > mc->prm->max_ref_lcu_down + mc->prm->max_ref_lcu_right) return 0;
-  return 1;
+  const orc_me_params *prm = mc->prm;
+  const int is_frac_luma = x % 4 != 0 || y % 4 != 0, is_frac_chroma = x % 8 != 0 || y % 8 != 0;
+  const int org_x = pu->x - prm->tile_x, org_y = pu->y - prm->tile_y;
+  if (prm->wpp_owf) {                                   /* :95-139: only final pixels of the reference may be read */
+    int margin = is_frac_luma ? 4 : (is_frac_chroma ? 2 : 0);
+    margin += prm->ref_delay_px;
+    const int lcu_x = org_x / 64, lcu_y = org_y / 64;
+    const int mv_lcu_x = ((org_x + pu->width + margin) * 4 + x) / (64 << 2) - lcu_x;
+    const int mv_lcu_y = ((org_y + pu->height + margin) * 4 + y) / (64 << 2) - lcu_y;
+    if (mv_lcu_y > prm->max_ref_lcu_down) return 0;
+    if (mv_lcu_x + mv_lcu_y > prm->max_ref_lcu_down + prm->max_ref_lcu_right) return 0;
+  }
+  if (prm->mv_constraint == 0) return 1;                /* :142-144 */
+  int margin_q = 0;                                     /* :146-154: quarter-pel margin, only for FRAME_AND_TILE_MARGIN */
+  if (prm->mv_constraint == 4) margin_q = is_frac_luma ? 4 << 2 : (is_frac_chroma ? 2 << 2 : 0);
+  const int abs_x = org_x * 4 + x, abs_y = org_y * 4 + y;
+  const int from_right = (prm->tile_w << 2) - (abs_x + (pu->width << 2));
+  const int from_bottom = (prm->tile_h << 2) - (abs_y + (pu->height << 2));
+  return abs_x >= margin_q && abs_y >= margin_q && from_right >= margin_q && from_bottom >= margin_q;
 }
 
 /* get_ep_ex_golomb_bitcost (:235-254) */
@@ -1101,6 +1111,11 @@ void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, i
 {
   me_info in;
   memset(&in, 0, sizeof(in));
+  orc_me_params whole;
+  if (prm->tile_w == 0 && prm->tile_h == 0) {            /* no tiles: the picture (same size as its references) is the tile */
+    whole = *prm; whole.tile_x = 0; whole.tile_y = 0; whole.tile_w = ref_w; whole.tile_h = ref_h;
+    prm = &whole;
+  }
   in.pic = pic; in.ref = ref; in.pic_stride = pic_stride; in.ref_w = ref_w; in.ref_h = ref_h;
   in.mc.pu = pu; in.mc.prm = prm;
   if (prm->algorithm == 1) me_diamond(&in);
@@ -1588,4 +1603,27 @@ void orc_deblock_frame(orc_pixel *y, int stride_y, orc_pixel *u, orc_pixel *v, i
           db_chroma_segment(v + (size_t)yc * stride_c + xc, dir ? stride_c : 1, dir ? 1 : stride_c, tc);
         }
       }
+}
+
+/* ---- whole-launch checks (tests/test_gpu_fullsize.py): the per-block functions above over `count` contiguous blocks.
+ * Pure loops, so that a test can hand disjoint ranges to several host threads. ---- */
+void orc_cost_nxn_many(int satd, int n, const orc_pixel *b1, const orc_pixel *b2, size_t count, unsigned *costs)
+{
+  const size_t bs = (size_t)n * n;
+  for (size_t i = 0; i < count; ++i)
+    costs[i] = satd ? orc_satd_nxn(n, b1 + i * bs, b2 + i * bs) : orc_sad_nxn(n, b1 + i * bs, b2 + i * bs);
+}
+void orc_transform_many(int kind, int n, const int16_t *in, int16_t *out, size_t count)
+{
+  const size_t bs = (size_t)n * n;
+  for (size_t i = 0; i < count; ++i) orc_transform(kind, n, in + i * bs, out + i * bs);
+}
+void orc_quantize_residual_many(const orc_quant_params *p, int cu_is_intra, int width, int color, int scan_order, int use_trskip,
+                                const orc_pixel *ref_in, const orc_pixel *pred_in, orc_pixel *rec_out, orc_coeff *coeff_out,
+                                int32_t *has_coeffs, size_t count)
+{
+  const size_t bs = (size_t)width * width;
+  for (size_t i = 0; i < count; ++i)
+    has_coeffs[i] = orc_quantize_residual(p, cu_is_intra, width, color, scan_order, use_trskip, width, width,
+                                          ref_in + i * bs, pred_in + i * bs, rec_out + i * bs, coeff_out + i * bs);
 }

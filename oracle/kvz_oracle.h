@@ -202,8 +202,11 @@ typedef struct {
   int32_t algorithm;             /* cfg.ime_algorithm: 0 hexbs (hexagon_search), 1 dia (diamond_search :796-883), 2 tz (tz_search :595-672),
                                     3 full (search_mv_full :886-962) */
   int32_t search_range;          /* algorithm 3: 8, 16, 32 or 64 (search_inter.c:1208-1215) */
-  int32_t size_classes, reserved;   /* launch hints of the GPU entry; unused here */
-} orc_me_params;                 /* 48 bytes */
+  int32_t size_classes;          /* launch hint of the GPU entry; unused here */
+  int32_t mv_constraint;         /* cfg.mv_constraint (kvazaar.h:113-119): the branches of fracmv_within_tile :142-171 */
+  int32_t tile_x, tile_y;        /* state->tile->offset_x / _y in the picture */
+  int32_t tile_w, tile_h;        /* state->tile->frame->width / height; 0 x 0 = the picture is one tile */
+} orc_me_params;                 /* 64 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */
   uint32_t cost, bitcost;        /* info->best_cost, info->best_bitcost */
@@ -274,4 +277,11 @@ void orc_deblock_frame(orc_pixel *y, int stride_y, orc_pixel *u, orc_pixel *v, i
 #ifdef __cplusplus
 }
 #endif
+/* the per-block functions over `count` contiguous blocks (whole-launch parity checks, one range per host thread) */
+void orc_cost_nxn_many(int satd, int n, const orc_pixel *b1, const orc_pixel *b2, size_t count, unsigned *costs);
+void orc_transform_many(int kind, int n, const int16_t *in, int16_t *out, size_t count);
+void orc_quantize_residual_many(const orc_quant_params *p, int cu_is_intra, int width, int color, int scan_order, int use_trskip,
+                                const orc_pixel *ref_in, const orc_pixel *pred_in, orc_pixel *rec_out, orc_coeff *coeff_out,
+                                int32_t *has_coeffs, size_t count);
+
 #endif

@@ -300,6 +300,24 @@ double ref_bench_transform(const char *type, const char *name, int n, const int1
   return (double)done / (t1 - t0);
 }
 
+/* whole-launch parity checks: one strategy function over `count` contiguous blocks (a test gives each host thread a range) */
+int ref_cost_nxn_many(const char *type, const char *name, int n, const kvz_pixel *a, const kvz_pixel *b, size_t count, unsigned *costs)
+{
+  cost_pixel_nxn_func *f = (cost_pixel_nxn_func *)ref_strategy(type, name);
+  if (!f) return -1;
+  const size_t bs = (size_t)n * n;
+  for (size_t i = 0; i < count; ++i) costs[i] = f(a + i * bs, b + i * bs);
+  return 0;
+}
+int ref_transform_many(const char *type, const char *name, int n, const int16_t *in, int16_t *out, size_t count)
+{
+  dct_func *f = (dct_func *)ref_strategy(type, name);
+  if (!f) return -1;
+  const size_t bs = (size_t)n * n;
+  for (size_t i = 0; i < count; ++i) f(8, in + i * bs, out + i * bs);
+  return 0;
+}
+
 double ref_bench_reg_sad(const char *name, const kvz_pixel *a, const kvz_pixel *b, int stride, int fw, int fh,
                          int bw, int bh, double budget_s, unsigned *checksum)
 {

@@ -31,12 +31,16 @@ typedef struct {
   int32_t lambda_cost, early_termination;
   uint32_t max_steps;
   int32_t fme_level, wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right;
-  int32_t algorithm, search_range, size_classes, reserved;
+  int32_t algorithm, search_range, size_classes, mv_constraint;
+  int32_t tile_x, tile_y, tile_w, tile_h;
 } me_params_t;
 typedef struct { int32_t mv[2]; uint32_t cost, bitcost; int32_t merged, merge_idx, mv_cand, reserved; } me_result_t;
 
 /* the hexbs path of search_pu_inter_ref (search_inter.c:1134-1300) on a fabricated encoder state:
- * one reference picture (ref_idx 0 = L0[0]), no tiles, mv_constraint none, mv_rdo off */
+ * one reference picture (ref_idx 0 = L0[0]), mv_rdo off.  With a tile (tile_w x tile_h at tile_x, tile_y; 0 x 0 = the
+ * whole frame) the state is set up the way encoderstate.c does for a tile: state->tile->offset_x/_y, a tile frame of
+ * the tile's size whose source is a sub-image of the picture, info->origin relative to the tile; references stay whole
+ * frames (kvz_image_calc_sad / kvz_get_extended_block add the tile offset themselves). */
 void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_w, int frame_h,
                       const me_pu_t *pu, const me_params_t *prm, me_result_t *res)
 {
@@ -55,12 +59,16 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   ctrl.cfg.wpp = prm->wpp_owf ? 1 : 0;
   ctrl.cfg.sao_type = prm->ref_delay_px == SAO_DELAY_PX ? 1 : 0;
   ctrl.cfg.deblock_enable = prm->ref_delay_px == DEBLOCK_DELAY_PX ? 1 : 0;
-  ctrl.cfg.mv_constraint = KVZ_MV_CONSTRAIN_NONE;
+  ctrl.cfg.mv_constraint = (enum kvz_mv_constraint)prm->mv_constraint;
+  const int tiled = prm->tile_w != 0 || prm->tile_h != 0;
+  const int tx = tiled ? prm->tile_x : 0, ty = tiled ? prm->tile_y : 0;
+  const int tw = tiled ? prm->tile_w : frame_w, th = tiled ? prm->tile_h : frame_h;
   ctrl.cfg.mv_rdo = 0;
   ctrl.max_inter_ref_lcu.down = prm->max_ref_lcu_down;
   ctrl.max_inter_ref_lcu.right = prm->max_ref_lcu_right;
-  vframe.width = frame_w; vframe.height = frame_h;
+  vframe.width = tw; vframe.height = th;
   tile.frame = &vframe;
+  tile.offset_x = tx; tile.offset_y = ty;
   frame.ref_LX[0][0] = 0; frame.ref_LX[0][1] = 1; frame.ref_LX_size[0] = 2;
   state.encoder_control = &ctrl;
   state.tile = &tile;
@@ -70,12 +78,12 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
 
   kvz_picture pic, ref;
   memset(&pic, 0, sizeof(pic)); memset(&ref, 0, sizeof(ref));
-  pic.y = (kvz_pixel *)pic_y; pic.width = frame_w; pic.height = frame_h; pic.stride = frame_w;
+  pic.y = (kvz_pixel *)pic_y + (size_t)ty * frame_w + tx; pic.width = tw; pic.height = th; pic.stride = frame_w;   /* kvz_image_make_subimage */
   ref.y = (kvz_pixel *)ref_y; ref.width = frame_w; ref.height = frame_h; ref.stride = frame_w;
 
   inter_search_info_t info = {
     .state = &state, .pic = &pic, .ref = &ref, .ref_idx = 0,
-    .origin = { pu->x, pu->y }, .width = pu->width, .height = pu->height,
+    .origin = { pu->x - tx, pu->y - ty }, .width = pu->width, .height = pu->height,
     .mvd_cost_func = calc_mvd_cost,
   };
   memcpy(info.mv_cand, pu->mv_cand, sizeof(info.mv_cand));
@@ -97,8 +105,8 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   if (prm->fme_level > 0 && info.best_cost < UINT32_MAX) {
     search_frac(&info);
   } else if (info.best_cost < UINT32_MAX) {
-    info.best_cost = kvz_image_calc_satd(&pic, &ref, pu->x, pu->y, pu->x + (info.best_mv.x >> 2), pu->y + (info.best_mv.y >> 2),
-                                         pu->width, pu->height);
+    info.best_cost = kvz_image_calc_satd(&pic, &ref, info.origin.x, info.origin.y, tx + info.origin.x + (info.best_mv.x >> 2),
+                                         ty + info.origin.y + (info.best_mv.y >> 2), pu->width, pu->height);   /* :1236-1248 */
     info.best_cost += info.best_bitcost * (int)(state.lambda_sqrt + 0.5);
   }
   memset(res, 0, sizeof(*res));

@@ -3,6 +3,7 @@
  * taken from the reference's own unit tests, a frame graph, and the error channel.
  * Built by __graft_entry__.build() with gcc and linked against kvazaar_amd/libkvzhip.so; run by tests/test_gpu_c_host.py.
  * Exit code 0 = every check passed. */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -11,6 +12,38 @@
 
 #define CHECK(cond, ...) do { if (!(cond)) { fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); \
                                              fprintf(stderr, " (%s)\n", kvz_hip_last_error()); return 1; } } while (0)
+
+/* One worker thread of a multi-device host (the reference's workers are pthreads, threadqueue.c:263): binds itself to
+ * a device with kvz_hip_set_device and runs known-answer launches there with its own stream and buffers.  On a
+ * 1-GPU box both workers get device 0 -- two threads, two streams, one context; with more devices each gets its own. */
+typedef struct { int device; int seed; int failed; char msg[256]; } worker_arg;
+#define WCHECK(cond, ...) do { if (!(cond)) { snprintf(a->msg, sizeof(a->msg), __VA_ARGS__); a->failed = 1; return NULL; } } while (0)
+static void *worker(void *p)
+{
+  worker_arg *a = p;
+  enum { N = 4096 };
+  WCHECK(kvz_hip_set_device(a->device) == KVZ_HIP_OK, "set_device(%d): %s", a->device, kvz_hip_last_error());
+  WCHECK(kvz_hip_get_device() == a->device, "get_device = %d, want %d", kvz_hip_get_device(), a->device);
+  kvz_hip_stream st = kvz_hip_stream_create();
+  unsigned char *h_a = malloc(N * 64), *h_b = malloc(N * 64);
+  uint32_t *h_cost = malloc(N * sizeof(uint32_t));
+  for (int i = 0; i < N; ++i) { memset(h_a + i * 64, (i * 7 + a->seed) & 255, 64); memset(h_b + i * 64, (i * 3) & 255, 64); }
+  kvz_hip_pixel *d_a = kvz_hip_malloc(N * 64), *d_b = kvz_hip_malloc(N * 64);
+  uint32_t *d_cost = kvz_hip_malloc(N * sizeof(uint32_t));
+  WCHECK(st && d_a && d_b && d_cost, "alloc on device %d: %s", a->device, kvz_hip_last_error());
+  for (int rep = 0; rep < 20; ++rep) {
+    WCHECK(kvz_hip_memcpy_h2d(d_a, h_a, N * 64, st) == KVZ_HIP_OK && kvz_hip_memcpy_h2d(d_b, h_b, N * 64, st) == KVZ_HIP_OK, "h2d");
+    WCHECK(kvz_hip_satd_nxn_batch(8, d_a, d_b, N, d_cost, st) == KVZ_HIP_OK, "satd: %s", kvz_hip_last_error());
+    WCHECK(kvz_hip_memcpy_d2h(h_cost, d_cost, N * sizeof(uint32_t), st) == KVZ_HIP_OK, "d2h");
+    for (int i = 0; i < N; ++i) {
+      const int d = abs(((i * 7 + a->seed) & 255) - ((i * 3) & 255));
+      WCHECK(h_cost[i] == (64u * (unsigned)d + 2) >> 2, "thread seed %d: satd_8x8[%d] = %u, flat difference %d", a->seed, i, h_cost[i], d);
+    }
+  }
+  kvz_hip_free(d_a); kvz_hip_free(d_b); kvz_hip_free(d_cost); kvz_hip_stream_destroy(st);
+  free(h_a); free(h_b); free(h_cost);
+  return NULL;
+}
 
 int main(void)
 {
@@ -70,6 +103,49 @@ int main(void)
   /* ---- the error channel: an unsupported size is refused with a message, nothing is launched ---- */
   CHECK(kvz_hip_sad_nxn_batch(7, d_a, d_b, N, d_cost, st) == KVZ_HIP_ERR_INVALID, "sad_nxn_batch(7) must be refused");
   CHECK(strstr(kvz_hip_last_error(), "kvz_hip_sad_nxn_batch") != NULL, "error text names the entry");
+
+  /* ---- the NULL stream is ordered like the legacy default stream: a memset queued there with no synchronisation is
+   * seen by the entry, and the entry's result by a following default-stream copy (kvz_hip.h, kvz_hip_stream) ---- */
+  CHECK(kvz_hip_memset(d_a, 9, N * 64, NULL) == KVZ_HIP_OK && kvz_hip_memset(d_b, 4, N * 64, NULL) == KVZ_HIP_OK, "memset");
+  CHECK(kvz_hip_sad_nxn_batch(8, d_a, d_b, N, d_cost, NULL) == KVZ_HIP_OK, "sad on the NULL stream");
+  CHECK(kvz_hip_memcpy_d2h(h_cost, d_cost, N * sizeof(uint32_t), NULL) == KVZ_HIP_OK, "d2h");
+  for (int i = 0; i < N; ++i) CHECK(h_cost[i] == 64u * 5u, "NULL-stream sad_8x8[%d] = %u", i, h_cost[i]);
+
+  /* ---- several contexts in one process: every visible device gets a context; a second init of another index is a
+   * second context, an index beyond the device count is refused; two pthreads drive (up to) two devices at once ---- */
+  const int ndev = kvz_hip_device_count();
+  CHECK(ndev >= 1, "device count");
+  CHECK(kvz_hip_init(ndev) == KVZ_HIP_ERR_INVALID, "init of a device index beyond the count must be refused");
+  CHECK(strstr(kvz_hip_last_error(), "out of range") != NULL, "error text");
+  const int home = kvz_hip_get_device();
+  for (int d = 0; d < ndev; ++d) CHECK(kvz_hip_init(d) == KVZ_HIP_OK && kvz_hip_get_device() == d, "init(%d)", d);
+  CHECK(kvz_hip_set_device(home) == KVZ_HIP_OK, "back to device %d", home);
+  worker_arg wa[2] = { { 0, 1, 0, "" }, { ndev > 1 ? 1 : 0, 2, 0, "" } };
+  pthread_t th[2];
+  for (int i = 0; i < 2; ++i) CHECK(pthread_create(&th[i], NULL, worker, &wa[i]) == 0, "pthread_create");
+  for (int i = 0; i < 2; ++i) pthread_join(th[i], NULL);
+  for (int i = 0; i < 2; ++i) CHECK(!wa[i].failed, "worker %d on device %d: %s", i, wa[i].device, wa[i].msg);
+  CHECK(kvz_hip_get_device() == home, "the main thread's device is untouched by the workers");
+  /* shard-boundary exchange inside one process: rows of device A's plane into device B's halo (same device on a 1-GPU box) */
+  {
+    const int da = 0, db = ndev > 1 ? 1 : 0;
+    enum { ROWS = 80, W = 3840 };
+    CHECK(kvz_hip_set_device(da) == KVZ_HIP_OK, "set_device");
+    unsigned char *src = kvz_hip_malloc((size_t)ROWS * W);
+    CHECK(src && kvz_hip_memset(src, 0x5A, (size_t)ROWS * W, NULL) == KVZ_HIP_OK, "src rows");
+    CHECK(kvz_hip_set_device(db) == KVZ_HIP_OK, "set_device");
+    unsigned char *halo = kvz_hip_malloc((size_t)ROWS * W);
+    CHECK(halo && kvz_hip_memset(halo, 0, (size_t)ROWS * W, NULL) == KVZ_HIP_OK, "halo rows");
+    CHECK(kvz_hip_set_device(da) == KVZ_HIP_OK && kvz_hip_stream_sync(NULL) == KVZ_HIP_OK, "src ready");
+    CHECK(kvz_hip_set_device(db) == KVZ_HIP_OK, "set_device");
+    CHECK(kvz_hip_memcpy_peer(halo, db, src, da, (size_t)ROWS * W, NULL) == KVZ_HIP_OK, "memcpy_peer");
+    unsigned char *back = malloc((size_t)ROWS * W);
+    CHECK(kvz_hip_memcpy_d2h(back, halo, (size_t)ROWS * W, NULL) == KVZ_HIP_OK, "d2h");
+    for (int i = 0; i < ROWS * W; i += 997) CHECK(back[i] == 0x5A, "halo byte %d = %d", i, back[i]);
+    free(back); kvz_hip_free(halo);
+    CHECK(kvz_hip_set_device(da) == KVZ_HIP_OK, "set_device"); kvz_hip_free(src);
+    CHECK(kvz_hip_set_device(home) == KVZ_HIP_OK, "set_device");
+  }
 
   kvz_hip_free(d_a); kvz_hip_free(d_b); kvz_hip_free(d_cost); kvz_hip_free(d_res); kvz_hip_free(d_coef);
   kvz_hip_stream_destroy(st);

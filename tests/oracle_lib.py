@@ -82,8 +82,54 @@ def lib():
         L.orc_search_frac_costs.restype = None
         L.orc_search_frac_costs.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int] + [C.c_int] * 6 + \
             [u32p, C.POINTER(C.c_int)]
+        L.orc_cost_nxn_many.restype = None
+        L.orc_cost_nxn_many.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_transform_many.restype = None
+        L.orc_transform_many.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.orc_quantize_residual_many.restype = None
+        L.orc_quantize_residual_many.argtypes = [C.POINTER(QuantParams)] + [C.c_int] * 5 + [C.c_void_p] * 5 + [C.c_size_t]
         _LIB = L
     return _LIB
+
+
+def host_threads():
+    try:
+        return max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(32, os.cpu_count() or 1))
+
+
+def run_ranges(count, fn, threads=None):
+    """fn(lo, hi) over [0, count) cut into one contiguous range per host thread (ctypes calls release the GIL)"""
+    import concurrent.futures
+    threads = threads or host_threads()
+    step = (count + threads - 1) // threads if count else 1
+    ranges = [(lo, min(count, lo + step)) for lo in range(0, count, step)]
+    if len(ranges) <= 1:
+        for lo, hi in ranges:
+            fn(lo, hi)
+        return
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(lambda r: fn(*r), ranges))
+
+
+def cost_nxn_many(kind, n, blk1, blk2, threads=None):
+    """cost_nxn_batch for whole launches: the loop runs in C, one range of blocks per host thread"""
+    blk1, blk2 = _u8(blk1).reshape(-1, n * n), _u8(blk2).reshape(-1, n * n)
+    out = np.empty(blk1.shape[0], dtype=np.uint32)
+    L, bs = lib(), n * n
+    run_ranges(blk1.shape[0], lambda lo, hi: L.orc_cost_nxn_many(int(kind == "satd"), n, blk1.ctypes.data + lo * bs, blk2.ctypes.data + lo * bs,
+                                                                 hi - lo, out.ctypes.data + 4 * lo), threads)
+    return out
+
+
+def transform_many(kind, n, blocks, threads=None):
+    blocks = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, n * n)
+    out = np.empty_like(blocks)
+    L, bs, k = lib(), 2 * n * n, {"dct": 0, "idct": 1, "dst": 2, "idst": 3}[kind]
+    L.orc_dct_matrix(n)                    # builds the oracle's lazily generated matrices before the threads start
+    run_ranges(blocks.shape[0], lambda lo, hi: L.orc_transform_many(k, n, blocks.ctypes.data + lo * bs, out.ctypes.data + lo * bs, hi - lo), threads)
+    return out
 
 
 def _p(a, t):
@@ -241,6 +287,23 @@ def quantize_residual_batch(ref_in, pred_in, w, qp, color, scan_order_, cu_is_in
         has[i] = lib().orc_quantize_residual(C.byref(p), int(cu_is_intra), w, color, scan_order_, int(use_trskip),
                                              w, w, _p(ref_in[i], u8p), _p(pred_in[i], u8p), _p(rec[i], u8p),
                                              _p(coeff[i], i16p))
+    return rec, coeff, has
+
+
+def quantize_residual_many(ref_in, pred_in, w, qp, color, scan_order_, cu_is_intra, slice_is_intra=0, signhide=0, use_trskip=0,
+                           threads=None):
+    """quantize_residual_batch for whole launches (C loop, one range of TUs per host thread)"""
+    ref_in, pred_in = _u8(ref_in).reshape(-1, w * w), _u8(pred_in).reshape(-1, w * w)
+    rec = np.zeros_like(ref_in)
+    coeff = np.zeros(ref_in.shape, dtype=np.int16)
+    has = np.zeros(ref_in.shape[0], dtype=np.int32)
+    p, keep = _qp(qp, slice_is_intra, signhide)
+    L, bs = lib(), w * w
+    L.orc_dct_matrix(w)
+    L.orc_scan_order(scan_order_, {4: 2, 8: 3, 16: 4, 32: 5}[w])
+    run_ranges(ref_in.shape[0], lambda lo, hi: L.orc_quantize_residual_many(
+        C.byref(p), int(cu_is_intra), w, color, scan_order_, int(use_trskip), ref_in.ctypes.data + lo * bs, pred_in.ctypes.data + lo * bs,
+        rec.ctypes.data + lo * bs, coeff.ctypes.data + 2 * lo * bs, has.ctypes.data + 4 * lo, hi - lo), threads)
     return rec, coeff, has
 
 

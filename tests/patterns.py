@@ -129,19 +129,24 @@ ME_PU = np.dtype([("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"
                   ("merge", [("mv", "<i2", (2,)), ("usable", "u1"), ("same_ref", "u1")], (5,)), ("pad", "<i2")])
 ME_PARAMS = np.dtype([("lambda_cost", "<i4"), ("early_termination", "<i4"), ("max_steps", "<u4"), ("fme_level", "<i4"),
                       ("wpp_owf", "<i4"), ("ref_delay_px", "<i4"), ("max_ref_lcu_down", "<i4"), ("max_ref_lcu_right", "<i4"),
-                      ("algorithm", "<i4"), ("search_range", "<i4"), ("size_classes", "<i4"), ("reserved", "<i4")])
+                      ("algorithm", "<i4"), ("search_range", "<i4"), ("size_classes", "<i4"), ("mv_constraint", "<i4"),
+                      ("tile_x", "<i4"), ("tile_y", "<i4"), ("tile_w", "<i4"), ("tile_h", "<i4")])
 ME_RESULT = np.dtype([("mv", "<i4", (2,)), ("cost", "<u4"), ("bitcost", "<u4"), ("merged", "<i4"), ("merge_idx", "<i4"),
                       ("mv_cand", "<i4"), ("reserved", "<i4")])
-assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 48 and ME_RESULT.itemsize == 32
+assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 64 and ME_RESULT.itemsize == 32
 
 
 def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_level=4, wpp_owf=0, ref_delay_px=0,
-              max_ref_lcu_down=1, max_ref_lcu_right=1, algorithm=0, search_range=0):
+              max_ref_lcu_down=1, max_ref_lcu_right=1, algorithm=0, search_range=0, mv_constraint=0, tile=None):
+    """tile: (x, y, w, h) of state->tile in the picture, None = the picture is one tile"""
     p = np.zeros(1, dtype=ME_PARAMS)
     p["lambda_cost"], p["early_termination"], p["max_steps"], p["fme_level"] = lambda_cost, early_termination, max_steps, fme_level
     p["wpp_owf"], p["ref_delay_px"], p["max_ref_lcu_down"], p["max_ref_lcu_right"] = wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right
     p["algorithm"] = algorithm
     p["search_range"] = search_range
+    p["mv_constraint"] = mv_constraint
+    if tile is not None:
+        p["tile_x"], p["tile_y"], p["tile_w"], p["tile_h"] = tile
     return p
 
 
@@ -190,6 +195,20 @@ def me_random_pus(w, h, count, seed, hint=None,
                 pus[i]["merge"][k]["same_ref"] = int(i % 4 != 0)
             else:
                 pus[i]["mv_cand"][int(g.integers(0, 2))] = hint
+    return pus
+
+
+def me_pus_in_tile(pus, prm):
+    """with tiles the reference only ever searches PUs of the tile: move the random PUs into it"""
+    tw, th = int(prm["tile_w"][0]), int(prm["tile_h"][0])
+    if tw == 0:
+        return pus
+    tx, ty = int(prm["tile_x"][0]), int(prm["tile_y"][0])
+    pus = pus.copy()
+    pus["width"] = np.minimum(pus["width"], tw)
+    pus["height"] = np.minimum(pus["height"], th)
+    pus["x"] = tx + np.minimum(pus["x"] % tw, tw - pus["width"]) // 8 * 8
+    pus["y"] = ty + np.minimum(pus["y"] % th, th - pus["height"]) // 8 * 8
     return pus
 
 

@@ -80,6 +80,10 @@ def lib():
         L.ref_bench_transform.argtypes = [S, S, C.c_int, i16p, i16p, C.c_size_t, C.c_double]
         L.ref_bench_reg_sad.restype = C.c_double
         L.ref_bench_reg_sad.argtypes = [S, u8p, u8p] + [C.c_int] * 5 + [C.c_double, u32p]
+        L.ref_cost_nxn_many.restype = C.c_int
+        L.ref_cost_nxn_many.argtypes = [S, S, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ref_transform_many.restype = C.c_int
+        L.ref_transform_many.argtypes = [S, S, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         # the selector prints its "Available/In use" banner on stderr
         if not L.ref_init():
             raise RuntimeError("reference strategyselector init failed")
@@ -127,6 +131,34 @@ def cost_nxn_batch(kind, n, blk1, blk2, name="generic"):
     out = np.empty(blk1.shape[0], dtype=np.uint32)
     for i in range(blk1.shape[0]):
         out[i] = lib().ref_cost_nxn(t, name.encode(), blk1[i].ctypes.data, blk2[i].ctypes.data)
+    return out
+
+
+def cost_nxn_many(kind, n, blk1, blk2, name="generic", threads=None):
+    """whole launches: the strategy function looped in C, one range of blocks per host thread"""
+    from oracle_lib import run_ranges
+    blk1 = _aligned(_u8(blk1).reshape(-1, n * n))
+    blk2 = _aligned(_u8(blk2).reshape(-1, n * n))
+    t, nm, bs = ("%s_%dx%d" % (kind, n, n)).encode(), name.encode(), n * n
+    out = np.empty(blk1.shape[0], dtype=np.uint32)
+    L = lib()
+
+    def part(lo, hi):
+        assert L.ref_cost_nxn_many(t, nm, n, blk1.ctypes.data + lo * bs, blk2.ctypes.data + lo * bs, hi - lo, out.ctypes.data + 4 * lo) == 0
+    run_ranges(blk1.shape[0], part, threads)
+    return out
+
+
+def transform_many(kind, n, blocks, name="generic", threads=None):
+    from oracle_lib import run_ranges
+    blocks = _aligned(np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, n * n))
+    out = _aligned(np.zeros_like(blocks))
+    t, nm, bs = _TR_TYPE[(kind, n)].encode(), name.encode(), 2 * n * n
+    L = lib()
+
+    def part(lo, hi):
+        assert L.ref_transform_many(t, nm, n, blocks.ctypes.data + lo * bs, out.ctypes.data + lo * bs, hi - lo) == 0
+    run_ranges(blocks.shape[0], part, threads)
     return out
 
 

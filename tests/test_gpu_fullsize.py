@@ -1,13 +1,16 @@
 """The headline kernels at the benchmark's FULL batch size (1080p CTU grid x 128 frames: 4 147 200 8x8 pairs, 253 440 32x32
-blocks -- bench.py's workload), checked through properties that do not need the oracle to chew through gigabytes:
-sums against an independent torch computation, symmetry / identity, the forward-inverse round trip, and an exact comparison
-with the oracle on a strided sample of the very same launch."""
+blocks -- bench.py's workload): EVERY output of the launch bench.py times is compared bit for bit with the oracle (its C
+loops run over the host cores, a few seconds per launch), next to size-independent properties (symmetry / identity, sums
+against an independent torch computation, the forward-inverse round trip).  The same for one 4K frame's worth of blocks
+(BASELINE.json configs[4]: 3840x2160) of every SAD / SATD size and every transform, with ragged counts, so that every
+grid-cap and tail branch of the launch code is taken at counts far beyond the small parity cases."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
 import oracle_lib as O
+import ref_lib as R
 
 pytestmark = pytest.mark.gpu
 
@@ -57,11 +60,12 @@ def test_sad_satd_8x8_full_batch(env):
     _lib.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), cur.data_ptr(), N8, out[3].data_ptr(), None), "satd self")
     _lib.check(L.kvz_hip_stream_sync(None), "sync")
     assert int(out[3].abs().max()) == 0
-    # exact against the oracle on a strided sample of the same launch (incl. the last block)
-    idx = torch.cat([torch.arange(0, N8, 2039, device=dev), torch.tensor([N8 - 1], device=dev)])
-    a, b = cur[idx].cpu().numpy(), ref[idx].cpu().numpy()
-    np.testing.assert_array_equal(sad[idx].cpu().numpy().astype(np.uint32), O.cost_nxn_batch("sad", 8, a, b))
-    np.testing.assert_array_equal(satd[idx].cpu().numpy().astype(np.uint32), O.cost_nxn_batch("satd", 8, a, b))
+    # exact against the oracle, every one of the 4 147 200 results of the launch the benchmark times
+    a, b = cur.cpu().numpy(), ref.cpu().numpy()
+    np.testing.assert_array_equal(sad.cpu().numpy().view(np.uint32), O.cost_nxn_many("sad", 8, a, b))
+    np.testing.assert_array_equal(satd.cpu().numpy().view(np.uint32), O.cost_nxn_many("satd", 8, a, b))
+    if R.available():                                           # and against the reference's own generic strategy
+        np.testing.assert_array_equal(satd.cpu().numpy().view(np.uint32), R.cost_nxn_many("satd", 8, a, b))
 
 
 def test_dct_32x32_full_batch(env):
@@ -84,18 +88,66 @@ def test_dct_32x32_full_batch(env):
     err = (back.to(torch.int32) - res.to(torch.int32)).abs()
     assert int(err.max()) <= 8, int(err.max())
     assert float(err.to(torch.float32).mean()) < 0.85
-    # exact against the oracle on a strided sample of the same launch (incl. the last block)
-    idx = torch.cat([torch.arange(0, N32, 997, device=dev), torch.tensor([N32 - 1], device=dev)])
-    x = res[idx].cpu().numpy()
-    np.testing.assert_array_equal(coef[idx].cpu().numpy(), O.transform_batch("dct", 32, x))
-    np.testing.assert_array_equal(back[idx].cpu().numpy(), O.transform_batch("idct", 32, coef[idx].cpu().numpy()))
+    # exact against the oracle: all 253 440 blocks of both launches
+    x, c = res.cpu().numpy(), coef.cpu().numpy()
+    np.testing.assert_array_equal(c, O.transform_many("dct", 32, x))
+    np.testing.assert_array_equal(back.cpu().numpy(), O.transform_many("idct", 32, c))
+    if R.available():
+        np.testing.assert_array_equal(c, R.transform_many("dct", 32, x))
+
+
+def _frame_4k_count(n):
+    return (3840 // n) * (2160 // n)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32, 64])
+def test_sad_satd_4k_frame_every_size(env, n):
+    """one 3840x2160 frame's worth of n x n block pairs (+ a ragged tail of 13 blocks), plain and dual, every result exact"""
+    torch, _lib, L, dev, g = env
+    count = _frame_4k_count(n) + 13
+    cur = torch.randint(0, 256, (count, n * n), dtype=torch.uint8, device=dev, generator=g)
+    noise = torch.randint(-30, 31, (count, n * n), dtype=torch.int16, device=dev, generator=g)
+    ref = (cur.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+    ref[::11] = 255 - cur[::11]                                 # large differences as well
+    out = [torch.empty(count, dtype=torch.int32, device=dev) for _ in range(2)]
+    _lib.check(L.kvz_hip_sad_nxn_batch(n, cur.data_ptr(), ref.data_ptr(), count, out[0].data_ptr(), None), "sad")
+    _lib.check(L.kvz_hip_satd_nxn_batch(n, cur.data_ptr(), ref.data_ptr(), count, out[1].data_ptr(), None), "satd")
+    _lib.check(L.kvz_hip_stream_sync(None), "sync")
+    a, b = cur.cpu().numpy(), ref.cpu().numpy()
+    np.testing.assert_array_equal(out[0].cpu().numpy().view(np.uint32), O.cost_nxn_many("sad", n, a, b))
+    np.testing.assert_array_equal(out[1].cpu().numpy().view(np.uint32), O.cost_nxn_many("satd", n, a, b))
+    # dual entries (sad / satd_NxN_dual): two predictions per original, contiguous here (pred_stride n*n, item stride 2 n*n)
+    items = count // 2
+    dual = [torch.empty(2 * items, dtype=torch.int32, device=dev) for _ in range(2)]
+    orig = ref[:items].contiguous()
+    _lib.check(L.kvz_hip_sad_nxn_dual_batch(n, cur.data_ptr(), n * n, 2 * n * n, orig.data_ptr(), items, dual[0].data_ptr(), None), "sad dual")
+    _lib.check(L.kvz_hip_satd_nxn_dual_batch(n, cur.data_ptr(), n * n, 2 * n * n, orig.data_ptr(), items, dual[1].data_ptr(), None), "satd dual")
+    _lib.check(L.kvz_hip_stream_sync(None), "sync")
+    o2 = np.repeat(orig.cpu().numpy(), 2, axis=0)
+    np.testing.assert_array_equal(dual[0].cpu().numpy().view(np.uint32), O.cost_nxn_many("sad", n, a[:2 * items], o2))
+    np.testing.assert_array_equal(dual[1].cpu().numpy().view(np.uint32), O.cost_nxn_many("satd", n, a[:2 * items], o2))
+
+
+@pytest.mark.parametrize("kind,n", [("dct", 4), ("dct", 8), ("dct", 16), ("dct", 32), ("idct", 4), ("idct", 8), ("idct", 16), ("idct", 32),
+                                    ("dst", 4), ("idst", 4)])
+def test_transforms_4k_frame_every_size(env, kind, n):
+    """one 3840x2160 frame's worth of n x n residual / coefficient blocks (+ 13), incl. +-32768 extremes, every output exact"""
+    torch, _lib, L, dev, g = env
+    count = _frame_4k_count(n) + 13
+    x = torch.randint(-255, 256, (count, n * n), dtype=torch.int16, device=dev, generator=g)
+    x[::9] = torch.randint(-32768, 32768, x[::9].shape, dtype=torch.int32, device=dev, generator=g).to(torch.int16)
+    x[3::101] = 32767; x[5::101] = -32768
+    y = torch.empty_like(x)
+    _lib.check(L.kvz_hip_transform_batch({"dct": 0, "idct": 1, "dst": 2, "idst": 3}[kind], n, x.data_ptr(), y.data_ptr(), count, None), kind)
+    _lib.check(L.kvz_hip_stream_sync(None), "sync")
+    np.testing.assert_array_equal(y.cpu().numpy(), O.transform_many(kind, n, x.cpu().numpy()))
 
 
 @pytest.mark.parametrize("width", [4, 8, 16, 32])
 def test_quantize_residual_frame_is_consistent_with_the_separate_entries(env, width):
     """every TU of 8 1080p frames through the fused entry; the same result must come out of the chain of separate entries
-    (residual -> dct -> quant -> dequant -> idct -> reconstruct), TUs without coefficients must keep their prediction, and a
-    strided sample must equal the oracle"""
+    (residual -> dct -> quant -> dequant -> idct -> reconstruct), TUs without coefficients must keep their prediction, and
+    every TU must equal the oracle"""
     torch, _lib, L, dev, g = env
     from kvazaar_amd._lib import QuantParams
     n = (1920 // width) * (1080 // width) * 8
@@ -124,13 +176,11 @@ def test_quantize_residual_frame_is_consistent_with_the_separate_entries(env, wi
     # with coefficients: the chain's reconstruction; without: the prediction (quant-generic.c:262-271)
     want = torch.where(nz[:, None], rec2.view(n, -1), pred.view(n, -1))
     assert bool((rec.view(n, -1) == want).all())
-    idx = list(range(0, n, max(1, n // 60))) + [n - 1]
     w2 = width * width
-    sel = torch.tensor(idx, device=dev)
-    r, c, h = O.quantize_residual_batch(ref.view(n, w2)[sel].cpu().numpy(), pred.view(n, w2)[sel].cpu().numpy(), width, 32, 0, 0, 0)
-    np.testing.assert_array_equal(rec.view(n, w2)[sel].cpu().numpy(), r)
-    np.testing.assert_array_equal(coef.view(n, w2)[sel].cpu().numpy(), c)
-    np.testing.assert_array_equal(has[sel].cpu().numpy() != 0, h != 0)
+    r, c, h = O.quantize_residual_many(ref.view(n, w2).cpu().numpy(), pred.view(n, w2).cpu().numpy(), width, 32, 0, 0, 0)
+    np.testing.assert_array_equal(rec.view(n, w2).cpu().numpy(), r)
+    np.testing.assert_array_equal(coef.view(n, w2).cpu().numpy(), c)
+    np.testing.assert_array_equal(has.cpu().numpy() != 0, h != 0)
 
 
 def test_sample_luma_integer_position_is_the_identity_over_a_frame(env):

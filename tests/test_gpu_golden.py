@@ -109,10 +109,14 @@ def test_golden_sao(api):
 
 
 def test_golden_motion_search(api):
+    from patterns import ME_PARAMS, ME_PU, me_pus_in_tile
     d = gold("me.npz")
-    for i in range(6):
-        got = api.search_pu_batch(d["pic"], d["ref"], np.ascontiguousarray(d["pus"]).view(np.dtype(("V", 64))).reshape(-1),
-                                  np.ascontiguousarray(d["params%d" % i]))
+    pus = np.ascontiguousarray(d["pus"]).view(ME_PU).reshape(-1)
+    n_cfg = sum(1 for k in d.files if k.startswith("params"))
+    assert n_cfg >= 10
+    for i in range(n_cfg):
+        prm = np.ascontiguousarray(d["params%d" % i]).view(ME_PARAMS)
+        got = api.search_pu_batch(d["pic"], d["ref"], me_pus_in_tile(pus, prm), prm)
         np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])
 
 

@@ -306,7 +306,7 @@ def test_intra_predict_on_built_references():
 
 
 # ---- motion search: hexagon_search + search_frac with MV costs ----
-from patterns import me_frames, me_params, me_random_pus  # noqa: E402
+from patterns import me_frames, me_params, me_pus_in_tile, me_random_pus  # noqa: E402
 
 ME_CONFIGS = [
     dict(),                                                        # preset medium: hexbs, early termination on, subme 4
@@ -319,6 +319,14 @@ ME_CONFIGS = [
     dict(algorithm=1), dict(algorithm=1, early_termination=0, max_steps=3, lambda_cost=50), dict(algorithm=1, fme_level=2, early_termination=2),
     dict(algorithm=2), dict(algorithm=2, early_termination=0, lambda_cost=6), dict(algorithm=2, wpp_owf=1, ref_delay_px=10, fme_level=3),
     dict(algorithm=3, search_range=8), dict(algorithm=3, search_range=16, lambda_cost=40, wpp_owf=1, ref_delay_px=8, fme_level=2),
+    # kvz_mv_constraint (kvazaar.h:113-119), the branches of fracmv_within_tile search_inter.c:142-171: the frame as one tile ...
+    dict(mv_constraint=1), dict(mv_constraint=2, lambda_cost=7, early_termination=0), dict(mv_constraint=3, algorithm=1),
+    dict(mv_constraint=4), dict(mv_constraint=4, algorithm=2, fme_level=2), dict(mv_constraint=4, algorithm=3, search_range=8, lambda_cost=33),
+    # ... and real tiles (state->tile->offset_x/_y, info->origin relative to the tile), alone and under the WPP / OWF rule
+    dict(mv_constraint=3, tile=(64, 0, 128, 128)), dict(mv_constraint=4, tile=(0, 64, 192, 64), lambda_cost=11),
+    dict(mv_constraint=4, tile=(64, 64, 64, 64), early_termination=0, fme_level=3),
+    dict(mv_constraint=0, tile=(64, 0, 128, 128), wpp_owf=1, ref_delay_px=10, max_ref_lcu_down=1, max_ref_lcu_right=1),
+    dict(mv_constraint=4, tile=(0, 64, 192, 64), wpp_owf=1, ref_delay_px=8, max_ref_lcu_down=0, max_ref_lcu_right=1, algorithm=1),
 ]
 
 
@@ -327,13 +335,13 @@ def test_search_pu(cfg):
     prm = me_params(**ME_CONFIGS[cfg])
     for k, motion in enumerate(((3, -2), (-7, 5), (0, 0), (14, 9))):
         pic, ref = me_frames(192, 128, 900 + k, motion)
-        pus = me_random_pus(192, 128, 40, 77 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1]))
+        pus = me_pus_in_tile(me_random_pus(192, 128, 40, 77 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1])), prm)
         a, b = O.search_pu_batch(pic, ref, pus, prm), R.search_pu_batch(pic, ref, pus, prm)
         for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
             np.testing.assert_array_equal(a[f], b[f], err_msg="%s cfg %d motion %s" % (f, cfg, motion))
     # flat frames: every candidate ties, the reference's first-wins order decides
     flat = np.full((128, 192), 77, np.uint8)
-    pus = me_random_pus(192, 128, 12, 5)
+    pus = me_pus_in_tile(me_random_pus(192, 128, 12, 5), prm)
     a, b = O.search_pu_batch(flat, flat, pus, prm), R.search_pu_batch(flat, flat, pus, prm)
     np.testing.assert_array_equal(a.view(np.int32), b.view(np.int32))
 
