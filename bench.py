@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- kernel-level throughput of the block-kernel hot path on MI355X.
+"""bench.py -- kernel-level throughput of the block-kernel hot path on MI355X, through the kvz_hip C ABI.
 
 Metric (BASELINE.json): Mblocks/s (SAD8 / SATD8 / DCT32) per GPU.
-Workload (BASELINE.json configs[1] + the DCT32 of the headline metric): the
-1080p CTU grid -- per frame 32 400 8x8 luma block pairs for sad_8x8 and for
-satd_8x8 and 1 980 full 32x32 residual blocks for dct_32x32 -- batched over
-FRAMES frames per launch so that every operand array (>= 0.5 GB) is larger than
-the 256 MiB Infinity Cache: the kernels stream from HBM.
 
-A "step" = one pass of the hot path over one batch: one launch each of
-kvz_hip_sad_nxn_batch(8), kvz_hip_satd_nxn_batch(8), kvz_hip_transform_batch(DCT,32)
-through the C ABI, inputs resident in HBM.  `value` = all blocks processed by all
-ranks / wall time (barrier + device sync on both sides, max over ranks).
+Headline leg (`value`; BASELINE.json configs[1] + the DCT32 of the metric): the 1080p CTU grid -- per frame 32 400 8x8
+luma block pairs for sad_8x8 and for satd_8x8 and 1 980 full 32x32 residual blocks for dct_32x32 -- batched over
+FRAMES frames per launch so that every operand array (>= 0.5 GB) is larger than the 256 MiB Infinity Cache: the
+kernels stream from HBM.  A "step" = one launch each of kvz_hip_sad_nxn_batch(8), kvz_hip_satd_nxn_batch(8),
+kvz_hip_transform_batch(DCT, 32), inputs resident in HBM.  With N ranks every rank runs its own batch (independent
+blocks, no collective): "scaling": "weak".
 
-Multi-GPU: blocks are independent, so each rank owns its own batch (CTU-row
-shards of different frames) and there is no data-path collective: "scaling":
-"weak".  Launch: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+Shard leg (`shard_4k`; BASELINE.json configs[4]: 3840x2160, CTU rows sharded across the GPUs of one node, border
+exchange over RCCL): ONE fixed batch for every N -- strong scaling.  kvazaar_amd/shard.py cuts the 34 CTU rows of a 4K
+frame into contiguous shards; rank r owns its rows of EVERY frame of the batch.
+  * kernels: sad_8x8 + satd_8x8 + dct_32x32 over the rank's blocks of FRAMES_4K frames (129 600 8x8 pairs and 8 040
+    32x32 blocks per frame in total); no data-path collective; checksums of all results, summed over ranks, are the
+    same for every N (reported, so the sharded result can be compared with the unsharded one).
+  * search: a sequence of 4K frames, frame by frame: the rank's rows of the previous frame's reconstruction are placed
+    in its extended reference buffer, the 80 boundary rows are exchanged with the ring neighbours
+    (shard.exchange_halo_into: RCCL send / recv, enqueued on the kernel stream, no host sync), then every 8x8, 16x16,
+    32x32 and 64x64 PU of the rank's rows is searched by kvz_hip_search_pu_batch (hexbs + fractional search, preset
+    medium settings) with mv_constraint = frame-and-tile-margin on the extended buffer, i.e. no vector may read
+    beyond the halo.  All inside the timed region.
+Both legs: W untimed warmup steps, then exactly K steps between barrier + device sync, MAX over ranks.
+
+Launch: python bench.py [--steps K --warmup W]            (1 GPU)
+        python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -30,15 +41,28 @@ sys.path.insert(0, ROOT)
 
 BLK8_PER_FRAME = 32400          # (1920/8) * (1080/8)
 BLK32_PER_FRAME = 1980          # (1920/32) * floor(1080/32)
+W4K, H4K = 3840, 2160
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); copy-shaped kernels measure 6.3-6.75 TB/s on this pool
 BYTES = {"sad_8x8": 132, "satd_8x8": 132, "dct_32x32": 4096}   # SURVEY 8(d) algorithmic bytes per block
+NAMES = ("sad_8x8", "satd_8x8", "dct_32x32")
+SEED = 12345
 
 
-def cpu_baseline(budget_s=3.0):
-    """The reference's best SIMD strategy (avx2) -- or our scalar port if the compiled
-    reference is absent -- timed on this host's cores on a bounded sample of the same
-    workload: 4 frames (129 600 8x8 pairs = 16.6 MB, 7 920 32x32 blocks = 32 MB in+out),
-    larger than L2 so the CPU also streams.  One harness thread per core."""
+def kernel_sources_digest():
+    """sha1 over the kernel sources: ties a committed PMC capture (profiles/pmc_traffic.json) to the code it was taken on"""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "kvazaar_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(budget_s=2.0):
+    """The reference's strategies -- its best SIMD (avx2) and its generic C, both named by north_star -- or our scalar
+    port if the compiled reference is absent, timed on this host's cores on a bounded sample of the same workload:
+    4 frames (129 600 8x8 pairs = 16.6 MB, 7 920 32x32 blocks = 32 MB in+out), larger than L2 so the CPU also
+    streams.  One harness thread per core.  `value` = the avx2 rate for the block mix of one GPU step."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     frames = 4
@@ -48,12 +72,14 @@ def cpu_baseline(budget_s=3.0):
     except AttributeError:
         cores = os.cpu_count() or 1
     g = np.random.default_rng(12345)
-    rates, kind, strategy = {}, None, None
+
+    def mix(rates, idx):
+        t = BLK8_PER_FRAME / rates["sad_8x8"][idx] + BLK8_PER_FRAME / rates["satd_8x8"][idx] + BLK32_PER_FRAME / rates["dct_32x32"][idx]
+        return (2 * BLK8_PER_FRAME + BLK32_PER_FRAME) / t / 1e6
+
     import ref_lib as R
     if R.available():
         L = R.lib()
-        kind = "reference"
-        strategy = "avx2" if R.has_strategy("satd_8x8", "avx2") else "generic"
 
         def run_threads(fn):
             out = [0.0] * cores
@@ -71,78 +97,165 @@ def cpu_baseline(budget_s=3.0):
             y = R._aligned(np.zeros(n32 * 1024, np.int16))
             bufs.append((a, b, x, y))
         u8p, i16p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16)
-        for name, t in (("sad_8x8", b"sad_8x8"), ("satd_8x8", b"satd_8x8")):
-            r = run_threads(lambda i: L.ref_bench_cost_nxn(t, strategy.encode(), 8, bufs[i][0].ctypes.data_as(u8p),
-                                                           bufs[i][1].ctypes.data_as(u8p), n8, budget_s, None))
-            rates[name] = (sum(r), r[0])
-        r = run_threads(lambda i: L.ref_bench_transform(b"dct_32x32", strategy.encode(), 32, bufs[i][2].ctypes.data_as(i16p),
-                                                        bufs[i][3].ctypes.data_as(i16p), n32, budget_s))
-        rates["dct_32x32"] = (sum(r), r[0])
-    else:
-        import oracle_lib as O
-        kind, strategy, cores = "port", "oracle (scalar C restatement of generic)", 1
-        a = g.integers(0, 256, (20000, 64), dtype=np.uint8)
-        b = g.integers(0, 256, (20000, 64), dtype=np.uint8)
-        for name, k in (("sad_8x8", "sad"), ("satd_8x8", "satd")):
-            t0 = time.time(); O.cost_nxn_batch(k, 8, a, b); dt = time.time() - t0
-            rates[name] = (20000 / dt, 20000 / dt)
-        x = g.integers(-255, 256, (2000, 1024)).astype(np.int16)
-        t0 = time.time(); O.transform_batch("dct", 32, x); dt = time.time() - t0
-        rates["dct_32x32"] = (2000 / dt, 2000 / dt)
-    # the same block mix as one GPU step: time per frame at the measured per-function rates
-    def mix(idx):
-        t = BLK8_PER_FRAME / rates["sad_8x8"][idx] + BLK8_PER_FRAME / rates["satd_8x8"][idx] + BLK32_PER_FRAME / rates["dct_32x32"][idx]
-        return (2 * BLK8_PER_FRAME + BLK32_PER_FRAME) / t / 1e6
-    return {
-        "value": round(mix(0), 3), "unit": "Mblocks/s", "cores": cores, "kind": kind,
-        "sample": "%s strategy, %d thread(s), each %.0f s per function over 4 frames of the 1080p grid "
-                  "(129600 8x8 pairs, 7920 32x32 blocks; streaming working set); value = same SAD8+SATD8+DCT32 block mix as a GPU step"
-                  % (strategy, cores, budget_s),
-        "per_thread_value_under_load": round(mix(1), 3),
-        "per_function_Mblocks_s": {k: round(v[0] / 1e6, 3) for k, v in rates.items()},
-        "per_function_Mblocks_s_one_thread_under_load": {k: round(v[1] / 1e6, 3) for k, v in rates.items()},
-    }
+        per = {}
+        for strategy in ("avx2", "generic"):
+            if not R.has_strategy("satd_8x8", strategy):
+                continue
+            rates = {}
+            for name, t in (("sad_8x8", b"sad_8x8"), ("satd_8x8", b"satd_8x8")):
+                r = run_threads(lambda i: L.ref_bench_cost_nxn(t, strategy.encode(), 8, bufs[i][0].ctypes.data_as(u8p),
+                                                               bufs[i][1].ctypes.data_as(u8p), n8, budget_s, None))
+                rates[name] = (sum(r), r[0])
+            r = run_threads(lambda i: L.ref_bench_transform(b"dct_32x32", strategy.encode(), 32, bufs[i][2].ctypes.data_as(i16p),
+                                                            bufs[i][3].ctypes.data_as(i16p), n32, budget_s))
+            rates["dct_32x32"] = (sum(r), r[0])
+            per[strategy] = rates
+        best = "avx2" if "avx2" in per else "generic"
+        out = {
+            "value": round(mix(per[best], 0), 3), "unit": "Mblocks/s", "cores": cores, "kind": "reference",
+            "sample": "the reference's %s strategy (oracle/_ref), %d thread(s), each %.0f s per function over 4 frames of the 1080p grid "
+                      "(129600 8x8 pairs, 7920 32x32 blocks; streaming working set); value = same SAD8+SATD8+DCT32 block mix as a GPU step"
+                      % (best, cores, budget_s),
+            "per_thread_value_under_load": round(mix(per[best], 1), 3),
+        }
+        for s, rates in per.items():
+            out["%s_Mblocks_s" % s] = {"mix": round(mix(rates, 0), 3), **{k: round(v[0] / 1e6, 3) for k, v in rates.items()}}
+        return out
+    import oracle_lib as O
+    rates = {}
+    a = g.integers(0, 256, (400000, 64), dtype=np.uint8)
+    b = g.integers(0, 256, (400000, 64), dtype=np.uint8)
+    for name, k in (("sad_8x8", "sad"), ("satd_8x8", "satd")):
+        t0 = time.time(); O.cost_nxn_many(k, 8, a, b, threads=1); dt = time.time() - t0
+        rates[name] = (len(a) / dt, len(a) / dt)
+    x = g.integers(-255, 256, (4000, 1024)).astype(np.int16)
+    t0 = time.time(); O.transform_many("dct", 32, x, threads=1); dt = time.time() - t0
+    rates["dct_32x32"] = (len(x) / dt, len(x) / dt)
+    return {"value": round(mix(rates, 0), 3), "unit": "Mblocks/s", "cores": 1, "kind": "port",
+            "sample": "oracle (scalar C restatement of generic), 1 thread: 400000 8x8 pairs, 4000 32x32 blocks",
+            "generic_Mblocks_s": {"mix": round(mix(rates, 0), 3), **{k: round(v[0] / 1e6, 3) for k, v in rates.items()}}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=128, help="1080p frames per batch (per GPU)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Env:
+    """process-wide handles shared by the legs"""
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: kvazaar_amd has no CPU path")
-    # rehearsal knobs for a 1-GPU box (never set by the driver): ranks share device 0 and rendezvous over gloo,
-    # because RCCL refuses two ranks on one device
-    backend = os.environ.get("KVZ_BENCH_BACKEND", "nccl")
-    if os.environ.get("KVZ_BENCH_SHARE_DEVICE") == "1":
-        local_rank = 0
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: kvazaar_amd has no CPU path")
+        # rehearsal knobs for a 1-GPU box (never set by the driver): ranks share device 0 and rendezvous over gloo,
+        # because RCCL refuses two ranks on one device; the halo exchange then bounces through pinned host memory
+        self.backend = os.environ.get("KVZ_BENCH_BACKEND", "nccl")
+        if os.environ.get("KVZ_BENCH_SHARE_DEVICE") == "1":
+            local_rank = 0
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(local_rank)
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend=self.backend)
+            self.dist = dist
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
+        self.dev = torch.device("cuda", local_rank)
+        self.red_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
+        from kvazaar_amd import _lib
+        self._lib = _lib
+        self.L = _lib.init(local_rank)
+        self.stream = self.L.kvz_hip_stream_create()
+        self.tstream = torch.cuda.ExternalStream(int(self.stream), device=self.dev)   # torch's view of the same stream
+        self.args = args
 
-    from kvazaar_amd import _lib
-    L = _lib.init(local_rank)
+    def check(self, rc, what):
+        self._lib.check(rc, what)
 
-    F = args.frames
-    n8, n32 = BLK8_PER_FRAME * F, BLK32_PER_FRAME * F
-    gen = torch.Generator(device=dev); gen.manual_seed(12345 + rank)
+    def sync(self):
+        self.check(self.L.kvz_hip_stream_sync(self.stream), "stream_sync")
+        self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def timed(self, step, steps, warmup):
+        """the contract's bracket: W untimed steps, then K steps between barrier + device sync on both sides, MAX over ranks"""
+        for _ in range(warmup):
+            step(None)
+        self.sync(); self.barrier(); self.sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        self.sync(); self.barrier(); self.sync()
+        dt = time.perf_counter() - t0
+        if self.dist:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.red_dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def all_sum(self, values):
+        """int64 sums over ranks (checksums; outside the timed regions)"""
+        if not self.dist:
+            return [int(v) for v in values]
+        t = self.torch.tensor([int(v) for v in values], dtype=self.torch.int64, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [int(v) for v in t.tolist()]
+
+    def events(self, n):
+        return [self.L.kvz_hip_event_create() for _ in range(n)]
+
+    def elapsed(self, a, b):
+        f = C.c_float()
+        self.check(self.L.kvz_hip_event_elapsed_ms(a, b, C.byref(f)), "event_elapsed")
+        return f.value
+
+
+def kernel_stats(ms_lists, blocks):
+    """per-kernel launch statistics from the HIP events recorded inside the timed region"""
+    kern = {}
+    for name in NAMES:
+        v = sorted(ms_lists[name])
+        avg = sum(v) / len(v)
+        gbs = BYTES[name] * blocks[name] / (avg * 1e-3) / 1e9
+        kern[name] = {"Mblocks_s": round(blocks[name] / (avg * 1e-3) / 1e6, 1), "avg_launch_ms": round(avg, 5),
+                      "median_launch_ms": round(v[len(v) // 2], 5), "min_launch_ms": round(v[0], 5), "max_launch_ms": round(v[-1], 5),
+                      "blocks_per_launch": blocks[name], "algorithmic_bytes_per_block": BYTES[name],
+                      "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    return kern
+
+
+def three_kernel_step(env, cur, ref, res, sad, satd, coef, n8, n32):
+    L, st = env.L, env.stream
+
+    def step(ev):
+        if ev: L.kvz_hip_event_record(ev[0], st)
+        env.check(L.kvz_hip_sad_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, sad.data_ptr(), st), "sad_8x8")
+        if ev: L.kvz_hip_event_record(ev[1], st)
+        env.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd.data_ptr(), st), "satd_8x8")
+        if ev: L.kvz_hip_event_record(ev[2], st)
+        env.check(L.kvz_hip_transform_batch(0, 32, res.data_ptr(), coef.data_ptr(), n32, st), "dct_32x32")
+        if ev: L.kvz_hip_event_record(ev[3], st)
+    return step
+
+
+def collect_event_ms(env, evs):
+    ms = {n: [] for n in NAMES}
+    for ev in evs:
+        for i, name in enumerate(NAMES):
+            ms[name].append(env.elapsed(ev[i], ev[i + 1]))
+    return ms
+
+
+def headline_leg(env, steps, warmup, frames):
+    torch, dev = env.torch, env.dev
+    n8, n32 = BLK8_PER_FRAME * frames, BLK32_PER_FRAME * frames
+    gen = torch.Generator(device=dev); gen.manual_seed(SEED + env.rank)
     cur = torch.randint(0, 256, (n8, 64), dtype=torch.uint8, device=dev, generator=gen)
     noise = torch.randint(-8, 9, (n8, 64), dtype=torch.int16, device=dev, generator=gen)
     ref = (cur.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
@@ -152,68 +265,185 @@ def main():
     satd = torch.empty(n8, dtype=torch.int32, device=dev)
     coef = torch.empty_like(res)
     torch.cuda.synchronize()
-
-    stream = L.kvz_hip_stream_create()
-    evs = [[L.kvz_hip_event_create() for _ in range(4)] for _ in range(args.steps)]
-
-    def step(ev=None):
-        if ev: L.kvz_hip_event_record(ev[0], stream)
-        _lib.check(L.kvz_hip_sad_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, sad.data_ptr(), stream), "sad_8x8")
-        if ev: L.kvz_hip_event_record(ev[1], stream)
-        _lib.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd.data_ptr(), stream), "satd_8x8")
-        if ev: L.kvz_hip_event_record(ev[2], stream)
-        _lib.check(L.kvz_hip_transform_batch(0, 32, res.data_ptr(), coef.data_ptr(), n32, stream), "dct_32x32")
-        if ev: L.kvz_hip_event_record(ev[3], stream)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(evs[k])
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # per-kernel device time from the HIP events recorded inside the timed region
-    ms = {"sad_8x8": 0.0, "satd_8x8": 0.0, "dct_32x32": 0.0}
-    f = C.c_float()
-    for ev in evs:
-        for i, name in enumerate(("sad_8x8", "satd_8x8", "dct_32x32")):
-            _lib.check(L.kvz_hip_event_elapsed_ms(ev[i], ev[i + 1], C.byref(f)), "event_elapsed")
-            ms[name] += f.value
-    avg_ms = {k: v / args.steps for k, v in ms.items()}
-    blocks = {"sad_8x8": n8, "satd_8x8": n8, "dct_32x32": n32}
-
-    # light integrity property at full size (parity proper lives in tests/): SAD of a block with itself is 0,
-    # SATD >= SAD/.. is not generally true, so check idempotence: a second launch gives identical costs
+    evs = [env.events(4) for _ in range(steps)]
+    launch = three_kernel_step(env, cur, ref, res, sad, satd, coef, n8, n32)
+    dt = env.timed(lambda k: launch(evs[k] if k is not None else None), steps, warmup)
+    ms = collect_event_ms(env, evs)
+    # light integrity property at full size (parity proper lives in tests/): a second launch gives identical costs
     satd2 = torch.empty_like(satd)
-    _lib.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd2.data_ptr(), stream), "satd_8x8")
-    L.kvz_hip_stream_sync(stream)
-    torch.cuda.synchronize()
+    env.check(env.L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd2.data_ptr(), env.stream), "satd_8x8")
+    env.sync()
     assert bool((satd2 == satd).all()), "non-deterministic satd"
+    blocks = {"sad_8x8": n8, "satd_8x8": n8, "dct_32x32": n32}
+    return dt, ms, blocks
+
+
+def shard_kernel_leg(env, sh, steps, warmup, frames):
+    """the three block kernels over this rank's CTU rows of a fixed batch of 4K frames"""
+    from kvazaar_amd import shard as S
+    torch, dev = env.torch, env.dev
+    cur, ref, res = [], [], []
+    for r, h in sh.ctu_row_heights():
+        c, f = S.block_pairs_of_ctu_row(torch, dev, SEED, r, h, sh.width, frames, 8)
+        cur.append(c); ref.append(f)
+        res.append(S.residual_blocks_of_ctu_row(torch, dev, SEED, r, h, sh.width, frames, 32))
+    cur, ref, res = torch.cat(cur), torch.cat(ref), torch.cat(res)
+    n8, n32 = cur.shape[0], res.shape[0]
+    assert n8 == sh.blocks(8) * frames and n32 == sh.blocks(32) * frames
+    sad = torch.empty(n8, dtype=torch.int32, device=dev)
+    satd = torch.empty(n8, dtype=torch.int32, device=dev)
+    coef = torch.empty_like(res)
+    torch.cuda.synchronize()
+    evs = [env.events(4) for _ in range(steps)]
+    launch = three_kernel_step(env, cur, ref, res, sad, satd, coef, n8, n32)
+    dt = env.timed(lambda k: launch(evs[k] if k is not None else None), steps, warmup)
+    ms = collect_event_ms(env, evs)
+    ca, cw = S.coeff_checksum(torch, coef)
+    sums = env.all_sum([S.cost_checksum(sad), S.cost_checksum(satd), ca, cw, n8, n32])
+    return dt, ms, {"sad_8x8": n8, "satd_8x8": n8, "dct_32x32": n32}, sums
+
+
+def shard_search_leg(env, sh, steps, warmup, frames):
+    """frame after frame: reconstruction rows of frame f-1 -> extended reference buffer -> halo exchange -> motion search of
+    every PU of the rank's rows of frame f"""
+    import numpy as np
+    from kvazaar_amd import shard as S
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patterns import ME_PU, ME_RESULT, me_params          # layouts of kvz_hip_me_pu / _params / _result (plain numpy dtypes)
+    torch, dev, L, st = env.torch, env.dev, env.L, env.stream
+    W = sh.width
+    pics = [S.shard_plane(torch, dev, sh, SEED, f, 0) for f in range(frames)]                      # source, extended layout
+    recs = [S.shard_plane(torch, dev, sh, SEED, f, 1, extended=False) for f in range(frames)]      # reconstruction, own rows
+    ext_ref = torch.zeros((sh.ext_rows, W), dtype=torch.uint8, device=dev)
+    pus_np, spans = S.shard_pus(np, sh, (8, 16, 32, 64), ME_PU)
+    pus = torch.from_numpy(pus_np.view(np.uint8).reshape(-1, 64)).to(dev)
+    results = torch.zeros((frames, len(pus_np), 8), dtype=torch.int32, device=dev)
+    # preset medium: hexbs, early termination on, fme_level 4; mv_constraint 4 on the extended buffer (= the tile):
+    # no vector may make the search or its interpolation read beyond the halo
+    groups = []                                   # (first PU, count, params) per launch: <=16x16 in one, 32x32, 64x64
+    a8, c8 = spans[8]; a16, c16 = spans[16]
+    for first, count, hint in ((a8, c8 + c16, 1), (spans[32][0], spans[32][1], 2), (spans[64][0], spans[64][1], 4)):
+        p = me_params(lambda_cost=20, early_termination=1, fme_level=4, mv_constraint=4)
+        p["size_classes"] = hint
+        groups.append((first, count, p))
+    staging = {}
+    torch.cuda.synchronize()
+    evs = [[env.events(3) for _ in range(frames)] for _ in range(steps)]
+    row_bytes = sh.rows * W
+
+    def step(k):
+        for f in range(frames):
+            ev = evs[k][f] if k is not None else None
+            if ev: L.kvz_hip_event_record(ev[0], st)
+            prev = recs[(f - 1) % frames]
+            env.check(L.kvz_hip_memcpy_d2d(ext_ref.data_ptr() + sh.top * W, prev.data_ptr(), row_bytes, st), "rec rows")
+            if env.dist:
+                with torch.cuda.stream(env.tstream):
+                    S.exchange_halo_into(ext_ref, sh, env.dist, staging)
+            if ev: L.kvz_hip_event_record(ev[1], st)
+            for first, count, p in groups:
+                if count:
+                    env.check(L.kvz_hip_search_pu_batch(pics[f].data_ptr(), W, W, sh.ext_rows, ext_ref.data_ptr(), W, W, sh.ext_rows,
+                                                        pus.data_ptr() + 64 * first, count, p.ctypes.data,
+                                                        results[f].data_ptr() + 32 * first, st), "search_pu")
+            if ev: L.kvz_hip_event_record(ev[2], st)
+
+    dt = env.timed(step, steps, warmup)
+    ex_ms, se_ms = [], []
+    for k in range(steps):
+        for f in range(frames):
+            ex_ms.append(env.elapsed(evs[k][f][0], evs[k][f][1]))
+            se_ms.append(env.elapsed(evs[k][f][1], evs[k][f][2]))
+    r = results.cpu().numpy().view(ME_RESULT).reshape(frames, -1)
+    found = int((r["cost"] != 0xFFFFFFFF).sum())
+    sums = env.all_sum([len(pus_np), found, int(r["mv"].astype(np.int64).sum()), int(r["cost"].astype(np.int64).sum()),
+                        int((np.abs(r["mv"][..., 0] - S.NOMINAL_MV[0]) + np.abs(r["mv"][..., 1] - S.NOMINAL_MV[1]) <= 2).sum())])
+    return dt, ex_ms, se_ms, sums
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=128, help="1080p frames per batch (per GPU), headline leg")
+    ap.add_argument("--frames-4k", type=int, default=128, help="4K frames of the fixed batch of the shard leg (whole job)")
+    ap.add_argument("--search-frames", type=int, default=8, help="4K frames per step of the sharded search sequence")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-leg", action="store_true")
+    args = ap.parse_args()
+    env = Env(args)
+    torch, world, rank = env.torch, env.world, env.rank
+    F = args.frames
+
+    dt, ms, blocks = headline_leg(env, args.steps, args.warmup, F)
+    torch.cuda.empty_cache()
+
+    shard_out = None
+    if not args.no_shard_leg:
+        from kvazaar_amd import shard as S
+        sh = S.RowShard(W4K, H4K, world, rank, S.HALO_ROWS)
+        F4, FS = args.frames_4k, args.search_frames
+        kdt, kms, kblocks, ksums = shard_kernel_leg(env, sh, args.steps, args.warmup, F4)
+        torch.cuda.empty_cache()
+        s_steps, s_warm = max(1, args.steps // 10), max(1, args.warmup // 10)        # a search step is FS frames, ~8 ms at N = 1
+        sdt, ex_ms, se_ms, ssums = shard_search_leg(env, sh, s_steps, s_warm, FS)
+        descr = [None] * world
+        if env.dist:
+            env.dist.all_gather_object(descr, sh.describe())
+        else:
+            descr = [sh.describe()]
+        if rank == 0:
+            tot8, tot32 = ksums[4], ksums[5]
+            assert tot8 == 129600 * F4 and tot32 == 8040 * F4, (tot8, tot32)
+            kern = kernel_stats(kms, kblocks)
+            n_pus = ssums[0]
+            shard_out = {
+                "metric": "Mblocks/s (SAD8/SATD8/DCT32) over ONE fixed batch of 4K frames cut by CTU rows across the ranks",
+                "value": round((2 * tot8 + tot32) * args.steps / kdt / 1e6, 1), "unit": "Mblocks/s", "scaling": "strong",
+                "n_gpus": world, "steps": args.steps, "ms_per_step": round(kdt / args.steps * 1e3, 5),
+                "workload": "3840x2160 x %d frames, fixed for every N: %d 8x8 pairs (sad_8x8 + satd_8x8) and %d 32x32 residual blocks "
+                            "(dct_32x32) in total; rank r owns its CTU rows (kvazaar_amd/shard.py row_range over 34 rows) of every frame; "
+                            "no data-path collective" % (F4, tot8, tot32),
+                "rows_per_rank": descr,
+                "rank0_kernels": kern,
+                "checksums_over_all_ranks": {"sum_sad": ksums[0], "sum_satd": ksums[1], "sum_abs_coeff": ksums[2], "sum_weighted_coeff": ksums[3],
+                                             "note": "partition-independent: equal for every n_gpus"},
+                "search": {
+                    "metric": "PU searches/s, whole job (kvz_hip_search_pu_batch: hexbs + fractional, every 8x8/16x16/32x32/64x64 PU of each frame)",
+                    "value": round(n_pus * FS * s_steps / sdt / 1e6, 3), "unit": "M PUs/s", "scaling": "strong",
+                    "frames_per_s": round(FS * s_steps / sdt, 1), "ms_per_frame": round(sdt / (FS * s_steps) * 1e3, 4),
+                    "steps": s_steps, "frames_per_step": FS, "PUs_per_frame": n_pus,
+                    "rank0_ms_per_frame": {"rec_rows_copy_plus_halo_exchange": round(sum(ex_ms) / len(ex_ms), 4),
+                                           "exchange_median": round(sorted(ex_ms)[len(ex_ms) // 2], 4),
+                                           "search_launches": round(sum(se_ms) / len(se_ms), 4)},
+                    "exchange": {"backend": env.backend if world > 1 else None, "halo_rows": S.HALO_ROWS,
+                                 "bytes_per_boundary_per_frame_each_way": S.HALO_ROWS * W4K,
+                                 "what": "luma rows of the previous frame's reconstruction, isend/irecv between ring neighbours, "
+                                         "enqueued on the kernel stream inside the timed region"},
+                    "mv_constraint": "4 (frame and tile margin) with the tile = the rank's rows + halo: no read beyond the halo",
+                    "results": {"searched": ssums[0] * FS, "found": ssums[1], "within_half_pel_of_true_motion": ssums[4],
+                                "sum_mv": ssums[2], "sum_cost": ssums[3],
+                                "note": "depends on the partition (the halo bounds the vectors), like tiles in the reference"},
+                },
+            }
 
     if rank == 0:
-        total_blocks = (2 * n8 + n32) * world * args.steps
-        kern = {}
-        for name in ms:
-            gbs = BYTES[name] * blocks[name] / (avg_ms[name] * 1e-3) / 1e9
-            kern[name] = {"Mblocks_s": round(blocks[name] / (avg_ms[name] * 1e-3) / 1e6, 1), "avg_launch_ms": round(avg_ms[name], 5),
-                          "blocks_per_launch": blocks[name], "algorithmic_bytes_per_block": BYTES[name],
-                          "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        dom = max(ms, key=lambda k: ms[k])
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from a separate rocprofv3 --pmc pass
+        total_blocks = (2 * blocks["sad_8x8"] + blocks["dct_32x32"]) * world * args.steps
+        kern = kernel_stats(ms, blocks)
+        dom = max(NAMES, key=lambda k: kern[k]["avg_launch_ms"])
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from separate rocprofv3 --pmc passes of this command
         if os.path.exists(tfile) and F == 128:                          # the PMC passes were taken at the default batch size
             try:
-                traffic = json.load(open(tfile)).get(dom)
+                t = json.load(open(tfile))
+                cap = t.get("_captured", {})
+                if cap.get("kernel_sources_sha1_16") == kernel_sources_digest():
+                    traffic = t.get(dom)
+                    traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (bytes per "
+                                   "launch), captured %s at commit %s on these kernel sources" % (cap.get("date"), cap.get("commit")))
+                else:
+                    traffic_src = "profiles/pmc_traffic.json was captured on other kernel sources (%s): not quoted" % cap.get("commit")
             except Exception:
                 traffic = None
         out = {
@@ -226,20 +456,21 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "1080p CTU grid x %d frames per launch per GPU: sad_8x8 + satd_8x8 on %d 8x8 block pairs, "
                                    "dct_32x32 on %d int16 residual blocks, via the kvz_hip C ABI (batched 'hip' strategy entries)"
-                                   % (F, n8, n32),
-                       "frames_per_batch": F, "parallelism": "independent batches per GPU, no data-path collective"},
+                                   % (F, blocks["sad_8x8"], blocks["dct_32x32"]),
+                       "frames_per_batch": F, "parallelism": "independent batches per GPU, no data-path collective (value); "
+                                                             "CTU-row shards of one fixed 4K batch + RCCL halo exchange (shard_4k)"},
             "kernels": kern,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic,
-                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (bytes per launch)"
-                                           if traffic is not None else None},
+                         "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_src},
         }
+        if shard_out is not None:
+            out["shard_4k"] = shard_out
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if env.dist:
+        env.dist.barrier()
+        env.dist.destroy_process_group()
 
 
 if __name__ == "__main__":
