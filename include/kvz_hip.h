@@ -84,7 +84,7 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
 /* Launch-geometry / kernel-selection knobs for A/B runs (tools/bench_all.py --tune key=v1,v2);
  * value < 0 restores the built-in default.  Keys: "{sad,satd8,dct,dct16,idct16,dct32,idct32,qr,qr16,
  * qr32}_wgs_per_cu" (workgroups per CU of the streaming grids), "idct16_use_mfma", "qr16_use_mfma",
- * "qr4_lane_kernel", "sao_edge_fast" (0/1), "me_big_threads" (256/512/1024 threads per PU larger than 32x32), "me_medium_threads" (64/128/256 per PU up to 32x32),
+ * "qr4_lane_kernel", "qr8_reg_kernel", "sao_edge_fast" (0/1), "me_big_threads" (256/512/1024 threads per PU larger than 32x32), "me_medium_threads" (64/128/256 per PU up to 32x32),
  * "intra_rough_waves" (4/8 waves per workgroup of the rough search), "pair_wave_kernel" (0/1: one wave per
  * descriptor for frame-level pair batches of up to 4096 descriptors).
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
@@ -226,9 +226,10 @@ KVZ_HIP_API int kvz_hip_bipred_blend_batch(int w, int h, int hi_prec0, const voi
 /* ------------------------------------------------------------------ */
 /* (2) batched entries -- dct group (strategies/strategies-dct.h:31)   */
 /* ------------------------------------------------------------------ */
-enum { KVZ_HIP_DCT = 0, KVZ_HIP_IDCT = 1, KVZ_HIP_DST = 2, KVZ_HIP_IDST = 3 };
+enum { KVZ_HIP_DCT = 0, KVZ_HIP_IDCT = 1, KVZ_HIP_DST = 2, KVZ_HIP_IDST = 3, KVZ_HIP_TRSKIP = 4, KVZ_HIP_ITRSKIP = 5 };
 /* dct_func over `count` contiguous N*N int16 blocks (generic/dct-generic.c:567-617).
- * kind DCT/IDCT: n in {4,8,16,32}; DST/IDST: n == 4 (fast_forward_dst_4x4 / inverse). */
+ * kind DCT/IDCT: n in {4,8,16,32}; DST/IDST: n == 4 (fast_forward_dst_4x4 / inverse);
+ * TRSKIP/ITRSKIP: kvz_transformskip / kvz_itransformskip (transform.c:150-180), n in {4,8,16,32}. */
 KVZ_HIP_API int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16_t *out,
                                         size_t count, kvz_hip_stream s);
 
@@ -558,10 +559,13 @@ typedef struct {
   kvz_hip_pixel *(*lcu_rec_y)(void *lcu);
   kvz_hip_pixel *(*lcu_rec_u)(void *lcu);
   kvz_hip_pixel *(*lcu_rec_v)(void *lcu);
-  /* optional (may be NULL): what quantize_residual needs when cfg.rdoq_enable (quant-generic.c:214-221).  kvz_rdoq
-   * (rdo.c:548) is the encoder's CABAC-context dependent quantiser -- control plane, not part of this library; like
-   * the avx2 strategy, the hip quantize_residual calls the host's own function between the transform and the
-   * dequantisation.  Without these four the function refuses to run with RDOQ enabled. */
+  /* What quantize_residual needs when cfg.rdoq_enable (quant-generic.c:214-221).  kvz_rdoq (rdo.c:548) is the
+   * encoder's CABAC-context dependent quantiser -- control plane, not part of this library; like the avx2 strategy,
+   * the hip quantize_residual calls the host's own function between the transform (or transform skip) and the
+   * dequantisation.  quantize_residual is registered only when rdoq_enable and these four are all supplied, or when
+   * rdoq_enable itself is NULL (= the host vouches that RDOQ is never on); likewise quant / dequant /
+   * quantize_residual need quant_coeff and dequant_coeff whenever scaling_list_enable is supplied.  A group function
+   * that is not registered stays on the host's next-best strategy -- nothing diverges or aborts at run time. */
   int (*rdoq_skip)(const void *state);                 /* cfg.rdoq_skip */
   int (*cu_rdoq_tr_depth)(const void *cur_cu);         /* tr_depth - depth + (part_size == SIZE_NxN) */
   int (*cu_type)(const void *cur_cu);                  /* cur_cu->type, handed to kvz_rdoq as block_type */

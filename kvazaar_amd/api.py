@@ -15,7 +15,7 @@ import numpy as np
 from . import _lib
 from ._lib import BlockPair, IpolBlock, QuantParams, KvzHipError, check
 
-KINDS = {"dct": 0, "idct": 1, "dst": 2, "idst": 3}
+KINDS = {"dct": 0, "idct": 1, "dst": 2, "idst": 3, "trskip": 4, "itrskip": 5}
 
 
 class DeviceBuffer:

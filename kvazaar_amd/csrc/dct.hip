@@ -67,6 +67,22 @@ static bool dct32_use_valu()
   return v;
 }
 
+// kvz_transformskip / kvz_itransformskip (transform.c:150-180): coeff = (int16)(block << shift);
+// block = (int16)((coeff + (1 << (shift - 1))) >> shift), shift = 15 - 8 - log2(n).  8 values (16 bytes) per lane.
+template <bool INV>
+__global__ __launch_bounds__(256) void transform_skip_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t total, int shift)
+{
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+  const int offset = 1 << (shift - 1);
+  for (size_t i = tid * 8; i < total; i += nthreads * 8) {
+    union { uint4 v; i16 s[8]; } a, b;
+    a.v = ld_stream_u4(in + i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b.s[j] = INV ? (i16)(((int)a.s[j] + offset) >> shift) : (i16)((int)a.s[j] << shift);
+    st_stream_u4(out + i, b.v);
+  }
+}
+
 template <int N, int KIND>
 static int launch_transform(const i16 *in, i16 *out, size_t count, hipStream_t st)
 {
@@ -108,6 +124,18 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
       break;
     case KVZ_HIP_IDST:
       if (n == 4) return launch_transform<4, 3>(in, out, count, st);
+      break;
+    case KVZ_HIP_TRSKIP:
+    case KVZ_HIP_ITRSKIP:
+      if (n == 4 || n == 8 || n == 16 || n == 32) {
+        const size_t total = count * (size_t)n * n;
+        const int shift = 15 - 8 - (n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5);
+        const unsigned grid = stream_grid(total, 2048, 256);
+        if (kind == KVZ_HIP_TRSKIP) hipLaunchKernelGGL(transform_skip_kernel<false>, dim3(grid), dim3(256), 0, st, in, out, total, shift);
+        else hipLaunchKernelGGL(transform_skip_kernel<true>, dim3(grid), dim3(256), 0, st, in, out, total, shift);
+        KVZ_CHECK_LAUNCH("transform_skip_kernel");
+        return KVZ_HIP_OK;
+      }
       break;
   }
   return kvzhip::invalid_arg(__func__);

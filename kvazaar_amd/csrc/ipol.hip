@@ -452,7 +452,24 @@ __global__ __launch_bounds__(256) void frac_step_kernel(const u8 *__restrict__ w
   }
 }
 
+// kvz_get_extended_block's copy (ipol-generic.c:759-783): out[dy][dx] = rect[clip(dy - oy)][clip(dx - ox)], where rect is
+// the part of the reference plane the window overlaps (rw x rh, contiguous) and (ox, oy) its position inside the window
+__global__ __launch_bounds__(256) void extend_block_kernel(const u8 *__restrict__ rect, int rw, int rh, int ox, int oy,
+                                                           u8 *__restrict__ out, int ow, int oh)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ow * oh; i += gridDim.x * blockDim.x) {
+    const int dy = i / ow, dx = i - dy * ow;
+    out[i] = rect[clampi(dy - oy, 0, rh - 1) * rw + clampi(dx - ox, 0, rw - 1)];
+  }
+}
+
 namespace kvzhip {
+int launch_extend_block(const u8 *rect, int rw, int rh, int ox, int oy, u8 *out, int ow, int oh, hipStream_t st)
+{
+  hipLaunchKernelGGL(extend_block_kernel, dim3((unsigned)((ow * oh + 255) / 256)), dim3(256), 0, st, rect, rw, rh, ox, oy, out, ow, oh);
+  KVZ_CHECK_LAUNCH("extend_block_kernel");
+  return KVZ_HIP_OK;
+}
 int launch_frac_step(const u8 *win, int w, int h, int step, int fme_level, int hx, int hy,
                      u8 *filtered, i16 *hor_out, i16 *cols_out, hipStream_t st)
 {

@@ -163,16 +163,13 @@ __device__ __forceinline__ int scan_pos(int scan_idx, int log2_size, int idx)
   return ((grp / g) * 4 + (p >> 2)) * n + (grp % g) * 4 + (p & 3);
 }
 
+// One coefficient group (16 coefficients in scan order, positions pos16) of the sign-hiding pass, quant-generic.c:82-156.
+// A group reads and changes only its own coefficients; what it needs from the rest of the block is whether it is the
+// "last" group -- the highest one in scan order that holds a non-zero level (last_cg, :99-101, :153).
 template <typename CP, typename QP>
-__device__ void sign_hide_block(CP coef, QP q_coef, int width, int scan_idx, const quant_consts &k)
+__device__ __forceinline__ void sign_hide_cg(CP coef, QP q_coef, const int (&pos16)[16], bool is_last_cg, const quant_consts &k)
 {
-  const int log2_size = width == 4 ? 2 : width == 8 ? 3 : width == 16 ? 4 : 5;
-  const int n_coef = width * width;
   const int q_bits8 = k.q_bits - 8;
-  unsigned ac_sum = 0;
-  for (int n = 0; n < n_coef; ++n) ac_sum += (unsigned)quant_level(coef[n], k.qtable ? k.qtable[n] : k.flat_qc, k);
-  if (ac_sum < 2) return;
-
   auto delta_u = [&](int pos) -> int {
     const int qc = k.qtable ? k.qtable[pos] : k.flat_qc;
     const int c = coef[pos];
@@ -180,53 +177,86 @@ __device__ void sign_hide_block(CP coef, QP q_coef, int width, int scan_idx, con
     const int level = (int)((prod + k.add) >> k.q_bits);
     return (int)((prod - (long long)(int)((unsigned)level << k.q_bits)) >> q_bits8);
   };
+  int first_nz = 16, last_nz = -1, abssum = 0;
+  for (int n = 15; n >= 0; --n) if (q_coef[pos16[n]]) { last_nz = n; break; }
+  for (int n = 0; n < 16; ++n) if (q_coef[pos16[n]]) { first_nz = n; break; }
+  for (int n = first_nz; n <= last_nz; ++n) abssum += q_coef[pos16[n]];
+  if (last_nz - first_nz < 4) return;
+  const int signbit = q_coef[pos16[first_nz]] > 0 ? 0 : 1;
+  if (signbit == (abssum & 1)) return;
+  int min_cost_inc = 0x7fffffff, min_pos = -1, cur_cost = 0x7fffffff;
+  int final_change = 0, cur_change = 0;
+  for (int n = (is_last_cg ? last_nz : 15); n >= 0; --n) {
+    const int pos = pos16[n];
+    const int q = q_coef[pos];
+    if (q != 0) {
+      const int du = delta_u(pos);
+      if (du > 0) { cur_cost = -du; cur_change = 1; }
+      else if (n == first_nz && (q == 1 || q == -1)) { cur_cost = 0x7fffffff; }
+      else { cur_cost = du; cur_change = -1; }
+    } else if (n < first_nz && ((coef[pos] >= 0) ? 0 : 1) != signbit) {
+      cur_cost = 0x7fffffff;
+    } else { cur_cost = -delta_u(pos); cur_change = 1; }
+    if (cur_cost < min_cost_inc) { min_cost_inc = cur_cost; final_change = cur_change; min_pos = pos; }
+  }
+  const int qm = q_coef[min_pos];
+  if (qm == 32767 || qm == -32768) final_change = -1;
+  if (coef[min_pos] >= 0) q_coef[min_pos] = (i16)(qm + final_change);
+  else q_coef[min_pos] = (i16)(qm - final_change);
+}
 
-  int last_cg = -1;
+// the whole block on one thread, groups from the last to the first like the reference (used inside the fused kernel)
+template <typename CP, typename QP>
+__device__ void sign_hide_block(CP coef, QP q_coef, int width, int scan_idx, const quant_consts &k)
+{
+  const int log2_size = width == 4 ? 2 : width == 8 ? 3 : width == 16 ? 4 : 5;
+  const int n_coef = width * width;
+  unsigned ac_sum = 0;
+  for (int n = 0; n < n_coef; ++n) ac_sum += (unsigned)quant_level(coef[n], k.qtable ? k.qtable[n] : k.flat_qc, k);
+  if (ac_sum < 2) return;
+  bool seen_nz = false;
   for (int subset = (n_coef - 1) >> 4; subset >= 0; --subset) {
-    const int subpos = subset << 4;
     int pos16[16];
+    bool nz = false;
 #pragma unroll
-    for (int n = 0; n < 16; ++n) pos16[n] = scan_pos(scan_idx, log2_size, subpos + n);
-    int first_nz = 16, last_nz = -1, abssum = 0;
-    for (int n = 15; n >= 0; --n) if (q_coef[pos16[n]]) { last_nz = n; break; }
-    for (int n = 0; n < 16; ++n) if (q_coef[pos16[n]]) { first_nz = n; break; }
-    for (int n = first_nz; n <= last_nz; ++n) abssum += q_coef[pos16[n]];
-    if (last_nz >= 0 && last_cg == -1) last_cg = 1;
-    if (last_nz - first_nz >= 4) {
-      const int signbit = q_coef[pos16[first_nz]] > 0 ? 0 : 1;
-      if (signbit != (abssum & 1)) {
-        int min_cost_inc = 0x7fffffff, min_pos = -1, cur_cost = 0x7fffffff;
-        int final_change = 0, cur_change = 0;
-        for (int n = (last_cg == 1 ? last_nz : 15); n >= 0; --n) {
-          const int pos = pos16[n];
-          const int q = q_coef[pos];
-          if (q != 0) {
-            const int du = delta_u(pos);
-            if (du > 0) { cur_cost = -du; cur_change = 1; }
-            else if (n == first_nz && (q == 1 || q == -1)) { cur_cost = 0x7fffffff; }
-            else { cur_cost = du; cur_change = -1; }
-          } else if (n < first_nz && ((coef[pos] >= 0) ? 0 : 1) != signbit) {
-            cur_cost = 0x7fffffff;
-          } else { cur_cost = -delta_u(pos); cur_change = 1; }
-          if (cur_cost < min_cost_inc) { min_cost_inc = cur_cost; final_change = cur_change; min_pos = pos; }
-        }
-        const int qm = q_coef[min_pos];
-        if (qm == 32767 || qm == -32768) final_change = -1;
-        if (coef[min_pos] >= 0) q_coef[min_pos] = (i16)(qm + final_change);
-        else q_coef[min_pos] = (i16)(qm - final_change);
-      }
-    }
-    if (last_cg == 1) last_cg = 0;
+    for (int n = 0; n < 16; ++n) { pos16[n] = scan_pos(scan_idx, log2_size, (subset << 4) + n); nz = nz || q_coef[pos16[n]] != 0; }
+    sign_hide_cg(coef, q_coef, pos16, nz && !seen_nz, k);
+    seen_nz = seen_nz || nz;
   }
 }
 
-__global__ __launch_bounds__(64) void sign_hide_kernel(const i16 *__restrict__ coef, i16 *__restrict__ q_coef,
-                                                       size_t count, int width, int scan_idx, quant_consts k)
+// Batched form: one LANE per coefficient group -- NCG = (width / 4)^2 adjacent lanes share a block.  The block-level facts a
+// group needs come from its neighbours in the wave: ac_sum (:52-68) is a sum over the block's lanes, "last group" a
+// ballot of the lanes that hold a non-zero level.  (The first version ran one thread per BLOCK.)
+template <int NCG>
+__global__ __launch_bounds__(256) void sign_hide_kernel(const i16 *__restrict__ coef, i16 *__restrict__ q_coef,
+                                                        size_t count, int width, int scan_idx, quant_consts k)
 {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const size_t off = i * (size_t)(width * width);
-  sign_hide_block(coef + off, q_coef + off, width, scan_idx, k);
+  const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t blk = item / NCG;
+  const int cg = (int)(item % NCG), lane = threadIdx.x & 63;
+  const bool valid = blk < count;
+  const size_t off = (valid ? blk : count - 1) * (size_t)(width * width);
+  const i16 *c = coef + off;
+  i16 *q = q_coef + off;
+  const int log2_size = width == 4 ? 2 : width == 8 ? 3 : width == 16 ? 4 : 5;
+  int pos16[16];
+  bool nz = false;
+  u32 ac = 0;
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    pos16[n] = scan_pos(scan_idx, log2_size, (cg << 4) + n);
+    nz = nz || q[pos16[n]] != 0;
+    ac += (u32)quant_level(c[pos16[n]], k.qtable ? k.qtable[pos16[n]] : k.flat_qc, k);
+  }
+  ac = group_sum<NCG>(ac);
+  const unsigned long long bal = __ballot(nz && valid);
+  // lanes of my block above me: bits lane + 1 .. base + NCG - 1
+  const int base = lane & ~(NCG - 1);
+  const unsigned long long group = (NCG == 64 ? ~0ull : ((1ull << NCG) - 1ull)) << base;
+  const unsigned long long above = group & ~((2ull << lane) - 1ull);
+  const bool is_last = nz && (bal & above) == 0ull;
+  if (valid && ac >= 2) sign_hide_cg(c, q, pos16, is_last, k);
 }
 
 // coeff_abs_sum (quant-generic.c:323-330): one wave per block
@@ -535,6 +565,9 @@ int launch_quantize_residual32_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec
 int launch_quantize_residual16_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
                                     int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
                                     int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
+int launch_quantize_residual8_reg(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
+                                  int q_bits, int add, int flat_qc, int dq_shift, int dq_add, int dq_scale,
+                                  u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
 }
 
 extern "C" {
@@ -552,7 +585,15 @@ int kvz_hip_quant_batch(const kvz_hip_quant_params *p, const kvz_hip_coeff *coef
   hipLaunchKernelGGL(quant_kernel, dim3(stream_grid(total, 2048, (unsigned)tuning("quant_wgs_per_cu", 256))), dim3(256), 0, st, coef, q_coef, total, width * width, k);
   KVZ_CHECK_LAUNCH("quant_kernel");
   if (k.signhide) {
-    hipLaunchKernelGGL(sign_hide_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, coef, q_coef, count, width, scan_idx, k);
+    const size_t ncg = (size_t)(width / 4) * (width / 4), items = count * ncg;
+    const dim3 grid((unsigned)((items + 255) / 256));
+    if (items > 0xffffffffull * 256ull) return kvzhip::invalid_arg(__func__);
+    switch (width) {
+      case 4: hipLaunchKernelGGL(sign_hide_kernel<1>, grid, dim3(256), 0, st, coef, q_coef, count, width, scan_idx, k); break;
+      case 8: hipLaunchKernelGGL(sign_hide_kernel<4>, grid, dim3(256), 0, st, coef, q_coef, count, width, scan_idx, k); break;
+      case 16: hipLaunchKernelGGL(sign_hide_kernel<16>, grid, dim3(256), 0, st, coef, q_coef, count, width, scan_idx, k); break;
+      default: hipLaunchKernelGGL(sign_hide_kernel<64>, grid, dim3(256), 0, st, coef, q_coef, count, width, scan_idx, k); break;
+    }
     KVZ_CHECK_LAUNCH("sign_hide_kernel");
   }
   return KVZ_HIP_OK;
@@ -603,6 +644,9 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   if (width == 16 && !use_trskip && !k.signhide && tuning("qr16_use_mfma", 1))
     return launch_quantize_residual16_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
                                            k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
+  if (width == 8 && !use_trskip && !k.signhide && !k.qtable && k.dq_mode == 0 && tuning("qr8_reg_kernel", 1))
+    return launch_quantize_residual8_reg(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc,
+                                         k.dq_shift, k.dq_add, k.dq_scale, ssd_out, abs_sum_out, st);
   if (width == 4 && !k.signhide && tuning("qr4_lane_kernel", 1)) {
     const unsigned grid = stream_grid(count, 256, (unsigned)tuning("qr4_wgs_per_cu", 96)       /* measured: 16: 4.8 TB/s, 64: 5.4, 128: 5.4 */);
     if (use_trskip) hipLaunchKernelGGL((quantize_residual4_lane_kernel<4>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);

@@ -28,6 +28,7 @@ extern "C" int kvz_strategyselector_register(void *opaque, const char *type, con
 namespace kvzhip {
 int launch_frac_step(const u8 *win, int w, int h, int step, int fme_level, int hx, int hy,
                      u8 *filtered, i16 *hor_out, i16 *cols_out, hipStream_t st);
+int launch_extend_block(const u8 *rect, int rw, int rh, int ox, int oy, u8 *out, int ow, int oh, hipStream_t st);
 }
 
 namespace {
@@ -97,6 +98,7 @@ void die(const char *what, int rc)
 #define HMUST(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { set_error(#call, e__); die(#call, KVZ_HIP_ERR_RUNTIME); } } while (0)
 
 inline size_t up16(size_t v) { return (v + 15) & ~(size_t)15; }
+inline int clampi_host(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 std::atomic<unsigned long long> g_dropin_calls{0};
 
@@ -321,20 +323,19 @@ unsigned hip_quantize_residual(void *state, const void *cur_cu, const int width,
   if (g_acc.rdoq_enable && g_acc.rdoq_enable(state) && (w > 4 || !(g_acc.rdoq_skip && g_acc.rdoq_skip(state)))) {
     // quant-generic.c:214-221: the quantiser is the host's kvz_rdoq (CABAC-context dependent control plane, called
     // by every strategy's quantize_residual); residual, transforms, dequantisation and reconstruction stay on the GPU
-    if (!g_acc.rdoq || !g_acc.rdoq_skip || !g_acc.cu_rdoq_tr_depth || !g_acc.cu_type || use_trskip) {
-      std::fprintf(stderr, "kvzhip: quantize_residual with rdoq enabled needs the rdoq accessors of kvz_hip_state_accessors "
-                           "(INTEGRATION.md) and no transform skip; select another strategy with KVAZAAR_OVERRIDE_quantize_residual\n");
-      std::abort();
-    }
+    // (registration guarantees the four rdoq accessors: kvz_strategy_register_quant_hip)
     const size_t n = (size_t)w * w;
     const bool dst = (w == 4 && color == 0 && intra);               // strategies-dct.c:66-85
+    // quant-generic.c:206-212: transform skip replaces the transform pair, RDOQ still quantises
+    const int fwd_kind = use_trskip ? KVZ_HIP_TRSKIP : (dst ? KVZ_HIP_DST : KVZ_HIP_DCT);
+    const int inv_kind = use_trskip ? KVZ_HIP_ITRSKIP : (dst ? KVZ_HIP_IDST : KVZ_HIP_IDCT);
     kvz_hip_quant_params p = flatten_state(state, w, tq, tdq, intra, s, c);
     size_t orf = s.take(n), opr = s.take(n), in_end = s.off;
     size_t ors = s.take(n * 2), oco = s.take(n * 2);
     pack_rows(c.h + orf, ref_in, w, w, (size_t)in_stride); pack_rows(c.h + opr, pred_in, w, w, (size_t)in_stride);
     s.h2d(0, in_end);
     MUST(kvz_hip_residual_batch(c.d + orf, c.d + opr, (kvz_hip_coeff *)(c.d + ors), n, c.st));
-    MUST(kvz_hip_transform_batch(dst ? KVZ_HIP_DST : KVZ_HIP_DCT, w, (const kvz_hip_coeff *)(c.d + ors), (kvz_hip_coeff *)(c.d + oco), 1, c.st));
+    MUST(kvz_hip_transform_batch(fwd_kind, w, (const kvz_hip_coeff *)(c.d + ors), (kvz_hip_coeff *)(c.d + oco), 1, c.st));
     s.d2h(oco, n * 2); s.sync();
     g_acc.rdoq(state, (kvz_hip_coeff *)(c.h + oco), coeff_out, w, w, (int8_t)tq, (int8_t)scan_order, (int8_t)g_acc.cu_type(cur_cu),
                (int8_t)g_acc.cu_rdoq_tr_depth(cur_cu));
@@ -345,7 +346,7 @@ unsigned hip_quantize_residual(void *state, const void *cur_cu, const int width,
       std::memcpy(c.h + oq, coeff_out, n * 2);
       s.h2d(oq, q_end - oq);
       MUST(kvz_hip_dequant_batch(&p, (const kvz_hip_coeff *)(c.d + oq), (kvz_hip_coeff *)(c.d + odq), w, tdq, 1, c.st));
-      MUST(kvz_hip_transform_batch(dst ? KVZ_HIP_IDST : KVZ_HIP_IDCT, w, (const kvz_hip_coeff *)(c.d + odq), (kvz_hip_coeff *)(c.d + ors), 1, c.st));
+      MUST(kvz_hip_transform_batch(inv_kind, w, (const kvz_hip_coeff *)(c.d + odq), (kvz_hip_coeff *)(c.d + ors), 1, c.st));
       MUST(kvz_hip_reconstruct_batch((const kvz_hip_coeff *)(c.d + ors), c.d + opr, c.d + ore, n, c.st));
       s.d2h(ore, n); s.sync();
       for (int y = 0; y < w; ++y) std::memcpy(rec_out + (size_t)y * out_stride, c.h + ore + (size_t)y * w, (size_t)w);
@@ -392,6 +393,46 @@ void hip_sample(const void *encoder, kvz_hip_pixel *src, int16_t src_stride, int
   const size_t esz = OUT14 ? 2 : 1;
   for (int y = 0; y < height; ++y)
     std::memcpy((u8 *)dst + (size_t)y * dst_stride * esz, c.h + oo + (size_t)y * width * esz, (size_t)width * esz);
+}
+
+// epol_func (strategies-ipol.h:41-42), kvz_get_extended_block_generic (ipol-generic.c:731-784): a window that lies inside the
+// reference plane is returned as pointers into it, exactly like generic (no copy, no launch); one that leaves the plane
+// is built with edge replication in a malloc'ed buffer the caller frees (malloc_used = 1).  The replication runs on the
+// GPU: the part of the plane the window overlaps is staged, extend_block_kernel clamps, the result is copied back.
+struct ext_block { kvz_hip_pixel *buffer; kvz_hip_pixel *orig_topleft; unsigned stride; unsigned malloc_used; };   // kvz_extended_block, strategies-ipol.h:35
+unsigned hip_get_extended_block(int xpos, int ypos, int mv_x, int mv_y, int off_x, int off_y, kvz_hip_pixel *ref, int ref_width,
+                                int ref_height, int filter_size, int width, int height, void *out_v)
+{
+  ext_block *out = (ext_block *)out_v;
+  const int half = filter_size >> 1;
+  const int min_y = ypos - half + off_y + mv_y, max_y = min_y + height + filter_size;
+  const int min_x = xpos - half + off_x + mv_x, max_x = min_x + width + filter_size;
+  out->buffer = ref + (ptrdiff_t)min_y * ref_width + min_x;
+  out->stride = (unsigned)ref_width;
+  out->orig_topleft = out->buffer + (ptrdiff_t)out->stride * half + half;
+  out->malloc_used = 0;
+  const bool oob = (min_y < 0) || (max_y >= ref_height) || (min_x < 0) || (max_x >= ref_width);
+  if (!oob) return 0;
+  // rows / columns the loops of :759-783 visit: ypos - half .. ypos + height + half - 1 (+ offsets), i.e. height + 2 * half
+  const int ow = width + filter_size, oh = height + filter_size;
+  const int nrows = height + 2 * half, ncols = width + 2 * half;
+  out->buffer = (kvz_hip_pixel *)std::malloc((size_t)ow * oh);
+  if (!out->buffer) { std::fprintf(stderr, "kvzhip: get_extended_block: out of memory\n"); std::abort(); }
+  out->stride = (unsigned)ow;
+  out->orig_topleft = out->buffer + (size_t)out->stride * half + half;
+  out->malloc_used = 1;
+  // the clamped source rectangle [cx0, cx1] x [cy0, cy1] (never empty: clamping maps every coordinate into the plane)
+  const int cy0 = clampi_host(min_y, 0, ref_height - 1), cy1 = clampi_host(min_y + nrows - 1, 0, ref_height - 1);
+  const int cx0 = clampi_host(min_x, 0, ref_width - 1), cx1 = clampi_host(min_x + ncols - 1, 0, ref_width - 1);
+  const int rw = cx1 - cx0 + 1, rh = cy1 - cy0 + 1;
+  call_ctx &c = tls(); stage s(c);
+  size_t oi = s.take((size_t)rw * rh), in_end = s.off, oo = s.take((size_t)ncols * nrows);
+  pack_rows(c.h + oi, ref + (size_t)cy0 * ref_width + cx0, rw, rh, (size_t)ref_width);
+  s.h2d(0, in_end);
+  MUST(launch_extend_block(c.d + oi, rw, rh, cx0 - min_x, cy0 - min_y, c.d + oo, ncols, nrows, c.st));
+  s.d2h(oo, (size_t)ncols * nrows); s.sync();
+  for (int y = 0; y < nrows; ++y) std::memcpy(out->buffer + (size_t)y * out->stride, c.h + oo + (size_t)y * ncols, (size_t)ncols);
+  return 0;
 }
 
 // ipol_blocks_func (strategies-ipol.h:36-38): one of the four frac-search filter steps.  The caller owns
@@ -680,18 +721,22 @@ int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth)
   if (!hook_ready(bitdepth)) return 0;
   int ok = 1;
   ok &= reg(opaque, "coeff_abs_sum", (void *)&hip_coeff_abs_sum);
-  if (g_have_acc) {
+  // quant / dequant read the state through the accessors; with a scaling-list switch they also need the two tables
+  const bool tables_ok = !g_acc.scaling_list_enable || (g_acc.quant_coeff && g_acc.dequant_coeff);
+  // quantize_residual additionally calls the host's kvz_rdoq when RDOQ is on: all of its accessors, or no RDOQ switch at all
+  const bool rdoq_ok = !g_acc.rdoq_enable || (g_acc.rdoq && g_acc.rdoq_skip && g_acc.cu_rdoq_tr_depth && g_acc.cu_type);
+  if (g_have_acc && tables_ok) {
     ok &= reg(opaque, "quant", (void *)&hip_quant);
     ok &= reg(opaque, "dequant", (void *)&hip_dequant);
-    ok &= reg(opaque, "quantize_residual", (void *)&hip_quantize_residual);
+    if (rdoq_ok) ok &= reg(opaque, "quantize_residual", (void *)&hip_quantize_residual);
   }
   return ok;
 }
 
 // STRATEGIES_IPOL_EXPORTS, strategies-ipol.h:65-74: the four sample filters and the four
 // frac-search filter steps (each writes the caller's scratch exactly like generic; the
-// throughput form is the fused kvz_hip_search_frac_batch).  get_extended_block is host
-// pointer/malloc logic (it returns host memory the caller frees) and stays on the CPU.
+// throughput form is the fused kvz_hip_search_frac_batch), and get_extended_block (in-plane windows are pointers into the
+// caller's plane like generic's; the edge replication of the others runs on the GPU).
 int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
 {
   if (!hook_ready(bitdepth)) return 0;
@@ -704,6 +749,7 @@ int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
   ok &= reg(opaque, "filter_hpel_blocks_diag_luma", (void *)&hip_filter_step<1>);
   ok &= reg(opaque, "filter_qpel_blocks_hor_ver_luma", (void *)&hip_filter_step<2>);
   ok &= reg(opaque, "filter_qpel_blocks_diag_luma", (void *)&hip_filter_step<3>);
+  ok &= reg(opaque, "get_extended_block", (void *)&hip_get_extended_block);
   return ok;
 }
 

@@ -201,6 +201,26 @@ unsigned ref_image_calc_satd(const char *name, kvz_pixel *pic, int pw, int ph, k
   return kvz_image_calc_satd(&a, &b, pic_x, pic_y, ref_x, ref_y, bw, bh);
 }
 
+/* epol_func (strategies-ipol.h:41-42) of the named strategy: copies the (height + filter_size) x (width + filter_size)
+ * window it describes into win_out, reports malloc_used, the stride and -- for an in-plane window -- the offset of
+ * .buffer and .orig_topleft inside the plane; frees what the strategy allocated, like the callers do */
+int ref_get_extended_block(const char *name, int xpos, int ypos, int mv_x, int mv_y, int off_x, int off_y, kvz_pixel *ref, int ref_w, int ref_h,
+                           int filter_size, int width, int height, kvz_pixel *win_out, long *info /* stride, buffer - ref, topleft - buffer */)
+{
+  epol_func *f = (epol_func *)ref_strategy("get_extended_block", name);
+  if (!f) return -1;
+  kvz_extended_block b = { 0, 0, 0, 0 };
+  f(xpos, ypos, mv_x, mv_y, off_x, off_y, ref, ref_w, ref_h, filter_size, width, height, &b);
+  const int half = filter_size >> 1;
+  for (int y = 0; y < height + 2 * half; ++y) memcpy(win_out + (size_t)y * (width + 2 * half), b.buffer + (size_t)y * b.stride, (size_t)(width + 2 * half));
+  info[0] = (long)b.stride;
+  info[1] = b.malloc_used ? -1 : (long)(b.buffer - ref);
+  info[2] = (long)(b.orig_topleft - b.buffer);
+  const int used = (int)b.malloc_used;
+  if (b.malloc_used) free(b.buffer);
+  return used;
+}
+
 /* The filter + quad-SATD sequence of search_frac (search_inter.c:965-1128),
  * driven through the reference's strategy functions, without MV bit costs:
  * validates orc_search_frac_costs. */

@@ -273,6 +273,21 @@ def sample(kind, frame, x, y, w, h, mvx, mvy, name="generic"):
     return dst
 
 
+def get_extended_block(frame, xpos, ypos, mv_x, mv_y, filter_size, width, height, off_x=0, off_y=0, name="generic"):
+    """epol_func of the named strategy -> (window [height + fs, width + fs], malloc_used, (stride, buffer - ref or -1, topleft - buffer))"""
+    L = lib()
+    L.ref_get_extended_block.restype = C.c_int
+    L.ref_get_extended_block.argtypes = [S] + [C.c_int] * 6 + [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_long)]
+    frame = _u8(frame)
+    half = filter_size >> 1
+    win = np.zeros((height + 2 * half, width + 2 * half), dtype=np.uint8)
+    info = (C.c_long * 3)()
+    used = L.ref_get_extended_block(name.encode(), xpos, ypos, mv_x, mv_y, off_x, off_y, frame.ctypes.data, frame.shape[1], frame.shape[0],
+                                    filter_size, width, height, win.ctypes.data, info)
+    assert used >= 0
+    return win, used, tuple(info)
+
+
 def filter_frac_steps(frame, x, y, w, h, offs, fme_level=4, name="generic"):
     frame = _u8(frame)
     stride = frame.shape[1]

@@ -205,6 +205,8 @@ ENCODER_CONFIGS = [
     (192, 128, 4, "preset=medium,rdoq=0,me=tz,subme=4,smp=1,amp=1,bipred=1,gop=8,qp=24,threads=2"),
     (128, 128, 4, "preset=medium,rdoq=0,rd=2,qp=30,threads=2"),                       # full RD: SSD / coefficient costs everywhere
     (128, 64, 4, "preset=fast,rdoq=0,transform-skip=1,rd=1,qp=26,threads=0"),          # 4x4 transform skip + its SAD test
+    # transform skip with RDOQ quantising the skipped 4x4 blocks (quant-generic.c:206-221: kvz_transformskip, then kvz_rdoq)
+    (128, 64, 4, "preset=medium,transform-skip=1,rdoq=1,rdoq-skip=0,rd=1,qp=26,threads=0"),
     (128, 128, 3, "preset=medium,rdoq=0,scaling-list=default,qp=28,threads=2"),        # scaling-list tables through the accessors
     (128, 64, 4, "preset=fast,rdoq=0,me=dia,full-intra-search=1,mv-rdo=1,qp=35,threads=0"),
     (64, 64, 3, "preset=medium,rdoq=0,lossless=1,threads=0"),
@@ -297,3 +299,66 @@ def test_device_staging_mode_in_a_child_process():
     env = dict(os.environ, KVZ_HIP_ZEROCOPY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "child ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_quant_group_registers_only_what_its_accessors_support():
+    """kvz_strategy_register_quant_hip with partial accessor tables: a function whose state accessors are missing is not
+    registered (the host keeps its next-best strategy) instead of aborting or diverging at run time.  Own process: the
+    accessor table and the registrar are process-global."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from kvazaar_amd import _lib\n"
+        "L = _lib.init(0)\n"
+        "seen = []\n"
+        "REG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p)\n"
+        "cb = REG(lambda o, t, n, p, f: (seen.append(t.decode()), 1)[1])\n"
+        "L.kvz_hip_set_registrar(C.cast(cb, C.c_void_p))\n"
+        "F = C.CFUNCTYPE(C.c_int, C.c_void_p)\n"
+        "one = F(lambda s: 1)\n"
+        "ptr = lambda f: C.cast(f, C.c_void_p).value\n"
+        "def run(fields):\n"
+        "    tab = (C.c_void_p * 18)()\n"
+        "    for i in fields: tab[i] = ptr(one)\n"
+        "    L.kvz_hip_set_state_accessors(C.cast(tab, C.c_void_p))\n"
+        "    del seen[:]\n"
+        "    assert L.kvz_strategy_register_quant_hip(None, 8) == 1\n"
+        "    return sorted(seen)\n"
+        "base = [0, 1, 2, 7]                      # qp, slice_is_intra, signhide_enable, cu_is_intra\n"
+        "assert run([]) == ['coeff_abs_sum']\n"
+        "assert run(base) == ['coeff_abs_sum', 'dequant', 'quant', 'quantize_residual']\n"
+        "assert run(base + [3]) == ['coeff_abs_sum']                        # scaling_list_enable without the two tables\n"
+        "assert run(base + [3, 4, 5]) == ['coeff_abs_sum', 'dequant', 'quant', 'quantize_residual']\n"
+        "assert run(base + [6]) == ['coeff_abs_sum', 'dequant', 'quant']    # rdoq_enable without kvz_rdoq and its accessors\n"
+        "assert run(base + [6, 14, 15, 16, 17]) == ['coeff_abs_sum', 'dequant', 'quant', 'quantize_residual']\n"
+        "print('child ok')\n"
+    ) % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "child ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_get_extended_block_through_registry(hip):
+    """the ninth ipol type (strategies-ipol.h:74): windows inside the plane come back as pointers into it, like generic's;
+    windows that leave it are edge replicated (on the GPU) into a malloc'ed buffer the caller frees"""
+    assert R.has_strategy("get_extended_block", "hip")
+    g = rng(77)
+    frame = g.integers(0, 256, (72, 96), dtype=np.uint8)
+    cases = []
+    for fs in (8, 4):                                    # KVZ_LUMA_FILTER_TAPS, KVZ_CHROMA_FILTER_TAPS
+        for (w, h) in ((9, 9), (17, 17), (65, 65), (8, 4), (4, 16)):
+            for (x, y, mx, my) in ((20, 20, 0, 0), (0, 0, -1, -1), (90, 60, 3, 5), (40, -30, 0, 0), (-70, 30, 2, 2), (95, 71, 40, 40),
+                                   (10, 10, -200, 3), (30, 200, 0, 0), (5, 62, 1, 1), (0, 30, 4, 0)):
+                cases.append((x, y, mx, my, fs, w, h))
+    n_malloc = 0
+    for (x, y, mx, my, fs, w, h) in cases:
+        a, ua, ia = R.get_extended_block(frame, x, y, mx, my, fs, w, h, name="hip")
+        b, ub, ib = R.get_extended_block(frame, x, y, mx, my, fs, w, h, name="generic")
+        assert ua == ub and ia == ib, (x, y, mx, my, fs, w, h, ua, ub, ia, ib)
+        np.testing.assert_array_equal(a, b, err_msg=str((x, y, mx, my, fs, w, h)))
+        n_malloc += ua
+    assert 0 < n_malloc < len(cases)
+    a, _, _ = R.get_extended_block(frame, 3, 4, 0, 0, 8, 9, 9, off_x=16, off_y=8, name="hip")      # tile offsets (search_inter.c:1007-1012)
+    b, _, _ = R.get_extended_block(frame, 3, 4, 0, 0, 8, 9, 9, off_x=16, off_y=8, name="generic")
+    np.testing.assert_array_equal(a, b)

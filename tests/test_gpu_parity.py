@@ -519,6 +519,31 @@ def test_intra_rough_matches_predict_plus_satd_at_frame_scale(api):
         np.testing.assert_array_equal(satd[:, m], c, err_msg="mode %d" % m)
 
 
+@pytest.mark.parametrize("log2_width_c", [2, 3, 4, 5])
+def test_intra_chroma_rough_search(api, log2_width_c):
+    """search_intra_chroma_rough (search_intra.c:329-370): for the five candidate chroma modes, cost = satd(U prediction) +
+    satd(V prediction) with kvz_intra_predict(..., COLOR_U / COLOR_V, filter_boundary false) -- the rough kernel with
+    KVZ_HIP_INTRA_LUMA clear (no reference smoothing, no DC / boundary filters), one launch per plane; the host adds the
+    two tables and sorts like sort_modes"""
+    count, n = 40, 1 << log2_width_c
+    refs_u = intra_ref_cases(log2_width_c, count, 610 + log2_width_c)
+    refs_v = intra_ref_cases(log2_width_c, count, 650 + log2_width_c)
+    orig_u = _intra_orig(refs_u, log2_width_c, 3)
+    orig_v = _intra_orig(refs_v, log2_width_c, 4)
+    got = api.intra_rough_batch(refs_u, log2_width_c, orig_u, flags=0).astype(np.int64) + \
+        api.intra_rough_batch(refs_v, log2_width_c, orig_v, flags=0).astype(np.int64)
+    for luma_mode in (0, 26, 14):
+        modes = [0, 26, 10, 1, 34 if luma_mode in (0, 26, 10, 1) else luma_mode]       # search_intra.c:766-778
+        want = np.zeros((count, 5), np.int64)
+        for refs, orig in ((refs_u, orig_u), (refs_v, orig_v)):
+            pred = O.intra_predict_batch(refs, log2_width_c, modes, is_luma=0, filter_boundary=0)
+            for k in range(5):
+                want[:, k] += O.cost_nxn_batch("satd", n, np.ascontiguousarray(pred[:, k, :]), orig)
+        np.testing.assert_array_equal(got[:, modes], want)
+        # the decision: same order after the reference's insertion sort (stable: ties keep list order)
+        np.testing.assert_array_equal(np.argsort(got[:, modes], axis=1, kind="stable"), np.argsort(want, axis=1, kind="stable"))
+
+
 def test_intra_argument_errors(api):
     from kvazaar_amd._lib import KvzHipError
     refs = intra_ref_cases(3, 2, 1)
@@ -996,3 +1021,28 @@ def test_contexts_per_device_and_thread_binding(api):
     ts = [threading.Thread(target=work, args=(50 + i, i % ndev)) for i in range(4)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert not errs, errs
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_transform_skip_kinds(api, n):
+    """KVZ_HIP_TRSKIP / KVZ_HIP_ITRSKIP = kvz_transformskip / kvz_itransformskip (transform.c:150-180): a shift by
+    15 - 8 - log2(n) with the reference's int16 stores; pinned through the oracle's quantize_residual (trskip path) below
+    and, closed form, here"""
+    g = rng(300 + n)
+    x = g.integers(-32768, 32768, (257, n * n)).astype(np.int16)
+    shift = 15 - 8 - {4: 2, 8: 3, 16: 4, 32: 5}[n]
+    np.testing.assert_array_equal(api.transform_batch("trskip", n, x), (x.astype(np.int32) << shift).astype(np.int16))
+    np.testing.assert_array_equal(api.transform_batch("itrskip", n, x), ((x.astype(np.int32) + (1 << (shift - 1))) >> shift).astype(np.int16))
+    # the chain residual -> trskip -> quant -> dequant -> itrskip -> reconstruct equals the fused trskip path of the oracle (4x4, the only
+    # size the encoder uses it for)
+    if n == 4:
+        ref = g.integers(0, 256, (500, 16), dtype=np.uint8)
+        pred = np.clip(ref.astype(np.int32) + g.integers(-40, 41, ref.shape), 0, 255).astype(np.uint8)
+        rec, coef, has = O.quantize_residual_many(ref, pred, 4, 30, 0, 0, 0, use_trskip=1)
+        res = ref.astype(np.int16) - pred.astype(np.int16)
+        q = api.quant_batch(api.transform_batch("trskip", 4, res), 4, 30, 0, 0)
+        np.testing.assert_array_equal(q, coef)
+        back = api.transform_batch("itrskip", 4, api.dequant_batch(q, 4, 30, 0))
+        want = np.clip((back.astype(np.int32) + pred).astype(np.int16), 0, 255).astype(np.uint8)
+        nz = (q != 0).any(axis=1)
+        np.testing.assert_array_equal(rec[nz], want[nz])

@@ -24,7 +24,7 @@ def main():
                 k = r["Kernel_Name"]
                 if not any(s in k for s in subs):
                     continue
-                short = k.split("(")[0].replace("void ", "")
+                short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
                 acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta[short] = (r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"])
     lines = []
