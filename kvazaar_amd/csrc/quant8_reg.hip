@@ -262,7 +262,7 @@ int launch_quantize_residual8_reg(const u8 *ref_in, const u8 *pred_in, u8 *rec_o
   const q8_consts k = { q_bits, add, flat_qc, dq_shift, dq_add, dq_scale };
   const size_t ngroups = (count + 7) / 8;
   size_t wgs = (ngroups + 3) / 4;                       // 4 waves per workgroup, one group of 8 TUs per wave step
-  const size_t cap = (size_t)num_cus() * (size_t)tuning("qr8_wgs_per_cu", 128);   // measured: 16: 3.77, 64: 3.83, 128: 3.86, 256: 3.65 TB/s (first version)
+  const size_t cap = (size_t)num_cus() * (size_t)tuning("qr8_wgs_per_cu", 32);   // measured (0.5 GiB operands): 32: 4.95, 64: 4.84, 128: 4.79, 192: 4.67 TB/s
   if (wgs > cap) wgs = cap;
   if (ssd_out)
     hipLaunchKernelGGL(quantize_residual8_reg_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out,
