@@ -34,10 +34,10 @@ struct tune_entry { const char *key; std::atomic<int> value; };
 static tune_entry g_tune[] = { { "sad_wgs_per_cu", {-1} }, { "satd8_wgs_per_cu", {-1} }, { "dct32_wgs_per_cu", {-1} },
                                { "idct32_wgs_per_cu", {-1} }, { "dct_wgs_per_cu", {-1} }, { "qr32_wgs_per_cu", {-1} },
                                { "qr_wgs_per_cu", {-1} }, { "dct16_wgs_per_cu", {-1} }, { "idct16_wgs_per_cu", {-1} }, { "idct16_use_mfma", {-1} },
-                               { "qr16_wgs_per_cu", {-1} }, { "qr16_use_mfma", {-1} }, { "qr4_lane_kernel", {-1} },
+                               { "qr16_wgs_per_cu", {-1} }, { "qr4_lane_kernel", {-1} },
                                { "me_big_threads", {-1} }, { "sao_edge_fast", {-1} }, { "me_medium_threads", {-1} },
                                { "intra_rough_waves", {-1} }, { "pair_wave_kernel", {-1} }, { "qr4_wgs_per_cu", {-1} }, { "quant_wgs_per_cu", {-1} },
-                               { "qr8_reg_kernel", {-1} }, { "qr8_wgs_per_cu", {-1} } };
+                               { "qr8_reg_kernel", {-1} }, { "qr8_wgs_per_cu", {-1} }, { "qr_tile_kernel", {-1} } };
 int tuning(const char *key, int dflt)
 {
   for (auto &e : g_tune) if (!std::strcmp(e.key, key)) { const int v = e.value.load(std::memory_order_relaxed); return v >= 0 ? v : dflt; }

@@ -559,12 +559,9 @@ __global__ __launch_bounds__(256) void reconstruct_kernel(const i16 *__restrict_
 }
 
 namespace kvzhip {
-int launch_quantize_residual32_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
-                                    int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
-                                    int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
-int launch_quantize_residual16_mfma(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
-                                    int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
-                                    int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
+int launch_quantize_residual_tile(int n, const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
+                                  int q_bits, int add, int flat_qc, const int32_t *qtable, int dq_mode, int dq_shift, int dq_add,
+                                  int dq_scale, const int32_t *dqtable, u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
 int launch_quantize_residual8_reg(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count,
                                   int q_bits, int add, int flat_qc, int dq_shift, int dq_add, int dq_scale,
                                   u32 *ssd_out, u32 *abs_sum_out, hipStream_t st);
@@ -638,12 +635,9 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   if (count == 0) return KVZ_HIP_OK;
   hipStream_t st = ctx_stream(s);
   const bool dst = (width == 4 && color == 0 && cu_is_intra);     // strategies-dct.c:66-85
-  if (width == 32 && !use_trskip && !k.signhide)
-    return launch_quantize_residual32_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
-                                           k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
-  if (width == 16 && !use_trskip && !k.signhide && tuning("qr16_use_mfma", 1))
-    return launch_quantize_residual16_mfma(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
-                                           k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
+  if ((width == 32 || width == 16) && !use_trskip && !k.signhide && tuning("qr_tile_kernel", 1))
+    return launch_quantize_residual_tile(width, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
+                                         k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
   if (width == 8 && !use_trskip && !k.signhide && !k.qtable && k.dq_mode == 0 && tuning("qr8_reg_kernel", 1))
     return launch_quantize_residual8_reg(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc,
                                          k.dq_shift, k.dq_add, k.dq_scale, ssd_out, abs_sum_out, st);

@@ -285,27 +285,37 @@ def test_quantize_residual(api, w):
     np.testing.assert_array_equal(got[0], want[0])
 
 
-def test_quantize_residual_16_both_kernels(api):
-    """16x16 TUs run on the matrix cores by default (two TUs per MFMA tile); the VALU kernel stays selectable.  Odd and
-    even counts (the pair tail), TUs with and without coefficients inside one pair."""
+@pytest.mark.parametrize("n", [8, 16, 32])
+def test_quantize_residual_fast_and_lds_kernels(api, n):
+    """8x8 TUs run in registers (8 per wave), 16x16 / 32x32 on the matrix cores (four 16x16 TUs or one 32x32 per MFMA tile) by
+    default; the LDS butterfly kernel stays selectable.  Counts that leave the last wave step / tile partly empty, TUs with and
+    without coefficients inside one step, both rd=0 cost outputs, luma and chroma QP mapping."""
     from kvazaar_amd import _lib
     L = _lib.init(0)
-    g = rng(160)
-    for count in (1, 2, 7, 64):
-        ref_in = g.integers(0, 256, (count, 256), dtype=np.uint8)
-        pred = np.clip(ref_in.astype(np.int32) + g.integers(-50, 51, ref_in.shape), 0, 255).astype(np.uint8)
-        pred[::2] = ref_in[::2]                              # every other TU quantises to nothing
-        for qp in (10, 27, 44):
-            want = O.quantize_residual_batch(ref_in, pred, 16, qp, 0, 0, 0)
-            for use in (1, 0):
-                _lib.check(L.kvz_hip_set_tuning(b"qr16_use_mfma", use), "tuning")
-                got = api.quantize_residual_batch(ref_in, pred, 16, qp, 0, 0, 0, with_costs=True)
-                for a, b, nm in zip(got[:3], want, ("rec", "coeff", "has")):
-                    np.testing.assert_array_equal(a, b, err_msg="%s count=%d qp=%d mfma=%d" % (nm, count, qp, use))
-                for i in range(count):
-                    assert got[3][i] == O.pixels_calc_ssd(ref_in[i], 0, want[0][i], 0, 16, 16, 16)
-                    assert got[4][i] == O.coeff_abs_sum(want[1][i])
-    L.kvz_hip_set_tuning(b"qr16_use_mfma", -1)
+    g = rng(160 + n)
+    key = b"qr8_reg_kernel" if n == 8 else b"qr_tile_kernel"
+    try:
+        for count in (1, 2, 3, 5, 7, 9, 64, 67):
+            ref_in = g.integers(0, 256, (count, n * n), dtype=np.uint8)
+            pred = np.clip(ref_in.astype(np.int32) + g.integers(-50, 51, ref_in.shape), 0, 255).astype(np.uint8)
+            pred[::2] = ref_in[::2]                              # every other TU quantises to nothing
+            if count > 4:
+                pred[3] = 255 - ref_in[3]                        # extreme residuals
+            for qp, color in ((10, 0), (27, 0), (44, 0), (33, 1), (51, 2)):
+                want = O.quantize_residual_batch(ref_in, pred, n, qp, color, 0, 0)
+                for use in (1, 0):
+                    _lib.check(L.kvz_hip_set_tuning(key, use), "tuning")
+                    got = api.quantize_residual_batch(ref_in, pred, n, qp, color, 0, 0, with_costs=True)
+                    for a, b, nm in zip(got[:3], want, ("rec", "coeff", "has")):
+                        np.testing.assert_array_equal(a, b, err_msg="%s n=%d count=%d qp=%d fast=%d" % (nm, n, count, qp, use))
+                    for i in range(count):
+                        assert got[3][i] == O.pixels_calc_ssd(ref_in[i], 0, want[0][i], 0, n, n, n)
+                        assert got[4][i] == O.coeff_abs_sum(want[1][i])
+                    plain = api.quantize_residual_batch(ref_in, pred, n, qp, color, 0, 0)
+                    for a, b in zip(plain[:3], want):
+                        np.testing.assert_array_equal(a, b)
+    finally:
+        L.kvz_hip_set_tuning(key, -1)
 
 
 def test_quantize_residual_4_both_kernels(api):
