@@ -94,6 +94,10 @@ KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);
 /* Thin device-memory helpers so a C host needs no HIP headers. */
 KVZ_HIP_API void *kvz_hip_malloc(size_t bytes);
 KVZ_HIP_API void kvz_hip_free(void *dptr);
+/* page-locked host memory: what kvz_hip_memcpy_h2d / _d2h move without an intermediate copy (a host that feeds the
+ * batched entries front by front -- descriptors up, results down -- stages them here) */
+KVZ_HIP_API void *kvz_hip_malloc_host(size_t bytes);
+KVZ_HIP_API void kvz_hip_free_host(void *hptr);
 KVZ_HIP_API int kvz_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, kvz_hip_stream s);
 KVZ_HIP_API int kvz_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, kvz_hip_stream s);
 KVZ_HIP_API int kvz_hip_memset(void *dst, int value, size_t bytes, kvz_hip_stream s);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "kvz_hip_set_tuning": (_I, [C.c_char_p, _I]),
     "kvz_hip_malloc": (_P, [_SZ]),
     "kvz_hip_free": (None, [_P]),
+    "kvz_hip_malloc_host": (_P, [_SZ]),
+    "kvz_hip_free_host": (None, [_P]),
     "kvz_hip_memcpy_h2d": (_I, [_P, _P, _SZ, _P]),
     "kvz_hip_memcpy_d2h": (_I, [_P, _P, _SZ, _P]),
     "kvz_hip_memset": (_I, [_P, _I, _SZ, _P]),

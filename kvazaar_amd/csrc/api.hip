@@ -218,6 +218,15 @@ void *kvz_hip_malloc(size_t bytes)
   return p;
 }
 void kvz_hip_free(void *dptr) { if (dptr) (void)hipFree(dptr); }
+void *kvz_hip_malloc_host(size_t bytes)
+{
+  if (!ctx_enter() && (kvz_hip_init(-1) != KVZ_HIP_OK || !ctx_enter())) return nullptr;
+  void *p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { set_error("hipHostMalloc", e); return nullptr; }
+  return p;
+}
+void kvz_hip_free_host(void *hptr) { if (hptr) (void)hipHostFree(hptr); }
 
 int kvz_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, kvz_hip_stream s)
 {

@@ -191,6 +191,36 @@ def me():
     np.savez_compressed(os.path.join(OUT, "me.npz"), **d)
 
 
+FRONT_OPTS = "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=32,threads=0,smp=0,amp=0,period=0"
+
+
+def fronts():
+    """What the reference ENCODER searched: every 2Nx2N inter search of real encodes (harness recorder, oracle/ref_harness.c:
+    __wrap_kvz_search_cu_inter) with the AMVP / merge candidates and start vectors the encoder derived and the decisions the
+    reference search took.  Small sequence: planes stored whole.  One 1080p P frame (42 900 searches, BASELINE config 4): the
+    source planes are regenerated by ref_lib.synthetic_sequence, the reference picture (the encoder's reconstruction of frame
+    0) is stored as its int8 difference from the source frame 0."""
+    d = {}
+    w, h = 192, 128
+    rec = R.record_inter_searches(R.synthetic_sequence(w, h, 4), w, h, FRONT_OPTS)
+    assert rec["skipped"] == 0 and len(rec["pus"]) == 3 * 510
+    d["small_pic"], d["small_ref"] = rec["pic"], rec["ref"]
+    d["small_pus"] = rec["pus"].view(np.uint8).reshape(-1, 64)
+    d["small_results"] = rec["results"].view(np.int32).reshape(-1, 8)
+    d["small_meta"], d["small_params"] = rec["meta"], rec["params"].view(np.int32).reshape(16)
+    w, h = 1920, 1080
+    frames = R.synthetic_sequence(w, h, 2)
+    rec = R.record_inter_searches(frames, w, h, FRONT_OPTS, max_records=60000)
+    assert rec["skipped"] == 0 and len(rec["pus"]) == 42900 and (rec["pic"][0] == frames[1, :h]).all()
+    delta = rec["ref"][0].astype(np.int16) - frames[0, :h].astype(np.int16)
+    assert np.abs(delta).max() < 128
+    d["hd_ref_delta"] = delta.astype(np.int8)
+    d["hd_pus"] = rec["pus"].view(np.uint8).reshape(-1, 64)
+    d["hd_results"] = rec["results"].view(np.int32).reshape(-1, 8)
+    d["hd_meta"], d["hd_params"] = rec["meta"], rec["params"].view(np.int32).reshape(16)
+    np.savez_compressed(os.path.join(OUT, "fronts.npz"), **d)
+
+
 def deblock():
     """kvz_filter_deblock_lcu over every LCU (oracle/ref_harness.c: ref_deblock_frame) on three fabricated frames"""
     from patterns import deblock_case, deblock_params
@@ -213,7 +243,7 @@ if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, sao=sao, me=me, deblock=deblock)
+    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, sao=sao, me=me, deblock=deblock, fronts=fronts)
     for name in (sys.argv[1:] or list(groups)):          # python oracle/gen_golden.py [group ...]
         groups[name]()
     for f in sorted(os.listdir(OUT)):

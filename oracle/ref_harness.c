@@ -659,3 +659,177 @@ void ref_sao_reconstruct_color(const char *name, const kvz_pixel *rec, kvz_pixel
 }
 
 int ref_sizeof_sao_info(void) { return (int)sizeof(sao_info_t); }
+
+
+/* ------------------------------------------------------------------------
+ * Recorder of the reference's OWN inter searches during a real encode (the "driver" half of
+ * SURVEY 8f row 1).  oracle/Makefile links this library with -Wl,--wrap=kvz_search_cu_inter, so that the call in
+ * search.c reaches __wrap_kvz_search_cu_inter below, which -- when recording -- derives the PU's AMVP / merge
+ * candidates and start vector with the encoder's own functions exactly as search_pu_inter / search_pu_inter_ref do
+ * (search_inter.c:1492-1500, :1175-1206; pure functions of the state), runs the untouched reference search
+ * (__real_kvz_search_cu_inter) and notes what it decided.  With ONE reference picture and no bi-prediction the
+ * outputs of kvz_search_cu_inter are the outputs of the single search_pu_inter_ref call (:1275-1290): inter_cost =
+ * best_cost, inter_bitcost = best_bitcost, cur_cu->inter.mv[0] = best_mv, merged / merge_idx / mv_cand.
+ * Nothing here changes what the encoder does; without ref_record_begin the wrapper is a plain call-through.
+ * ------------------------------------------------------------------------ */
+#include "search_inter.h"
+#include "inter.h"
+
+typedef struct { int16_t mv[2]; uint8_t usable; uint8_t same_ref; } rec_merge_t;
+typedef struct {                              /* = kvz_hip_me_pu / orc_me_pu */
+  int32_t x, y, width, height;
+  int16_t mv_cand[2][2];
+  int16_t extra_mv[2];
+  int16_t num_merge_cand, reserved;
+  rec_merge_t merge[5];
+  int16_t pad;
+} rec_pu_t;
+typedef struct { int32_t mv[2]; uint32_t cost, bitcost; int32_t merged, merge_idx, mv_cand, reserved; } rec_result_t;
+typedef struct { int32_t frame, lcu_x, lcu_y, seq, lambda_cost, depth; } rec_meta_t;
+typedef struct {                              /* = kvz_hip_me_params / orc_me_params */
+  int32_t lambda_cost, early_termination;
+  uint32_t max_steps;
+  int32_t fme_level, wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right;
+  int32_t algorithm, search_range, size_classes, mv_constraint;
+  int32_t tile_x, tile_y, tile_w, tile_h;
+} rec_params_t;
+
+static struct {
+  int on, max, count, skipped;
+  rec_pu_t *pu; rec_result_t *res; rec_meta_t *meta;
+  rec_params_t params;
+  int n_frames, max_frames, w, h;
+  int32_t *frame_poc;
+  kvz_pixel *pic, *ref;                       /* [frame][h][w] luma: the source and the reference picture searched */
+  int cur_lcu_x, cur_lcu_y, cur_frame, seq;
+} g_rec;
+
+void __real_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost);
+
+static void rec_copy_plane(kvz_pixel *dst, const kvz_picture *p, int w, int h)
+{
+  for (int r = 0; r < h; ++r) memcpy(dst + (size_t)r * w, p->y + (size_t)r * p->stride, (size_t)w);
+}
+
+void __wrap_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
+{
+  const encoder_control_t *ctrl = state->encoder_control;
+  const int usable = g_rec.on && state->frame->ref->used_size == 1 && state->frame->slicetype == KVZ_SLICE_P &&
+                     !ctrl->cfg.mv_rdo && state->tile->offset_x == 0 && state->tile->offset_y == 0;
+  if (!usable || g_rec.count >= g_rec.max) {
+    if (g_rec.on) ++g_rec.skipped;
+    __real_kvz_search_cu_inter(state, x, y, depth, lcu, inter_cost, inter_bitcost);
+    return;
+  }
+  const int width = LCU_WIDTH >> depth;
+  rec_pu_t pu; memset(&pu, 0, sizeof(pu));
+  pu.x = x; pu.y = y; pu.width = width; pu.height = width;
+  cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
+  /* search_pu_inter :1492-1500 */
+  inter_merge_cand_t merge[MRG_MAX_NUM_CANDS];
+  const int n_merge = kvz_inter_get_merge_cand(state, x, y, width, width, true, true, merge, lcu);
+  pu.num_merge_cand = (int16_t)n_merge;
+  for (int i = 0; i < n_merge; ++i) {
+    const int dir = merge[i].dir;
+    pu.merge[i].usable = dir != 3;
+    if (dir != 3) {
+      pu.merge[i].mv[0] = merge[i].mv[dir - 1][0]; pu.merge[i].mv[1] = merge[i].mv[dir - 1][1];
+      pu.merge[i].same_ref = state->frame->ref_LX[dir - 1][merge[i].ref[dir - 1]] == 0;
+    }
+  }
+  /* search_pu_inter_ref :1170-1187 (reference 0 = L0[0]) */
+  const int8_t saved = cur_cu->inter.mv_ref[0];
+  const uint8_t saved_cand0 = cur_cu->inter.mv_cand0, saved_cand1 = cur_cu->inter.mv_cand1;
+  cur_cu->inter.mv_ref[0] = 0;
+  kvz_inter_get_mv_cand(state, x, y, width, width, pu.mv_cand, cur_cu, lcu, 0);
+  cur_cu->inter.mv_ref[0] = saved;
+  cur_cu->inter.mv_cand0 = saved_cand0; cur_cu->inter.mv_cand1 = saved_cand1;
+  /* :1190-1206 */
+  {
+    const cu_info_t *ref_cu = kvz_cu_array_at_const(state->frame->ref->cu_arrays[0], x + (width >> 1), y + (width >> 1));
+    if (ref_cu->type == CU_INTER) {
+      const int l = (ref_cu->inter.mv_dir & 1) ? 0 : 1;
+      pu.extra_mv[0] = ref_cu->inter.mv[l][0]; pu.extra_mv[1] = ref_cu->inter.mv[l][1];
+    }
+  }
+  /* planes of a new frame, the encoder settings, the position in the frame's dependency order */
+  const int poc = state->frame->poc;
+  if (g_rec.n_frames == 0 || g_rec.frame_poc[g_rec.n_frames - 1] != poc) {
+    if (g_rec.n_frames >= g_rec.max_frames) { ++g_rec.skipped; __real_kvz_search_cu_inter(state, x, y, depth, lcu, inter_cost, inter_bitcost); return; }
+    const size_t off = (size_t)g_rec.n_frames * g_rec.w * g_rec.h;
+    rec_copy_plane(g_rec.pic + off, state->tile->frame->source, g_rec.w, g_rec.h);
+    rec_copy_plane(g_rec.ref + off, state->frame->ref->images[0], g_rec.w, g_rec.h);
+    g_rec.frame_poc[g_rec.n_frames++] = poc;
+    g_rec.cur_lcu_x = g_rec.cur_lcu_y = -1;
+    rec_params_t *p = &g_rec.params;
+    memset(p, 0, sizeof(*p));
+    p->early_termination = ctrl->cfg.me_early_termination;
+    p->max_steps = ctrl->cfg.me_max_steps;
+    p->fme_level = ctrl->cfg.fme_level;
+    p->wpp_owf = ctrl->cfg.owf && ctrl->cfg.wpp;
+    p->ref_delay_px = ctrl->cfg.sao_type ? SAO_DELAY_PX : (ctrl->cfg.deblock_enable ? DEBLOCK_DELAY_PX : 0);
+    p->max_ref_lcu_down = ctrl->max_inter_ref_lcu.down; p->max_ref_lcu_right = ctrl->max_inter_ref_lcu.right;
+    switch (ctrl->cfg.ime_algorithm) {
+      case KVZ_IME_DIA: p->algorithm = 1; break;
+      case KVZ_IME_TZ: p->algorithm = 2; break;
+      case KVZ_IME_FULL64: p->algorithm = 3; p->search_range = 64; break;
+      case KVZ_IME_FULL32: case KVZ_IME_FULL: p->algorithm = 3; p->search_range = 32; break;
+      case KVZ_IME_FULL16: p->algorithm = 3; p->search_range = 16; break;
+      case KVZ_IME_FULL8: p->algorithm = 3; p->search_range = 8; break;
+      default: p->algorithm = 0; break;
+    }
+    p->mv_constraint = ctrl->cfg.mv_constraint;
+  }
+  const int lx = x / LCU_WIDTH, ly = y / LCU_WIDTH;
+  if (lx != g_rec.cur_lcu_x || ly != g_rec.cur_lcu_y) { g_rec.cur_lcu_x = lx; g_rec.cur_lcu_y = ly; g_rec.seq = 0; }
+
+  __real_kvz_search_cu_inter(state, x, y, depth, lcu, inter_cost, inter_bitcost);
+
+  const int i = g_rec.count++;
+  g_rec.pu[i] = pu;
+  rec_result_t *r = &g_rec.res[i];
+  memset(r, 0, sizeof(*r));
+  if (*inter_cost < (double)MAX_INT) {
+    r->mv[0] = cur_cu->inter.mv[0][0]; r->mv[1] = cur_cu->inter.mv[0][1];
+    r->cost = (uint32_t)*inter_cost; r->bitcost = *inter_bitcost;
+    r->merged = cur_cu->merged; r->merge_idx = cur_cu->merge_idx;
+    r->mv_cand = cur_cu->merged ? 0 : cur_cu->inter.mv_cand0;
+  } else {
+    r->cost = 0xffffffffu;
+  }
+  rec_meta_t *m = &g_rec.meta[i];
+  m->frame = g_rec.n_frames - 1; m->lcu_x = lx; m->lcu_y = ly; m->seq = g_rec.seq++;
+  m->lambda_cost = (int32_t)(state->lambda_sqrt + 0.5); m->depth = depth;
+}
+
+/* start recording: room for max_records searches and max_frames frames of w x h luma */
+int ref_record_begin(int max_records, int max_frames, int w, int h)
+{
+  memset(&g_rec, 0, sizeof(g_rec));
+  g_rec.max = max_records; g_rec.max_frames = max_frames; g_rec.w = w; g_rec.h = h;
+  g_rec.pu = calloc((size_t)max_records, sizeof(rec_pu_t));
+  g_rec.res = calloc((size_t)max_records, sizeof(rec_result_t));
+  g_rec.meta = calloc((size_t)max_records, sizeof(rec_meta_t));
+  g_rec.frame_poc = calloc((size_t)max_frames, sizeof(int32_t));
+  g_rec.pic = malloc((size_t)max_frames * w * h); g_rec.ref = malloc((size_t)max_frames * w * h);
+  if (!g_rec.pu || !g_rec.res || !g_rec.meta || !g_rec.frame_poc || !g_rec.pic || !g_rec.ref) return -1;
+  g_rec.on = 1;
+  return 0;
+}
+/* stop; copies out what was recorded (any pointer may be NULL) and frees the recorder.  Returns the record count;
+ * info[0] = frames, info[1] = searches that could not be recorded (not a single-reference P search, or no room) */
+int ref_record_end(void *pus, void *results, void *meta, void *params, void *pic, void *ref, int *info)
+{
+  g_rec.on = 0;
+  const int n = g_rec.count;
+  if (pus) memcpy(pus, g_rec.pu, (size_t)n * sizeof(rec_pu_t));
+  if (results) memcpy(results, g_rec.res, (size_t)n * sizeof(rec_result_t));
+  if (meta) memcpy(meta, g_rec.meta, (size_t)n * sizeof(rec_meta_t));
+  if (params) memcpy(params, &g_rec.params, sizeof(rec_params_t));
+  if (pic) memcpy(pic, g_rec.pic, (size_t)g_rec.n_frames * g_rec.w * g_rec.h);
+  if (ref) memcpy(ref, g_rec.ref, (size_t)g_rec.n_frames * g_rec.w * g_rec.h);
+  if (info) { info[0] = g_rec.n_frames; info[1] = g_rec.skipped; }
+  free(g_rec.pu); free(g_rec.res); free(g_rec.meta); free(g_rec.frame_poc); free(g_rec.pic); free(g_rec.ref);
+  memset(&g_rec, 0, sizeof(g_rec));
+  return n;
+}

@@ -327,3 +327,38 @@ def deblock_case(w, h, seed, intra_share=0.35, slice_is_b=0, qp=34):
         return np.clip(img, 0, 255).astype(np.uint8)
 
     return plane(w, h, 8), plane(w // 2, h // 2, 4), plane(w // 2, h // 2, 4), cus
+
+
+# ---- searches recorded from real encodes (oracle/ref_harness.c recorder; tests/golden/fronts.npz) ----
+def fronts_fixture(d, which):
+    """-> list of per-frame (pic, ref, pus, results, meta, params): which = "small" (3 P frames of 192x128) or "hd" (one 1080p P frame;
+    its planes are rebuilt from the deterministic synthetic sequence + the stored reconstruction delta)"""
+    pus = np.ascontiguousarray(d[which + "_pus"]).view(ME_PU).reshape(-1)
+    res = np.ascontiguousarray(d[which + "_results"]).view(ME_RESULT).reshape(-1)
+    meta = d[which + "_meta"]
+    prm0 = np.ascontiguousarray(d[which + "_params"]).view(ME_PARAMS)
+    if which == "small":
+        pics, refs = d["small_pic"], d["small_ref"]
+    else:
+        from ref_lib import synthetic_sequence          # pure numpy
+        fr = synthetic_sequence(1920, 1080, 2)
+        pics = fr[1:2, :1080]
+        refs = (fr[0:1, :1080].astype(np.int16) + d["hd_ref_delta"][None].astype(np.int16)).astype(np.uint8)
+    out = []
+    for f in range(len(pics)):
+        sel = np.where(meta[:, 0] == f)[0]
+        prm = prm0.copy()
+        prm["lambda_cost"] = meta[sel[0], 4]
+        assert (meta[sel, 4] == meta[sel[0], 4]).all()
+        out.append((np.ascontiguousarray(pics[f]), np.ascontiguousarray(refs[f]), pus[sel], res[sel], meta[sel], prm))
+    return out
+
+
+def front_groups(meta):
+    """Dependency fronts of a frame's recorded searches: LCU (x, y) may start when (x - 1, y) and (x + 1, y - 1) are done (WPP,
+    encoderstate.c:807-817) -> wavefront index x + 2y; inside an LCU the searches of the quadtree walk follow each other (seq).
+    Returns the list of index arrays, in execution order."""
+    key = (meta[:, 1] + 2 * meta[:, 2]).astype(np.int64) * 1000 + meta[:, 3]
+    order = np.argsort(key, kind="stable")
+    cuts = np.flatnonzero(np.diff(key[order])) + 1
+    return np.split(order, cuts)

@@ -358,6 +358,34 @@ def encode(frames, w, h, opts, strategy=None, cap=1 << 22):
     return out[:n].tobytes(), inst.value
 
 
+def record_inter_searches(frames, w, h, opts, max_records=400000):
+    """Runs the reference encoder over the frames with the harness recorder on: every 2Nx2N inter search the encoder
+    itself performed on a single-reference P frame, with the candidates the encoder derived for it and what the
+    reference search decided.  -> dict(pus [n] ME_PU, results [n] ME_RESULT, meta [n] (frame, lcu_x, lcu_y, seq, lambda_cost,
+    depth), params ME_PARAMS (lambda_cost 0: per record), pic / ref uint8 [frames, h, w], skipped)."""
+    from patterns import ME_PARAMS, ME_PU, ME_RESULT
+    L = lib()
+    L.ref_record_begin.restype = C.c_int
+    L.ref_record_begin.argtypes = [C.c_int] * 4
+    L.ref_record_end.restype = C.c_int
+    L.ref_record_end.argtypes = [C.c_void_p] * 6 + [C.POINTER(C.c_int)]
+    nf = len(frames)
+    assert L.ref_record_begin(max_records, nf, w, h) == 0
+    try:
+        bitstream, _ = encode(frames, w, h, opts)
+    finally:
+        pus = np.zeros(max_records, dtype=ME_PU)
+        res = np.zeros(max_records, dtype=ME_RESULT)
+        meta = np.zeros((max_records, 6), dtype=np.int32)
+        prm = np.zeros(1, dtype=ME_PARAMS)
+        pic = np.zeros((nf, h, w), dtype=np.uint8)
+        ref = np.zeros((nf, h, w), dtype=np.uint8)
+        info = (C.c_int * 2)()
+        n = L.ref_record_end(pus.ctypes.data, res.ctypes.data, meta.ctypes.data, prm.ctypes.data, pic.ctypes.data, ref.ctypes.data, info)
+    return dict(pus=pus[:n].copy(), results=res[:n].copy(), meta=meta[:n].copy(), params=prm, pic=pic[:info[0]].copy(), ref=ref[:info[0]].copy(),
+                skipped=int(info[1]), bitstream=bitstream)
+
+
 # ---- intra group ----
 def _intra_sigs():
     L = lib()

@@ -132,3 +132,24 @@ def test_golden_deblock(api):
         if chroma:
             np.testing.assert_array_equal(got[1], d["out_u%d" % i])
             np.testing.assert_array_equal(got[2], d["out_v%d" % i])
+
+
+def test_golden_front_replay(api):
+    """Searches recorded from real encodes of the reference encoder (tests/golden/fronts.npz: candidates the encoder derived,
+    decisions the reference search took) replayed through kvz_hip_search_pu_batch: the whole frame in one launch, and front by
+    front in the encoder's dependency order (WPP wavefront x + 2y, then the position in the LCU's quadtree walk), as a driver
+    that derives candidates on the host would issue them.  1080p: all 42 900 searches of one P frame (BASELINE config 4)."""
+    from patterns import ME_RESULT, fronts_fixture, front_groups
+    d = gold("fronts.npz")
+    for which in ("small", "hd"):
+        for (pic, ref, pus, want, meta, prm) in fronts_fixture(d, which):
+            got = api.search_pu_batch(pic, ref, pus, prm).view(ME_RESULT).reshape(-1)
+            for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+                np.testing.assert_array_equal(got[f], want[f], err_msg="%s %s" % (which, f))
+            groups = front_groups(meta)
+            if which == "hd":
+                assert len(pus) == 42900 and len(groups) == 62 * 85
+                groups = groups[::9]                           # every ninth front here; tools/front_replay.py times them all
+            for g_ in groups:
+                part = api.search_pu_batch(pic, ref, pus[g_], prm).view(ME_RESULT).reshape(-1)
+                np.testing.assert_array_equal(part.view(np.int32).reshape(-1, 8)[:, :7], want[g_].view(np.int32).reshape(-1, 8)[:, :7])

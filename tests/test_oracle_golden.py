@@ -188,3 +188,19 @@ def test_golden_deblock():
         if chroma:
             np.testing.assert_array_equal(got[1], d["out_u%d" % i])
             np.testing.assert_array_equal(got[2], d["out_v%d" % i])
+
+
+def test_golden_front_replay():
+    """searches recorded from real encodes by the reference encoder itself (candidates the encoder derived, decisions the
+    reference search took): the oracle must take the same decisions -- every search of the small sequence, a strided sample of
+    the 1080p frame"""
+    from patterns import fronts_fixture
+    d = gold("fronts.npz")
+    total = 0
+    for which, stride in (("small", 1), ("hd", 97)):
+        for (pic, ref, pus, want, meta, prm) in fronts_fixture(d, which):
+            got = O.search_pu_batch(pic, ref, pus[::stride], prm)
+            for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+                np.testing.assert_array_equal(got[f], want[::stride][f], err_msg="%s %s" % (which, f))
+            total += len(got)
+    assert total > 1900

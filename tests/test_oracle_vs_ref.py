@@ -464,3 +464,33 @@ def test_deblock_frame(cfg):
         if not int(prm["chroma"][0]):
             np.testing.assert_array_equal(want[1], u)
     assert changed > 0                      # the filter did something
+
+
+# ---- the encoder's own searches, recorded and replayed ----
+@pytest.mark.parametrize("opts", [
+    "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=30,threads=0,smp=0,amp=0,period=0",
+    "preset=fast,ref=1,bipred=0,gop=0,rdoq=0,qp=37,threads=0,me=dia,subme=2,deblock=1,sao=off,owf=0,wpp=0,period=0",
+    "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=24,threads=0,me=tz,me-early-termination=sensitive,mv-constraint=frametilemargin,period=0",
+])
+def test_recorded_encoder_searches_replay(opts):
+    """the reference ENCODER runs (kvz_api); the harness notes every 2Nx2N inter search with the candidates the encoder derived;
+    the recorded decisions must be what the reference's static search (ref_me_harness.c) and the oracle compute from the
+    recorded inputs -- and recording must not change the bitstream"""
+    from patterns import front_groups
+    w, h = 192, 128
+    frames = R.synthetic_sequence(w, h, 3, seed=11)
+    plain, _ = R.encode(frames, w, h, opts)
+    rec = R.record_inter_searches(frames, w, h, opts)
+    assert rec["bitstream"] == plain and rec["skipped"] == 0 and len(rec["pus"]) >= 2 * 6 * 85 // 2
+    m = rec["meta"]
+    for f in range(len(rec["pic"])):
+        sel = np.where(m[:, 0] == f)[0]
+        prm = rec["params"].copy()
+        prm["lambda_cost"] = m[sel[0], 4]
+        a = R.search_pu_batch(rec["pic"][f], rec["ref"][f], rec["pus"][sel], prm)
+        b = O.search_pu_batch(rec["pic"][f], rec["ref"][f], rec["pus"][sel], prm)
+        for fld in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+            np.testing.assert_array_equal(a[fld], rec["results"][sel][fld], err_msg="static search, %s" % fld)
+            np.testing.assert_array_equal(b[fld], rec["results"][sel][fld], err_msg="oracle, %s" % fld)
+        groups = front_groups(m[sel])
+        assert sum(len(g_) for g_ in groups) == len(sel) and max(len(g_) for g_ in groups) <= 3      # <= LCUs on a wavefront of a 3 x 2 grid

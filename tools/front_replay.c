@@ -1,0 +1,84 @@
+/* front_replay.c -- times kvz_hip_search_pu_batch driven the way a host that derives candidates itself has to drive it:
+ * front by front in the encoder's dependency order.  Input: a binary file written by tools/front_replay.py from searches
+ * RECORDED during real encodes of the reference encoder (oracle/ref_harness.c recorder): planes, the frame's PU records
+ * sorted by front, the fronts' offsets, the decisions the reference took.  Plain C99 host of include/kvz_hip.h.
+ *   per front: descriptors -> pinned buffer -> device, one kvz_hip_search_pu_batch, results -> host, stream sync
+ *   (the next front's candidates depend on these results: inter.c:1209,1314)
+ * Prints one JSON line; every replayed result is compared with the recorded one.  NOT an encoder: candidate derivation,
+ * mode decision, reconstruction are not here. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "kvz_hip.h"
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+#define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, " (%s)\n", kvz_hip_last_error()); return 1; } while (0)
+
+int main(int argc, char **argv)
+{
+  if (argc < 2) { fprintf(stderr, "usage: front_replay FILE [repeats]\n"); return 2; }
+  const int repeats = argc > 2 ? atoi(argv[2]) : 3;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) { perror(argv[1]); return 2; }
+  int32_t hdr[4];                                     /* width, height, PUs, fronts */
+  if (fread(hdr, 4, 4, f) != 4) return 2;
+  const int w = hdr[0], h = hdr[1], n = hdr[2], ng = hdr[3];
+  uint8_t *pic = malloc((size_t)w * h), *ref = malloc((size_t)w * h);
+  kvz_hip_me_params prm;
+  kvz_hip_me_pu *pus = malloc((size_t)n * sizeof(*pus));
+  kvz_hip_me_result *want = malloc((size_t)n * sizeof(*want));
+  int32_t *off = malloc((size_t)(ng + 1) * 4);
+  if (fread(pic, 1, (size_t)w * h, f) != (size_t)w * h || fread(ref, 1, (size_t)w * h, f) != (size_t)w * h ||
+      fread(&prm, sizeof(prm), 1, f) != 1 || fread(pus, sizeof(*pus), (size_t)n, f) != (size_t)n ||
+      fread(want, sizeof(*want), (size_t)n, f) != (size_t)n || fread(off, 4, (size_t)(ng + 1), f) != (size_t)(ng + 1)) { fprintf(stderr, "short file\n"); return 2; }
+  fclose(f);
+
+  if (kvz_hip_init(-1) != KVZ_HIP_OK) DIE("kvz_hip_init");
+  kvz_hip_stream st = kvz_hip_stream_create();
+  uint8_t *d_pic = kvz_hip_malloc((size_t)w * h), *d_ref = kvz_hip_malloc((size_t)w * h);
+  kvz_hip_me_pu *d_pus = kvz_hip_malloc((size_t)n * sizeof(*pus));
+  kvz_hip_me_result *d_res = kvz_hip_malloc((size_t)n * sizeof(*want));
+  kvz_hip_me_pu *h_pus = kvz_hip_malloc_host((size_t)n * sizeof(*pus));
+  kvz_hip_me_result *h_res = kvz_hip_malloc_host((size_t)n * sizeof(*want));
+  if (!st || !d_pic || !d_ref || !d_pus || !d_res || !h_pus || !h_res) DIE("allocation");
+  if (kvz_hip_memcpy_h2d(d_pic, pic, (size_t)w * h, st) || kvz_hip_memcpy_h2d(d_ref, ref, (size_t)w * h, st) || kvz_hip_stream_sync(st)) DIE("planes");
+
+  int max_front = 0;
+  for (int g = 0; g < ng; ++g) if (off[g + 1] - off[g] > max_front) max_front = off[g + 1] - off[g];
+  double best_fronts = 1e30, best_whole = 1e30;
+  long mismatches = 0;
+  for (int rep = 0; rep < repeats + 1; ++rep) {              /* the first pass warms up */
+    /* (a) front by front */
+    memset(h_res, 0, (size_t)n * sizeof(*want));
+    double t0 = now_s();
+    for (int g = 0; g < ng; ++g) {
+      const int a = off[g], c = off[g + 1] - off[g];
+      memcpy(h_pus + a, pus + a, (size_t)c * sizeof(*pus));                      /* the host "derives" the front's descriptors */
+      if (kvz_hip_memcpy_h2d(d_pus + a, h_pus + a, (size_t)c * sizeof(*pus), st)) DIE("h2d");
+      if (kvz_hip_search_pu_batch(d_pic, (uint32_t)w, w, h, d_ref, (uint32_t)w, w, h, d_pus + a, (size_t)c, &prm, d_res + a, st)) DIE("search");
+      if (kvz_hip_memcpy_d2h(h_res + a, d_res + a, (size_t)c * sizeof(*want), st)) DIE("d2h");     /* syncs the stream */
+    }
+    double dt = now_s() - t0;
+    if (rep > 0 && dt < best_fronts) best_fronts = dt;
+    for (int i = 0; i < n; ++i)
+      if (memcmp(&h_res[i], &want[i], 28) != 0) ++mismatches;                    /* mv, cost, bitcost, merged, merge_idx, mv_cand */
+    /* (b) the whole frame in one launch (no dependency order: what the kernel can do when every candidate is known) */
+    memcpy(h_pus, pus, (size_t)n * sizeof(*pus));
+    t0 = now_s();
+    if (kvz_hip_memcpy_h2d(d_pus, h_pus, (size_t)n * sizeof(*pus), st)) DIE("h2d");
+    if (kvz_hip_search_pu_batch(d_pic, (uint32_t)w, w, h, d_ref, (uint32_t)w, w, h, d_pus, (size_t)n, &prm, d_res, st)) DIE("search");
+    if (kvz_hip_memcpy_d2h(h_res, d_res, (size_t)n * sizeof(*want), st)) DIE("d2h");
+    dt = now_s() - t0;
+    if (rep > 0 && dt < best_whole) best_whole = dt;
+    for (int i = 0; i < n; ++i)
+      if (memcmp(&h_res[i], &want[i], 28) != 0) ++mismatches;
+  }
+  printf("{\"frame\": \"%dx%d\", \"searches\": %d, \"fronts\": %d, \"largest_front\": %d, \"mismatches_vs_recorded\": %ld, "
+         "\"fronts_ms_per_frame\": %.3f, \"fronts_searches_per_s\": %.0f, \"fronts_frames_per_s\": %.2f, \"us_per_front\": %.2f, "
+         "\"one_launch_ms_per_frame\": %.3f, \"one_launch_searches_per_s\": %.0f, \"device\": \"%s\"}\n",
+         w, h, n, ng, max_front, mismatches, best_fronts * 1e3, n / best_fronts, 1.0 / best_fronts, best_fronts * 1e6 / ng,
+         best_whole * 1e3, n / best_whole, kvz_hip_device_name());
+  return mismatches ? 1 : 0;
+}

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Search-only timing of kvz_hip_search_pu_batch on searches RECORDED from real encodes of the reference encoder, issued front
+by front in the encoder's dependency order (tools/front_replay.c does the timed loop in C; this script prepares its input
+from tests/golden/fronts.npz -- or from a fresh recording with --live when oracle/_ref is present -- builds the C program and
+prints its JSON line).  Not an encoder: labelled "search only, fronts" wherever it is quoted.
+
+  python3 tools/front_replay.py [--live FRAMES] [--repeats N]"""
+import argparse
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def build():
+    exe = os.path.join(ROOT, "tools", "front_replay")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "front_replay.c"),
+                           "-o", exe, "-L" + os.path.join(ROOT, "kvazaar_amd"), "-lkvzhip", "-Wl,-rpath," + os.path.join(ROOT, "kvazaar_amd")])
+    return exe
+
+
+def write_case(path, pic, ref, pus, res, meta, prm):
+    from patterns import front_groups
+    groups = front_groups(meta)
+    order = np.concatenate(groups)
+    off = np.concatenate([[0], np.cumsum([len(g) for g in groups])]).astype(np.int32)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4i", pic.shape[1], pic.shape[0], len(order), len(groups)))
+        f.write(np.ascontiguousarray(pic).tobytes()); f.write(np.ascontiguousarray(ref).tobytes())
+        f.write(np.ascontiguousarray(prm).tobytes())
+        f.write(np.ascontiguousarray(pus[order]).tobytes()); f.write(np.ascontiguousarray(res[order]).tobytes())
+        f.write(off.tobytes())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--live", type=int, default=0, help="record a fresh 1080p encode of this many frames with oracle/_ref instead of the fixture")
+    ap.add_argument("--repeats", type=int, default=3)
+    args = ap.parse_args()
+    from patterns import fronts_fixture
+    exe = build()
+    cases = []
+    if args.live:
+        import ref_lib as R
+        w, h = 1920, 1080
+        rec = R.record_inter_searches(R.synthetic_sequence(w, h, args.live), w, h,
+                                      "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=32,threads=0,smp=0,amp=0,period=0", max_records=60000 * args.live)
+        m = rec["meta"]
+        for fr in range(len(rec["pic"])):
+            sel = np.where(m[:, 0] == fr)[0]
+            prm = rec["params"].copy(); prm["lambda_cost"] = m[sel[0], 4]
+            cases.append((rec["pic"][fr], rec["ref"][fr], rec["pus"][sel], rec["results"][sel], m[sel], prm))
+    else:
+        d = np.load(os.path.join(ROOT, "tests", "golden", "fronts.npz"))
+        cases = fronts_fixture(d, "hd")
+    for i, c in enumerate(cases):
+        path = "/tmp/kvz_front_case_%d.bin" % i
+        write_case(path, *c)
+        sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats)], text=True))
+        os.remove(path)
+
+
+if __name__ == "__main__":
+    main()
