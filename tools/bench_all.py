@@ -4,7 +4,7 @@ resident in HBM, working sets larger than the 256 MiB Infinity Cache where the k
 streams).  Development tool; bench.py is the contract benchmark.
 
   python tools/bench_all.py                       # table of all kernels
-  python tools/bench_all.py --only dct --tune dct32_wgs_per_cu=3,4,5,6,8   # interleaved A/B in one process
+  python tools/bench_all.py --only dct --tune dct32_wgs_per_cu=3,4,5,6,8   # interleaved A/B in one process (--only a,b: several substrings)
 """
 import argparse
 import ctypes as C
@@ -128,7 +128,7 @@ def main():
                           picf.data_ptr(), W, reff.data_ptr(), W, W, F * H, prs_d.data_ptr(), k, co.data_ptr(), be.data_ptr(), st)))
 
     # whole-PU motion search (hexagon + fractional, with MV costs): every n x n PU of 4 frames
-    me_prm = np.zeros(12, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
+    me_prm = np.zeros(16, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
     for n in (8, 16, 32, 64):
         rows = [(x, f * H + y) for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)]
         pus = np.zeros((len(rows), 16), dtype=np.int32)
@@ -195,7 +195,7 @@ def main():
     torch.cuda.synchronize()         # the operands above were written on torch's stream; the library's stream does not wait for it
     print("%-26s %10s %12s %10s %8s" % ("kernel", "tune", "Mblocks/s", "GB/s", "ms"))
     for name, blocks, bpb, fn in cases:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         best = {}
         for _ in range(args.rounds):

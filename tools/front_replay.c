@@ -18,8 +18,9 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 
 int main(int argc, char **argv)
 {
-  if (argc < 2) { fprintf(stderr, "usage: front_replay FILE [repeats]\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: front_replay FILE [repeats] [size-class hint 0/1]\n"); return 2; }
   const int repeats = argc > 2 ? atoi(argv[2]) : 3;
+  const int hint = argc > 3 ? atoi(argv[3]) : 1;
   FILE *f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 2; }
   int32_t hdr[4];                                     /* width, height, PUs, fronts */
@@ -57,7 +58,12 @@ int main(int argc, char **argv)
       const int a = off[g], c = off[g + 1] - off[g];
       memcpy(h_pus + a, pus + a, (size_t)c * sizeof(*pus));                      /* the host "derives" the front's descriptors */
       if (kvz_hip_memcpy_h2d(d_pus + a, h_pus + a, (size_t)c * sizeof(*pus), st)) DIE("h2d");
-      if (kvz_hip_search_pu_batch(d_pic, (uint32_t)w, w, h, d_ref, (uint32_t)w, w, h, d_pus + a, (size_t)c, &prm, d_res + a, st)) DIE("search");
+      /* the searches of one front sit at the same place of their LCUs' quadtree walk, i.e. have one size: name the size class, so
+       * that one kernel is launched instead of three (kvz_hip_me_params.size_classes) */
+      kvz_hip_me_params fp = prm;
+      const int sz = pus[a].width > pus[a].height ? pus[a].width : pus[a].height;
+      fp.size_classes = hint ? (sz <= 16 ? 1 : (sz <= 32 ? 2 : 4)) : 0;
+      if (kvz_hip_search_pu_batch(d_pic, (uint32_t)w, w, h, d_ref, (uint32_t)w, w, h, d_pus + a, (size_t)c, &fp, d_res + a, st)) DIE("search");
       if (kvz_hip_memcpy_d2h(h_res + a, d_res + a, (size_t)c * sizeof(*want), st)) DIE("d2h");     /* syncs the stream */
     }
     double dt = now_s() - t0;
@@ -75,10 +81,10 @@ int main(int argc, char **argv)
     for (int i = 0; i < n; ++i)
       if (memcmp(&h_res[i], &want[i], 28) != 0) ++mismatches;
   }
-  printf("{\"frame\": \"%dx%d\", \"searches\": %d, \"fronts\": %d, \"largest_front\": %d, \"mismatches_vs_recorded\": %ld, "
+  printf("{\"what\": \"search only, fronts (NOT an encoder)\", \"size_class_hint\": %d, \"frame\": \"%dx%d\", \"searches\": %d, \"fronts\": %d, \"largest_front\": %d, \"mismatches_vs_recorded\": %ld, "
          "\"fronts_ms_per_frame\": %.3f, \"fronts_searches_per_s\": %.0f, \"fronts_frames_per_s\": %.2f, \"us_per_front\": %.2f, "
          "\"one_launch_ms_per_frame\": %.3f, \"one_launch_searches_per_s\": %.0f, \"device\": \"%s\"}\n",
-         w, h, n, ng, max_front, mismatches, best_fronts * 1e3, n / best_fronts, 1.0 / best_fronts, best_fronts * 1e6 / ng,
+         hint, w, h, n, ng, max_front, mismatches, best_fronts * 1e3, n / best_fronts, 1.0 / best_fronts, best_fronts * 1e6 / ng,
          best_whole * 1e3, n / best_whole, kvz_hip_device_name());
   return mismatches ? 1 : 0;
 }

@@ -62,7 +62,8 @@ def main():
     for i, c in enumerate(cases):
         path = "/tmp/kvz_front_case_%d.bin" % i
         write_case(path, *c)
-        sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats)], text=True))
+        for hint in (1, 0):
+            sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats), str(hint)], text=True))
         os.remove(path)
 
 

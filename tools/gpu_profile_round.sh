@@ -1,0 +1,34 @@
+#!/bin/bash
+# End-of-work profile set of one build, written under gpurun_out/TAG_* (copy what is to be judged into profiles/):
+#   1. bench.py (all legs) under rocprofv3 --kernel-trace --stats: TAG_bench_profiled.json + TAG_kernel_stats.csv
+#   2. bench.py headline leg under --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -> TAG_pmc_traffic.json
+#   3. the fused quantize_residual kernels under the SQ / TCC counter groups -> TAG_qr_pmc.txt
+#   4. the frame-level sampling / SATD kernels under the same groups -> TAG_frame_kernels_pmc.txt
+#   5. every entry of the ABI: TAG_bench_all_kernels.txt
+# The program always follows `--` directly (no env / bash -c hop).  usage: tools/gpu_profile_round.sh TAG COMMIT
+set -e
+TAG=${1:-r02}
+COMMIT=${2:-unknown}
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O/${TAG}_prof
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats -o p --output-format csv -- python3 bench.py --steps 50 --warmup 5 > $O/${TAG}_bench_profiled.json 2> $O/${TAG}_prof/stats.log
+cp $O/${TAG}_prof/stats/p_kernel_stats.csv $O/${TAG}_kernel_stats.csv
+rm -rf $O/${TAG}_prof/stats
+B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-shard-leg"
+rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_prof/fetch -o p --output-format csv -- $B > $O/${TAG}_prof/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_prof/write -o p --output-format csv -- $B > $O/${TAG}_prof/write.log 2>&1
+for p in fetch write; do python3 tools/pmc_filter.py $O/${TAG}_prof/$p sad_nxn_kernel,satd8_kernel,dct32_mfma_kernel; done
+python3 tools/pmc_traffic.py $O/${TAG}_prof/fetch $O/${TAG}_prof/write $O/${TAG}_pmc_traffic.json $COMMIT > /dev/null
+tools/gpu_pmc_qr.sh ${TAG}
+# frame-level kernels: sampling and descriptor SATD
+F="python3 tools/bench_all.py --only sample_luma,image_satd --rounds 1"
+KS=sample_small_kernel,sample_big_kernel,pair_satd
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/${TAG}_prof/f1 -o p --output-format csv -- $F > $O/${TAG}_prof/f1.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d $O/${TAG}_prof/f2 -o p --output-format csv -- $F > $O/${TAG}_prof/f2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_prof/f3 -o p --output-format csv -- $F > $O/${TAG}_prof/f3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_prof/f4 -o p --output-format csv -- $F > $O/${TAG}_prof/f4.log 2>&1
+for p in f1 f2 f3 f4; do python3 tools/pmc_filter.py $O/${TAG}_prof/$p $KS; done
+python3 tools/pmc_kernels.py $O/${TAG}_frame_kernels_pmc.txt $KS $O/${TAG}_prof/f1 $O/${TAG}_prof/f2 $O/${TAG}_prof/f3 $O/${TAG}_prof/f4 > /dev/null
+python3 tools/bench_all.py > $O/${TAG}_bench_all_kernels.txt 2>&1
+echo "profile set $TAG done"

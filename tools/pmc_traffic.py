@@ -8,7 +8,10 @@ reports exactly half the bytes of a wide coalesced (16 B/lane) streaming read, s
 is doubled; WRITE_SIZE is exact for 16 B/lane streaming stores (the 4-byte cost
 stores of the SAD/SATD kernels are < 4 % of their traffic and uncalibrated).
 
-usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+The result is tagged with the commit, the date and a digest of the kernel sources it was captured on; bench.py quotes it as
+`roofline.traffic` only while the kernel sources are unchanged.
+
+usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [commit]"""
 import csv
 import glob
 import json
@@ -42,6 +45,11 @@ def main():
         detail[k] = {"read_bytes_corrected": round(rd), "write_bytes": round(wr), "FETCH_SIZE_KiB_raw": fetch.get(k),
                      "WRITE_SIZE_KiB_raw": write.get(k), "dispatches": [nf.get(k, 0), nw.get(k, 0)]}
     res["_detail"] = detail
+    import datetime
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_sources_digest
+    res["_captured"] = {"commit": sys.argv[4] if len(sys.argv) > 4 else "unknown", "date": datetime.date.today().isoformat(),
+                        "kernel_sources_sha1_16": kernel_sources_digest()}
     res["_method"] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py; KiB*1024; FETCH_SIZE doubled (gfx950)"
     json.dump(res, open(outp, "w"), indent=1)
     print(json.dumps(res, indent=1))
