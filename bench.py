@@ -157,10 +157,12 @@ class Env:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.cuda.set_device(local_rank)
+            import datetime
+            tmo = datetime.timedelta(seconds=180)       # a failed exchange surfaces as an error within minutes, not as a hung job
             if self.backend == "nccl":
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
             else:
-                dist.init_process_group(backend=self.backend)
+                dist.init_process_group(backend=self.backend, timeout=tmo)
             self.dist = dist
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
@@ -384,16 +386,24 @@ def main():
         from kvazaar_amd import shard as S
         sh = S.RowShard(W4K, H4K, world, rank, S.HALO_ROWS)
         F4, FS = args.frames_4k, args.search_frames
-        kdt, kms, kblocks, ksums = shard_kernel_leg(env, sh, args.steps, args.warmup, F4)
-        torch.cuda.empty_cache()
-        s_steps, s_warm = max(1, args.steps // 10), max(1, args.warmup // 10)        # a search step is FS frames, ~8 ms at N = 1
-        sdt, ex_ms, se_ms, ssums = shard_search_leg(env, sh, s_steps, s_warm, FS)
-        descr = [None] * world
-        if env.dist:
-            env.dist.all_gather_object(descr, sh.describe())
-        else:
-            descr = [sh.describe()]
-        if rank == 0:
+        shard_err = None
+        try:
+            kdt, kms, kblocks, ksums = shard_kernel_leg(env, sh, args.steps, args.warmup, F4)
+            torch.cuda.empty_cache()
+            s_steps, s_warm = max(1, args.steps // 10), max(1, args.warmup // 10)        # a search step is FS frames, ~8 ms at N = 1
+            sdt, ex_ms, se_ms, ssums = shard_search_leg(env, sh, s_steps, s_warm, FS)
+            descr = [None] * world
+            if env.dist:
+                env.dist.all_gather_object(descr, sh.describe())
+            else:
+                descr = [sh.describe()]
+        except Exception as e:              # noqa: BLE001 -- the headline line must still be printed; the failure is reported in it
+            import traceback
+            shard_err = "%s: %s" % (type(e).__name__, e)
+            sys.stderr.write("rank %d: shard_4k leg failed\n%s\n" % (rank, traceback.format_exc()))
+        if shard_err is not None:
+            shard_out = {"error": shard_err, "note": "the shard_4k leg failed on rank 0; `value` (headline leg) is unaffected"}
+        elif rank == 0:
             tot8, tot32 = ksums[4], ksums[5]
             assert tot8 == 129600 * F4 and tot32 == 8040 * F4, (tot8, tot32)
             kern = kernel_stats(kms, kblocks)

@@ -58,11 +58,16 @@ int main(int argc, char **argv)
       const int a = off[g], c = off[g + 1] - off[g];
       memcpy(h_pus + a, pus + a, (size_t)c * sizeof(*pus));                      /* the host "derives" the front's descriptors */
       if (kvz_hip_memcpy_h2d(d_pus + a, h_pus + a, (size_t)c * sizeof(*pus), st)) DIE("h2d");
-      /* the searches of one front sit at the same place of their LCUs' quadtree walk, i.e. have one size: name the size class, so
-       * that one kernel is launched instead of three (kvz_hip_me_params.size_classes) */
+      /* the searches of one front sit at the same place of their LCUs' quadtree walk, i.e. mostly have one size (the ragged last LCU
+       * row walks a smaller tree): name the size classes present, so that one kernel is launched instead of three
+       * (kvz_hip_me_params.size_classes) */
       kvz_hip_me_params fp = prm;
-      const int sz = pus[a].width > pus[a].height ? pus[a].width : pus[a].height;
-      fp.size_classes = hint ? (sz <= 16 ? 1 : (sz <= 32 ? 2 : 4)) : 0;
+      int classes = 0;
+      for (int i = a; i < a + c; ++i) {
+        const int sz = pus[i].width > pus[i].height ? pus[i].width : pus[i].height;
+        classes |= sz <= 16 ? 1 : (sz <= 32 ? 2 : 4);
+      }
+      fp.size_classes = hint ? classes : 0;
       if (kvz_hip_search_pu_batch(d_pic, (uint32_t)w, w, h, d_ref, (uint32_t)w, w, h, d_pus + a, (size_t)c, &fp, d_res + a, st)) DIE("search");
       if (kvz_hip_memcpy_d2h(h_res + a, d_res + a, (size_t)c * sizeof(*want), st)) DIE("d2h");     /* syncs the stream */
     }
