@@ -78,7 +78,7 @@ KVZ_HIP_API const char *kvz_hip_last_error(void);    /* text of the calling thre
 KVZ_HIP_API const char *kvz_hip_device_name(void);   /* of the calling thread's current device */
 /* Version of this header's ABI as the library was built (layouts of the kvz_hip_* structs, entry signatures); a host
  * compares it with the KVZ_HIP_ABI_VERSION it was compiled against before it registers the strategies. */
-#define KVZ_HIP_ABI_VERSION 2   /* 2: per-device contexts, kvz_hip_me_params with tile / mv-constraint fields */
+#define KVZ_HIP_ABI_VERSION 2   /* 2: per-device contexts, kvz_hip_me_params with tile / mv-constraint / mv-rdo fields */
 KVZ_HIP_API int kvz_hip_abi_version(void);
 
 /* Launch-geometry / kernel-selection knobs for A/B runs (tools/bench_all.py --tune key=v1,v2);
@@ -346,11 +346,20 @@ typedef struct {
   int16_t mv_cand[2][2];         /* AMVP candidates (kvz_inter_get_mv_cand), quarter-pel */
   int16_t extra_mv[2];           /* start vector from the co-located CU (search_inter.c:1190-1206), quarter-pel */
   int16_t num_merge_cand;        /* 0..5 */
-  int16_t reserved;
+  int16_t reserved;              /* mv_rdo: index of this PU's snapshot in kvz_hip_me_params.cabac */
   kvz_hip_me_merge merge[5];
   int16_t pad;
 } kvz_hip_me_pu;                 /* 64 bytes */
-/* the encoder settings the search reads (mv_rdo off) */
+/* The CABAC state kvz_calc_mvd_cost_cabac (rdo.c:908-1060, --mv-rdo) starts from: what it reads of state->cabac
+ * (cabac_data_t, cabac.h:41-88).  The encoder's contexts change from LCU to LCU; a batch carries one snapshot per
+ * distinct state and every PU names its own (kvz_hip_me_pu.reserved). */
+typedef struct {
+  uint16_t range;                /* cabac.range */
+  uint8_t ctx[8];                /* uc_state of ctx.cu_merge_flag_ext_model, cu_merge_idx_ext_model, cu_ref_pic_model[0], [1],
+                                    cu_mvd_model[0], [1], mvp_idx_model[0]; [7] unused */
+  uint8_t pad[6];
+} kvz_hip_me_cabac;              /* 16 bytes */
+/* the encoder settings the search reads */
 typedef struct {
   int32_t lambda_cost;           /* (int32_t)(state->lambda_sqrt + 0.5), search_inter.c:411 */
   int32_t early_termination;     /* cfg.me_early_termination: 0 off, 1 on, 2 sensitive */
@@ -373,7 +382,13 @@ typedef struct {
                                     A CTU-row shard of a frame is a tile of full width: with mv_constraint 3 or 4 its
                                     search reads nothing outside its own rows (+ nothing at all beyond them), with wpp_owf and
                                     max_ref_lcu_down = 1 nothing beyond one CTU row + ref_delay_px + 4 rows below them. */
-} kvz_hip_me_params;             /* 64 bytes */
+  int32_t mv_rdo;                /* cfg.mv_rdo: MV bit costs from the CABAC model (kvz_calc_mvd_cost_cabac, rdo.c:908-1060, and
+                                    kvz_get_mvd_coding_cost_cabac in select_mv_cand) instead of the exp-Golomb estimate */
+  int32_t ref_idx;               /* mv_rdo: info->ref_idx of the reference picture searched */
+  int32_t refs_before;           /* mv_rdo: pictures of state->frame->ref with poc < current poc (rdo.c:990-998); ref_idx is coded when > 1 */
+  int32_t reserved;
+  const kvz_hip_me_cabac *cabac; /* mv_rdo: DEVICE array of snapshots, indexed by kvz_hip_me_pu.reserved; else unused (NULL) */
+} kvz_hip_me_params;             /* 88 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */
   uint32_t cost, bitcost;        /* info->best_cost, info->best_bitcost; cost 0xFFFFFFFF: nothing allowed / bad descriptor */

@@ -305,16 +305,21 @@ def intra_rough_batch(refs, log2_width, orig, flags=INTRA_LUMA | INTRA_FILTER_BO
 
 
 # ---- motion search of whole PUs ----
-def search_pu_batch(pic, ref, pus, params):
-    """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (64 bytes).
+def search_pu_batch(pic, ref, pus, params, cabac=None):
+    """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (88 bytes).
     Returns the raw results as int32 [count, 8] (= kvz_hip_me_result)."""
     L = _lib.init()
     pic = np.ascontiguousarray(pic, dtype=np.uint8)
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     pus = np.ascontiguousarray(pus)
     params = np.ascontiguousarray(params)
-    assert pus.dtype.itemsize == 64 and params.nbytes == 64
+    assert pus.dtype.itemsize == 64 and params.nbytes == 88
     count = pus.shape[0]
+    cb = None
+    if cabac is not None:                       # --mv-rdo: kvz_hip_me_cabac snapshots, staged to the device
+        cb = DeviceBuffer.from_numpy(np.ascontiguousarray(cabac).view(np.uint8))
+        params = params.copy()
+        params.view(np.uint8).reshape(-1)[80:88] = np.frombuffer(np.uint64(cb.ptr).tobytes(), dtype=np.uint8)
     a, b, d = DeviceBuffer.from_numpy(pic), DeviceBuffer.from_numpy(ref), DeviceBuffer.from_numpy(pus.view(np.uint8))
     out = DeviceBuffer(max(1, 32 * count))
     check(L.kvz_hip_search_pu_batch(a.ptr, pic.shape[1], pic.shape[1], pic.shape[0], b.ptr, ref.shape[1], ref.shape[1], ref.shape[0],

@@ -24,7 +24,67 @@ namespace {
 // calc_mvd_cost / fracmv_within_tile on the flattened encoder state (include/kvz_hip.h).  The descriptor is copied
 // into (scalar) registers once per PU: the cost model runs for every one of the ~60 candidates of a search, and
 // reading the merge list from memory each time made scalar loads the longest chain of the kernel.
-struct me_cost_model {
+// --mv-rdo: the CABAC probability tables of ITU-T H.265 (Tables 9-46 rangeTabLps, 9-47 transIdxLps) -- the reference's
+// kvz_g_auc_lpst_table / kvz_g_auc_next_state_lps (cabac.c:28-75); an MPS moves to min(state + 1, 62); the
+// renormalisation shift kvz_g_auc_renorm_table[lps >> 3] is clz(lps >> 3) - 26
+__constant__ unsigned char c_range_lps[64 * 4] = {
+  128,176,208,240, 128,167,197,227, 128,158,187,216, 123,150,178,205, 116,142,169,195, 111,135,160,185, 105,128,152,175, 100,122,144,166,
+   95,116,137,158,  90,110,130,150,  85,104,123,142,  81, 99,117,135,  77, 94,111,128,  73, 89,105,122,  69, 85,100,116,  66, 80, 95,110,
+   62, 76, 90,104,  59, 72, 86, 99,  56, 69, 81, 94,  53, 65, 77, 89,  51, 62, 73, 85,  48, 59, 69, 80,  46, 56, 66, 76,  43, 53, 63, 72,
+   41, 50, 59, 69,  39, 48, 56, 65,  37, 45, 54, 62,  35, 43, 51, 59,  33, 41, 48, 56,  32, 39, 46, 53,  30, 37, 43, 50,  29, 35, 41, 48,
+   27, 33, 39, 45,  26, 31, 37, 43,  24, 30, 35, 41,  23, 28, 33, 39,  22, 27, 32, 37,  21, 26, 30, 35,  20, 24, 29, 33,  19, 23, 27, 31,
+   18, 22, 26, 30,  17, 21, 25, 28,  16, 20, 23, 27,  15, 19, 22, 25,  14, 18, 21, 24,  14, 17, 20, 23,  13, 16, 19, 22,  12, 15, 18, 21,
+   12, 14, 17, 20,  11, 14, 16, 19,  11, 13, 15, 18,  10, 12, 15, 17,  10, 12, 14, 16,   9, 11, 13, 15,   9, 11, 12, 14,   8, 10, 12, 14,
+    8,  9, 11, 13,   7,  9, 11, 12,   7,  9, 10, 12,   7,  8, 10, 11,   6,  8,  9, 11,   6,  7,  9, 10,   6,  7,  8,  9,   2,  2,  2,  2 };
+__constant__ unsigned char c_trans_lps[64] = {
+   0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12,13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
+  24,25,26,26,27,27,28,29,29,30,30,30,31,32,32,33,33,33,34,34,35,35,35,36,36,36,37,37,37,38,38,63 };
+
+// what kvz_calc_mvd_cost_cabac reads of state->cabac, and the bits its counting-mode encoder produces: the count
+// (23 - bits_left) + 8 * num_buffered_bytes (cabac.c:95-140) is the number of renormalisation shifts, a function of `range`
+// and the context states alone
+struct cabac_model {
+  u32 range;
+  u32 ctx[7];        // uc_state of merge_flag, merge_idx, ref_pic[0], ref_pic[1], mvd[0], mvd[1], mvp_idx[0]
+  template <int C>
+  __device__ __forceinline__ u32 bin(bool b)           // kvz_cabac_encode_bin, cabac.c:90-122
+  {
+    const u32 uc = ctx[C], st = uc >> 1, lps = c_range_lps[st * 4 + ((range >> 6) & 3)];
+    range -= lps;
+    if ((b ? 1u : 0u) != (uc & 1u)) {
+      const u32 n = (u32)__clz((int)(lps >> 3)) - 26u;
+      range = lps << n;
+      ctx[C] = ((u32)c_trans_lps[st] << 1) | ((uc & 1u) ^ (st == 0 ? 1u : 0u));
+      return n;
+    }
+    ctx[C] = ((st < 62 ? st + 1 : st) << 1) | (uc & 1u);
+    if (range >= 256) return 0;
+    range <<= 1;
+    return 1;
+  }
+  // kvz_cabac_write_ep_ex_golomb(symbol, 1), cabac.c:535-570: number of bypass bins
+  static __device__ __forceinline__ u32 ex_golomb1(u32 symbol)
+  {
+    u32 n = 0, count = 1;
+    while (symbol >= (1u << count)) { ++n; symbol -= 1u << count; ++count; }
+    return n + 1 + count;
+  }
+  // kvz_encode_mvd, encode_coding_tree.c:1156-1202
+  __device__ __forceinline__ u32 mvd(int hor, int ver)
+  {
+    const u32 ah = (u32)(hor < 0 ? -hor : hor), av = (u32)(ver < 0 ? -ver : ver);
+    u32 bits = bin<4>(hor != 0);
+    bits += bin<4>(ver != 0);
+    if (hor) bits += bin<5>(ah > 1);
+    if (ver) bits += bin<5>(av > 1);
+    if (hor) bits += (ah > 1 ? ex_golomb1(ah - 2) : 0u) + 1u;
+    if (ver) bits += (av > 1 ? ex_golomb1(av - 2) : 0u) + 1u;
+    return bits;
+  }
+};
+
+template <bool RDO>
+struct me_cost_model_t {
   int px, py, pw, ph;
   int cand[2][2];
   int n_merge;
@@ -33,9 +93,18 @@ struct me_cost_model {
   u32 mkey[5];                                         // merge vector i as (x & 0xffff) | y << 16, for merge_match
   int lambda_cost, wpp_owf, ref_delay_px, max_down, max_right;
   int constraint, ox, oy, tw, th;                      // cfg.mv_constraint, tile-relative origin of the PU, tile size
+  cabac_model cab;                                     // RDO only
+  int rdo_ref_idx, rdo_refs_before;
 
-  __device__ __forceinline__ me_cost_model(const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm)
+  __device__ __forceinline__ me_cost_model_t(const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm)
   {
+    if (RDO) {
+      const kvz_hip_me_cabac &c = prm.cabac[pu.reserved];
+      cab.range = c.range;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) cab.ctx[i] = c.ctx[i];
+      rdo_ref_idx = prm.ref_idx; rdo_refs_before = prm.refs_before;
+    }
     px = pu.x; py = pu.y; pw = pu.width; ph = pu.height;
     cand[0][0] = pu.mv_cand[0][0]; cand[0][1] = pu.mv_cand[0][1]; cand[1][0] = pu.mv_cand[1][0]; cand[1][1] = pu.mv_cand[1][1];
     n_merge = pu.num_merge_cand;
@@ -126,11 +195,62 @@ struct me_cost_model {
       if ((live >> i & 1u) && mkey[i] == key) m = i;
     return ((u32)(x + 32768) < 65536u && (u32)(y + 32768) < 65536u) ? m : -1;
   }
+  // kvz_get_mvd_coding_cost_cabac (rdo.c:883-903): a fresh copy of the state per call
+  __device__ __forceinline__ u32 mvd_bits_cabac(int dx, int dy) const
+  {
+    cabac_model m = cab;
+    return m.mvd(dx, dy);
+  }
+  // select_mv_cand (:326-370) with --mv-rdo, cost_out == NULL
+  __device__ __forceinline__ int select_cand_cabac(int mvx, int mvy) const
+  {
+    const u32 c1 = mvd_bits_cabac(mvx - cand[0][0], mvy - cand[0][1]), c2 = mvd_bits_cabac(mvx - cand[1][0], mvy - cand[1][1]);
+    return c2 < c1 ? 1 : 0;
+  }
+  // kvz_calc_mvd_cost_cabac (rdo.c:908-1060)
+  __device__ __forceinline__ u32 cost_cabac(int x, int y, u32 &bits) const
+  {
+    const int mi = merge_match(x, y);
+    int cur_cand = 0, dx = 0, dy = 0;
+    if (mi < 0) {
+      const int d1x = x - cand[0][0], d1y = y - cand[0][1], d2x = x - cand[1][0], d2y = y - cand[1][1];
+      const u32 c1 = mvd_bits_cabac(d1x, d1y), c2 = mvd_bits_cabac(d2x, d2y);
+      if (c2 < c1) { cur_cand = 1; dx = d2x; dy = d2y; } else { dx = d1x; dy = d1y; }
+    }
+    cabac_model m = cab;
+    u32 b = m.template bin<0>(mi >= 0);
+    if (mi >= 0) {
+      for (int ui = 0; ui < 4; ++ui) {                   // MRG_MAX_NUM_CANDS - 1
+        const bool symbol = ui != mi;
+        b += ui == 0 ? m.template bin<1>(symbol) : 1u;
+        if (!symbol) break;
+      }
+    } else {
+      if (rdo_refs_before > 1) {
+        int ref_frame = rdo_ref_idx;
+        b += m.template bin<2>(ref_frame != 0);
+        if (ref_frame > 0) {
+          const int ref_num = rdo_refs_before - 2;
+          --ref_frame;
+          for (int i = 0; i < ref_num; ++i) {
+            const bool symbol = i != ref_frame;
+            b += i == 0 ? m.template bin<3>(symbol) : 1u;
+            if (!symbol) break;
+          }
+        }
+      }
+      b += m.mvd(dx, dy);
+      b += m.template bin<6>(cur_cand != 0);
+    }
+    bits = b;
+    return __umul24(b, (u32)lambda_cost);
+  }
   // calc_mvd_cost (:373-412)
   __device__ __forceinline__ u32 cost(int x, int y, int mv_shift, u32 &bits) const
   {
     x *= 1 << mv_shift;
     y *= 1 << mv_shift;
+    if (RDO) return cost_cabac(x, y, bits);
     const int m = merge_match(x, y);
     if (m >= 0) bits = (u32)m;
     else select_cand(x, y, bits);
@@ -146,6 +266,7 @@ struct me_cost_model {
     return hit;
   }
 };
+typedef me_cost_model_t<false> me_cost_model;
 
 __constant__ signed char c_large_hex[9][2] = { { 0, 0 }, { 1, -2 }, { 2, 0 }, { 1, 2 }, { -1, 2 }, { -2, 0 }, { -1, -2 }, { 1, -2 }, { 2, 0 } };
 __constant__ signed char c_small_hex[9][2] = { { 0, 0 }, { 0, -1 }, { -1, 0 }, { 1, 0 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
@@ -157,7 +278,7 @@ struct me_shared { u32 sad[ME_GROUP]; int cx[ME_GROUP], cy[ME_GROUP]; };
 
 // One PU.  T threads (a wave with wave-private LDS, or the whole workgroup) share the work; every thread
 // carries the same search state, so all decisions are uniform across them.
-template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0>
+template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0, bool RDO = false>
 __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, const u8 *__restrict__ pic, u32 pic_stride,
                                                const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm,
                                                kvz_hip_me_result *__restrict__ out)
@@ -165,7 +286,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   typedef frac_geom<MAXW> G;
   u8 *s_cur = lds + G::P_BYTES;                        // same place search_frac_core keeps the current block
   auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
-  const me_cost_model mvc(pu, prm);
+  const me_cost_model_t<RDO> mvc(pu, prm);
   const int w = FW ? FW : pu.width, h = FH ? FH : pu.height;                       // FW, FH: compile-time size (0 = runtime)
   // a row is cut into 8-pixel segments, or 4-pixel ones when the width is 4 or 12 (AMP / SMP shapes)
   const bool seg4 = !FW && (w & 4);
@@ -523,7 +644,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   if (best_cost != 0xffffffffu) {
     sync();
     const kvz_hip_block_pair d = { pu.x, pu.y, pu.x + best_x, pu.y + best_y, w, h };
-    const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model, FW, FH>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
+    const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model_t<RDO>, FW, FH>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
     best_cost = fr.cost;                               // level 0: satd + bits(int mv) * lambda, the same bits as best_bits
     if (prm.fme_level > 0) { mv_x = fr.mvx; mv_y = fr.mvy; best_bits = fr.bitcost; }
   }
@@ -536,7 +657,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
     r.merged = m >= 0;
     r.merge_idx = m >= 0 ? m : mvc.n_merge;
     u32 unused;
-    r.mv_cand = m >= 0 ? 0 : mvc.select_cand(mv_x, mv_y, unused);   // :1268-1273
+    r.mv_cand = m >= 0 ? 0 : (RDO ? mvc.select_cand_cabac(mv_x, mv_y) : mvc.select_cand(mv_x, mv_y, unused));   // :1268-1273
     r.reserved = 0;
     *out = r;
   }
@@ -566,6 +687,20 @@ __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__
   if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   if (pu.width <= 32 && pu.height <= 32) return;       // the one-wave-per-PU kernels'
   search_pu_core<64, T, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+}
+
+// --mv-rdo (cfg.mv_rdo, off in every preset): MV bits from the CABAC model.  One workgroup per PU for every size -- a
+// correctness path; the model walks probability tables per candidate and is kept out of the kernels above so that their
+// register budget is untouched.
+__global__ __launch_bounds__(256) void search_pu_rdo_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
+                                                            const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
+                                                            kvz_hip_me_result *__restrict__ out)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
+  __shared__ me_shared sh;
+  const kvz_hip_me_pu &pu = pus[blockIdx.x];
+  if (!pu_ok(pu, pic_w, pic_h) || pu.reserved < 0) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  search_pu_core<64, 256, false, 0, 0, true>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
 
 // PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier.  The register budget is held at
@@ -659,6 +794,15 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   const refplane_t r = { ref, ref_stride, ref_w, ref_h };
   // one launch per size class over the same descriptor list; each kernel takes its class and skips the rest.  The big
   // kernel also flags malformed descriptors, so it only goes when the caller vouches for the classes it names.
+  if (params->mv_rdo) {
+    if (!params->cabac || params->refs_before < 1 || params->refs_before > 16 || params->ref_idx < 0 || params->ref_idx >= 16) {
+      set_error_msg("kvz_hip_search_pu_batch: mv_rdo needs the cabac snapshots (device array), refs_before 1..16 and ref_idx 0..15");
+      return KVZ_HIP_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(search_pu_rdo_kernel, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
+    KVZ_CHECK_LAUNCH("search_pu_rdo_kernel");
+    return KVZ_HIP_OK;
+  }
   const int classes = (params->size_classes & 7) ? (params->size_classes & 7) : 7;
   if (classes != 7) {
     // with a hint, PUs of a class it does not name are searched by no kernel: they read cost 0xFFFFFFFF, reserved -1

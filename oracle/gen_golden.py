@@ -180,14 +180,22 @@ def me():
             # the mv_constraint branches of fracmv_within_tile (search_inter.c:142-171), frame = one tile and a real tile
             dict(mv_constraint=1, lambda_cost=12), dict(mv_constraint=4, lambda_cost=12, early_termination=0),
             dict(mv_constraint=3, tile=(64, 0, 128, 128), lambda_cost=18),
-            dict(mv_constraint=4, tile=(0, 64, 192, 64), wpp_owf=1, ref_delay_px=10, lambda_cost=9, algorithm=1)]
+            dict(mv_constraint=4, tile=(0, 64, 192, 64), wpp_owf=1, ref_delay_px=10, lambda_cost=9, algorithm=1),
+            # --mv-rdo: kvz_calc_mvd_cost_cabac as the cost model, from the CABAC snapshots stored beside the results
+            dict(mv_rdo=1, lambda_cost=14), dict(mv_rdo=1, refs_before=3, ref_idx=1, algorithm=2, lambda_cost=22)]
     pic, ref = me_frames(192, 128, SEED + 7, (5, -3))
     pus = me_random_pus(192, 128, 48, SEED + 8, hint=(-18, 12))
     d["pic"], d["ref"], d["pus"] = pic, ref, pus.view(np.uint8).reshape(len(pus), 64)
+    from patterns import me_cabac_states
+    cab = me_cabac_states(6, SEED + 9)
+    d["cabac"] = cab.view(np.uint8).reshape(-1, 16)
+    pus["reserved"] = np.arange(len(pus)) % 6                       # read only with mv_rdo
+    d["pus"] = pus.view(np.uint8).reshape(len(pus), 64)
     for i, c in enumerate(cfgs):
         prm = me_params(**c)
-        d["params%d" % i] = prm.view(np.int32).reshape(16)
-        d["results%d" % i] = R.search_pu_batch(pic, ref, me_pus_in_tile(pus, prm), prm).view(np.int32).reshape(len(pus), 8)
+        d["params%d" % i] = prm.view(np.uint8).reshape(-1)           # the pointer field stays 0: loaders attach the snapshots
+        d["results%d" % i] = R.search_pu_batch(pic, ref, me_pus_in_tile(pus, prm), prm,
+                                               cabac=cab if c.get("mv_rdo") else None).view(np.int32).reshape(len(pus), 8)
     np.savez_compressed(os.path.join(OUT, "me.npz"), **d)
 
 
@@ -207,7 +215,7 @@ def fronts():
     d["small_pic"], d["small_ref"] = rec["pic"], rec["ref"]
     d["small_pus"] = rec["pus"].view(np.uint8).reshape(-1, 64)
     d["small_results"] = rec["results"].view(np.int32).reshape(-1, 8)
-    d["small_meta"], d["small_params"] = rec["meta"], rec["params"].view(np.int32).reshape(16)
+    d["small_meta"], d["small_params"] = rec["meta"], rec["params"].view(np.uint8).reshape(-1)
     w, h = 1920, 1080
     frames = R.synthetic_sequence(w, h, 2)
     rec = R.record_inter_searches(frames, w, h, FRONT_OPTS, max_records=60000)
@@ -217,7 +225,7 @@ def fronts():
     d["hd_ref_delta"] = delta.astype(np.int8)
     d["hd_pus"] = rec["pus"].view(np.uint8).reshape(-1, 64)
     d["hd_results"] = rec["results"].view(np.int32).reshape(-1, 8)
-    d["hd_meta"], d["hd_params"] = rec["meta"], rec["params"].view(np.int32).reshape(16)
+    d["hd_meta"], d["hd_params"] = rec["meta"], rec["params"].view(np.uint8).reshape(-1)
     np.savez_compressed(os.path.join(OUT, "fronts.npz"), **d)
 
 

@@ -815,10 +815,147 @@ static int me_select_cand(const orc_me_pu *pu, int mvx, int mvy, unsigned *cost_
   return c2 < c1 ? 1 : 0;
 }
 
+/* ---- --mv-rdo: kvz_calc_mvd_cost_cabac (rdo.c:908-1060) and kvz_get_mvd_coding_cost_cabac (:883-903) ----
+ * The reference runs its CABAC encoder in counting mode on a copy of state->cabac.  What it counts,
+ * (23 - bits_left) + 8 * num_buffered_bytes (cabac.c:95-140), is the number of renormalisation shifts, which depends
+ * only on `range` and on the states of the contexts used -- `low` and the byte buffering never matter.
+ * Tables: ITU-T H.265 (04/2013) Table 9-46 (rangeTabLps), Table 9-47 (transIdxLps); an MPS moves to min(state + 1, 62). */
+static const unsigned char cabac_range_lps[64][4] = {
+  {128,176,208,240},{128,167,197,227},{128,158,187,216},{123,150,178,205},{116,142,169,195},{111,135,160,185},{105,128,152,175},{100,122,144,166},
+  { 95,116,137,158},{ 90,110,130,150},{ 85,104,123,142},{ 81, 99,117,135},{ 77, 94,111,128},{ 73, 89,105,122},{ 69, 85,100,116},{ 66, 80, 95,110},
+  { 62, 76, 90,104},{ 59, 72, 86, 99},{ 56, 69, 81, 94},{ 53, 65, 77, 89},{ 51, 62, 73, 85},{ 48, 59, 69, 80},{ 46, 56, 66, 76},{ 43, 53, 63, 72},
+  { 41, 50, 59, 69},{ 39, 48, 56, 65},{ 37, 45, 54, 62},{ 35, 43, 51, 59},{ 33, 41, 48, 56},{ 32, 39, 46, 53},{ 30, 37, 43, 50},{ 29, 35, 41, 48},
+  { 27, 33, 39, 45},{ 26, 31, 37, 43},{ 24, 30, 35, 41},{ 23, 28, 33, 39},{ 22, 27, 32, 37},{ 21, 26, 30, 35},{ 20, 24, 29, 33},{ 19, 23, 27, 31},
+  { 18, 22, 26, 30},{ 17, 21, 25, 28},{ 16, 20, 23, 27},{ 15, 19, 22, 25},{ 14, 18, 21, 24},{ 14, 17, 20, 23},{ 13, 16, 19, 22},{ 12, 15, 18, 21},
+  { 12, 14, 17, 20},{ 11, 14, 16, 19},{ 11, 13, 15, 18},{ 10, 12, 15, 17},{ 10, 12, 14, 16},{  9, 11, 13, 15},{  9, 11, 12, 14},{  8, 10, 12, 14},
+  {  8,  9, 11, 13},{  7,  9, 11, 12},{  7,  9, 10, 12},{  7,  8, 10, 11},{  6,  8,  9, 11},{  6,  7,  9, 10},{  6,  7,  8,  9},{  2,  2,  2,  2} };
+static const unsigned char cabac_trans_lps[64] = {
+   0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9,11,11,12,13,13,15,15,16,16,18,18,19,19,21,21,22,22,23,24,
+  24,25,26,26,27,27,28,29,29,30,30,30,31,32,32,33,33,33,34,34,35,35,35,36,36,36,37,37,37,38,38,63 };
+/* uc_state = (state << 1) | mps (cabac.h:119-122) */
+static unsigned cabac_next_mps(unsigned uc) { const unsigned s = uc >> 1; return ((s < 62 ? s + 1 : s) << 1) | (uc & 1); }
+static unsigned cabac_next_lps(unsigned uc) { const unsigned s = uc >> 1; return ((unsigned)cabac_trans_lps[s] << 1) | ((uc & 1) ^ (s == 0)); }
+/* kvz_g_auc_renorm_table[lps >> 3]: the shift that brings the smallest lps of the octet to >= 256; 6 for the first octet
+ * (rangeTabLps never goes below 6 for the states a context can reach) */
+static unsigned cabac_renorm(unsigned lps)
+{
+  const unsigned i = lps >> 3;
+  unsigned n = 0;
+  if (i == 0) return 6;
+  while (((i << 3) << n) < 256) ++n;
+  return n;
+}
+int orc_cabac_table(int kind, int i)
+{
+  switch (kind) {
+    case 0: return cabac_range_lps[i >> 2][i & 3];
+    case 1: return (int)cabac_next_mps((unsigned)i);
+    case 2: return (int)cabac_next_lps((unsigned)i);
+    default: return (int)cabac_renorm((unsigned)i << 3);
+  }
+}
+typedef struct { unsigned range; unsigned char ctx[8]; } cabac_model;
+enum { CTX_MERGE_FLAG = 0, CTX_MERGE_IDX, CTX_REF0, CTX_REF1, CTX_MVD0, CTX_MVD1, CTX_MVP };
+/* kvz_cabac_encode_bin (cabac.c:90-122), bits produced */
+static unsigned cabac_bin(cabac_model *m, int ctx, int bin)
+{
+  const unsigned uc = m->ctx[ctx], lps = cabac_range_lps[uc >> 1][(m->range >> 6) & 3];
+  m->range -= lps;
+  if ((unsigned)(bin ? 1 : 0) != (uc & 1)) {
+    const unsigned n = cabac_renorm(lps);
+    m->range = lps << n;
+    m->ctx[ctx] = (unsigned char)cabac_next_lps(uc);
+    return n;
+  }
+  m->ctx[ctx] = (unsigned char)cabac_next_mps(uc);
+  if (m->range >= 256) return 0;
+  m->range <<= 1;
+  return 1;
+}
+/* kvz_cabac_write_ep_ex_golomb (cabac.c:535-570): bypass bins of symbol with parameter count */
+static unsigned cabac_ex_golomb_bins(unsigned symbol, unsigned count)
+{
+  unsigned n = 0;
+  while (symbol >= (1u << count)) { ++n; symbol -= 1u << count; ++count; }
+  return n + 1 + count;
+}
+/* kvz_encode_mvd (encode_coding_tree.c:1156-1202) */
+static unsigned cabac_mvd_bits(cabac_model *m, int hor, int ver)
+{
+  const unsigned ah = (unsigned)abs(hor), av = (unsigned)abs(ver);
+  unsigned bits = cabac_bin(m, CTX_MVD0, hor != 0);
+  bits += cabac_bin(m, CTX_MVD0, ver != 0);
+  if (hor) bits += cabac_bin(m, CTX_MVD1, ah > 1);
+  if (ver) bits += cabac_bin(m, CTX_MVD1, av > 1);
+  if (hor) bits += (ah > 1 ? cabac_ex_golomb_bins(ah - 2, 1) : 0) + 1;      /* + sign */
+  if (ver) bits += (av > 1 ? cabac_ex_golomb_bins(av - 2, 1) : 0) + 1;
+  return bits;
+}
+static cabac_model cabac_start(const me_ctx *mc)
+{
+  const orc_me_cabac *c = &mc->prm->cabac[mc->pu->reserved];
+  cabac_model m;
+  m.range = c->range;
+  memcpy(m.ctx, c->ctx, 8);
+  return m;
+}
+/* kvz_get_mvd_coding_cost_cabac (rdo.c:883-903) on a fresh copy of the state */
+static unsigned me_mvd_bits_cabac(const me_ctx *mc, int dx, int dy)
+{
+  cabac_model m = cabac_start(mc);
+  return cabac_mvd_bits(&m, dx, dy);
+}
+/* kvz_calc_mvd_cost_cabac (rdo.c:908-1060) */
+static unsigned me_mv_cost_cabac(const me_ctx *mc, int x, int y, int mv_shift, unsigned *bitcost)
+{
+  const orc_me_pu *pu = mc->pu;
+  const orc_me_params *prm = mc->prm;
+  int merged = 0, merge_idx, cur_cand = 0, mvd[2] = { 0, 0 };
+  x *= 1 << mv_shift;
+  y *= 1 << mv_shift;
+  for (merge_idx = 0; merge_idx < pu->num_merge_cand; ++merge_idx) {
+    if (!pu->merge[merge_idx].usable) continue;
+    if (pu->merge[merge_idx].mv[0] == x && pu->merge[merge_idx].mv[1] == y && pu->merge[merge_idx].same_ref) { merged = 1; break; }
+  }
+  if (!merged) {                                                  /* :952-972 */
+    const int d1[2] = { x - pu->mv_cand[0][0], y - pu->mv_cand[0][1] }, d2[2] = { x - pu->mv_cand[1][0], y - pu->mv_cand[1][1] };
+    const unsigned c1 = me_mvd_bits_cabac(mc, d1[0], d1[1]), c2 = me_mvd_bits_cabac(mc, d2[0], d2[1]);
+    if (c2 < c1) { cur_cand = 1; mvd[0] = d2[0]; mvd[1] = d2[1]; } else { mvd[0] = d1[0]; mvd[1] = d1[1]; }
+  }
+  cabac_model m = cabac_start(mc);
+  unsigned bits = cabac_bin(&m, CTX_MERGE_FLAG, merged);          /* :976 */
+  if (merged) {                                                   /* :978-992: MRG_MAX_NUM_CANDS = 5 */
+    for (int ui = 0; ui < 4; ++ui) {
+      const int symbol = ui != merge_idx;
+      bits += ui == 0 ? cabac_bin(&m, CTX_MERGE_IDX, symbol) : 1;
+      if (!symbol) break;
+    }
+  } else {
+    if (prm->refs_before > 1) {                                   /* :1004-1030 */
+      int ref_frame = prm->ref_idx;
+      bits += cabac_bin(&m, CTX_REF0, ref_frame != 0);
+      if (ref_frame > 0) {
+        const int ref_num = prm->refs_before - 2;
+        --ref_frame;
+        for (int i = 0; i < ref_num; ++i) {
+          const int symbol = i == ref_frame ? 0 : 1;
+          bits += i == 0 ? cabac_bin(&m, CTX_REF1, symbol) : 1;
+          if (!symbol) break;
+        }
+      }
+    }
+    bits += cabac_mvd_bits(&m, mvd[0], mvd[1]);                   /* :1033-1037 */
+    bits += cabac_bin(&m, CTX_MVP, cur_cand);                     /* kvz_cabac_write_unary_max_symbol(.., cur_mv_cand, 1, 1): one bin */
+  }
+  *bitcost = bits;
+  return bits * (unsigned)prm->lambda_cost;
+}
+
 /* calc_mvd_cost (:373-412) */
 static unsigned me_mv_cost(const me_ctx *mc, int x, int y, int mv_shift, unsigned *bitcost)
 {
   if (!mc) { *bitcost = 0; return 0; }
+  if (mc->prm->mv_rdo) return me_mv_cost_cabac(mc, x, y, mv_shift, bitcost);
   const orc_me_pu *pu = mc->pu;
   unsigned bits = 0;
   int merged = 0;
@@ -1142,6 +1279,11 @@ void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, i
   res->merge_idx = idx;
   if (!res->merged) {
     /* select_mv_cand with cost_out == NULL returns 0 for identical candidates (:332-338): same answer */
+    if (prm->mv_rdo) {   /* select_mv_cand with kvz_get_mvd_coding_cost_cabac (:343-344) */
+      const unsigned c1 = me_mvd_bits_cabac(&in.mc, in.best_mv[0] - pu->mv_cand[0][0], in.best_mv[1] - pu->mv_cand[0][1]);
+      const unsigned c2 = me_mvd_bits_cabac(&in.mc, in.best_mv[0] - pu->mv_cand[1][0], in.best_mv[1] - pu->mv_cand[1][1]);
+      res->mv_cand = c2 < c1 ? 1 : 0;
+    } else
     res->mv_cand = me_select_cand(pu, in.best_mv[0], in.best_mv[1], NULL);
   }
 }

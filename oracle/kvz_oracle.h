@@ -187,7 +187,7 @@ typedef struct {
   int16_t mv_cand[2][2];         /* AMVP candidates (kvz_inter_get_mv_cand), quarter-pel */
   int16_t extra_mv[2];           /* start vector taken from the co-located CU (:1190-1206), quarter-pel */
   int16_t num_merge_cand;        /* 0..5 */
-  int16_t reserved;
+  int16_t reserved;              /* mv_rdo: index of the PU's CABAC snapshot in orc_me_params.cabac */
   orc_me_merge merge[5];
   int16_t pad;
 } orc_me_pu;                     /* 64 bytes */
@@ -206,7 +206,18 @@ typedef struct {
   int32_t mv_constraint;         /* cfg.mv_constraint (kvazaar.h:113-119): the branches of fracmv_within_tile :142-171 */
   int32_t tile_x, tile_y;        /* state->tile->offset_x / _y in the picture */
   int32_t tile_w, tile_h;        /* state->tile->frame->width / height; 0 x 0 = the picture is one tile */
-} orc_me_params;                 /* 64 bytes */
+  int32_t mv_rdo;                /* cfg.mv_rdo: MV bits from the CABAC model, kvz_calc_mvd_cost_cabac (rdo.c:908-1060) */
+  int32_t ref_idx;               /* info->ref_idx of the reference picture searched (coded when refs_before > 1) */
+  int32_t refs_before;           /* pictures of state->frame->ref with poc < the current poc (rdo.c:990-998) */
+  int32_t reserved;
+  const struct orc_me_cabac *cabac;   /* mv_rdo: snapshots of state->cabac; a PU uses entry pu->reserved */
+} orc_me_params;                 /* 88 bytes */
+typedef struct orc_me_cabac {    /* what kvz_calc_mvd_cost_cabac reads of cabac_data_t (cabac.h:41-88) */
+  uint16_t range;                /* .range */
+  uint8_t ctx[8];                /* uc_state of cu_merge_flag_ext_model, cu_merge_idx_ext_model, cu_ref_pic_model[0], [1],
+                                    cu_mvd_model[0], [1], mvp_idx_model[0], unused */
+  uint8_t pad[6];
+} orc_me_cabac;                  /* 16 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */
   uint32_t cost, bitcost;        /* info->best_cost, info->best_bitcost */
@@ -280,6 +291,9 @@ void orc_deblock_frame(orc_pixel *y, int stride_y, orc_pixel *u, orc_pixel *v, i
 /* the per-block functions over `count` contiguous blocks (whole-launch parity checks, one range per host thread) */
 void orc_cost_nxn_many(int satd, int n, const orc_pixel *b1, const orc_pixel *b2, size_t count, unsigned *costs);
 void orc_transform_many(int kind, int n, const int16_t *in, int16_t *out, size_t count);
+/* the CABAC tables of ITU-T H.265 9.3.4.3 as the oracle restates them (checked against the reference's in tests): kind 0
+ * rangeTabLps[state][quarter] (i = 4 state + q), 1 next state after an MPS, 2 after an LPS (index uc_state), 3 renormalisation shifts */
+int orc_cabac_table(int kind, int i);
 void orc_quantize_residual_many(const orc_quant_params *p, int cu_is_intra, int width, int color, int scan_order, int use_trskip,
                                 const orc_pixel *ref_in, const orc_pixel *pred_in, orc_pixel *rec_out, orc_coeff *coeff_out,
                                 int32_t *has_coeffs, size_t count);

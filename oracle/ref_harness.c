@@ -320,6 +320,19 @@ double ref_bench_transform(const char *type, const char *name, int n, const int1
   return (double)done / (t1 - t0);
 }
 
+/* the reference's CABAC tables (cabac.c:28-75), for the test that pins the oracle's restatement of ITU-T H.265 Tables 9-46 / 9-47:
+ * kind 0 kvz_g_auc_lpst_table[i >> 2][i & 3], 1 kvz_g_auc_next_state_mps[i], 2 kvz_g_auc_next_state_lps[i], 3 kvz_g_auc_renorm_table[i] */
+#include "cabac.h"
+int ref_cabac_table(int kind, int i)
+{
+  switch (kind) {
+    case 0: return kvz_g_auc_lpst_table[i >> 2][i & 3];
+    case 1: return kvz_g_auc_next_state_mps[i];
+    case 2: return kvz_g_auc_next_state_lps[i];
+    default: return kvz_g_auc_renorm_table[i];
+  }
+}
+
 /* whole-launch parity checks: one strategy function over `count` contiguous blocks (a test gives each host thread a range) */
 int ref_cost_nxn_many(const char *type, const char *name, int n, const kvz_pixel *a, const kvz_pixel *b, size_t count, unsigned *costs)
 {
@@ -692,6 +705,8 @@ typedef struct {                              /* = kvz_hip_me_params / orc_me_pa
   int32_t fme_level, wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right;
   int32_t algorithm, search_range, size_classes, mv_constraint;
   int32_t tile_x, tile_y, tile_w, tile_h;
+  int32_t mv_rdo, ref_idx, refs_before, reserved;
+  const void *cabac;
 } rec_params_t;
 
 static struct {

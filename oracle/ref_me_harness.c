@@ -33,7 +33,10 @@ typedef struct {
   int32_t fme_level, wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right;
   int32_t algorithm, search_range, size_classes, mv_constraint;
   int32_t tile_x, tile_y, tile_w, tile_h;
+  int32_t mv_rdo, ref_idx, refs_before, reserved;
+  const struct me_cabac_s *cabac;
 } me_params_t;
+typedef struct me_cabac_s { uint16_t range; uint8_t ctx[8]; uint8_t pad[6]; } me_cabac_t;
 typedef struct { int32_t mv[2]; uint32_t cost, bitcost; int32_t merged, merge_idx, mv_cand, reserved; } me_result_t;
 
 /* the hexbs path of search_pu_inter_ref (search_inter.c:1134-1300) on a fabricated encoder state:
@@ -63,13 +66,36 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   const int tiled = prm->tile_w != 0 || prm->tile_h != 0;
   const int tx = tiled ? prm->tile_x : 0, ty = tiled ? prm->tile_y : 0;
   const int tw = tiled ? prm->tile_w : frame_w, th = tiled ? prm->tile_h : frame_h;
-  ctrl.cfg.mv_rdo = 0;
+  ctrl.cfg.mv_rdo = prm->mv_rdo ? 1 : 0;
   ctrl.max_inter_ref_lcu.down = prm->max_ref_lcu_down;
   ctrl.max_inter_ref_lcu.right = prm->max_ref_lcu_right;
   vframe.width = tw; vframe.height = th;
   tile.frame = &vframe;
   tile.offset_x = tx; tile.offset_y = ty;
-  frame.ref_LX[0][0] = 0; frame.ref_LX[0][1] = 1; frame.ref_LX_size[0] = 2;
+  for (int i = 0; i < 16; ++i) frame.ref_LX[0][i] = (uint8_t)i;
+  frame.ref_LX_size[0] = 16;
+  const int search_ref = prm->mv_rdo ? prm->ref_idx : 0;           /* info->ref_idx; the merge candidates' "same_ref" is relative to it */
+  /* --mv-rdo (rdo.c:908-1060): the CABAC state the cost model starts from, and the reference list it codes ref_idx against */
+  static image_list_t reflist;
+  static int32_t pocs[16];
+  memset(&reflist, 0, sizeof(reflist));
+  if (prm->mv_rdo) {
+    const me_cabac_t *cb = &prm->cabac[pu->reserved];
+    state.cabac.range = cb->range;
+    state.cabac.bits_left = 23;
+    state.cabac.ctx.cu_merge_flag_ext_model.uc_state = cb->ctx[0];
+    state.cabac.ctx.cu_merge_idx_ext_model.uc_state = cb->ctx[1];
+    state.cabac.ctx.cu_ref_pic_model[0].uc_state = cb->ctx[2];
+    state.cabac.ctx.cu_ref_pic_model[1].uc_state = cb->ctx[3];
+    state.cabac.ctx.cu_mvd_model[0].uc_state = cb->ctx[4];
+    state.cabac.ctx.cu_mvd_model[1].uc_state = cb->ctx[5];
+    state.cabac.ctx.mvp_idx_model[0].uc_state = cb->ctx[6];
+    frame.poc = 100;
+    reflist.used_size = prm->refs_before > 0 ? prm->refs_before : 1;
+    for (int i = 0; i < 16; ++i) pocs[i] = 99 - i;
+    reflist.pocs = pocs;
+    frame.ref = &reflist;
+  }
   state.encoder_control = &ctrl;
   state.tile = &tile;
   state.frame = &frame;
@@ -84,14 +110,15 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   inter_search_info_t info = {
     .state = &state, .pic = &pic, .ref = &ref, .ref_idx = 0,
     .origin = { pu->x - tx, pu->y - ty }, .width = pu->width, .height = pu->height,
-    .mvd_cost_func = calc_mvd_cost,
+    .mvd_cost_func = prm->mv_rdo ? kvz_calc_mvd_cost_cabac : calc_mvd_cost,
   };
+  info.ref_idx = search_ref;
   memcpy(info.mv_cand, pu->mv_cand, sizeof(info.mv_cand));
   info.num_merge_cand = pu->num_merge_cand;
   for (int i = 0; i < pu->num_merge_cand; ++i) {
     memset(&info.merge_cand[i], 0, sizeof(info.merge_cand[i]));
     info.merge_cand[i].dir = pu->merge[i].usable ? 1 : 3;
-    info.merge_cand[i].ref[0] = pu->merge[i].same_ref ? 0 : 1;
+    info.merge_cand[i].ref[0] = pu->merge[i].same_ref ? search_ref : (search_ref + 1) % 4;
     info.merge_cand[i].mv[0][0] = pu->merge[i].mv[0];
     info.merge_cand[i].mv[0][1] = pu->merge[i].mv[1];
   }
@@ -115,7 +142,7 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   int idx;
   for (idx = 0; idx < info.num_merge_cand; ++idx)
     if (info.merge_cand[idx].dir != 3 && info.merge_cand[idx].mv[0][0] == info.best_mv.x &&
-        info.merge_cand[idx].mv[0][1] == info.best_mv.y && frame.ref_LX[0][info.merge_cand[idx].ref[0]] == 0) { res->merged = 1; break; }
+        info.merge_cand[idx].mv[0][1] == info.best_mv.y && frame.ref_LX[0][info.merge_cand[idx].ref[0]] == search_ref) { res->merged = 1; break; }
   res->merge_idx = idx;
   if (!res->merged) res->mv_cand = select_mv_cand(&state, info.mv_cand, info.best_mv.x, info.best_mv.y, NULL);
 }

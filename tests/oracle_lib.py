@@ -428,7 +428,7 @@ def intra_rough_costs_batch(refs, log2_width, orig, filter_boundary=1):
 
 
 # ---- motion search ----
-def search_pu_batch(pic, ref, pus, params):
+def search_pu_batch(pic, ref, pus, params, cabac=None):
     """orc_search_pu over a structured array of patterns.ME_PU; returns patterns.ME_RESULT array"""
     from patterns import ME_RESULT
     L = lib()
@@ -436,7 +436,10 @@ def search_pu_batch(pic, ref, pus, params):
     L.orc_search_pu.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     pic, ref = _u8(pic), _u8(ref)
     pus = np.ascontiguousarray(pus)
-    params = np.ascontiguousarray(params)
+    params = np.ascontiguousarray(params).copy()
+    if cabac is not None:                       # --mv-rdo: ME_CABAC snapshots; pus["reserved"] indexes them
+        cabac = np.ascontiguousarray(cabac)
+        params["cabac"] = cabac.ctypes.data
     out = np.zeros(len(pus), dtype=ME_RESULT)
     for i in range(len(pus)):
         L.orc_search_pu(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],

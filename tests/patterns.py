@@ -130,15 +130,19 @@ ME_PU = np.dtype([("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4"
 ME_PARAMS = np.dtype([("lambda_cost", "<i4"), ("early_termination", "<i4"), ("max_steps", "<u4"), ("fme_level", "<i4"),
                       ("wpp_owf", "<i4"), ("ref_delay_px", "<i4"), ("max_ref_lcu_down", "<i4"), ("max_ref_lcu_right", "<i4"),
                       ("algorithm", "<i4"), ("search_range", "<i4"), ("size_classes", "<i4"), ("mv_constraint", "<i4"),
-                      ("tile_x", "<i4"), ("tile_y", "<i4"), ("tile_w", "<i4"), ("tile_h", "<i4")])
+                      ("tile_x", "<i4"), ("tile_y", "<i4"), ("tile_w", "<i4"), ("tile_h", "<i4"),
+                      ("mv_rdo", "<i4"), ("ref_idx", "<i4"), ("refs_before", "<i4"), ("reserved", "<i4"), ("cabac", "<u8")])
+ME_CABAC = np.dtype([("range", "<u2"), ("ctx", "u1", (8,)), ("pad", "u1", (6,))])
 ME_RESULT = np.dtype([("mv", "<i4", (2,)), ("cost", "<u4"), ("bitcost", "<u4"), ("merged", "<i4"), ("merge_idx", "<i4"),
                       ("mv_cand", "<i4"), ("reserved", "<i4")])
-assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 64 and ME_RESULT.itemsize == 32
+assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 88 and ME_RESULT.itemsize == 32 and ME_CABAC.itemsize == 16
 
 
 def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_level=4, wpp_owf=0, ref_delay_px=0,
-              max_ref_lcu_down=1, max_ref_lcu_right=1, algorithm=0, search_range=0, mv_constraint=0, tile=None):
-    """tile: (x, y, w, h) of state->tile in the picture, None = the picture is one tile"""
+              max_ref_lcu_down=1, max_ref_lcu_right=1, algorithm=0, search_range=0, mv_constraint=0, tile=None,
+              mv_rdo=0, ref_idx=0, refs_before=1):
+    """tile: (x, y, w, h) of state->tile in the picture, None = the picture is one tile.  mv_rdo: the caller sets p["cabac"] to the
+    address of an ME_CABAC array (host for the oracle / reference, device for the GPU entry) and pus["reserved"] to each PU's entry."""
     p = np.zeros(1, dtype=ME_PARAMS)
     p["lambda_cost"], p["early_termination"], p["max_steps"], p["fme_level"] = lambda_cost, early_termination, max_steps, fme_level
     p["wpp_owf"], p["ref_delay_px"], p["max_ref_lcu_down"], p["max_ref_lcu_right"] = wpp_owf, ref_delay_px, max_ref_lcu_down, max_ref_lcu_right
@@ -147,7 +151,28 @@ def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_lev
     p["mv_constraint"] = mv_constraint
     if tile is not None:
         p["tile_x"], p["tile_y"], p["tile_w"], p["tile_h"] = tile
+    p["mv_rdo"], p["ref_idx"], p["refs_before"] = mv_rdo, ref_idx, refs_before
     return p
+
+
+def me_params_from(raw):
+    """a stored parameter record (any earlier, shorter layout: the struct only ever grew at its end) -> ME_PARAMS"""
+    b = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    p = np.zeros(1, dtype=ME_PARAMS)
+    p.view(np.uint8).reshape(-1)[:len(b)] = b[:ME_PARAMS.itemsize]
+    if p["refs_before"][0] == 0:
+        p["refs_before"] = 1
+    return p
+
+
+def me_cabac_states(count, seed):
+    """random but valid CABAC snapshots: range in 256..510, context states 0..62 with either MPS"""
+    g = np.random.default_rng(seed)
+    c = np.zeros(count, dtype=ME_CABAC)
+    c["range"] = g.integers(256, 511, count)
+    c["ctx"] = (g.integers(0, 63, (count, 8)) << 1) | g.integers(0, 2, (count, 8))
+    c["ctx"][:, 7] = 0
+    return c
 
 
 def me_frames(w, h, seed, motion=(3, -2)):
@@ -336,7 +361,7 @@ def fronts_fixture(d, which):
     pus = np.ascontiguousarray(d[which + "_pus"]).view(ME_PU).reshape(-1)
     res = np.ascontiguousarray(d[which + "_results"]).view(ME_RESULT).reshape(-1)
     meta = d[which + "_meta"]
-    prm0 = np.ascontiguousarray(d[which + "_params"]).view(ME_PARAMS)
+    prm0 = me_params_from(d[which + "_params"])
     if which == "small":
         pics, refs = d["small_pic"], d["small_ref"]
     else:

@@ -442,7 +442,7 @@ def intra_build_reference(log2_width, x, y, pic_w, pic_h, rec_y, top_y, left_y, 
 
 
 # ---- motion search: the reference's static hexagon_search + search_frac (oracle/ref_me_harness.c) ----
-def search_pu_batch(pic, ref, pus, params):
+def search_pu_batch(pic, ref, pus, params, cabac=None):
     from patterns import ME_RESULT
     L = lib()
     L.ref_me_search_pu.restype = None
@@ -450,7 +450,10 @@ def search_pu_batch(pic, ref, pus, params):
     pic, ref = _u8(pic), _u8(ref)
     assert pic.shape == ref.shape
     pus = np.ascontiguousarray(pus)
-    params = np.ascontiguousarray(params)
+    params = np.ascontiguousarray(params).copy()
+    if cabac is not None:                       # --mv-rdo: ME_CABAC snapshots; pus["reserved"] indexes them
+        cabac = np.ascontiguousarray(cabac)
+        params["cabac"] = cabac.ctypes.data
     out = np.zeros(len(pus), dtype=ME_RESULT)
     for i in range(len(pus)):
         L.ref_me_search_pu(_p(pic, u8p), _p(ref, u8p), pic.shape[1], pic.shape[0],

@@ -646,6 +646,35 @@ def test_search_pu_hint_leaves_no_result_unwritten(api):
         np.testing.assert_array_equal(r[small][f], want[f], err_msg=f)
 
 
+MV_RDO_CONFIGS = [
+    dict(mv_rdo=1), dict(mv_rdo=1, refs_before=3, ref_idx=2, lambda_cost=11), dict(mv_rdo=1, refs_before=2, ref_idx=0, algorithm=1, fme_level=2),
+    dict(mv_rdo=1, refs_before=4, ref_idx=1, algorithm=2, early_termination=0), dict(mv_rdo=1, fme_level=0, refs_before=2, ref_idx=1),
+    dict(mv_rdo=1, refs_before=5, ref_idx=4, mv_constraint=4, lambda_cost=40),
+]
+
+
+@pytest.mark.parametrize("cfg", range(len(MV_RDO_CONFIGS)))
+def test_search_pu_mv_rdo(api, cfg):
+    """--mv-rdo: kvz_calc_mvd_cost_cabac / kvz_get_mvd_coding_cost_cabac (rdo.c:883-1060) as the search's cost model, from per-PU
+    CABAC snapshots; every PU size (one workgroup per PU), SMP / AMP shapes included"""
+    from patterns import me_cabac_states
+    prm = me_params(**MV_RDO_CONFIGS[cfg])
+    for k, motion in enumerate(((3, -2), (-7, 5), (0, 0))):
+        pic, ref = me_frames(192, 128, 900 + k, motion)
+        pus = me_random_pus(192, 128, 60, 277 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1]),
+                            sizes=((8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (64, 32), (24, 32), (32, 8), (8, 4), (16, 12)))
+        pus["x"] = np.minimum(pus["x"], 192 - pus["width"]); pus["y"] = np.minimum(pus["y"], 128 - pus["height"])
+        cab = me_cabac_states(9, 15 + k + cfg)
+        pus["reserved"] = np.arange(len(pus)) % 9
+        got = api.search_pu_batch(pic, ref, pus, prm, cabac=cab).view(ME_RESULT).reshape(-1)
+        want = O.search_pu_batch(pic, ref, pus, prm, cabac=cab)
+        for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+            np.testing.assert_array_equal(got[f], want[f], err_msg="%s cfg %d motion %s" % (f, cfg, motion))
+    from kvazaar_amd._lib import KvzHipError
+    with pytest.raises(KvzHipError):
+        api.search_pu_batch(pic, ref, pus, prm)            # mv_rdo without the snapshots is refused
+
+
 def test_search_pu_flat_and_borders(api):
     """flat frames (every candidate ties: the reference's first-wins order decides) and vectors that leave the frame"""
     prm = me_params(lambda_cost=3, early_termination=0)

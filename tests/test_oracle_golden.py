@@ -165,14 +165,17 @@ def test_golden_sao():
 
 
 def test_golden_motion_search():
-    from patterns import ME_PARAMS, ME_PU, me_pus_in_tile
+    from patterns import ME_PARAMS, ME_PU, me_params_from, me_pus_in_tile
     d = gold("me.npz")
     pus = np.ascontiguousarray(d["pus"]).view(ME_PU).reshape(-1)
     n_cfg = sum(1 for k in d.files if k.startswith("params"))
-    assert n_cfg >= 10
+    assert n_cfg >= 12
+    from patterns import ME_CABAC
+    cab = np.ascontiguousarray(d["cabac"]).view(ME_CABAC).reshape(-1)
     for i in range(n_cfg):
-        prm = np.ascontiguousarray(d["params%d" % i]).view(ME_PARAMS)
-        got = O.search_pu_batch(d["pic"], d["ref"], me_pus_in_tile(pus, prm), prm).view(np.int32).reshape(len(pus), 8)
+        prm = me_params_from(d["params%d" % i])
+        kw = dict(cabac=cab) if int(prm["mv_rdo"][0]) else {}
+        got = O.search_pu_batch(d["pic"], d["ref"], me_pus_in_tile(pus, prm), prm, **kw).view(np.int32).reshape(len(pus), 8)
         np.testing.assert_array_equal(got[:, :7], d["results%d" % i][:, :7])
 
 

@@ -494,3 +494,42 @@ def test_recorded_encoder_searches_replay(opts):
             np.testing.assert_array_equal(b[fld], rec["results"][sel][fld], err_msg="oracle, %s" % fld)
         groups = front_groups(m[sel])
         assert sum(len(g_) for g_ in groups) == len(sel) and max(len(g_) for g_ in groups) <= 3      # <= LCUs on a wavefront of a 3 x 2 grid
+
+
+# ---- --mv-rdo: MV bits from the CABAC model (rdo.c:883-1060) ----
+MV_RDO_CONFIGS = [
+    dict(mv_rdo=1), dict(mv_rdo=1, refs_before=3, ref_idx=2, lambda_cost=11), dict(mv_rdo=1, refs_before=2, ref_idx=0, algorithm=1, fme_level=2),
+    dict(mv_rdo=1, refs_before=4, ref_idx=1, algorithm=2, early_termination=0), dict(mv_rdo=1, fme_level=0, refs_before=2, ref_idx=1),
+    dict(mv_rdo=1, refs_before=5, ref_idx=4, mv_constraint=4, lambda_cost=40),
+]
+
+
+def test_cabac_tables_are_the_references():
+    """the oracle restates ITU-T H.265 Tables 9-46 / 9-47 and the two derived ones; they must equal the reference's
+    kvz_g_auc_lpst_table, kvz_g_auc_next_state_mps / _lps and kvz_g_auc_renorm_table (cabac.c:28-75)"""
+    import ctypes as C
+    L, LO = R.lib(), O.lib()
+    L.ref_cabac_table.restype = C.c_int; L.ref_cabac_table.argtypes = [C.c_int, C.c_int]
+    LO.orc_cabac_table.restype = C.c_int; LO.orc_cabac_table.argtypes = [C.c_int, C.c_int]
+    for kind, n in ((0, 256), (1, 128), (2, 128), (3, 32)):
+        assert [L.ref_cabac_table(kind, i) for i in range(n)] == [LO.orc_cabac_table(kind, i) for i in range(n)], kind
+
+
+@pytest.mark.parametrize("cfg", range(len(MV_RDO_CONFIGS)))
+def test_search_pu_mv_rdo(cfg):
+    """the search with kvz_calc_mvd_cost_cabac as its cost function and kvz_get_mvd_coding_cost_cabac in select_mv_cand, from random
+    (valid) CABAC states: the oracle's bit counting must follow the reference's counting-mode encoder exactly"""
+    from patterns import me_cabac_states
+    prm = me_params(**MV_RDO_CONFIGS[cfg])
+    differs = 0
+    for k, motion in enumerate(((3, -2), (-7, 5), (0, 0))):
+        pic, ref = me_frames(192, 128, 900 + k, motion)
+        pus = me_random_pus(192, 128, 40, 77 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1]))
+        cab = me_cabac_states(7, 5 + k + cfg)
+        pus["reserved"] = np.arange(len(pus)) % 7
+        a, b = O.search_pu_batch(pic, ref, pus, prm, cabac=cab), R.search_pu_batch(pic, ref, pus, prm, cabac=cab)
+        for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+            np.testing.assert_array_equal(a[f], b[f], err_msg="%s cfg %d motion %s" % (f, cfg, motion))
+        est = dict(MV_RDO_CONFIGS[cfg]); est.pop("mv_rdo")
+        differs += int((O.search_pu_batch(pic, ref, pus, me_params(**est))["bitcost"] != a["bitcost"]).sum())
+    assert differs > 60          # the CABAC bit counts are not the exp-Golomb estimate

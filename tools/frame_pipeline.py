@@ -43,7 +43,7 @@ def build_stages(L, dev):
     keep += [cur, ref, pred]
     stages = {"me": [], "intra": [], "tu": [], "sao": []}      # "sao": the in-loop filter stage, deblocking + SAO statistics
 
-    me_prm = np.zeros(16, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
+    me_prm = np.zeros(22, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
     for n in (8, 16, 32, 64):
         xy = [(x, y) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)]
         pus = np.zeros((len(xy), 16), dtype=np.int32)
