@@ -33,7 +33,7 @@ static thread_local char g_err[512] = "";     // last error of the calling threa
 struct tune_entry { const char *key; std::atomic<int> value; };
 static tune_entry g_tune[] = { { "sad_wgs_per_cu", {-1} }, { "satd8_wgs_per_cu", {-1} }, { "dct32_wgs_per_cu", {-1} },
                                { "idct32_wgs_per_cu", {-1} }, { "dct_wgs_per_cu", {-1} }, { "qr32_wgs_per_cu", {-1} },
-                               { "qr_wgs_per_cu", {-1} }, { "dct16_wgs_per_cu", {-1} }, { "idct16_wgs_per_cu", {-1} }, { "idct16_use_mfma", {-1} },
+                               { "qr_wgs_per_cu", {-1} }, { "dct16_wgs_per_cu", {-1} }, { "idct16_wgs_per_cu", {-1} },
                                { "qr16_wgs_per_cu", {-1} }, { "qr4_lane_kernel", {-1} },
                                { "me_big_threads", {-1} }, { "sao_edge_fast", {-1} }, { "me_medium_threads", {-1} },
                                { "intra_rough_waves", {-1} }, { "pair_wave_kernel", {-1} }, { "qr4_wgs_per_cu", {-1} }, { "quant_wgs_per_cu", {-1} },

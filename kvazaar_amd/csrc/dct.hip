@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ 
 
 namespace kvzhip {
 int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipStream_t st);
-int launch_dct16_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipStream_t st);
+int launch_dct16_tile(bool inverse, const i16 *in, i16 *out, size_t count, hipStream_t st);
 }
 
 // KVZ_HIP_DCT32_VALU=1 selects the VALU/LDS butterfly kernel for 32x32 and 16x16 (A/B comparison only)
@@ -106,7 +106,7 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
       switch (n) {
         case 4: return launch_transform<4, 0>(in, out, count, st);
         case 8: return launch_transform<8, 0>(in, out, count, st);
-        case 16: return dct32_use_valu() ? launch_transform<16, 0>(in, out, count, st) : launch_dct16_mfma(false, in, out, count, st);
+        case 16: return dct32_use_valu() ? launch_transform<16, 0>(in, out, count, st) : launch_dct16_tile(false, in, out, count, st);
         case 32: return dct32_use_valu() ? launch_transform<32, 0>(in, out, count, st) : launch_dct32_mfma(false, in, out, count, st);
       }
       break;
@@ -114,8 +114,8 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
       switch (n) {
         case 4: return launch_transform<4, 1>(in, out, count, st);
         case 8: return launch_transform<8, 1>(in, out, count, st);
-        // measured: the MFMA inverse (6 MFMA + transposition per pair) is ~4 % slower than the butterflies at 16x16
-        case 16: return tuning("idct16_use_mfma", 0) ? launch_dct16_mfma(true, in, out, count, st) : launch_transform<16, 1>(in, out, count, st);
+        // four blocks per MFMA tile: 6.1-6.2 TB/s against 5.2 for the butterflies and less for the earlier two-blocks-per-tile MFMA kernel
+        case 16: return dct32_use_valu() ? launch_transform<16, 1>(in, out, count, st) : launch_dct16_tile(true, in, out, count, st);
         case 32: return dct32_use_valu() ? launch_transform<32, 1>(in, out, count, st) : launch_dct32_mfma(true, in, out, count, st);
       }
       break;

@@ -33,15 +33,22 @@
 
 using namespace kvzhip;
 
-template <bool INVERSE>
+// N = 32: one block per tile.  N = 16: FOUR blocks per tile, arranged 2 x 2, with the block-diagonal coefficient matrix
+// diag(M16, M16) (dct32_mfma_core.h): the same instruction stream, every lane and accumulator register live -- the round-1
+// two-blocks-per-tile 16x16 kernel left half of K dead (5.7 TB/s forward) and its inverse lost to the VALU butterflies (5.2).
+// `count` is in blocks; a tile's chunks are permuted between memory order and tile order on the way through LDS.
+template <int N, bool INVERSE>
 __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
 {
+  constexpr int LOG2N = N == 32 ? 5 : 4;
+  constexpr int BPT = N == 32 ? 1 : 4;                 // blocks per tile
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+  const size_t ntiles = (count + BPT - 1) / BPT;
   // constant operands: one precomputed record per lane (dct32_mfma_core.h)
   op16 t_nat, t_kap, t_col, t_id;
-  const dct32_lane_consts &lc = c_dct32_lanes.l[lane];
+  const dct32_lane_consts &lc = N == 32 ? c_dct32_lanes.l[lane] : c_dct16x4_lanes.l[lane];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { t_nat.w[q] = lc.t_nat[q]; t_kap.w[q] = lc.t_kap[q]; t_col.w[q] = lc.t_col[q]; t_id.w[q] = lc.t_id[q]; }
   const int rowsum = lc.rowsum, colsum = lc.colsum;
@@ -52,25 +59,58 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
   // (lane half, register): a 2 x 16 table in LDS, read back as broadcasts, instead of 16 live registers
   __shared__ __attribute__((aligned(16))) int s_c2[2][16];
   if (INVERSE) {
-    fill_inv_c2(s_c2);
+    if (N == 32) fill_inv_c2(s_c2); else fill_inv_c2_16x4(s_c2);
     __syncthreads();
   }
+  // this lane's two linear chunks of a tile (l, 64 + l) and where they sit in the tile; 16x16: which block they belong to
+  const int mc0 = lane, mc1 = 64 + lane;
+  const int tc0 = N == 32 ? mc0 : tile_chunk16(mc0), tc1 = N == 32 ? mc1 : tile_chunk16(mc1);
+  auto load = [&](size_t t, u32x4v (&c)[2]) {
+    if (N == 32) { load_chunks(in + t * 1024, lane, c); return; }
+    const u32x4v z = { 0u, 0u, 0u, 0u };
+    c[0] = t * 4 + (size_t)(mc0 >> 5) < count ? __builtin_nontemporal_load((const u32x4v *)(in + t * 1024) + mc0) : z;   // a tile past the last
+    c[1] = t * 4 + (size_t)(mc1 >> 5) < count ? __builtin_nontemporal_load((const u32x4v *)(in + t * 1024) + mc1) : z;   // block is padded with zeros
+  };
 
   size_t t = wave;
   u32x4v cur[2], nx1[2], nx2[2];
-  if (t < count) load_chunks(in + t * 1024, lane, cur);
-  if (t + nwaves < count) load_chunks(in + (t + nwaves) * 1024, lane, nx1);
-  for (; t < count; t += nwaves) {
+  if (t < ntiles) load(t, cur);
+  if (t + nwaves < ntiles) load(t + nwaves, nx1);
+  for (; t < ntiles; t += nwaves) {
     const size_t tn = t + 2 * nwaves;
-    if (tn < count) load_chunks(in + tn * 1024, lane, nx2);      // keep two of the wave's next blocks in flight
+    if (tn < ntiles) load(tn, nx2);                    // keep two of the wave's next tiles in flight
     u32 d[8];
-    chunks_to_rows(tile, lane, r, h, cur, d);
+    if (N == 32) chunks_to_rows(tile, lane, r, h, cur, d);
+    else {
+      *(u32x4v *)(tile + slot_of(tc0) * 16) = cur[0];
+      *(u32x4v *)(tile + slot_of(tc1) * 16) = cur[1];
+      wave_lds_fence();
+      const u32x4v a = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h) * 16);
+      const u32x4v b = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h + 1) * 16);
+      wave_lds_fence();
+      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    }
     op16 hi, lo;
     planes_from_rows(d, hi, lo);
     int o[16];
-    if (!INVERSE) fwd32_core(hi, lo, t_nat, t_kap, rowsum, o);
+    if (!INVERSE) fwd32_core<LOG2N>(hi, lo, t_nat, t_kap, rowsum, o);
     else inv32_core(hi, lo, t_id, t_col, colsum, s_c2[h], o);
-    rows_to_chunks_store(tile, lane, r, h, o, out + t * 1024);
+    if (N == 32) rows_to_chunks_store(tile, lane, r, h, o, out + t * 1024);
+    else {
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg) {
+        uint2 v;
+        v.x = __builtin_amdgcn_perm((u32)o[4 * gg + 1], (u32)o[4 * gg], 0x05040100u);
+        v.y = __builtin_amdgcn_perm((u32)o[4 * gg + 3], (u32)o[4 * gg + 2], 0x05040100u);
+        *(uint2 *)(tile + slot_of(4 * r + gg) * 16 + 8 * h) = v;
+      }
+      wave_lds_fence();
+      const u32x4v a = *(const u32x4v *)(tile + slot_of(tc0) * 16);
+      const u32x4v b = *(const u32x4v *)(tile + slot_of(tc1) * 16);
+      wave_lds_fence();
+      if (t * 4 + (size_t)(mc0 >> 5) < count) __builtin_nontemporal_store(a, (u32x4v *)(out + t * 1024) + mc0);
+      if (t * 4 + (size_t)(mc1 >> 5) < count) __builtin_nontemporal_store(b, (u32x4v *)(out + t * 1024) + mc1);
+    }
     cur[0] = nx1[0]; cur[1] = nx1[1]; nx1[0] = nx2[0]; nx1[1] = nx2[1];
   }
 }
@@ -88,9 +128,22 @@ int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipSt
   // per wave at this size); inverse 32: 5.83, 64: 6.07, 128: 6.17, 256: 5.29.
   const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 96) : tuning("dct32_wgs_per_cu", 192));
   if (wgs > cap) wgs = cap;
-  if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
-  else hipLaunchKernelGGL((dct32_mfma_kernel<false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
+  if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<32, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
+  else hipLaunchKernelGGL((dct32_mfma_kernel<32, false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   KVZ_CHECK_LAUNCH("dct32_mfma_kernel");
+  return KVZ_HIP_OK;
+}
+// 16x16 blocks, four per tile
+int launch_dct16_tile(bool inverse, const i16 *in, i16 *out, size_t count, hipStream_t st)
+{
+  const size_t ntiles = (count + 3) / 4;
+  size_t wgs = (ntiles + 3) / 4;
+  // workgroups per CU (0.5 GiB arrays): forward 64: 6.43, 96: 6.50, 128: 6.52, 192: 6.42, 256: 6.34 TB/s; inverse 32: 6.16, 64: 6.17, 96: 5.98, 128: 5.81
+  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct16_wgs_per_cu", 64) : tuning("dct16_wgs_per_cu", 128));
+  if (wgs > cap) wgs = cap;
+  if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<16, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
+  else hipLaunchKernelGGL((dct32_mfma_kernel<16, false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
+  KVZ_CHECK_LAUNCH("dct32_mfma_kernel<16>");
   return KVZ_HIP_OK;
 }
 }  // namespace kvzhip

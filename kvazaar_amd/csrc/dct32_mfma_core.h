@@ -64,6 +64,35 @@ struct dct32_lane_table {
 };
 static __constant__ dct32_lane_table c_dct32_lanes = dct32_lane_table();
 
+// The same records for a 32x32 tile whose coefficient matrix is block diagonal, diag(M16, M16): FOUR 16x16 blocks arranged
+// 2 x 2 transform independently with the instruction stream of one 32x32 block, every lane and accumulator register live.
+__host__ __device__ constexpr int tile_mx16(int a, int b) { return ((a >> 4) == (b >> 4)) ? dct_coef(16, a & 15, b & 15) : 0; }
+struct dct16x4_lane_table {
+  dct32_lane_consts l[64];
+  constexpr dct16x4_lane_table() : l()
+  {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int r = lane & 31, h = lane >> 5;
+      int rs = 0, cs = 0;
+      for (int n = 0; n < 32; ++n) { rs += tile_mx16(r, n); cs += tile_mx16(n, r); }
+      l[lane].rowsum = rs; l[lane].colsum = cs; l[lane].pad0 = 0; l[lane].pad1 = 0;
+      for (int q = 0; q < 4; ++q) {
+        u32 a = 0, b = 0, c = 0, d = 0, dk = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int e = 4 * q + k, kap = (e & 3) + 8 * (e >> 2) + 4 * h;
+          a |= ((u32)tile_mx16(r, 16 * h + e) & 255u) << (8 * k);
+          b |= ((u32)tile_mx16(r, kap) & 255u) << (8 * k);
+          c |= ((u32)tile_mx16(kap, r) & 255u) << (8 * k);
+          d |= (u32)(16 * h + e == r ? 1 : 0) << (8 * k);
+          dk |= (u32)(kap == r ? 1 : 0) << (8 * k);
+        }
+        l[lane].t_nat[q] = a; l[lane].t_kap[q] = b; l[lane].t_col[q] = c; l[lane].t_id[q] = d; l[lane].t_idk[q] = dk;
+      }
+    }
+  }
+};
+static __constant__ dct16x4_lane_table c_dct16x4_lanes = dct16x4_lane_table();
+
 // byte planes of 16 int16 held as 8 dwords (element pairs): hi = X >> 8, lo' = (X & 255) - 128
 __device__ __forceinline__ void planes_from_rows(const u32 (&d)[8], op16 &hi, op16 &lo)
 {
@@ -134,22 +163,24 @@ __device__ __forceinline__ void rows_to_chunks_store(u8 *tile, int lane, int r, 
 // forward 2-D core.  (hi, lo') = byte planes of the A operand (lane = row, 16 K elements in the order
 // table `tb1` uses: tb1 element e of lane (k, h) = M[k][column of element e]).  o[g] = out[r][kappa(h, g)]
 // before the (short) wrap.  dct-generic.c:458-511, :567-576: shifts 4 and 11.
+template <int LOG2N = 5>
 __device__ __forceinline__ void fwd32_core(const op16 &hi, const op16 &lo, const op16 &tb1, const op16 &t_kap, int rowsum, int (&o)[16])
 {
+  constexpr int S1 = LOG2N - 1, S2 = LOG2N + 6;          // dct-generic.c:567-576
   const i32x16 zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   // pass 1: T' = S * M^T  (A = S rows, B[n][k] = M[k][n]); D[j][k]: row j = kappa(h,g), col k = r
   const i32x16 ah = mfma_i8(hi, tb1, zero), al = mfma_i8(lo, tb1, zero);
-  const int c1 = 128 * rowsum + (1 << 3);
+  const int c1 = 128 * rowsum + (1 << (S1 - 1));
   int tt[16];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) tt[g] = ((ah[g] << 8) + al[g] + c1) >> 4;       // low 16 bits = (short) wrap
+  for (int g = 0; g < 16; ++g) tt[g] = ((ah[g] << 8) + al[g] + c1) >> S1;      // low 16 bits = (short) wrap
   // pass 2: D[k][x] = sum_j T'[j][k] * M[x][j] = out[x][k]  (A = T'^T from the accumulator, B[j][x] = M[x][j])
   op16 h2, l2;
   planes_from_regs(tt, h2, l2, 0x80808080u);
   const i32x16 bh = mfma_i8(h2, t_kap, zero), bl = mfma_i8(l2, t_kap, zero);
-  const int c2 = 128 * rowsum + (1 << 10);
+  const int c2 = 128 * rowsum + (1 << (S2 - 1));
 #pragma unroll
-  for (int g = 0; g < 16; ++g) o[g] = ((bh[g] << 8) + bl[g] + c2) >> 11;
+  for (int g = 0; g < 16; ++g) o[g] = ((bh[g] << 8) + bl[g] + c2) >> S2;
 }
 
 // inverse 2-D core.  (hi, lo') = byte planes of the input rows with K order matching the identity table
@@ -195,9 +226,34 @@ struct dct32_c2_table {
   }
 };
 static __constant__ dct32_c2_table c_dct32_c2 = dct32_c2_table();
+struct dct16x4_c2_table {
+  int v[32];
+  constexpr dct16x4_c2_table() : v()
+  {
+    for (int i = 0; i < 32; ++i) {
+      const int h = i >> 4, g = i & 15, row = (g & 3) + 8 * (g >> 2) + 4 * h;
+      int cs = 0;
+      for (int n = 0; n < 32; ++n) cs += tile_mx16(n, row);
+      v[i] = 128 * cs + (1 << 11);
+    }
+  }
+};
+static __constant__ dct16x4_c2_table c_dct16x4_c2 = dct16x4_c2_table();
 __device__ __forceinline__ void fill_inv_c2(int (*s_c2)[16])
 {
   if (threadIdx.x < 32) s_c2[threadIdx.x >> 4][threadIdx.x & 15] = c_dct32_c2.v[threadIdx.x];
+}
+__device__ __forceinline__ void fill_inv_c2_16x4(int (*s_c2)[16])
+{
+  if (threadIdx.x < 32) s_c2[threadIdx.x >> 4][threadIdx.x & 15] = c_dct16x4_c2.v[threadIdx.x];
+}
+
+// 16x16 blocks in a tile: the linear 16-byte chunk c of FOUR consecutive blocks (2 KiB; block c >> 5, row (c >> 1) & 15, half c & 1)
+// <-> the chunk of the 2 x 2 tile it occupies (block b at row half b & 1, column half b >> 1)
+__device__ __forceinline__ int tile_chunk16(int c)
+{
+  const int b = c >> 5, row = (c >> 1) & 15, half = c & 1;
+  return ((b & 1) * 16 + row) * 4 + (b >> 1) * 2 + half;
 }
 
 }  // namespace kvzhip

@@ -448,17 +448,17 @@ def test_ctu_sad_grid(api):
     assert (c[:, 0] == s8.sum(axis=(1, 2))).all()
 
 
-def test_transform_alternate_kernels(api):
-    """the non-default variants stay bit-exact: MFMA inverse 16x16 (default: butterflies)"""
+def test_transform_16x16_tile_tails(api):
+    """16x16 transforms run four blocks per matrix-core tile: every count modulo 4, extreme inputs, both directions; an unknown
+    tuning key is refused"""
     from kvazaar_amd import _lib
     L = _lib.load()
     g = rng(21)
-    x = g.integers(-32768, 32768, (131, 256)).astype(np.int16)
-    try:
-        _lib.check(L.kvz_hip_set_tuning(b"idct16_use_mfma", 1), "set_tuning")
-        np.testing.assert_array_equal(api.transform_batch("idct", 16, x), O.transform_batch("idct", 16, x))
-    finally:
-        L.kvz_hip_set_tuning(b"idct16_use_mfma", -1)
+    for count in (1, 2, 3, 4, 5, 6, 7, 131):
+        x = g.integers(-32768, 32768, (count, 256)).astype(np.int16)
+        x[0, :] = 32767 if count % 2 else -32768
+        for kind in ("dct", "idct"):
+            np.testing.assert_array_equal(api.transform_batch(kind, 16, x), O.transform_batch(kind, 16, x), err_msg="%s count %d" % (kind, count))
     assert L.kvz_hip_set_tuning(b"no_such_key", 1) != 0
 
 
