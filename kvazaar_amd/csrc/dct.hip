@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void transform_kernel(const i16 *__restrict__ 
 namespace kvzhip {
 int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipStream_t st);
 int launch_dct16_tile(bool inverse, const i16 *in, i16 *out, size_t count, hipStream_t st);
+int launch_dct4_tile(bool inverse, bool dst, const i16 *in, i16 *out, size_t count, hipStream_t st);
 }
 
 // KVZ_HIP_DCT32_VALU=1 selects the VALU/LDS butterfly kernel for 32x32 and 16x16 (A/B comparison only)
@@ -104,7 +105,7 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
   switch (kind) {
     case KVZ_HIP_DCT:
       switch (n) {
-        case 4: return launch_transform<4, 0>(in, out, count, st);
+        case 4: return tuning("dct4_tile", 1) ? launch_dct4_tile(false, false, in, out, count, st) : launch_transform<4, 0>(in, out, count, st);
         case 8: return launch_transform<8, 0>(in, out, count, st);
         case 16: return dct32_use_valu() ? launch_transform<16, 0>(in, out, count, st) : launch_dct16_tile(false, in, out, count, st);
         case 32: return dct32_use_valu() ? launch_transform<32, 0>(in, out, count, st) : launch_dct32_mfma(false, in, out, count, st);
@@ -112,7 +113,7 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
       break;
     case KVZ_HIP_IDCT:
       switch (n) {
-        case 4: return launch_transform<4, 1>(in, out, count, st);
+        case 4: return tuning("dct4_tile", 1) ? launch_dct4_tile(true, false, in, out, count, st) : launch_transform<4, 1>(in, out, count, st);
         case 8: return launch_transform<8, 1>(in, out, count, st);
         // four blocks per MFMA tile: 6.1-6.2 TB/s against 5.2 for the butterflies and less for the earlier two-blocks-per-tile MFMA kernel
         case 16: return dct32_use_valu() ? launch_transform<16, 1>(in, out, count, st) : launch_dct16_tile(true, in, out, count, st);
@@ -120,10 +121,10 @@ extern "C" int kvz_hip_transform_batch(int kind, int n, const int16_t *in, int16
       }
       break;
     case KVZ_HIP_DST:
-      if (n == 4) return launch_transform<4, 2>(in, out, count, st);
+      if (n == 4) return tuning("dct4_tile", 1) ? launch_dct4_tile(false, true, in, out, count, st) : launch_transform<4, 2>(in, out, count, st);
       break;
     case KVZ_HIP_IDST:
-      if (n == 4) return launch_transform<4, 3>(in, out, count, st);
+      if (n == 4) return tuning("dct4_tile", 1) ? launch_dct4_tile(true, true, in, out, count, st) : launch_transform<4, 3>(in, out, count, st);
       break;
     case KVZ_HIP_TRSKIP:
     case KVZ_HIP_ITRSKIP:

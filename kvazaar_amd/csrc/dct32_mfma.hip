@@ -37,18 +37,19 @@ using namespace kvzhip;
 // diag(M16, M16) (dct32_mfma_core.h): the same instruction stream, every lane and accumulator register live -- the round-1
 // two-blocks-per-tile 16x16 kernel left half of K dead (5.7 TB/s forward) and its inverse lost to the VALU butterflies (5.2).
 // `count` is in blocks; a tile's chunks are permuted between memory order and tile order on the way through LDS.
-template <int N, bool INVERSE>
+template <int N, bool INVERSE, bool DST = false>
 __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
 {
-  constexpr int LOG2N = N == 32 ? 5 : 4;
-  constexpr int BPT = N == 32 ? 1 : 4;                 // blocks per tile
+  constexpr int LOG2N = N == 32 ? 5 : N == 16 ? 4 : 2;
+  constexpr int BPT = (32 / N) * (32 / N);             // blocks per tile: 1, 4 or 64 (4x4, DCT or DST)
+  constexpr int CPB = N * N / 8;                       // 16-byte chunks per block: 128, 32 or 2
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
   const size_t ntiles = (count + BPT - 1) / BPT;
   // constant operands: one precomputed record per lane (dct32_mfma_core.h)
   op16 t_nat, t_kap, t_col, t_id;
-  const dct32_lane_consts &lc = N == 32 ? c_dct32_lanes.l[lane] : c_dct16x4_lanes.l[lane];
+  const dct32_lane_consts &lc = tile_lane_consts<N, DST>(lane);
 #pragma unroll
   for (int q = 0; q < 4; ++q) { t_nat.w[q] = lc.t_nat[q]; t_kap.w[q] = lc.t_kap[q]; t_col.w[q] = lc.t_col[q]; t_id.w[q] = lc.t_id[q]; }
   const int rowsum = lc.rowsum, colsum = lc.colsum;
@@ -59,17 +60,17 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
   // (lane half, register): a 2 x 16 table in LDS, read back as broadcasts, instead of 16 live registers
   __shared__ __attribute__((aligned(16))) int s_c2[2][16];
   if (INVERSE) {
-    if (N == 32) fill_inv_c2(s_c2); else fill_inv_c2_16x4(s_c2);
+    if (N == 32) fill_inv_c2(s_c2); else fill_inv_c2_tile<N, DST>(s_c2);
     __syncthreads();
   }
   // this lane's two linear chunks of a tile (l, 64 + l) and where they sit in the tile; 16x16: which block they belong to
   const int mc0 = lane, mc1 = 64 + lane;
-  const int tc0 = N == 32 ? mc0 : tile_chunk16(mc0), tc1 = N == 32 ? mc1 : tile_chunk16(mc1);
+  const int tc0 = N == 16 ? tile_chunk16(mc0) : mc0, tc1 = N == 16 ? tile_chunk16(mc1) : mc1;
   auto load = [&](size_t t, u32x4v (&c)[2]) {
     if (N == 32) { load_chunks(in + t * 1024, lane, c); return; }
     const u32x4v z = { 0u, 0u, 0u, 0u };
-    c[0] = t * 4 + (size_t)(mc0 >> 5) < count ? __builtin_nontemporal_load((const u32x4v *)(in + t * 1024) + mc0) : z;   // a tile past the last
-    c[1] = t * 4 + (size_t)(mc1 >> 5) < count ? __builtin_nontemporal_load((const u32x4v *)(in + t * 1024) + mc1) : z;   // block is padded with zeros
+    c[0] = t * BPT + (size_t)(mc0 / CPB) < count ? __builtin_nontemporal_load((const u32x4v *)(in + t * 1024) + mc0) : z;   // a tile past the last
+    c[1] = t * BPT + (size_t)(mc1 / CPB) < count ? __builtin_nontemporal_load((const u32x4v *)(in + t * 1024) + mc1) : z;   // block is padded with zeros
   };
 
   size_t t = wave;
@@ -82,8 +83,15 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
     u32 d[8];
     if (N == 32) chunks_to_rows(tile, lane, r, h, cur, d);
     else {
-      *(u32x4v *)(tile + slot_of(tc0) * 16) = cur[0];
-      *(u32x4v *)(tile + slot_of(tc1) * 16) = cur[1];
+      if (N == 16) {
+        *(u32x4v *)(tile + slot_of(tc0) * 16) = cur[0];
+        *(u32x4v *)(tile + slot_of(tc1) * 16) = cur[1];
+      } else {                                         // 4x4: a chunk is two rows of a block = two 8-byte pieces of the tile
+        *(uint2 *)(tile + tile_piece4(mc0, 0)) = make_uint2(cur[0].x, cur[0].y);
+        *(uint2 *)(tile + tile_piece4(mc0, 1)) = make_uint2(cur[0].z, cur[0].w);
+        *(uint2 *)(tile + tile_piece4(mc1, 0)) = make_uint2(cur[1].x, cur[1].y);
+        *(uint2 *)(tile + tile_piece4(mc1, 1)) = make_uint2(cur[1].z, cur[1].w);
+      }
       wave_lds_fence();
       const u32x4v a = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h) * 16);
       const u32x4v b = *(const u32x4v *)(tile + slot_of(4 * r + 2 * h + 1) * 16);
@@ -105,11 +113,18 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
         *(uint2 *)(tile + slot_of(4 * r + gg) * 16 + 8 * h) = v;
       }
       wave_lds_fence();
-      const u32x4v a = *(const u32x4v *)(tile + slot_of(tc0) * 16);
-      const u32x4v b = *(const u32x4v *)(tile + slot_of(tc1) * 16);
+      u32x4v a, b;
+      if (N == 16) {
+        a = *(const u32x4v *)(tile + slot_of(tc0) * 16);
+        b = *(const u32x4v *)(tile + slot_of(tc1) * 16);
+      } else {
+        const uint2 a0 = *(const uint2 *)(tile + tile_piece4(mc0, 0)), a1 = *(const uint2 *)(tile + tile_piece4(mc0, 1));
+        const uint2 b0 = *(const uint2 *)(tile + tile_piece4(mc1, 0)), b1 = *(const uint2 *)(tile + tile_piece4(mc1, 1));
+        a.x = a0.x; a.y = a0.y; a.z = a1.x; a.w = a1.y; b.x = b0.x; b.y = b0.y; b.z = b1.x; b.w = b1.y;
+      }
       wave_lds_fence();
-      if (t * 4 + (size_t)(mc0 >> 5) < count) __builtin_nontemporal_store(a, (u32x4v *)(out + t * 1024) + mc0);
-      if (t * 4 + (size_t)(mc1 >> 5) < count) __builtin_nontemporal_store(b, (u32x4v *)(out + t * 1024) + mc1);
+      if (t * BPT + (size_t)(mc0 / CPB) < count) __builtin_nontemporal_store(a, (u32x4v *)(out + t * 1024) + mc0);
+      if (t * BPT + (size_t)(mc1 / CPB) < count) __builtin_nontemporal_store(b, (u32x4v *)(out + t * 1024) + mc1);
     }
     cur[0] = nx1[0]; cur[1] = nx1[1]; nx1[0] = nx2[0]; nx1[1] = nx2[1];
   }
@@ -131,6 +146,26 @@ int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipSt
   if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<32, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   else hipLaunchKernelGGL((dct32_mfma_kernel<32, false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   KVZ_CHECK_LAUNCH("dct32_mfma_kernel");
+  return KVZ_HIP_OK;
+}
+// 4x4 blocks (DCT or the DST-VII of intra luma), sixty-four per tile
+int launch_dct4_tile(bool inverse, bool dst, const i16 *in, i16 *out, size_t count, hipStream_t st)
+{
+  const size_t ntiles = (count + 63) / 64;
+  size_t wgs = (ntiles + 3) / 4;
+  // workgroups per CU (0.5 GiB arrays): forward 64: 6.20, 128: 6.37, 192: 6.42, 256: 6.29 TB/s; inverse 32: 5.89, 64: 6.18, 96: 6.05, 128: 5.80
+  // (the LDS butterfly kernel these replace: 5.4 / 5.55)
+  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct4_wgs_per_cu", 64) : tuning("dct4_wgs_per_cu", 192));
+  if (wgs > cap) wgs = cap;
+  const dim3 g((unsigned)wgs), b(256);
+  if (dst) {
+    if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<4, true, true>), g, b, 0, st, in, out, count);
+    else hipLaunchKernelGGL((dct32_mfma_kernel<4, false, true>), g, b, 0, st, in, out, count);
+  } else {
+    if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<4, true, false>), g, b, 0, st, in, out, count);
+    else hipLaunchKernelGGL((dct32_mfma_kernel<4, false, false>), g, b, 0, st, in, out, count);
+  }
+  KVZ_CHECK_LAUNCH("dct32_mfma_kernel<4>");
   return KVZ_HIP_OK;
 }
 // 16x16 blocks, four per tile

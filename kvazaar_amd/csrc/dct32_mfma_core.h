@@ -64,25 +64,32 @@ struct dct32_lane_table {
 };
 static __constant__ dct32_lane_table c_dct32_lanes = dct32_lane_table();
 
-// The same records for a 32x32 tile whose coefficient matrix is block diagonal, diag(M16, M16): FOUR 16x16 blocks arranged
-// 2 x 2 transform independently with the instruction stream of one 32x32 block, every lane and accumulator register live.
-__host__ __device__ constexpr int tile_mx16(int a, int b) { return ((a >> 4) == (b >> 4)) ? dct_coef(16, a & 15, b & 15) : 0; }
-struct dct16x4_lane_table {
+// The same records for a 32x32 tile whose coefficient matrix is block diagonal, diag(M_N, ..., M_N): (32 / N)^2 N x N blocks
+// arranged as a grid transform independently with the instruction stream of one 32x32 block, every lane and accumulator
+// register live.  N = 16 (four blocks), N = 4 (sixty-four; DST: the 4x4 DST-VII matrix instead of the DCT's).
+template <int N, bool DST>
+__host__ __device__ constexpr int tile_mx(int a, int b)
+{
+  return (a / N == b / N) ? (DST ? dst_coef(a % N, b % N) : dct_coef(N, a % N, b % N)) : 0;
+}
+__host__ __device__ constexpr int tile_mx16(int a, int b) { return tile_mx<16, false>(a, b); }
+template <int N, bool DST>
+struct tile_lane_table {
   dct32_lane_consts l[64];
-  constexpr dct16x4_lane_table() : l()
+  constexpr tile_lane_table() : l()
   {
     for (int lane = 0; lane < 64; ++lane) {
       const int r = lane & 31, h = lane >> 5;
       int rs = 0, cs = 0;
-      for (int n = 0; n < 32; ++n) { rs += tile_mx16(r, n); cs += tile_mx16(n, r); }
+      for (int n = 0; n < 32; ++n) { rs += tile_mx<N, DST>(r, n); cs += tile_mx<N, DST>(n, r); }
       l[lane].rowsum = rs; l[lane].colsum = cs; l[lane].pad0 = 0; l[lane].pad1 = 0;
       for (int q = 0; q < 4; ++q) {
         u32 a = 0, b = 0, c = 0, d = 0, dk = 0;
         for (int k = 0; k < 4; ++k) {
           const int e = 4 * q + k, kap = (e & 3) + 8 * (e >> 2) + 4 * h;
-          a |= ((u32)tile_mx16(r, 16 * h + e) & 255u) << (8 * k);
-          b |= ((u32)tile_mx16(r, kap) & 255u) << (8 * k);
-          c |= ((u32)tile_mx16(kap, r) & 255u) << (8 * k);
+          a |= ((u32)tile_mx<N, DST>(r, 16 * h + e) & 255u) << (8 * k);
+          b |= ((u32)tile_mx<N, DST>(r, kap) & 255u) << (8 * k);
+          c |= ((u32)tile_mx<N, DST>(kap, r) & 255u) << (8 * k);
           d |= (u32)(16 * h + e == r ? 1 : 0) << (8 * k);
           dk |= (u32)(kap == r ? 1 : 0) << (8 * k);
         }
@@ -91,7 +98,9 @@ struct dct16x4_lane_table {
     }
   }
 };
-static __constant__ dct16x4_lane_table c_dct16x4_lanes = dct16x4_lane_table();
+static __constant__ tile_lane_table<16, false> c_dct16x4_lanes = tile_lane_table<16, false>();
+static __constant__ tile_lane_table<4, false> c_dct4x64_lanes = tile_lane_table<4, false>();
+static __constant__ tile_lane_table<4, true> c_dst4x64_lanes = tile_lane_table<4, true>();
 
 // byte planes of 16 int16 held as 8 dwords (element pairs): hi = X >> 8, lo' = (X & 255) - 128
 __device__ __forceinline__ void planes_from_rows(const u32 (&d)[8], op16 &hi, op16 &lo)
@@ -226,26 +235,38 @@ struct dct32_c2_table {
   }
 };
 static __constant__ dct32_c2_table c_dct32_c2 = dct32_c2_table();
-struct dct16x4_c2_table {
+template <int N, bool DST>
+struct tile_c2_table {
   int v[32];
-  constexpr dct16x4_c2_table() : v()
+  constexpr tile_c2_table() : v()
   {
     for (int i = 0; i < 32; ++i) {
       const int h = i >> 4, g = i & 15, row = (g & 3) + 8 * (g >> 2) + 4 * h;
       int cs = 0;
-      for (int n = 0; n < 32; ++n) cs += tile_mx16(n, row);
+      for (int n = 0; n < 32; ++n) cs += tile_mx<N, DST>(n, row);
       v[i] = 128 * cs + (1 << 11);
     }
   }
 };
-static __constant__ dct16x4_c2_table c_dct16x4_c2 = dct16x4_c2_table();
+static __constant__ tile_c2_table<16, false> c_dct16x4_c2 = tile_c2_table<16, false>();
+static __constant__ tile_c2_table<4, false> c_dct4x64_c2 = tile_c2_table<4, false>();
+static __constant__ tile_c2_table<4, true> c_dst4x64_c2 = tile_c2_table<4, true>();
 __device__ __forceinline__ void fill_inv_c2(int (*s_c2)[16])
 {
   if (threadIdx.x < 32) s_c2[threadIdx.x >> 4][threadIdx.x & 15] = c_dct32_c2.v[threadIdx.x];
 }
-__device__ __forceinline__ void fill_inv_c2_16x4(int (*s_c2)[16])
+template <int N, bool DST>
+__device__ __forceinline__ void fill_inv_c2_tile(int (*s_c2)[16])
 {
-  if (threadIdx.x < 32) s_c2[threadIdx.x >> 4][threadIdx.x & 15] = c_dct16x4_c2.v[threadIdx.x];
+  if (threadIdx.x < 32)
+    s_c2[threadIdx.x >> 4][threadIdx.x & 15] = N == 16 ? c_dct16x4_c2.v[threadIdx.x] : (DST ? c_dst4x64_c2.v[threadIdx.x] : c_dct4x64_c2.v[threadIdx.x]);
+}
+template <int N, bool DST>
+__device__ __forceinline__ const dct32_lane_consts &tile_lane_consts(int lane)
+{
+  if (N == 32) return c_dct32_lanes.l[lane];
+  if (N == 16) return c_dct16x4_lanes.l[lane];
+  return DST ? c_dst4x64_lanes.l[lane] : c_dct4x64_lanes.l[lane];
 }
 
 // 16x16 blocks in a tile: the linear 16-byte chunk c of FOUR consecutive blocks (2 KiB; block c >> 5, row (c >> 1) & 15, half c & 1)
@@ -254,6 +275,14 @@ __device__ __forceinline__ int tile_chunk16(int c)
 {
   const int b = c >> 5, row = (c >> 1) & 15, half = c & 1;
   return ((b & 1) * 16 + row) * 4 + (b >> 1) * 2 + half;
+}
+// 4x4 blocks in a tile: the linear chunk c of SIXTY-FOUR consecutive blocks (2 KiB) is rows 2p, 2p + 1 (p = c & 1) of block
+// c >> 1, two 8-byte pieces of the tile: block b sits at block row b >> 3, block column b & 7.  Byte address of the FIRST piece
+// (tile row 4 (b >> 3) + 2p, columns 4 (b & 7) ..) in the swizzled LDS tile; the second piece is the next tile row.
+__device__ __forceinline__ int tile_piece4(int c, int second)
+{
+  const int b = c >> 1, row = 4 * (b >> 3) + 2 * (c & 1) + second, bx = b & 7;
+  return slot_of(4 * row + (bx >> 1)) * 16 + (bx & 1) * 8;
 }
 
 }  // namespace kvzhip
