@@ -1,6 +1,9 @@
 #!/bin/bash
 # End-of-work profile set of one build, written under gpurun_out/TAG_* (copy what is to be judged into profiles/):
-#   1. bench.py (all legs) under rocprofv3 --kernel-trace --stats: TAG_bench_profiled.json + TAG_kernel_stats.csv
+#   0. bench.py as the driver runs it (no profiler): TAG_bench.json
+#   1. bench.py --no-shard-leg under rocprofv3 --kernel-trace --stats: TAG_bench_profiled.json + TAG_kernel_stats.csv (the headline
+#      leg alone, so that a kernel's average in the CSV is the average of the launches the bench line's roofline describes;
+#      with the shard_4k leg the same kernels also run on the four times larger 4K batch: TAG_kernel_stats_all_legs.csv)
 #   2. bench.py headline leg under --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -> TAG_pmc_traffic.json
 #   3. the fused quantize_residual kernels under the SQ / TCC counter groups -> TAG_qr_pmc.txt
 #   4. the frame-level sampling / SATD kernels under the same groups -> TAG_frame_kernels_pmc.txt
@@ -12,9 +15,13 @@ COMMIT=${2:-unknown}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O/${TAG}_prof
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats -o p --output-format csv -- python3 bench.py --steps 50 --warmup 5 > $O/${TAG}_bench_profiled.json 2> $O/${TAG}_prof/stats.log
+python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_prof/bench.log
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats -o p --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-shard-leg > $O/${TAG}_bench_profiled.json 2> $O/${TAG}_prof/stats.log
 cp $O/${TAG}_prof/stats/p_kernel_stats.csv $O/${TAG}_kernel_stats.csv
 rm -rf $O/${TAG}_prof/stats
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats2 -o p --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_profiled_all_legs.json 2> $O/${TAG}_prof/stats2.log
+cp $O/${TAG}_prof/stats2/p_kernel_stats.csv $O/${TAG}_kernel_stats_all_legs.csv
+rm -rf $O/${TAG}_prof/stats2
 B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-shard-leg"
 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_prof/fetch -o p --output-format csv -- $B > $O/${TAG}_prof/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_prof/write -o p --output-format csv -- $B > $O/${TAG}_prof/write.log 2>&1
