@@ -84,7 +84,7 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
 /* Launch-geometry / kernel-selection knobs for A/B runs (tools/bench_all.py --tune key=v1,v2);
  * value < 0 restores the built-in default.  Keys: "{sad,satd8,dct,dct16,idct16,dct32,idct32,qr,qr16,
  * qr32}_wgs_per_cu" (workgroups per CU of the streaming grids),
- * "qr4_lane_kernel", "qr8_reg_kernel", "qr_tile_kernel" (0: the LDS butterfly kernel instead of the register / matrix-core ones), "dct4_tile" (0: the LDS butterfly kernel for 4x4 transforms), "sao_edge_fast" (0/1), "me_big_threads" (256/512/1024 threads per PU larger than 32x32), "me_medium_threads" (64/128/256 per PU up to 32x32),
+ * "qr4_lane_kernel", "qr8_reg_kernel", "qr_tile_kernel" (0: the LDS butterfly kernel instead of the register / matrix-core ones), "dct4_tile" (0: the LDS butterfly kernel for 4x4 transforms), "sao_edge_fast" (0/1),
  * "intra_rough_waves" (4/8 waves per workgroup of the rough search), "pair_wave_kernel" (0/1: one wave per
  * descriptor for frame-level pair batches of up to 4096 descriptors).
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets

@@ -35,7 +35,7 @@ static tune_entry g_tune[] = { { "sad_wgs_per_cu", {-1} }, { "satd8_wgs_per_cu",
                                { "idct32_wgs_per_cu", {-1} }, { "dct_wgs_per_cu", {-1} }, { "qr32_wgs_per_cu", {-1} },
                                { "qr_wgs_per_cu", {-1} }, { "dct16_wgs_per_cu", {-1} }, { "idct16_wgs_per_cu", {-1} },
                                { "qr16_wgs_per_cu", {-1} }, { "qr4_lane_kernel", {-1} },
-                               { "me_big_threads", {-1} }, { "sao_edge_fast", {-1} }, { "me_medium_threads", {-1} },
+                               { "sao_edge_fast", {-1} }, 
                                { "intra_rough_waves", {-1} }, { "pair_wave_kernel", {-1} }, { "qr4_wgs_per_cu", {-1} }, { "quant_wgs_per_cu", {-1} },
                                { "qr8_reg_kernel", {-1} }, { "qr8_wgs_per_cu", {-1} }, { "qr_tile_kernel", {-1} }, { "dct4_tile", {-1} }, { "dct4_wgs_per_cu", {-1} }, { "idct4_wgs_per_cu", {-1} } };
 int tuning(const char *key, int dflt)

@@ -83,7 +83,9 @@ struct cabac_model {
   }
 };
 
-template <bool RDO>
+// RDO: --mv-rdo cost model.  CONSTR: some fracmv_within_tile rule is active (WPP / OWF availability or an mv_constraint); the
+// common unconstrained search is compiled without the rule and its scalar state (the kernels sit at the edge of their SGPR budget).
+template <bool RDO, bool CONSTR = true>
 struct me_cost_model_t {
   int px, py, pw, ph;
   int cand[2][2];
@@ -126,6 +128,7 @@ struct me_cost_model_t {
   // relative to the tile, and so are the LCU indices of the availability rule (C division: truncation toward zero).
   __device__ __forceinline__ bool within(int x, int y) const
   {
+    if (!CONSTR) return true;
     const bool frac_luma = x % 4 != 0 || y % 4 != 0, frac_chroma = x % 8 != 0 || y % 8 != 0;
     if (wpp_owf) {
       int margin = frac_luma ? 4 : (frac_chroma ? 2 : 0);
@@ -266,7 +269,7 @@ struct me_cost_model_t {
     return hit;
   }
 };
-typedef me_cost_model_t<false> me_cost_model;
+typedef me_cost_model_t<false, true> me_cost_model;
 
 __constant__ signed char c_large_hex[9][2] = { { 0, 0 }, { 1, -2 }, { 2, 0 }, { 1, 2 }, { -1, 2 }, { -2, 0 }, { -1, -2 }, { 1, -2 }, { 2, 0 } };
 __constant__ signed char c_small_hex[9][2] = { { 0, 0 }, { 0, -1 }, { -1, 0 }, { 1, 0 }, { 0, 1 }, { -1, -1 }, { 1, -1 }, { -1, 1 }, { 1, 1 } };
@@ -278,7 +281,7 @@ struct me_shared { u32 sad[ME_GROUP]; int cx[ME_GROUP], cy[ME_GROUP]; };
 
 // One PU.  T threads (a wave with wave-private LDS, or the whole workgroup) share the work; every thread
 // carries the same search state, so all decisions are uniform across them.
-template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0, bool RDO = false>
+template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0, bool RDO = false, bool CONSTR = true>
 __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, const u8 *__restrict__ pic, u32 pic_stride,
                                                const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm,
                                                kvz_hip_me_result *__restrict__ out)
@@ -286,7 +289,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   typedef frac_geom<MAXW> G;
   u8 *s_cur = lds + G::P_BYTES;                        // same place search_frac_core keeps the current block
   auto sync = [&]() { if (WAVE) wave_lds_fence(); else __syncthreads(); };
-  const me_cost_model_t<RDO> mvc(pu, prm);
+  const me_cost_model_t<RDO, CONSTR> mvc(pu, prm);
   const int w = FW ? FW : pu.width, h = FH ? FH : pu.height;                       // FW, FH: compile-time size (0 = runtime)
   // a row is cut into 8-pixel segments, or 4-pixel ones when the width is 4 or 12 (AMP / SMP shapes)
   const bool seg4 = !FW && (w & 4);
@@ -644,7 +647,7 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   if (best_cost != 0xffffffffu) {
     sync();
     const kvz_hip_block_pair d = { pu.x, pu.y, pu.x + best_x, pu.y + best_y, w, h };
-    const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model_t<RDO>, FW, FH>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
+    const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model_t<RDO, CONSTR>, FW, FH>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
     best_cost = fr.cost;                               // level 0: satd + bits(int mv) * lambda, the same bits as best_bits
     if (prm.fme_level > 0) { mv_x = fr.mvx; mv_y = fr.mvy; best_bits = fr.bitcost; }
   }
@@ -676,7 +679,7 @@ __device__ __forceinline__ void flag_bad(kvz_hip_me_result *out)
 }
 
 // PUs larger than 32x32 in either direction (and malformed descriptors, which are flagged): one workgroup (T threads) per PU
-template <int T>
+template <int T, bool CONSTR>
 __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                             const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
                                                             kvz_hip_me_result *__restrict__ out)
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__
   const kvz_hip_me_pu &pu = pus[blockIdx.x];            // uniform address: the compiler reads it with scalar loads
   if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   if (pu.width <= 32 && pu.height <= 32) return;       // the one-wave-per-PU kernels'
-  search_pu_core<64, T, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  search_pu_core<64, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
 
 // --mv-rdo (cfg.mv_rdo, off in every preset): MV bits from the CABAC model.  One workgroup per PU for every size -- a
@@ -705,6 +708,7 @@ __global__ __launch_bounds__(256) void search_pu_rdo_kernel(const u8 *__restrict
 
 // PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier.  The register budget is held at
 // 6 waves per SIMD (80 VGPRs): at 82 the kernel dropped to 5 and lost 8 % (measured A/B on one box).
+template <bool CONSTR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void search_pu_small_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                               const kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_me_params prm,
                                                               kvz_hip_me_result *__restrict__ out)
@@ -718,13 +722,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const int lane = threadIdx.x & 63;
   if (!pu_ok(pu, pic_w, pic_h)) { if (lane == 0) flag_bad(out + i); return; }
   if (pu.width > 16 || pu.height > 16) return;
-  if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
-  else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
-  else search_pu_core<16, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  else search_pu_core<16, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
 }
 
 // PUs up to 32x32 that are not the small kernel's: one wave per PU as well (two per workgroup: 15 KiB of LDS each).
 // With a workgroup per PU a 32x32 search spent its time in barriers around little work per thread (11 M PUs/s).
+template <bool CONSTR>
 __global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                                const kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_me_params prm,
                                                                kvz_hip_me_result *__restrict__ out)
@@ -738,13 +743,13 @@ __global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restr
   const int lane = threadIdx.x & 63;
   if (!pu_ok(pu, pic_w, pic_h)) { if (lane == 0) flag_bad(out + i); return; }
   if (pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
-  if (pu.width == 32 && pu.height == 32) search_pu_core<32, 64, true, 32, 32>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
-  else search_pu_core<32, 64, true>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  if (pu.width == 32 && pu.height == 32) search_pu_core<32, 64, true, 32, 32, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  else search_pu_core<32, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
 }
 
 // The same class with one workgroup of T threads per PU: lower latency per search (more lanes on each step, barriers
 // instead of wave-local fences), lower throughput -- for batches too small to fill the chip with one wave per PU.
-template <int T>
+template <int T, bool CONSTR>
 __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                                 const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
                                                                 kvz_hip_me_result *__restrict__ out)
@@ -754,11 +759,24 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
   const kvz_hip_me_pu &pu = pus[blockIdx.x];
   if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   if (pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
-  if (pu.width == 32 && pu.height == 32) search_pu_core<32, T, false, 32, 32>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
-  else search_pu_core<32, T, false>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  if (pu.width == 32 && pu.height == 32) search_pu_core<32, T, false, 32, 32, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  else search_pu_core<32, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
 
 }  // namespace
+
+template <bool CONSTR>
+static void launch_classes(int classes, const u8 *pic, u32 pic_stride, int pic_w, int pic_h, const refplane_t &r, const kvz_hip_me_pu *pus,
+                           size_t count, const kvz_hip_me_params &prm, kvz_hip_me_result *results, hipStream_t st)
+{
+  // one launch per size class over the same descriptor list; each kernel takes its class and skips the rest
+  if (classes == 7 || (classes & 4))
+    hipLaunchKernelGGL((search_pu_big_kernel<512, CONSTR>), dim3((unsigned)count), dim3(512), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, prm, results);
+  if (classes & 1)
+    hipLaunchKernelGGL((search_pu_small_kernel<CONSTR>), dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count, prm, results);
+  if (classes & 2)
+    hipLaunchKernelGGL((search_pu_medium_wg_kernel<128, CONSTR>), dim3((unsigned)count), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, prm, results);
+}
 
 extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
                                        const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
@@ -809,28 +827,11 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     hipError_t e = hipMemsetAsync(results, 0xFF, count * sizeof(kvz_hip_me_result), st);
     if (e != hipSuccess) { set_error("hipMemsetAsync(results)", e); return KVZ_HIP_ERR_RUNTIME; }
   }
-  if (classes == 7 || (classes & 4)) {
-    const int bt = tuning("me_big_threads", 512);      // measured at 480 and 1920 PUs of 64x64: 512 threads 10.5 M/s, 256: 9.5, 1024: 6.5
-    if (bt == 1024) hipLaunchKernelGGL(search_pu_big_kernel<1024>, dim3((unsigned)count), dim3(1024), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
-    else if (bt == 512) hipLaunchKernelGGL(search_pu_big_kernel<512>, dim3((unsigned)count), dim3(512), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
-    else hipLaunchKernelGGL(search_pu_big_kernel<256>, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
-    KVZ_CHECK_LAUNCH("search_pu_big_kernel");
-  }
-  if (classes & 1) {
-    hipLaunchKernelGGL(search_pu_small_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
-                       *params, results);
-    KVZ_CHECK_LAUNCH("search_pu_small_kernel");
-  }
-  if (classes & 2) {
-    const int mt = tuning("me_medium_threads", 128);   // measured (1980 and 7920 PUs of 32x32): 128 threads per PU 48.9 M/s, 256: 46.6, one wave: 42.6
-    if (mt == 256)
-      hipLaunchKernelGGL(search_pu_medium_wg_kernel<256>, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
-    else if (mt != 64)
-      hipLaunchKernelGGL(search_pu_medium_wg_kernel<128>, dim3((unsigned)count), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
-    else
-      hipLaunchKernelGGL(search_pu_medium_kernel, dim3((unsigned)((count + 1) / 2)), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count,
-                         *params, results);
-    KVZ_CHECK_LAUNCH("search_pu_medium_kernel");
-  }
+  // thread counts are measured choices: > 32x32: 512 threads per PU 10.5 M/s (256: 9.5, 1024: 6.5); <= 32x32: 128 per PU 48.9 M/s
+  // (256: 46.6, one wave: 42.6); <= 16x16: one wave per PU, four per workgroup
+  const bool constrained = params->wpp_owf != 0 || params->mv_constraint != 0;
+  if (constrained) launch_classes<true>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
+  else launch_classes<false>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
+  KVZ_CHECK_LAUNCH("search_pu kernels");
   return KVZ_HIP_OK;
 }
