@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import oracle_lib as O  # noqa: E402
 from kvazaar_amd import api, _lib  # noqa: E402
-from patterns import (ME_RESULT, intra_ref_cases, me_frames, me_params, me_random_pus, sao_blocks)  # noqa: E402
+from patterns import (ME_RESULT, intra_ref_cases, me_cabac_states, me_frames, me_params, me_pus_in_tile, me_random_pus, sao_blocks)  # noqa: E402
 
 
 def check(name, ok, detail=""):
@@ -45,8 +45,26 @@ def main():
         sizes = tuple((bw, bh) for bw in (8, 16, 24, 32, 48, 64) for bh in (8, 16, 24, 32, 48, 64) if bw <= w and bh <= h)
         sizes += ((8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16)) * 2          # the AMP / SMP shapes
         pus = me_random_pus(w, h, 150, int(g.integers(0, 1 << 30)), hint=(-4 * motion[0] + 2, -4 * motion[1]), sizes=sizes)
-        got = api.search_pu_batch(pic, ref, pus, prm).view(ME_RESULT).reshape(-1)
-        want = O.search_pu_batch(pic, ref, pus, prm)
+        # round 2: the mv_constraint branches with and without a real tile, and --mv-rdo from random CABAC snapshots
+        kw = {}
+        if it % 3 == 1:
+            prm["mv_constraint"] = int(g.integers(1, 5))
+            if g.integers(0, 2):
+                tx, ty = int(g.integers(0, w // 64)) * 64, int(g.integers(0, max(1, h // 64))) * 64
+                tw, th = int(g.integers(1, (w - tx) // 8 + 1)) * 8, int(g.integers(1, (h - ty) // 8 + 1)) * 8
+                prm["tile_x"], prm["tile_y"], prm["tile_w"], prm["tile_h"] = tx, ty, tw, th
+                pus = me_pus_in_tile(pus, prm)
+                pus = pus[(pus["width"] <= tw) & (pus["height"] <= th) & (pus["x"] + pus["width"] <= tx + tw) & (pus["y"] + pus["height"] <= ty + th)]
+        if it % 3 == 2:
+            prm["mv_rdo"], prm["refs_before"] = 1, int(g.integers(1, 6))
+            prm["ref_idx"] = int(g.integers(0, prm["refs_before"][0]))
+            cab = me_cabac_states(11, int(g.integers(0, 1 << 30)))
+            pus["reserved"] = g.integers(0, 11, len(pus))
+            kw = dict(cabac=cab)
+        if len(pus) == 0:
+            continue
+        got = api.search_pu_batch(pic, ref, pus, prm, **kw).view(ME_RESULT).reshape(-1)
+        want = O.search_pu_batch(pic, ref, pus, prm, **kw)
         for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
             check("search_pu." + f, np.array_equal(got[f], want[f]), "iter %d prm %s" % (it, prm))
         n += len(pus)
@@ -71,7 +89,7 @@ def main():
     # fused TU: random qp / flags / sizes, with the rd=0 costs
     for it in range(40 * a.scale):
         w = int(g.choice([4, 8, 16, 32]))
-        cnt = int(g.integers(1, 40))
+        cnt = int(g.integers(1, 40)) if it % 4 else int(g.integers(40, 200))      # every tail of the 8-TU wave step / 4-TU tile
         ref_in = g.integers(0, 256, (cnt, w * w), dtype=np.uint8)
         amp = int(g.choice([2, 10, 60, 255]))
         pred = np.clip(ref_in.astype(np.int32) + g.integers(-amp, amp + 1, ref_in.shape), 0, 255).astype(np.uint8)
@@ -135,7 +153,7 @@ def main():
 
     # transforms / quant / dequant on full-range inputs
     for n in (4, 8, 16, 32):
-        x = g.integers(-32768, 32768, (int(g.integers(1, 30)), n * n)).astype(np.int16)
+        x = g.integers(-32768, 32768, (int(g.integers(1, 300)), n * n)).astype(np.int16)      # tails of the 4- and 64-block tiles
         r = g.integers(-255, 256, x.shape).astype(np.int16)
         for kind, src in (("dct", r), ("idct", x)) + ((("dst", r), ("idst", x)) if n == 4 else ()):
             check("%s_%d" % (kind, n), np.array_equal(api.transform_batch(kind, n, src), O.transform_batch(kind, n, src)))
