@@ -441,6 +441,26 @@ typedef struct {
                                             (intra-generic.c:37-189) on the given references: no smoothing
                                             decision, no DC / boundary filters */
 
+/* Luma position of an intra PU in its (tile's) picture: the luma_px argument of
+ * kvz_intra_build_reference (intra.h:94-100). */
+typedef struct { int32_t x, y; } kvz_hip_intra_pos;
+
+/* kvz_intra_build_reference (intra.c:334-588) for every listed PU, gathered on
+ * the device from `rec`, the plane of `color` (0 Y, 1 U, 2 V; stride in pixels
+ * of that plane) of the reconstruction BEFORE deblocking -- what lcu->rec,
+ * lcu->top_ref and lcu->left_ref are views of (init_lcu_t,
+ * search.c:761-835).  pic_width / pic_height are pic_px, the luma size of
+ * the (tile) picture.  Which neighbours count as coded follows from the PU's
+ * place in the coding order of its LCU exactly as num_ref_pixels_top / _left
+ * (intra.c:35-70) say, so pixels of CUs that come later are never read and may
+ * hold anything.  Entries 0..2N of both arrays are the reference's, the rest
+ * is zero.  A position outside the picture or off the 4-pixel grid yields an
+ * all-zero record.  refs feeds kvz_hip_intra_predict_batch / _rough_batch on
+ * the same stream without a host round trip. */
+KVZ_HIP_API int kvz_hip_intra_build_reference_batch(int log2_width, int color, const kvz_hip_pixel *rec, int stride,
+                                                    int pic_width, int pic_height, const kvz_hip_intra_pos *pus, size_t count,
+                                                    kvz_hip_intra_ref *refs, kvz_hip_stream s);
+
 /* kvz_intra_predict (intra.c:281-331) for every PU x every listed mode:
  * reference smoothing (intra.c:164-192) chosen per mode and size, planar,
  * DC with its edge filter (intra.c:217-278), angular modes 2..34 with the

@@ -277,6 +277,20 @@ def search_frac_batch(pic, ref, pairs):
 INTRA_LUMA, INTRA_FILTER_BOUNDARY, INTRA_RAW = 1, 2, 4
 
 
+def intra_build_reference_batch(log2_width, color, plane, pic_w, pic_h, xy):
+    """kvz_intra_build_reference for the PUs of `color` at the luma positions xy (count, 2), gathered on the device from
+    the 2-D reconstruction plane of that colour; returns uint8 [count, 130] = kvz_intra_ref {left[65], top[65]}."""
+    L = _lib.init()
+    plane = np.ascontiguousarray(plane, dtype=np.uint8)
+    xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+    count = xy.shape[0]
+    p, q = DeviceBuffer.from_numpy(plane), DeviceBuffer.from_numpy(xy)
+    out = DeviceBuffer(max(1, 130 * count))
+    check(L.kvz_hip_intra_build_reference_batch(log2_width, color, p.ptr, plane.shape[1], pic_w, pic_h, q.ptr, count, out.ptr, None),
+          "intra_build_reference batch")
+    return out.to_numpy(np.uint8, (count, 130))
+
+
 def intra_predict_batch(refs, log2_width, modes, flags=INTRA_LUMA | INTRA_FILTER_BOUNDARY):
     """refs: (count, 130) uint8 = kvz_intra_ref {left[65], top[65]}.  kvz_intra_predict for every PU x every mode of
     `modes`; returns uint8 [count, len(modes), N*N]."""

@@ -4,7 +4,10 @@
 // src/intra.c:164-331 (reference smoothing, DC, edge filters, kvz_intra_predict) and the
 // cost loop of search_intra_rough, src/search_intra.c:404-520.  SURVEY.md section 8(f) row 2.
 //
-// Two kernels:
+// Three kernels:
+//   intra_build_reference_kernel  one wave per PU: the kvz_intra_ref of kvz_intra_build_reference
+//                          (intra.c:334-588) gathered from the reconstruction plane in HBM, so the
+//                          references of a wavefront of PUs never visit the host.
 //   intra_predict_kernel   one wave per (PU, mode): writes the N x N prediction (the drop-in
 //                          strategies and kvz_intra_predict for a list of modes).
 //   intra_rough_kernel     all 35 modes of a PU against its original block, SATD (and SAD) per
@@ -415,9 +418,96 @@ int launch_predict(const kvz_hip_intra_ref *refs, size_t count, const mode_list 
   return KVZ_HIP_OK;
 }
 
+// ---- kvz_intra_build_reference (intra.c:334-588) from the reconstruction plane ----
+// num_ref_pixels_left / num_ref_pixels_top (intra.c:35-70) in closed form.  (ux, uy) = the PU's 4x4 unit inside
+// its LCU; s = the largest power of two dividing the coordinate (16 on the LCU border).  Everything left of
+// the unit down to the end of its s-aligned group was coded before it, and so was everything above it up to
+// the end of the enclosing 2s-aligned group, never more than 64 pixels.
+__device__ __forceinline__ int intra_coded_left(int ux, int uy)
+{
+  const int s = ux ? (ux & -ux) : 16;
+  return 4 * (s - (uy & (s - 1)));
+}
+__device__ __forceinline__ int intra_coded_above(int ux, int uy)
+{
+  const int s2 = uy ? 2 * (uy & -uy) : 32;
+  const int n = 4 * (s2 - (ux & (s2 - 1)));
+  return n < 64 ? n : 64;
+}
+
+// One wave per PU.  Lane l owns left[1 + l] and top[1 + l] (2N <= 64), lane 0 also the corner; entries past
+// 2N are written as zero so a record is a function of its inputs alone.  A position outside the picture, or
+// off the 4-pixel grid, gives an all-zero record and reads nothing.
+__global__ __launch_bounds__(256) void intra_build_reference_kernel(const u8 *__restrict__ rec, int stride, int pic_w, int pic_h,
+                                                                    const kvz_hip_intra_pos *__restrict__ pus, size_t count, int log2_width,
+                                                                    int chroma, kvz_hip_intra_ref *__restrict__ refs)
+{
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= count) return;
+  const int l = threadIdx.x & 63;
+  const int n2 = 2 << log2_width;
+  const int lx = pus[i].x, ly = pus[i].y;
+  u8 *out = reinterpret_cast<u8 *>(refs + i);
+  const int span = (1 << log2_width) << chroma;
+  const bool ok = lx >= 0 && ly >= 0 && ((lx | ly) & 3) == 0 && lx + span <= pic_w && ly + span <= pic_h;
+  u8 left = 0, top = 0, corner = 0;
+  if (ok) {
+    const int x = lx >> chroma, y = ly >> chroma;
+    const int ux = (lx & 63) >> 2, uy = (ly & 63) >> 2;
+    const bool has_left = lx > 0, has_top = ly > 0;
+    const u8 *above = rec + (size_t)(has_top ? y - 1 : 0) * stride;   // the row over the PU
+    // intra.c:386-412 / :519-543
+    if (has_left) {
+      int avail = intra_coded_left(ux, uy) >> chroma;
+      avail = min(avail, min(n2, (pic_h - ly) >> chroma));
+      left = rec[(size_t)(y + min(l, avail - 1)) * stride + x - 1];
+    } else {
+      left = has_top ? above[x] : 128;
+    }
+    // intra.c:430-455 / :545-571
+    if (has_top) {
+      int avail = intra_coded_above(ux, uy) >> chroma;
+      avail = min(avail, min(n2, (pic_w - lx) >> chroma));
+      top = above[x + min(l, avail - 1)];
+    } else {
+      top = has_left ? rec[(size_t)y * stride + x - 1] : 128;
+    }
+    // intra.c:414-428 / :504-517; left[1] is the same value in every lane wherever it stands in for the corner
+    corner = (has_left && has_top) ? above[x - 1] : (has_left ? rec[(size_t)y * stride + x - 1] : left);
+    if (l >= n2) left = top = 0;
+  }
+  out[1 + l] = left;
+  out[65 + 1 + l] = top;
+  if (l == 0) { out[0] = corner; out[65] = corner; }
+}
+
 }  // namespace
 
 extern "C" {
+
+int kvz_hip_intra_build_reference_batch(int log2_width, int color, const kvz_hip_pixel *rec, int stride, int pic_width, int pic_height,
+                                        const kvz_hip_intra_pos *pus, size_t count, kvz_hip_intra_ref *refs, kvz_hip_stream stream)
+{
+  KVZ_CHECK_CTX();
+  if (log2_width < 2 || log2_width > 5 || color < 0 || color > 2) {
+    set_error_msg("kvz_hip_intra_build_reference_batch: log2_width 2..5 and color 0..2 required");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  const int chroma = color != 0;
+  if (pic_width <= 0 || pic_height <= 0 || ((pic_width | pic_height) & 7) || stride < (pic_width >> chroma)) {
+    set_error_msg("kvz_hip_intra_build_reference_batch: picture size must be a positive multiple of 8 and fit the stride");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  if (count == 0) return KVZ_HIP_OK;
+  if (!rec || !pus || !refs) { set_error_msg("kvz_hip_intra_build_reference_batch: null buffer"); return KVZ_HIP_ERR_INVALID; }
+  if (count > (size_t)0x7fffffff * 4) { set_error_msg("kvz_hip_intra_build_reference_batch: count too large"); return KVZ_HIP_ERR_INVALID; }
+  hipStream_t st = ctx_stream(stream);
+  hipLaunchKernelGGL(intra_build_reference_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, rec, stride, pic_width, pic_height,
+                     pus, count, log2_width, chroma, refs);
+  KVZ_CHECK_LAUNCH("intra_build_reference_kernel");
+  return KVZ_HIP_OK;
+}
+
 
 int kvz_hip_intra_predict_batch(int log2_width, int flags, const kvz_hip_intra_ref *refs, size_t count, const int8_t *modes,
                                 int num_modes, kvz_hip_pixel *dst, kvz_hip_stream stream)

@@ -146,6 +146,28 @@ def intra():
     np.savez_compressed(os.path.join(OUT, "intra.npz"), **d)
 
 
+def intra_ref():
+    """kvz_intra_build_reference (intra.c:334-588) at every PU position of a 104 x 88 picture (one whole LCU, a ragged
+    column and row of them), each PU on an lcu_t cut from the planes as init_lcu_t does, with everything that is coded
+    after the PU overwritten with noise"""
+    from patterns import intra_ref_positions
+    g = rng(SEED + 45)
+    pic_w, pic_h = 104, 88
+    d = {"size": np.array([pic_w, pic_h], np.int32)}
+    for color in (0, 1, 2):
+        plane = g.integers(0, 256, (pic_h >> (color > 0), pic_w >> (color > 0)), dtype=np.uint8)
+        d["plane%d" % color] = plane
+        for lg in (2, 3, 4, 5):
+            xy = intra_ref_positions(lg, color, pic_w, pic_h)
+            d["xy%d_c%d" % (lg, color)] = xy
+            refs = np.array([R.intra_build_reference_from_plane(lg, color, plane, pic_w, pic_h, int(x), int(y), poison=g) for (x, y) in xy])
+            n2 = 2 << lg
+            refs[:, n2 + 1:65] = 0
+            refs[:, 65 + n2 + 1:] = 0
+            d["refs%d_c%d" % (lg, color)] = refs
+    np.savez_compressed(os.path.join(OUT, "intra_ref.npz"), **d)
+
+
 def sao():
     g = rng(SEED + 5)
     d = {}
@@ -251,7 +273,7 @@ if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, sao=sao, me=me, deblock=deblock, fronts=fronts)
+    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, intra_ref=intra_ref, sao=sao, me=me, deblock=deblock, fronts=fronts)
     for name in (sys.argv[1:] or list(groups)):          # python oracle/gen_golden.py [group ...]
         groups[name]()
     for f in sorted(os.listdir(OUT)):

@@ -1438,6 +1438,84 @@ void orc_intra_rough_costs(const orc_intra_ref *ref, int log2_width, int filter_
   }
 }
 
+/* ---- kvz_intra_build_reference (intra.c:334-588), read from a whole reconstruction plane ----
+ * The reference reads lcu->rec inside the LCU and lcu->top_ref / left_ref on its border; both are views of the
+ * reconstruction before deblocking (init_lcu_t, search.c:761-835, fills the borders from the hor_buf / ver_buf
+ * kept before the loop filters), so on a plane the neighbour above
+ * is rec[(y - 1) * stride + x + i] and the neighbour to the left rec[(y + i) * stride + x - 1] wherever they exist. */
+
+/* position of a 4x4 unit in the coding order of its LCU: the bits of (ux, uy) interleaved */
+static unsigned intra_unit_order(unsigned ux, unsigned uy)
+{
+  unsigned z = 0;
+  for (int b = 0; b < 4; ++b) z |= ((ux >> b) & 1u) << (2 * b) | ((uy >> b) & 1u) << (2 * b + 1);
+  return z;
+}
+
+/* num_ref_pixels_top / num_ref_pixels_left (intra.c:35-70) from first principles: luma pixels of the row above /
+ * the column to the left that were coded before the unit at (ux, uy); the whole LCU row above and the LCU to the
+ * left are complete, the LCU below-left never is, and at most 64 pixels are ever asked for. */
+static int intra_coded_above(int ux, int uy)
+{
+  if (uy == 0) return 64;
+  int n = 0;
+  while (ux + n < 16 && intra_unit_order(ux + n, uy - 1) < intra_unit_order(ux, uy)) ++n;
+  return 4 * n;
+}
+
+static int intra_coded_left(int ux, int uy)
+{
+  int n = 0;
+  while (uy + n < 16 && (ux == 0 || intra_unit_order(ux - 1, uy + n) < intra_unit_order(ux, uy))) ++n;
+  return 4 * n;
+}
+
+void orc_intra_build_reference(int log2_width, int color, const orc_pixel *rec, int stride, int pic_w, int pic_h,
+                               int luma_x, int luma_y, orc_intra_ref *out)
+{
+  const int c = color != 0, n2 = 2 << log2_width;
+  const int x = luma_x >> c, y = luma_y >> c;                 /* position in the plane of `color` */
+  const int ux = (luma_x & 63) >> 2, uy = (luma_y & 63) >> 2;
+  const orc_pixel dc = 1 << 7;                                /* intra.c:348, KVZ_BIT_DEPTH 8 */
+  const int has_left = luma_x > 0, has_top = luma_y > 0;
+
+  /* left column, intra.c:386-412 / :519-543: the coded pixels, then the last of them repeated; at the left picture
+   * edge the first pixel above (or mid grey at the origin) */
+  if (has_left) {
+    int avail = intra_coded_left(ux, uy) >> c;
+    if (avail > n2) avail = n2;
+    if (avail > ((pic_h - luma_y) >> c)) avail = (pic_h - luma_y) >> c;
+    for (int i = 0; i < n2; ++i) out->left[1 + i] = rec[(y + (i < avail ? i : avail - 1)) * stride + x - 1];
+  } else {
+    const orc_pixel v = has_top ? rec[(y - 1) * stride + x] : dc;
+    for (int i = 0; i < n2; ++i) out->left[1 + i] = v;
+  }
+
+  /* corner, intra.c:414-428 / :504-517 */
+  out->left[0] = (has_left && has_top) ? rec[(y - 1) * stride + x - 1] : out->left[1];
+  out->top[0] = out->left[0];
+
+  /* row above, intra.c:430-455 / :545-571 */
+  if (has_top) {
+    int avail = intra_coded_above(ux, uy) >> c;
+    if (avail > n2) avail = n2;
+    if (avail > ((pic_w - luma_x) >> c)) avail = (pic_w - luma_x) >> c;
+    for (int i = 0; i < n2; ++i) out->top[1 + i] = rec[(y - 1) * stride + x + (i < avail ? i : avail - 1)];
+  } else {
+    const orc_pixel v = has_left ? rec[y * stride + x - 1] : dc;
+    for (int i = 0; i < n2; ++i) out->top[1 + i] = v;
+  }
+}
+
+void orc_intra_build_reference_many(int log2_width, int color, const orc_pixel *rec, int stride, int pic_w, int pic_h,
+                                    const int32_t *xy, size_t count, orc_intra_ref *out)
+{
+  for (size_t i = 0; i < count; ++i) {
+    memset(&out[i], 0, sizeof(out[i]));
+    orc_intra_build_reference(log2_width, color, rec, stride, pic_w, pic_h, xy[2 * i], xy[2 * i + 1], &out[i]);
+  }
+}
+
 /* =====================================================================
  * SAO group (sao-generic.c, sao.c)
  * ===================================================================== */

@@ -171,6 +171,14 @@ void orc_intra_predict(const orc_intra_ref *ref, int log2_width, int mode, int i
 void orc_intra_rough_costs(const orc_intra_ref *ref, int log2_width, int filter_boundary, const orc_pixel *orig,
                            unsigned satd_out[35], unsigned sad_out[35]);
 
+/* kvz_intra_build_reference (intra.c:334-588) for the PU of `color` (0 Y, 1 U, 2 V) at luma position
+ * (luma_x, luma_y) of a pic_w x pic_h (luma) picture, read from the not yet deblocked reconstruction plane of that
+ * colour (stride in pixels of the plane).  Entries past 2N of both arrays are left alone (_many zeroes them). */
+void orc_intra_build_reference(int log2_width, int color, const orc_pixel *rec, int stride, int pic_w, int pic_h,
+                               int luma_x, int luma_y, orc_intra_ref *out);
+void orc_intra_build_reference_many(int log2_width, int color, const orc_pixel *rec, int stride, int pic_w, int pic_h,
+                                    const int32_t *xy, size_t count, orc_intra_ref *out);
+
 /* ---- integer + fractional motion search of one PU against one reference picture:
  * hexagon_search (search_inter.c:690-778: select_starting_point :282-307, early_terminate
  * :415-460, check_mv_cost :195-232) followed by search_frac (:965-1128) with the MV bit

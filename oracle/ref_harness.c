@@ -618,17 +618,22 @@ void ref_intra_predict(const char *name, const uint8_t *refs_in /*130 bytes*/, i
   kvz_intra_pred_planar = save_p;
 }
 
-/* kvz_intra_build_reference (intra.c:574-588) on an LCU whose rec planes the caller filled:
+/* kvz_intra_build_reference (intra.c:574-588) on an LCU whose planes of `color` the caller filled
+ * (rec 64x64 luma / 32x32 chroma, top / left = the 96 / 48 border pixels after entry 0 = top_left):
  * used to produce realistic reference arrays (unavailable neighbours, picture edges). */
 void ref_intra_build_reference(int log2_width, int color, int luma_x, int luma_y, int pic_w, int pic_h,
-                               const kvz_pixel *rec_y, const kvz_pixel *top_y, const kvz_pixel *left_y, int top_left,
+                               const kvz_pixel *rec, const kvz_pixel *top, const kvz_pixel *left, int top_left,
                                uint8_t *refs_out /*130 bytes*/)
 {
   lcu_t *lcu = calloc(1, sizeof(lcu_t));
-  memcpy(lcu->rec.y, rec_y, 64 * 64);
-  memcpy(lcu->top_ref.y, top_y, sizeof(lcu->top_ref.y));
-  memcpy(lcu->left_ref.y, left_y, sizeof(lcu->left_ref.y));
-  lcu->top_ref.y[0] = lcu->left_ref.y[0] = (kvz_pixel)top_left;
+  kvz_pixel *rec_p = color == 0 ? lcu->rec.y : color == 1 ? lcu->rec.u : lcu->rec.v;
+  kvz_pixel *top_p = color == 0 ? lcu->top_ref.y : color == 1 ? lcu->top_ref.u : lcu->top_ref.v;
+  kvz_pixel *left_p = color == 0 ? lcu->left_ref.y : color == 1 ? lcu->left_ref.u : lcu->left_ref.v;
+  const int w = color ? LCU_WIDTH_C : LCU_WIDTH, nref = color ? LCU_REF_PX_WIDTH / 2 + 1 : LCU_REF_PX_WIDTH + 1;
+  memcpy(rec_p, rec, w * w);
+  memcpy(top_p, top, nref);
+  memcpy(left_p, left, nref);
+  top_p[0] = left_p[0] = (kvz_pixel)top_left;
   kvz_intra_references refs;
   memset(&refs, 0, sizeof(refs));
   vector2d_t luma_px = { luma_x, luma_y }, pic_px = { pic_w, pic_h };

@@ -377,6 +377,8 @@ def _intra_sigs():
     L.orc_intra_predict.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, u8p]
     L.orc_intra_rough_costs.restype = None
     L.orc_intra_rough_costs.argtypes = [u8p, C.c_int, C.c_int, u8p, u32p, u32p]
+    L.orc_intra_build_reference_many.restype = None
+    L.orc_intra_build_reference_many.argtypes = [C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, u8p]
     L._intra_done = True
     return L
 
@@ -410,6 +412,18 @@ def intra_predict_batch(refs, log2_width, modes, is_luma=1, filter_boundary=1):
         for j, m in enumerate(modes):
             d = out[i, j]
             L.orc_intra_predict(_p(r, u8p), log2_width, int(m), is_luma, filter_boundary, _p(d, u8p))
+    return out
+
+
+def intra_build_reference_batch(log2_width, color, plane, pic_w, pic_h, xy):
+    """kvz_intra_build_reference of every PU at the luma positions xy (count, 2) from the 2-D reconstruction plane of
+    `color` -> (count, 130) uint8, entries past 2N zero"""
+    L = _intra_sigs()
+    plane = np.ascontiguousarray(plane, dtype=np.uint8)
+    xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros((xy.shape[0], 130), dtype=np.uint8)
+    L.orc_intra_build_reference_many(log2_width, color, _p(plane, u8p), plane.shape[1], pic_w, pic_h, xy.ctypes.data, xy.shape[0],
+                                     _p(out, u8p))
     return out
 
 

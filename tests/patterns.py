@@ -98,6 +98,13 @@ def coeff_sum_input():
     return c, expected
 
 
+def intra_ref_positions(log2_width, color, pic_w, pic_h):
+    """every luma position kvz_intra_build_reference can be asked for in a pic_w x pic_h picture: the PU grid of the size
+    (chroma PUs of N pixels cover 2N luma pixels; a 4x4 chroma PU belongs to an 8x8 CU, search_intra.c:735-741)"""
+    step = (1 << log2_width) << (1 if color else 0)
+    return np.array([(x, y) for y in range(0, pic_h - step + 1, step) for x in range(0, pic_w - step + 1, step)], dtype=np.int32)
+
+
 def intra_ref_cases(log2_width, count, seed):
     """kvz_intra_ref arrays {left[65], top[65]} with left[0] == top[0]: random, flat, ramps, 0/255 extremes"""
     g = rng(seed)

@@ -431,14 +431,43 @@ def intra_predict(ref130, log2_width, mode, color=0, filter_boundary=1, name="ge
     return dst.copy()
 
 
-def intra_build_reference(log2_width, x, y, pic_w, pic_h, rec_y, top_y, left_y, top_left):
-    """kvz_intra_build_reference for a luma PU at picture position (x, y) (LCU-relative planes supplied by the caller)"""
+def intra_build_reference(log2_width, x, y, pic_w, pic_h, rec, top, left, top_left, color=0):
+    """kvz_intra_build_reference for the PU of `color` at luma picture position (x, y).  rec / top / left are the LCU's
+    planes of that colour: rec 64x64 (32x32 chroma), top / left 97 (49) entries of which entry 0 is replaced by top_left."""
     L = _intra_sigs()
     out = np.zeros(130, dtype=np.uint8)
-    rec_y, top_y, left_y = _u8(rec_y), _u8(top_y), _u8(left_y)
-    L.ref_intra_build_reference(log2_width, 0, x, y, pic_w, pic_h, _p(rec_y, u8p), _p(top_y, u8p), _p(left_y, u8p),
+    rec, top, left = _u8(rec), _u8(top), _u8(left)
+    w, nref = (32, 49) if color else (64, 97)
+    assert rec.size == w * w and top.size >= nref and left.size >= nref
+    L.ref_intra_build_reference(log2_width, color, x, y, pic_w, pic_h, _p(rec, u8p), _p(top, u8p), _p(left, u8p),
                                 int(top_left), _p(out, u8p))
     return out
+
+
+def intra_build_reference_from_plane(log2_width, color, plane, pic_w, pic_h, x, y, poison=None):
+    """kvz_intra_build_reference for the PU at luma position (x, y), its lcu_t filled from a whole reconstruction plane
+    of `color` the way init_lcu_t hands it over (search.c:761-835: rec of the LCU, top_ref / left_ref = the row
+    above / the column left of it).  With a poison generator, every 4x4 unit of the LCU that follows the PU in coding
+    order is overwritten first, so a read of a not yet coded pixel shows."""
+    c = 1 if color else 0
+    plane = np.asarray(plane, dtype=np.uint8)
+    ph, pw = plane.shape
+    w, nref = (32, 49) if c else (64, 97)
+    lx, ly = (x // 64) * 64 >> c, (y // 64) * 64 >> c
+    pad = np.zeros((ph + 2 * w + 1, pw + 2 * w + 1), dtype=np.uint8)
+    pad[1:ph + 1, 1:pw + 1] = plane
+    rec = pad[1 + ly:1 + ly + w, 1 + lx:1 + lx + w].copy()
+    if poison is not None:
+        def z(ux, uy):
+            return sum((((ux >> b) & 1) << (2 * b)) | (((uy >> b) & 1) << (2 * b + 1)) for b in range(4))
+        ux0, uy0, u = (x % 64) // 4, (y % 64) // 4, 4 >> c
+        for uy in range(16):
+            for ux in range(16):
+                if z(ux, uy) >= z(ux0, uy0):
+                    rec[uy * u:(uy + 1) * u, ux * u:(ux + 1) * u] = poison.integers(0, 256, (u, u), dtype=np.uint8)
+    top = pad[ly, lx:lx + nref].copy()
+    left = pad[ly:ly + nref, lx].copy()
+    return intra_build_reference(log2_width, x, y, pic_w, pic_h, rec, top, left, pad[ly, lx], color=color)
 
 
 # ---- motion search: the reference's static hexagon_search + search_frac (oracle/ref_me_harness.c) ----

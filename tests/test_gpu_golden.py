@@ -89,6 +89,15 @@ def test_golden_intra(api):
         np.testing.assert_array_equal(api.intra_predict_batch(refs, lg, list(range(35)), 2), d["pred%d_chroma" % lg])
 
 
+def test_golden_intra_ref(api):
+    d = gold("intra_ref.npz")
+    pic_w, pic_h = (int(v) for v in d["size"])
+    for color in (0, 1, 2):
+        for lg in (2, 3, 4, 5):
+            got = api.intra_build_reference_batch(lg, color, d["plane%d" % color], pic_w, pic_h, d["xy%d_c%d" % (lg, color)])
+            np.testing.assert_array_equal(got, d["refs%d_c%d" % (lg, color)], err_msg="color %d log2 %d" % (color, lg))
+
+
 def test_golden_sao(api):
     d = gold("sao.npz")
     for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):

@@ -554,6 +554,68 @@ def test_intra_chroma_rough_search(api, log2_width_c):
         np.testing.assert_array_equal(np.argsort(got[:, modes], axis=1, kind="stable"), np.argsort(want, axis=1, kind="stable"))
 
 
+@pytest.mark.parametrize("color", [0, 1, 2])
+@pytest.mark.parametrize("log2_width", [2, 3, 4, 5])
+def test_intra_build_reference(api, log2_width, color):
+    """kvz_intra_build_reference at every PU position of a 1080p reconstruction (17 x 30 LCUs, ragged last LCU row), read
+    from a plane wider than the picture"""
+    from patterns import intra_ref_positions
+    g = rng(700 + 10 * log2_width + color)
+    pic_w, pic_h, c = 1920, 1080, 1 if color else 0
+    plane = g.integers(0, 256, (pic_h >> c, (pic_w >> c) + 24), dtype=np.uint8)
+    xy = intra_ref_positions(log2_width, color, pic_w, pic_h)
+    got = api.intra_build_reference_batch(log2_width, color, plane, pic_w, pic_h, xy)
+    np.testing.assert_array_equal(got, O.intra_build_reference_batch(log2_width, color, plane, pic_w, pic_h, xy))
+
+
+def test_intra_build_reference_small_pictures_and_bad_positions(api):
+    """pictures narrower than one LCU (every PU on a picture edge), and positions the kernel must refuse without reading"""
+    g = rng(77)
+    for (pic_w, pic_h) in ((8, 8), (16, 8), (8, 64), (72, 24), (64, 64)):
+        for color in (0, 1):
+            plane = g.integers(0, 256, (pic_h >> color, pic_w >> color), dtype=np.uint8)
+            for log2_width in (2, 3, 4, 5):
+                from patterns import intra_ref_positions
+                xy = intra_ref_positions(log2_width, color, pic_w, pic_h)
+                if len(xy) == 0:
+                    continue
+                np.testing.assert_array_equal(api.intra_build_reference_batch(log2_width, color, plane, pic_w, pic_h, xy),
+                                              O.intra_build_reference_batch(log2_width, color, plane, pic_w, pic_h, xy))
+    plane = g.integers(1, 256, (64, 64), dtype=np.uint8)
+    xy = np.array([(8, 8), (-4, 0), (0, -8), (60, 0), (0, 60), (6, 8), (8, 2), (64, 0), (1 << 30, 1 << 30), (56, 56)], np.int32)
+    got = api.intra_build_reference_batch(3, 0, plane, 64, 64, xy)
+    want = O.intra_build_reference_batch(3, 0, plane, 64, 64, xy[[0, 9]])
+    np.testing.assert_array_equal(got[[0, 9]], want)
+    assert not got[1:9].any()
+
+
+def test_intra_references_feed_the_rough_search_on_the_device(api):
+    """build -> rough search chained on one stream through device buffers only (the references never visit the host):
+    same 35 costs per PU as the oracle's rough search on the oracle's references"""
+    from kvazaar_amd import _lib
+    from kvazaar_amd.api import DeviceBuffer, check
+    from patterns import intra_ref_positions
+    L = _lib.init()
+    g = rng(78)
+    pic_w, pic_h, lg = 192, 136, 3
+    rec = g.integers(0, 256, (pic_h, pic_w), dtype=np.uint8)
+    xy = intra_ref_positions(lg, 0, pic_w, pic_h)
+    count = len(xy)
+    orig = g.integers(0, 256, (count, 64), dtype=np.uint8)
+    d_rec, d_xy, d_orig = DeviceBuffer.from_numpy(rec), DeviceBuffer.from_numpy(xy), DeviceBuffer.from_numpy(orig)
+    d_refs, d_satd = DeviceBuffer(130 * count), DeviceBuffer(4 * 35 * count)
+    st = L.kvz_hip_stream_create()
+    assert st
+    try:
+        check(L.kvz_hip_intra_build_reference_batch(lg, 0, d_rec.ptr, pic_w, pic_w, pic_h, d_xy.ptr, count, d_refs.ptr, st), "build")
+        check(L.kvz_hip_intra_rough_batch(lg, 3, d_refs.ptr, d_orig.ptr, count, d_satd.ptr, None, st), "rough")
+        satd = d_satd.to_numpy(np.uint32, (count, 35), stream=st)
+    finally:
+        L.kvz_hip_stream_destroy(st)
+    refs = O.intra_build_reference_batch(lg, 0, rec, pic_w, pic_h, xy)
+    np.testing.assert_array_equal(satd, O.intra_rough_costs_batch(refs, lg, orig, 1)[0])
+
+
 def test_intra_argument_errors(api):
     from kvazaar_amd._lib import KvzHipError
     refs = intra_ref_cases(3, 2, 1)
@@ -564,6 +626,13 @@ def test_intra_argument_errors(api):
     with pytest.raises(KvzHipError):
         api.intra_rough_batch(refs, 3, np.zeros((2, 64), np.uint8), flags=4)
     assert api.intra_rough_batch(refs[:0], 3, np.zeros((0, 64), np.uint8)).shape == (0, 35)
+    plane, xy = np.zeros((64, 64), np.uint8), np.zeros((1, 2), np.int32)
+    for bad in (dict(log2_width=1), dict(log2_width=6), dict(color=3), dict(pic_w=60), dict(pic_h=0), dict(pic_w=72)):
+        a = dict(log2_width=3, color=0, plane=plane, pic_w=64, pic_h=64, xy=xy)
+        a.update(bad)
+        with pytest.raises(KvzHipError):
+            api.intra_build_reference_batch(**a)
+    assert api.intra_build_reference_batch(3, 0, plane, 64, 64, xy[:0]).shape == (0, 130)
 
 
 # ---- motion search of whole PUs ----

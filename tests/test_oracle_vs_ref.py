@@ -9,7 +9,7 @@ import pytest
 
 import oracle_lib as O
 import ref_lib as R
-from patterns import intra_ref_cases, lcg_bytes, rng
+from patterns import intra_ref_cases, intra_ref_positions, lcg_bytes, rng
 
 pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
 
@@ -303,6 +303,24 @@ def test_intra_predict_on_built_references():
             r = R.intra_build_reference(log2_width, x, y, 128, 128, rec, top, left, 99)
             for mode in range(35):
                 np.testing.assert_array_equal(O.intra_predict_batch(r, log2_width, [mode])[0, 0], R.intra_predict(r, log2_width, mode))
+
+
+@pytest.mark.parametrize("color", [0, 1, 2])
+@pytest.mark.parametrize("log2_width", [2, 3, 4, 5])
+def test_intra_build_reference(log2_width, color):
+    """the plane-based restatement against kvz_intra_build_reference on an lcu_t cut from the same plane, every PU
+    position of a picture with a ragged last LCU column / row; the pixels the PU must not see are poisoned in the lcu_t"""
+    g = rng(600 + 10 * log2_width + color)
+    pic_w, pic_h = 168, 136
+    c = 1 if color else 0
+    plane = g.integers(0, 256, (pic_h >> c, pic_w >> c), dtype=np.uint8)
+    xy = intra_ref_positions(log2_width, color, pic_w, pic_h)
+    ours = O.intra_build_reference_batch(log2_width, color, plane, pic_w, pic_h, xy)
+    n2 = 2 << log2_width
+    for i, (x, y) in enumerate(xy):
+        r = R.intra_build_reference_from_plane(log2_width, color, plane, pic_w, pic_h, x, y, poison=g)
+        np.testing.assert_array_equal(ours[i, :n2 + 1], r[:n2 + 1], err_msg="left of (%d, %d)" % (x, y))
+        np.testing.assert_array_equal(ours[i, 65:65 + n2 + 1], r[65:65 + n2 + 1], err_msg="top of (%d, %d)" % (x, y))
 
 
 # ---- motion search (SURVEY 8(f) row 1): hexagon_search + search_frac with MV costs ----

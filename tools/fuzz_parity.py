@@ -84,6 +84,17 @@ def main():
             got = api.intra_predict_batch(refs[:60], lg, list(range(35)), flags)
             want = O.intra_predict_batch(refs[:60], lg, list(range(35)), is_luma=flags & 1, filter_boundary=(flags >> 1) & 1)
             check("intra_predict", np.array_equal(got, want), "log2 %d flags %d" % (lg, flags))
+    # intra references from a reconstruction plane: random picture sizes (multiples of 8), strides, colours, every PU position
+    from patterns import intra_ref_positions
+    for it in range(6 * a.scale):
+        pw, ph, color, lg = 8 * int(g.integers(1, 40)), 8 * int(g.integers(1, 30)), int(g.integers(0, 3)), int(g.integers(2, 6))
+        c = 1 if color else 0
+        plane = g.integers(0, 256, (ph >> c, (pw >> c) + int(g.integers(0, 9))), dtype=np.uint8)
+        xy = intra_ref_positions(lg, color, pw, ph)
+        if len(xy):
+            check("intra_build_reference", np.array_equal(api.intra_build_reference_batch(lg, color, plane, pw, ph, xy),
+                                                          O.intra_build_reference_batch(lg, color, plane, pw, ph, xy)),
+                  "%dx%d color %d log2 %d" % (pw, ph, color, lg))
     print("intra ok (%.0f s)" % (time.time() - t0))
 
     # fused TU: random qp / flags / sizes, with the rd=0 costs
