@@ -678,6 +678,15 @@ __device__ __forceinline__ void flag_bad(kvz_hip_me_result *out)
   *out = r;
 }
 
+// size class of a PU as kvz_hip_me_params.size_classes names them: 1 = up to 16x16, 2 = up to 32x32, 4 = larger
+__device__ __forceinline__ int pu_class(const kvz_hip_me_pu &pu)
+{
+  return (pu.width > 32 || pu.height > 32) ? 4 : ((pu.width > 16 || pu.height > 16) ? 2 : 1);
+}
+// A launch with a size-class hint starts only the kernels of the classes named, so a PU of another class is searched by
+// no kernel: the kernel of the lowest class named flags it (cost 0xFFFFFFFF, reserved -1) on its way past.
+__device__ __forceinline__ bool pu_orphan(int cls, int mine, int hinted) { return !(hinted & cls) && mine == (hinted & -hinted); }
+
 // PUs larger than 32x32 in either direction (and malformed descriptors, which are flagged): one workgroup (T threads) per PU
 template <int T, bool CONSTR>
 __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
@@ -688,7 +697,11 @@ __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];            // uniform address: the compiler reads it with scalar loads
   if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
-  if (pu.width <= 32 && pu.height <= 32) return;       // the one-wave-per-PU kernels'
+  const int cls = pu_class(pu);
+  if (cls != 4) {                                       // the one-wave-per-PU kernels'
+    if (pu_orphan(cls, 4, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
+    return;
+  }
   search_pu_core<64, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
 
@@ -721,7 +734,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const kvz_hip_me_pu &pu = pus[i];
   const int lane = threadIdx.x & 63;
   if (!pu_ok(pu, pic_w, pic_h)) { if (lane == 0) flag_bad(out + i); return; }
-  if (pu.width > 16 || pu.height > 16) return;
+  const int cls = pu_class(pu);
+  if (cls != 1) {
+    if (pu_orphan(cls, 1, prm.size_classes) && lane == 0) flag_bad(out + i);
+    return;
+  }
   if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else search_pu_core<16, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
@@ -742,7 +759,11 @@ __global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restr
   const kvz_hip_me_pu &pu = pus[i];
   const int lane = threadIdx.x & 63;
   if (!pu_ok(pu, pic_w, pic_h)) { if (lane == 0) flag_bad(out + i); return; }
-  if (pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
+  const int cls = pu_class(pu);
+  if (cls != 2) {
+    if (pu_orphan(cls, 2, prm.size_classes) && lane == 0) flag_bad(out + i);
+    return;
+  }
   if (pu.width == 32 && pu.height == 32) search_pu_core<32, 64, true, 32, 32, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
   else search_pu_core<32, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
 }
@@ -758,7 +779,11 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];
   if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
-  if (pu.width > 32 || pu.height > 32 || (pu.width <= 16 && pu.height <= 16)) return;
+  const int cls = pu_class(pu);
+  if (cls != 2) {
+    if (pu_orphan(cls, 2, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
+    return;
+  }
   if (pu.width == 32 && pu.height == 32) search_pu_core<32, T, false, 32, 32, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
   else search_pu_core<32, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
 }
@@ -821,12 +846,10 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
     KVZ_CHECK_LAUNCH("search_pu_rdo_kernel");
     return KVZ_HIP_OK;
   }
+  // with a hint, PUs of a class it does not name are searched by no kernel: they read cost 0xFFFFFFFF, reserved -1
+  // (pu_orphan: written by the kernels themselves -- a separate fill would be one more command per dependency front)
   const int classes = (params->size_classes & 7) ? (params->size_classes & 7) : 7;
-  if (classes != 7) {
-    // with a hint, PUs of a class it does not name are searched by no kernel: they read cost 0xFFFFFFFF, reserved -1
-    hipError_t e = hipMemsetAsync(results, 0xFF, count * sizeof(kvz_hip_me_result), st);
-    if (e != hipSuccess) { set_error("hipMemsetAsync(results)", e); return KVZ_HIP_ERR_RUNTIME; }
-  }
+  prm_v.size_classes = classes;
   // thread counts are measured choices: > 32x32: 512 threads per PU 10.5 M/s (256: 9.5, 1024: 6.5); <= 32x32: 128 per PU 48.9 M/s
   // (256: 46.6, one wave: 42.6); <= 16x16: one wave per PU, four per workgroup
   const bool constrained = params->wpp_owf != 0 || params->mv_constraint != 0;

@@ -4,8 +4,12 @@
  * sorted by front, the fronts' offsets, the decisions the reference took.  Plain C99 host of include/kvz_hip.h.
  *   per front: descriptors -> pinned buffer -> device, one kvz_hip_search_pu_batch, results -> host, stream sync
  *   (the next front's candidates depend on these results: inter.c:1209,1314)
+ * With a 4th argument S > 1 the program instead runs S host threads, each replaying the frame front by front on its own
+ * stream, planes and pinned buffers -- S encoder instances (or S frames in flight under --owf, S tiles) of one process sharing
+ * the GPU through the per-thread contexts of the C ABI -- and reports the aggregate rate.
  * Prints one JSON line; every replayed result is compared with the recorded one.  NOT an encoder: candidate derivation,
  * mode decision, reconstruction are not here. */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,11 +20,93 @@
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, " (%s)\n", kvz_hip_last_error()); return 1; } while (0)
 
+/* ---- S sessions: one host thread each ---- */
+typedef struct {
+  int w, h, n, ng, repeats, hint, device;
+  const uint8_t *pic, *ref;
+  const kvz_hip_me_params *prm;
+  const kvz_hip_me_pu *pus;
+  const kvz_hip_me_result *want;
+  const int32_t *off;
+  pthread_barrier_t *start;
+  double seconds;      /* out: wall time of this thread's `repeats` frames */
+  long mismatches;     /* out */
+  int failed;          /* out */
+} session_t;
+
+static void *session_main(void *arg)
+{
+  session_t *s = arg;
+  const int w = s->w, h = s->h, n = s->n;
+  s->failed = 1;
+  uint8_t *d_pic = NULL, *d_ref = NULL;
+  kvz_hip_me_pu *h_pus = NULL;
+  kvz_hip_me_result *h_res = NULL;
+  kvz_hip_stream st = NULL;
+  int ready = kvz_hip_set_device(s->device) == KVZ_HIP_OK && (st = kvz_hip_stream_create()) != NULL &&
+              (d_pic = kvz_hip_malloc((size_t)w * h)) && (d_ref = kvz_hip_malloc((size_t)w * h)) &&
+              (h_pus = kvz_hip_malloc_host((size_t)n * sizeof(*h_pus))) && (h_res = kvz_hip_malloc_host((size_t)n * sizeof(*h_res))) &&
+              !kvz_hip_memcpy_h2d(d_pic, s->pic, (size_t)w * h, st) && !kvz_hip_memcpy_h2d(d_ref, s->ref, (size_t)w * h, st) && !kvz_hip_stream_sync(st);
+  for (int rep = 0; rep < s->repeats + 1; ++rep) {            /* the first pass warms up, the timed ones start together */
+    if (rep == 1) pthread_barrier_wait(s->start);
+    const double t0 = now_s();
+    if (ready) memset(h_res, 0, (size_t)n * sizeof(*h_res));
+    for (int g = 0; ready && g < s->ng; ++g) {
+      const int a = s->off[g], c = s->off[g + 1] - s->off[g];
+      memcpy(h_pus + a, s->pus + a, (size_t)c * sizeof(*h_pus));
+      kvz_hip_me_params fp = *s->prm;
+      int classes = 0;
+      for (int i = a; i < a + c; ++i) {
+        const int sz = s->pus[i].width > s->pus[i].height ? s->pus[i].width : s->pus[i].height;
+        classes |= sz <= 16 ? 1 : (sz <= 32 ? 2 : 4);
+      }
+      fp.size_classes = s->hint ? classes : 0;
+      if (kvz_hip_search_pu_batch(d_pic, (uint32_t)w, w, h, d_ref, (uint32_t)w, w, h, h_pus + a, (size_t)c, &fp, h_res + a, st) ||
+          kvz_hip_stream_sync(st)) { fprintf(stderr, "session: %s\n", kvz_hip_last_error()); ready = 0; }
+    }
+    if (rep >= 1) s->seconds += now_s() - t0;
+    for (int i = 0; ready && i < n; ++i)
+      if (memcmp(&h_res[i], &s->want[i], 28) != 0) ++s->mismatches;
+  }
+  if (s->repeats < 1) pthread_barrier_wait(s->start);
+  s->failed = !ready;
+  kvz_hip_free(d_pic); kvz_hip_free(d_ref); kvz_hip_free_host(h_pus); kvz_hip_free_host(h_res);
+  if (st) kvz_hip_stream_destroy(st);
+  return NULL;
+}
+
+static int run_sessions(int S, session_t proto)
+{
+  pthread_t *th = calloc((size_t)S, sizeof(*th));
+  session_t *ss = calloc((size_t)S, sizeof(*ss));
+  pthread_barrier_t start;
+  pthread_barrier_init(&start, NULL, (unsigned)S + 1);
+  proto.start = &start;
+  proto.device = kvz_hip_get_device();
+  for (int i = 0; i < S; ++i) { ss[i] = proto; if (pthread_create(&th[i], NULL, session_main, &ss[i])) { perror("pthread_create"); return 2; } }
+  pthread_barrier_wait(&start);
+  const double t0 = now_s();
+  for (int i = 0; i < S; ++i) pthread_join(th[i], NULL);
+  const double wall = now_s() - t0;
+  long mism = 0; int failed = 0; double slowest = 0;
+  for (int i = 0; i < S; ++i) { mism += ss[i].mismatches; failed |= ss[i].failed; if (ss[i].seconds > slowest) slowest = ss[i].seconds; }
+  const double frames = (double)S * proto.repeats;
+  printf("{\"what\": \"search only, fronts, %d host threads each replaying the frame on its own stream (NOT an encoder)\", \"sessions\": %d, "
+         "\"size_class_hint\": %d, \"frame\": \"%dx%d\", \"searches\": %d, \"fronts\": %d, \"frames_per_session\": %d, \"mismatches_vs_recorded\": %ld, "
+         "\"wall_s\": %.4f, \"aggregate_frames_per_s\": %.2f, \"aggregate_searches_per_s\": %.0f, \"ms_per_frame_in_a_session\": %.3f, "
+         "\"us_per_front_in_a_session\": %.2f, \"device\": \"%s\"}\n",
+         S, S, proto.hint, proto.w, proto.h, proto.n, proto.ng, proto.repeats, mism, wall, frames / wall, frames * proto.n / wall,
+         slowest * 1e3 / proto.repeats, slowest * 1e6 / proto.repeats / proto.ng, kvz_hip_device_name());
+  free(th); free(ss);
+  return (mism || failed) ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
-  if (argc < 2) { fprintf(stderr, "usage: front_replay FILE [repeats] [size-class hint 0/1]\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: front_replay FILE [repeats] [size-class hint 0/1] [sessions]\n"); return 2; }
   const int repeats = argc > 2 ? atoi(argv[2]) : 3;
   const int hint = argc > 3 ? atoi(argv[3]) : 1;
+  const int sessions = argc > 4 ? atoi(argv[4]) : 1;
   FILE *f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 2; }
   int32_t hdr[4];                                     /* width, height, PUs, fronts */
@@ -37,6 +123,11 @@ int main(int argc, char **argv)
   fclose(f);
 
   if (kvz_hip_init(-1) != KVZ_HIP_OK) DIE("kvz_hip_init");
+  if (sessions > 1) {
+    if (sessions > 64 || repeats < 1) { fprintf(stderr, "sessions 2..64, repeats >= 1\n"); return 2; }
+    session_t proto = { w, h, n, ng, repeats, hint, 0, pic, ref, &prm, pus, want, off, NULL, 0.0, 0, 0 };
+    return run_sessions(sessions, proto);
+  }
   kvz_hip_stream st = kvz_hip_stream_create();
   uint8_t *d_pic = kvz_hip_malloc((size_t)w * h), *d_ref = kvz_hip_malloc((size_t)w * h);
   kvz_hip_me_pu *d_pus = kvz_hip_malloc((size_t)n * sizeof(*pus));

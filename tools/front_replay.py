@@ -4,7 +4,7 @@ by front in the encoder's dependency order (tools/front_replay.c does the timed 
 from tests/golden/fronts.npz -- or from a fresh recording with --live when oracle/_ref is present -- builds the C program and
 prints its JSON line).  Not an encoder: labelled "search only, fronts" wherever it is quoted.
 
-  python3 tools/front_replay.py [--live FRAMES] [--repeats N]"""
+  python3 tools/front_replay.py [--live FRAMES] [--repeats N] [--sessions 2,4,8,16]"""
 import argparse
 import os
 import struct
@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def build():
     exe = os.path.join(ROOT, "tools", "front_replay")
-    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "front_replay.c"),
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "front_replay.c"),
                            "-o", exe, "-L" + os.path.join(ROOT, "kvazaar_amd"), "-lkvzhip", "-Wl,-rpath," + os.path.join(ROOT, "kvazaar_amd")])
     return exe
 
@@ -42,6 +42,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--live", type=int, default=0, help="record a fresh 1080p encode of this many frames with oracle/_ref instead of the fixture")
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--keep-case", default="", help="also leave the first frame's input file here (to run tools/front_replay under rocprofv3)")
+    ap.add_argument("--sessions", default="", help="comma list, e.g. 2,4,8,16: also replay with that many host threads at once")
     args = ap.parse_args()
     from patterns import fronts_fixture
     exe = build()
@@ -64,7 +66,13 @@ def main():
         write_case(path, *c)
         for hint in (1, 0):
             sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats), str(hint)], text=True))
-        os.remove(path)
+        for k in [int(v) for v in args.sessions.split(",") if v]:
+            sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats), "1", str(k)], text=True))
+            sys.stdout.flush()
+        if i == 0 and args.keep_case:
+            os.replace(path, args.keep_case)
+        else:
+            os.remove(path)
 
 
 if __name__ == "__main__":
