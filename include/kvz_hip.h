@@ -86,7 +86,9 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * qr32}_wgs_per_cu" (workgroups per CU of the streaming grids),
  * "qr4_lane_kernel", "qr8_reg_kernel", "qr_tile_kernel" (0: the LDS butterfly kernel instead of the register / matrix-core ones), "dct4_tile" (0: the LDS butterfly kernel for 4x4 transforms), "sao_edge_fast" (0/1),
  * "intra_rough_waves" (4/8 waves per workgroup of the rough search), "pair_wave_kernel" (0/1: one wave per
- * descriptor for frame-level pair batches of up to 4096 descriptors).
+ * descriptor for frame-level pair batches of up to 4096 descriptors), "wg_chunk_min_wgs" (the workgroup-per-descriptor
+ * kernels of the sampling / fractional search entries take up to 64 descriptors per workgroup once the list would give
+ * more workgroups than this; 0: always one).
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
  * knobs at kvz_hip_init() for A/B runs of an unmodified host. */
 KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);
