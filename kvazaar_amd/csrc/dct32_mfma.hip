@@ -140,8 +140,11 @@ int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipSt
   // dispatcher as waves retire -- are faster and steadier: forward 4: 5.81, 32: 5.94, 64: 6.24, 96: 6.35, 128: 6.33, 160: 6.00 TB/s;
   // inverse 8: 5.53, 32: 5.84, 64: 5.69, 128: 5.48 (0.5 GiB arrays, tools/bench_all.py --tune).  With the per-lane constants
   // precomputed (five vector loads per wave) the optimum moved out further: forward 96: 6.27, 192: 6.39, 256: 6.41 (one block
-  // per wave at this size); inverse 32: 5.83, 64: 6.07, 128: 6.17, 256: 5.29.
-  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 96) : tuning("dct32_wgs_per_cu", 192));
+  // per wave at this size); inverse 32: 5.83, 64: 6.07, 128: 6.17, 256: 5.29.  On the four times larger 4K batch of bench.py's shard
+  // leg (1 029 120 blocks) the forward kernel confirmed that what it wants is ONE BLOCK PER WAVE at any size, not a number of
+  // workgroups per CU: cap 192: 5.77, 384: 5.90, 768: 6.07, 1100 (no wave takes a second block): 6.14 TB/s -- so the forward cap only
+  // bounds the grid for lists beyond 4 M blocks.
+  const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 96) : tuning("dct32_wgs_per_cu", 4096));
   if (wgs > cap) wgs = cap;
   if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<32, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   else hipLaunchKernelGGL((dct32_mfma_kernel<32, false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
