@@ -18,7 +18,7 @@ import json
 import os
 import sys
 
-NAMES = {"sad_nxn_kernel<8": "sad_8x8", "satd8_kernel": "satd_8x8", "dct32_mfma_kernel<false>": "dct_32x32"}
+NAMES = {"sad_nxn_kernel<8": "sad_8x8", "satd8_kernel": "satd_8x8", "dct32_mfma_kernel<32, false": "dct_32x32"}
 
 
 def collect(d, counter):
