@@ -411,6 +411,66 @@ KVZ_HIP_API int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_s
                                         const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
                                         kvz_hip_me_result *results, kvz_hip_stream s);
 
+/* ---- candidate derivation next to the search: what a host derives between two dependency fronts ---- */
+/* One record per 4x4 SCU, row-major: the fields of cu_info_t (cu.h:117-153) the candidate derivation and the
+ * deblocking filter (below) read.  Inter CUs carry mv_dir 1..3. */
+typedef struct {
+  uint8_t type;                 /* cu_type_t: CU_INTRA 1, CU_INTER 2 (cu.h:38-43) */
+  uint8_t depth, part_size, tr_depth;
+  uint8_t cbf_y;                /* cbf_is_set(cu->cbf, cu->tr_depth, COLOR_Y) (cu.h:504-507) */
+  uint8_t mv_dir;               /* inter.mv_dir */
+  uint8_t qp;                   /* cu->qp */
+  uint8_t reserved;
+  int16_t mv[2][2];             /* inter.mv */
+  uint8_t mv_ref[2];            /* inter.mv_ref */
+  uint8_t pad[2];
+} kvz_hip_cu_info;              /* 20 bytes */
+/* What kvz_inter_get_mv_cand / kvz_inter_get_merge_cand (inter.c:1209-1446) read of the encoder state. */
+typedef struct {
+  int32_t poc;                   /* state->frame->poc */
+  int32_t slice_is_b;            /* state->frame->slicetype == KVZ_SLICE_B */
+  int32_t tmvp_enable;           /* cfg.tmvp_enable */
+  int32_t num_refs;              /* state->frame->ref->used_size, 0..16 */
+  int32_t ref_pocs[16];          /* state->frame->ref->pocs */
+  uint8_t ref_LX[2][16];         /* state->frame->ref_LX (encoderstate.h:100) */
+  uint8_t ref_LX_size[2];        /* state->frame->ref_LX_size */
+  uint8_t pad[2];
+  int32_t col_ref_pocs[16];      /* state->frame->ref->images[c]->ref_pocs, c = ref_LX[0][0]: the collocated picture (inter.c:1020-1055) */
+  uint8_t col_ref_LX[2][16];     /* state->frame->ref->ref_LXs[c] */
+  int32_t pic_width, pic_height; /* state->tile->frame->width / height; PU coordinates are relative to this (tile) picture */
+  int32_t in_width, in_height;   /* encoder_control->in.width / height: the bounds of the temporal neighbours (inter.c:747,763) */
+  int32_t tile_x, tile_y;        /* state->tile->offset_x / _y: added only by the start vector's lookup (search_inter.c:1193-1194) */
+  int32_t ref_idx;               /* info->ref_idx: the picture of state->frame->ref about to be searched */
+  int32_t cus_stride;            /* records per row of cus */
+  int32_t col_stride;            /* records per row of col_cus / ref_cus (cu_array_t: the picture width rounded up to whole LCUs, / 4) */
+  int32_t reserved;
+} kvz_hip_inter_params;          /* 252 bytes */
+/* inter_merge_cand_t (inter.h:36-41) */
+typedef struct {
+  uint8_t dir;                   /* 1 L0, 2 L1, 3 both */
+  uint8_t ref[2];                /* index in L0 / L1 */
+  uint8_t pad;
+  int16_t mv[2][2];
+} kvz_hip_merge_cand;            /* 12 bytes */
+/* Completes the search descriptors of `count` PUs on the device -- everything search_pu_inter and
+ * search_pu_inter_ref derive before the search of picture params->ref_idx (search_inter.c:1470-1500, :1143-1206):
+ *   in : pus[i].x, y, width, height (any PU shape of the inter search) and pus[i].pad: bit 0 = merge candidate A1
+ *        barred, bit 1 = B1 barred (the second PU of a two-PU CU, search_inter.c:1470-1475);
+ *   out: pus[i].num_merge_cand and merge[] (kvz_inter_get_merge_cand, inter.c:1314-1446, seen as calc_mvd_cost sees
+ *        it), mv_cand (kvz_inter_get_mv_cand, inter.c:1209-1240, for the list and index that hold ref_idx),
+ *        extra_mv (the vector of the CU of picture ref_idx under the PU's centre, search_inter.c:1190-1206);
+ *        merge_out (DEVICE, 5 per PU, may be NULL): the full inter_merge_cand_t list for the merge / skip evaluation.
+ * cus = the current (tile) picture's CUs, one kvz_hip_cu_info per 4x4 SCU, holding what lcu->cu holds while its LCU
+ * is searched: the decided neighbours (type 0 = not coded yet; of a record only type, mv_dir, mv, mv_ref are read);
+ * col_cus = the CUs of the collocated picture ref_LX[0][0] (needed when tmvp_enable and num_refs > 0), ref_cus = those
+ * of picture ref_idx (may be NULL: extra_mv 0), both whole-picture arrays.  params is a HOST struct.  A descriptor
+ * outside the picture or off the 4-pixel grid gets num_merge_cand -1.  The results feed kvz_hip_search_pu_batch on
+ * the same stream: with the CU arrays resident, a dependency front costs no host round trip for its candidates. */
+KVZ_HIP_API int kvz_hip_inter_candidates_batch(const kvz_hip_cu_info *cus, const kvz_hip_cu_info *col_cus, const kvz_hip_cu_info *ref_cus,
+                                               const kvz_hip_inter_params *params, kvz_hip_me_pu *pus, size_t count,
+                                               kvz_hip_merge_cand *merge_out, kvz_hip_stream s);
+
+
 /* Bi-prediction candidate cost of search_pu_inter_bipred (search_inter.c:1304-1440): for candidate i the luma of
  * kvz_inter_recon_bipred (inter.c:430-477; a 14-bit quarter-pel sample per reference when its vector is fractional,
  * else the edge-clamped pixels << 6, blended and clipped) scored with kvz_satd_any_size against the source block
@@ -532,19 +592,8 @@ KVZ_HIP_API int kvz_hip_sao_reconstruct_color_batch(const kvz_hip_pixel *rec, ui
 /*   every LCU (encoderstate.c:579-616), with filter.c:83-768 below it */
 /*   SURVEY.md section 8(f) row 4                                      */
 /* ------------------------------------------------------------------ */
-/* One record per 4x4 SCU, row-major, ceil(width / 4) records per row: the fields
- * of cu_info_t (cu.h:117-153) the filter reads.  Inter CUs carry mv_dir 1..3. */
-typedef struct {
-  uint8_t type;                 /* cu_type_t: CU_INTRA 1, CU_INTER 2 (cu.h:38-43) */
-  uint8_t depth, part_size, tr_depth;
-  uint8_t cbf_y;                /* cbf_is_set(cu->cbf, cu->tr_depth, COLOR_Y) (cu.h:504-507) */
-  uint8_t mv_dir;               /* inter.mv_dir */
-  uint8_t qp;                   /* cu->qp */
-  uint8_t reserved;
-  int16_t mv[2][2];             /* inter.mv */
-  uint8_t mv_ref[2];            /* inter.mv_ref */
-  uint8_t pad[2];
-} kvz_hip_cu_info;              /* 20 bytes */
+/* cus: kvz_hip_cu_info records (defined with the candidate derivation above), one per 4x4 SCU, row-major,
+ * ceil(width / 4) records per row. */
 typedef struct {
   int32_t beta_offset_div2;     /* cfg.deblock_beta */
   int32_t tc_offset_div2;       /* cfg.deblock_tc */

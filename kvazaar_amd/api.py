@@ -318,6 +318,25 @@ def intra_rough_batch(refs, log2_width, orig, flags=INTRA_LUMA | INTRA_FILTER_BO
     return (a, sad.to_numpy(np.uint32, (count, 35))) if with_sad else a
 
 
+# ---- AMVP / merge candidates of whole PUs ----
+def inter_candidates_batch(params, cus, col_cus, ref_cus, pus):
+    """kvz_hip_inter_candidates_batch: params = one kvz_hip_inter_params record (252 bytes), cus / col_cus / ref_cus = 2-D arrays of
+    kvz_hip_cu_info records (20 bytes), pus = kvz_hip_me_pu records with x, y, width, height, pad set.  Returns (the completed
+    descriptors as bytes [count, 64], the merge lists as bytes [count, 5, 12])."""
+    L = _lib.init()
+    params = np.ascontiguousarray(params)
+    assert params.nbytes == 252
+    pus = np.ascontiguousarray(pus)
+    count = pus.shape[0]
+    a, u = DeviceBuffer.from_numpy(np.ascontiguousarray(cus)), DeviceBuffer.from_numpy(pus)
+    b = DeviceBuffer.from_numpy(np.ascontiguousarray(col_cus)) if col_cus is not None else None
+    c = DeviceBuffer.from_numpy(np.ascontiguousarray(ref_cus)) if ref_cus is not None else None
+    m = DeviceBuffer(max(1, 60 * count))
+    check(L.kvz_hip_inter_candidates_batch(a.ptr, b.ptr if b else None, c.ptr if c else None, params.ctypes.data, u.ptr, count, m.ptr, None),
+          "inter_candidates batch")
+    return u.to_numpy(np.uint8, (count, 64)), m.to_numpy(np.uint8, (count, 5, 12))
+
+
 # ---- motion search of whole PUs ----
 def search_pu_batch(pic, ref, pus, params, cabac=None):
     """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (88 bytes).

@@ -168,6 +168,19 @@ def intra_ref():
     np.savez_compressed(os.path.join(OUT, "intra_ref.npz"), **d)
 
 
+def inter_cand():
+    """kvz_inter_get_merge_cand / kvz_inter_get_mv_cand / the start vector of search_pu_inter_ref (oracle/ref_harness.c:
+    ref_inter_candidates) for every inter PU of seeded random CU maps: P and B slices, one to four references, POC distances up
+    to the scaling clamp, TMVP on and off, a tile"""
+    from patterns import INTER_CAND_CONFIGS, inter_cand_case
+    d = {}
+    for (name, *_rest) in INTER_CAND_CONFIGS:
+        p, cus, col, refm, pus = inter_cand_case(name, 0)
+        out_pus, out_merge = R.inter_candidates(p, cus, col, refm, pus)
+        d[name + "_out_pus"], d[name + "_out_merge"] = out_pus, out_merge
+    np.savez_compressed(os.path.join(OUT, "inter_cand.npz"), **d)
+
+
 def sao():
     g = rng(SEED + 5)
     d = {}
@@ -273,7 +286,7 @@ if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, intra_ref=intra_ref, sao=sao, me=me, deblock=deblock, fronts=fronts)
+    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, intra_ref=intra_ref, inter_cand=inter_cand, sao=sao, me=me, deblock=deblock, fronts=fronts)
     for name in (sys.argv[1:] or list(groups)):          # python oracle/gen_golden.py [group ...]
         groups[name]()
     for f in sorted(os.listdir(OUT)):

@@ -1847,3 +1847,263 @@ void orc_quantize_residual_many(const orc_quant_params *p, int cu_is_intra, int 
     has_coeffs[i] = orc_quantize_residual(p, cu_is_intra, width, color, scan_order, use_trskip, width, width,
                                           ref_in + i * bs, pred_in + i * bs, rec_out + i * bs, coeff_out + i * bs);
 }
+
+/* =====================================================================
+ * AMVP / merge candidate derivation (inter.c:546-1446), flattened state
+ * ===================================================================== */
+
+/* a neighbour counts when its CU is an inter CU (inter.c:822-870: type == CU_INTER); its unused list reads mv 0, ref 255
+ * (inter_clear_cu_unused, inter.c:546-555) */
+typedef struct { int ok; int dir; int mv[2][2]; int ref[2]; } cand_view;
+
+static cand_view cand_at(const orc_cu_info *map, int stride, int x, int y)
+{
+  cand_view v;
+  memset(&v, 0, sizeof(v));
+  const orc_cu_info *c = &map[(y >> 2) * stride + (x >> 2)];
+  if (c->type != 2) return v;
+  v.ok = 1; v.dir = c->mv_dir;
+  for (int l = 0; l < 2; ++l) {
+    const int used = (c->mv_dir >> l) & 1;
+    v.mv[l][0] = used ? c->mv[l][0] : 0;
+    v.mv[l][1] = used ? c->mv[l][1] : 0;
+    v.ref[l] = used ? c->mv_ref[l] : 255;
+  }
+  return v;
+}
+
+/* is_a0_cand_coded / is_b0_cand_coded (inter.c:566-705) from first principles: the neighbour's 4x4 unit precedes, in the
+ * LCU's coding order, the aligned square at the PU's lower-left (A0) / upper-right (B0) corner whose side is the largest
+ * power of two dividing both PU dimensions; everything left of or above the LCU is coded. */
+static int corner_unit_coded(int nx, int ny, int sx, int sy)
+{
+  if ((nx >> 6) != (sx >> 6) || (ny >> 6) != (sy >> 6)) return nx < sx || ny < sy;
+  return intra_unit_order((unsigned)(nx & 63) >> 2, (unsigned)(ny & 63) >> 2) < intra_unit_order((unsigned)(sx & 63) >> 2, (unsigned)(sy & 63) >> 2);
+}
+
+typedef struct { cand_view a[2], b[3], tmp; } cand_set;    /* a0 a1 / b0 b1 b2 / the temporal one (H, else C3) */
+
+/* get_spatial_merge_candidates (inter.c:799-875) */
+static void spatial_cands(const orc_cu_info *cus, const orc_inter_params *p, int x, int y, int w, int h, cand_set *s)
+{
+  const int side = ((w & -w) < (h & -h)) ? (w & -w) : (h & -h);
+  const int xl = x & 63, yl = y & 63;
+  memset(s, 0, sizeof(*s));
+  if (x != 0) {
+    s->a[1] = cand_at(cus, p->cus_stride, x - 1, y + h - 1);
+    if (yl + h < 64 && y + h < p->pic_height && corner_unit_coded(x - 1, y + h, x, y + h - side))
+      s->a[0] = cand_at(cus, p->cus_stride, x - 1, y + h);
+  }
+  if (y != 0) {
+    if (x + w < p->pic_width && (xl + w < 64 || yl == 0) && corner_unit_coded(x + w, y - 1, x + w - side, y))
+      s->b[0] = cand_at(cus, p->cus_stride, x + w, y - 1);
+    s->b[1] = cand_at(cus, p->cus_stride, x + w - 1, y - 1);
+    if (x != 0) s->b[2] = cand_at(cus, p->cus_stride, x - 1, y - 1);
+  }
+}
+
+/* get_temporal_merge_candidates (inter.c:713-780) with ref_list 1, ref_idx 0 as every caller passes: H below-right of the
+ * PU unless that starts a new LCU row, else / otherwise C3 at the centre, both on the 16x16 grid of the collocated picture */
+static void temporal_cand(const orc_cu_info *col, const orc_inter_params *p, int x, int y, int w, int h, cand_set *s)
+{
+  memset(&s->tmp, 0, sizeof(s->tmp));
+  if (!p->num_refs || p->ref_LX_size[0] == 0 || !col) return;
+  const int bx = x + w, by = y + h, cx = x + w / 2, cy = y + h / 2;
+  cand_view hh, c3;
+  memset(&hh, 0, sizeof(hh)); memset(&c3, 0, sizeof(c3));
+  if (bx < p->in_width && by < p->in_height && (by & 63) != 0) hh = cand_at(col, p->col_stride, bx & ~15, by & ~15);
+  if (cx < p->in_width && cy < p->in_height) c3 = cand_at(col, p->col_stride, cx & ~15, cy & ~15);
+  s->tmp = hh.ok ? hh : c3;
+}
+
+/* apply_mv_scaling_pocs + get_scaled_mv (inter.c:955-980) */
+static void scale_mv(int cur_poc, int cur_ref_poc, int nb_poc, int nb_ref_poc, int mv[2])
+{
+  int dc = cur_poc - cur_ref_poc, dn = nb_poc - nb_ref_poc;
+  if (dc == dn || dn == 0) return;                      /* dn == 0: the reference divides by zero (a picture referencing itself) */
+  dc = dc < -128 ? -128 : dc > 127 ? 127 : dc;
+  dn = dn < -128 ? -128 : dn > 127 ? 127 : dn;
+  int scale = (dc * ((0x4000 + (abs(dn) >> 1)) / dn) + 32) >> 6;
+  scale = scale < -4096 ? -4096 : scale > 4095 ? 4095 : scale;
+  for (int k = 0; k < 2; ++k) {
+    const int prod = scale * (int16_t)mv[k];
+    const int v = (prod + 127 + (prod < 0)) >> 8;
+    mv[k] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+  }
+}
+
+/* add_temporal_candidate (inter.c:1011-1061): the collocated PU's vector of the list that points away from the current
+ * picture's future (L1 as soon as any reference lies in the future), else its other list, scaled by the POC distances */
+static int temporal_mv(const orc_inter_params *p, const cand_view *c, int cur_ref, int reflist, int out[2])
+{
+  if (!c->ok || p->ref_LX_size[0] == 0) return 0;
+  const int col_pic = p->ref_LX[0][0];
+  int l = reflist;
+  for (int i = 0; i < p->num_refs; ++i) if (p->ref_pocs[i] > p->poc) { l = 1; break; }
+  if (!(c->dir & (l + 1))) l = 1 - l;
+  out[0] = c->mv[l][0]; out[1] = c->mv[l][1];
+  scale_mv(p->poc, p->ref_pocs[cur_ref], p->ref_pocs[col_pic], p->col_ref_pocs[p->col_ref_LX[l][c->ref[l] & 15]], out);
+  return 1;
+}
+
+/* add_mvp_candidate (inter.c:1063-1098): list `reflist` of the neighbour first, then the other one */
+static int mvp_from(const orc_inter_params *p, const cand_view *c, int reflist, int cur_pic, int scaling, int out[2])
+{
+  if (!c->ok) return 0;
+  for (int i = 0; i < 2; ++i) {
+    const int l = i == 0 ? reflist : !reflist;
+    if (!(c->dir & (1 << l))) continue;
+    const int nb_pic = p->ref_LX[l][c->ref[l] & 15];
+    if (scaling) {
+      out[0] = c->mv[l][0]; out[1] = c->mv[l][1];
+      scale_mv(p->poc, p->ref_pocs[cur_pic], p->poc, p->ref_pocs[nb_pic], out);
+      return 1;
+    }
+    if (nb_pic == cur_pic) { out[0] = c->mv[l][0]; out[1] = c->mv[l][1]; return 1; }
+  }
+  return 0;
+}
+
+void orc_inter_get_mv_cand(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_inter_params *p,
+                           int x, int y, int width, int height, int reflist, int lx_idx, int16_t mv_cand[2][2])
+{
+  cand_set s;
+  spatial_cands(cus, p, x, y, width, height, &s);
+  temporal_cand(col_cus, p, x, y, width, height, &s);
+  const int cur_pic = p->ref_LX[reflist][lx_idx];
+  int mv[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, n = 0;
+  /* get_mv_cand_from_candidates (inter.c:1102-1195).  Left: the first of A0, A1 that points at the same picture, else
+   * the first that has a vector at all, scaled */
+  for (int sc = 0; sc < 2 && n == 0; ++sc)
+    for (int i = 0; i < 2; ++i) if (mvp_from(p, &s.a[i], reflist, cur_pic, sc, mv[n])) { ++n; break; }
+  /* above: the first of B0, B1, B2 pointing at the same picture ... */
+  int above = 0;
+  for (int i = 0; i < 3; ++i) if (mvp_from(p, &s.b[i], reflist, cur_pic, 0, mv[n])) { above = 1; break; }
+  n += above;
+  /* ... and a scaled one only when there is no left neighbour at all and the list is still short */
+  if (s.a[0].ok || s.a[1].ok) above = 1; else if (n != 2) above = 0;
+  if (!above)
+    for (int i = 0; i < 3; ++i) if (mvp_from(p, &s.b[i], reflist, cur_pic, 1, mv[n])) { ++n; break; }
+  if (n == 2 && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) n = 1;
+  if (p->tmvp_enable && p->poc > 1 && p->num_refs && n < 2 && s.tmp.ok && temporal_mv(p, &s.tmp, cur_pic, reflist, mv[n])) ++n;
+  for (; n < 2; ++n) mv[n][0] = mv[n][1] = 0;
+  for (int i = 0; i < 2; ++i) { mv_cand[i][0] = (int16_t)mv[i][0]; mv_cand[i][1] = (int16_t)mv[i][1]; }
+}
+
+/* is_duplicate_candidate (inter.c:1262-1278) */
+static int same_motion(const cand_view *a, const cand_view *b)
+{
+  if (!b->ok || a->dir != b->dir) return 0;
+  for (int l = 0; l < 2; ++l)
+    if ((a->dir >> l) & 1)
+      if (a->mv[l][0] != b->mv[l][0] || a->mv[l][1] != b->mv[l][1] || a->ref[l] != b->ref[l]) return 0;
+  return 1;
+}
+
+static int merge_push(const cand_view *c, const cand_view *d1, const cand_view *d2, orc_merge_cand *o)
+{
+  if (!c->ok || (d1 && same_motion(c, d1)) || (d2 && same_motion(c, d2))) return 0;
+  for (int l = 0; l < 2; ++l) { o->mv[l][0] = (int16_t)c->mv[l][0]; o->mv[l][1] = (int16_t)c->mv[l][1]; o->ref[l] = (uint8_t)c->ref[l]; }
+  o->dir = (uint8_t)c->dir;
+  return 1;
+}
+
+int orc_inter_get_merge_cand(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_inter_params *p,
+                             int x, int y, int width, int height, int use_a1, int use_b1, orc_merge_cand out[5])
+{
+  cand_set s;
+  int n = 0;
+  memset(out, 0, 5 * sizeof(out[0]));
+  spatial_cands(cus, p, x, y, width, height, &s);
+  if (!use_a1) s.a[1].ok = 0;
+  if (!use_b1) s.b[1].ok = 0;
+  /* inter.c:1338-1343: A1, B1, B0, A0, B2 with the pairwise duplicate checks of the standard */
+  n += merge_push(&s.a[1], NULL, NULL, &out[n]);
+  n += merge_push(&s.b[1], &s.a[1], NULL, &out[n]);
+  n += merge_push(&s.b[0], &s.b[1], NULL, &out[n]);
+  n += merge_push(&s.a[0], &s.a[1], NULL, &out[n]);
+  if (n < 4) n += merge_push(&s.b[2], &s.a[1], &s.b[1], &out[n]);
+  /* the temporal candidate always points at index 0 of a list (inter.c:1345-1375) */
+  if (p->tmvp_enable && n < 5 && p->num_refs) {
+    temporal_cand(col_cus, p, x, y, width, height, &s);
+    out[n].dir = 0;
+    for (int l = 0; l <= (p->slice_is_b ? 1 : 0); ++l) {
+      int mv[2];
+      if (temporal_mv(p, &s.tmp, p->ref_LX[l][0], l, mv)) {
+        out[n].mv[l][0] = (int16_t)mv[0]; out[n].mv[l][1] = (int16_t)mv[1];
+        out[n].ref[l] = 0;
+        out[n].dir |= (uint8_t)(1 << l);
+      }
+    }
+    if (out[n].dir) ++n;
+  }
+  /* B slices: pairs of an L0 and an L1 motion of the candidates so far (inter.c:1377-1413) */
+  if (n < 5 && p->slice_is_b) {
+    static const uint8_t first[12] = { 0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3 }, second[12] = { 1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2 };
+    const int cutoff = n;
+    for (int k = 0; k < cutoff * (cutoff - 1) && n != 5; ++k) {
+      const int i = first[k], j = second[k];
+      if (i >= n || j >= n) break;
+      if (!(out[i].dir & 1) || !(out[j].dir & 2)) continue;
+      out[n].dir = 3;
+      out[n].mv[0][0] = out[i].mv[0][0]; out[n].mv[0][1] = out[i].mv[0][1];
+      out[n].mv[1][0] = out[j].mv[1][0]; out[n].mv[1][1] = out[j].mv[1][1];
+      out[n].ref[0] = out[i].ref[0]; out[n].ref[1] = out[j].ref[1];
+      const int same = p->ref_LX[0][out[i].ref[0] & 15] == p->ref_LX[1][out[j].ref[1] & 15] &&
+                       out[i].mv[0][0] == out[j].mv[1][0] && out[i].mv[0][1] == out[j].mv[1][1];
+      if (!same) ++n;
+    }
+  }
+  /* zero vectors over the reference indices (inter.c:1415-1443) */
+  int num_ref = p->num_refs;
+  if (n < 5 && p->slice_is_b) {
+    int before = 0, after = 0;
+    for (int j = 0; j < p->num_refs; ++j) { if (p->ref_pocs[j] < p->poc) ++before; else ++after; }
+    num_ref = before < after ? before : after;
+  }
+  for (int zero_idx = 0; n != 5; ++zero_idx, ++n) {
+    out[n].mv[0][0] = out[n].mv[0][1] = 0;
+    out[n].ref[0] = (uint8_t)(zero_idx >= num_ref - 1 ? 0 : zero_idx);
+    out[n].ref[1] = out[n].ref[0];
+    out[n].dir = 1;
+    if (p->slice_is_b) { out[n].mv[1][0] = out[n].mv[1][1] = 0; out[n].dir = 3; }
+  }
+  return n;
+}
+
+void orc_inter_candidates(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_cu_info *ref_cus, const orc_inter_params *p,
+                          orc_me_pu *pus, size_t count, orc_merge_cand *merge_out)
+{
+  /* which list holds picture ref_idx, and where (search_pu_inter_ref, search_inter.c:1143-1166) */
+  int reflist = -1, lx = 0;
+  const int lx_max = p->ref_LX_size[0] > p->ref_LX_size[1] ? p->ref_LX_size[0] : p->ref_LX_size[1];
+  for (lx = 0; lx < lx_max; ++lx) {
+    if (lx < p->ref_LX_size[0] && p->ref_LX[0][lx] == p->ref_idx) { reflist = 0; break; }
+    if (lx < p->ref_LX_size[1] && p->ref_LX[1][lx] == p->ref_idx) { reflist = 1; break; }
+  }
+  for (size_t i = 0; i < count; ++i) {
+    orc_me_pu *u = &pus[i];
+    orc_merge_cand mc[5];
+    const int n = orc_inter_get_merge_cand(cus, col_cus, p, u->x, u->y, u->width, u->height, !(u->pad & 1), !(u->pad & 2), mc);
+    u->num_merge_cand = (int16_t)n;
+    for (int k = 0; k < 5; ++k) {
+      memset(&u->merge[k], 0, sizeof(u->merge[k]));
+      if (k >= n) continue;
+      u->merge[k].usable = mc[k].dir != 3;
+      if (mc[k].dir != 3) {
+        const int l = mc[k].dir - 1;
+        u->merge[k].mv[0] = mc[k].mv[l][0]; u->merge[k].mv[1] = mc[k].mv[l][1];
+        u->merge[k].same_ref = p->ref_LX[l][mc[k].ref[l] & 15] == p->ref_idx;
+      }
+    }
+    if (merge_out) memcpy(merge_out + 5 * i, mc, sizeof(mc));
+    memset(u->mv_cand, 0, sizeof(u->mv_cand));
+    if (reflist >= 0) orc_inter_get_mv_cand(cus, col_cus, p, u->x, u->y, u->width, u->height, reflist, lx, u->mv_cand);
+    /* the collocated CU's vector as one more start point (search_inter.c:1190-1206) */
+    u->extra_mv[0] = u->extra_mv[1] = 0;
+    if (ref_cus) {
+      const cand_view c = cand_at(ref_cus, p->col_stride, p->tile_x + u->x + (u->width >> 1), p->tile_y + u->y + (u->height >> 1));
+      if (c.ok) { const int l = (c.dir & 1) ? 0 : 1; u->extra_mv[0] = (int16_t)c.mv[l][0]; u->extra_mv[1] = (int16_t)c.mv[l][1]; }
+    }
+  }
+}

@@ -293,6 +293,49 @@ typedef struct {
 void orc_deblock_frame(orc_pixel *y, int stride_y, orc_pixel *u, orc_pixel *v, int stride_c, int width, int height,
                        const orc_cu_info *cus, const orc_deblock_params *prm);
 
+/* ---- AMVP / merge candidate derivation: src/inter.c:546-1446 (kvz_inter_get_mv_cand :1209-1240,
+ * kvz_inter_get_merge_cand :1314-1446) and the start vector of search_pu_inter_ref (search_inter.c:1190-1206).
+ * SURVEY.md section 8(f) row 1, the "driver" half: what a host has to derive between two dependency fronts.
+ * The encoder state is flattened: the current (tile) picture's CUs as one orc_cu_info per 4x4 SCU (what lcu->cu
+ * holds while an LCU is searched: decided neighbours, type 0 = not set), the collocated picture's the same way. */
+typedef struct {
+  int32_t poc;                   /* state->frame->poc */
+  int32_t slice_is_b;            /* state->frame->slicetype == KVZ_SLICE_B */
+  int32_t tmvp_enable;           /* cfg.tmvp_enable */
+  int32_t num_refs;              /* state->frame->ref->used_size */
+  int32_t ref_pocs[16];          /* state->frame->ref->pocs */
+  uint8_t ref_LX[2][16];         /* state->frame->ref_LX */
+  uint8_t ref_LX_size[2];        /* state->frame->ref_LX_size */
+  uint8_t pad[2];
+  int32_t col_ref_pocs[16];      /* state->frame->ref->images[c]->ref_pocs, c = ref_LX[0][0]: the collocated picture */
+  uint8_t col_ref_LX[2][16];     /* state->frame->ref->ref_LXs[c] */
+  int32_t pic_width, pic_height; /* state->tile->frame->width / height */
+  int32_t in_width, in_height;   /* encoder_control->in.width / height (bounds of the temporal candidates, inter.c:747,763) */
+  int32_t tile_x, tile_y;        /* state->tile->offset_x / _y: only the start vector's lookup adds them (search_inter.c:1193-1194) */
+  int32_t ref_idx;               /* info->ref_idx: which picture of state->frame->ref is searched */
+  int32_t cus_stride;            /* records per row of cus */
+  int32_t col_stride;            /* records per row of col_cus / ref_cus (cu_array_t: the width rounded up to whole LCUs / 4) */
+  int32_t reserved;
+} orc_inter_params;              /* 252 bytes */
+typedef struct {                 /* inter_merge_cand_t (inter.h:36-41) */
+  uint8_t dir;                   /* 1 L0, 2 L1, 3 both */
+  uint8_t ref[2];                /* index in L0 / L1 */
+  uint8_t pad;
+  int16_t mv[2][2];
+} orc_merge_cand;                /* 12 bytes */
+/* kvz_inter_get_mv_cand for the PU at (x, y) of the tile picture, list `reflist`, index `lx_idx` in that list */
+void orc_inter_get_mv_cand(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_inter_params *p,
+                           int x, int y, int width, int height, int reflist, int lx_idx, int16_t mv_cand[2][2]);
+/* kvz_inter_get_merge_cand; fields of `out` the reference leaves unwritten are zero */
+int orc_inter_get_merge_cand(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_inter_params *p,
+                             int x, int y, int width, int height, int use_a1, int use_b1, orc_merge_cand out[5]);
+/* What search_pu_inter + search_pu_inter_ref derive before the search of picture p->ref_idx, for every PU: in = x, y,
+ * width, height and pad (bit 0: A1 barred, bit 1: B1 barred -- the second PU of a two-PU CU, search_inter.c:1470-1475);
+ * out = mv_cand, extra_mv (ref_cus = the SCU map of picture ref_idx, may be NULL), num_merge_cand, merge[] as
+ * calc_mvd_cost reads them; merge_out (may be NULL) = the five inter_merge_cand_t per PU */
+void orc_inter_candidates(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_cu_info *ref_cus, const orc_inter_params *p,
+                          orc_me_pu *pus, size_t count, orc_merge_cand *merge_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -853,3 +853,157 @@ int ref_record_end(void *pus, void *results, void *meta, void *params, void *pic
   memset(&g_rec, 0, sizeof(g_rec));
   return n;
 }
+
+/* ------------------------------------------------------------------------
+ * AMVP / merge candidate derivation (inter.c:1209-1446) on a state fabricated from flat SCU maps: the counterpart of
+ * orc_inter_candidates (oracle/kvz_oracle.h) made of the reference's own kvz_inter_get_merge_cand /
+ * kvz_inter_get_mv_cand calls, in the order and with the arguments search_pu_inter / search_pu_inter_ref use
+ * (search_inter.c:1470-1500, :1143-1206).  The lcu_t of a PU is cut from the current picture's map the way lcu->cu is
+ * laid out (cu.h:324-344: the LCU's 16x16 SCUs, one row above, one column left, the corner, the top-right SCU).
+ * ------------------------------------------------------------------------ */
+typedef struct {                              /* = orc_cu_info / kvz_hip_cu_info */
+  uint8_t type, depth, part_size, tr_depth, cbf_y, mv_dir, qp, reserved;
+  int16_t mv[2][2];
+  uint8_t mv_ref[2], pad[2];
+} flat_cu_t;
+typedef struct {                              /* = orc_inter_params / kvz_hip_inter_params */
+  int32_t poc, slice_is_b, tmvp_enable, num_refs;
+  int32_t ref_pocs[16];
+  uint8_t ref_LX[2][16];
+  uint8_t ref_LX_size[2], pad[2];
+  int32_t col_ref_pocs[16];
+  uint8_t col_ref_LX[2][16];
+  int32_t pic_width, pic_height, in_width, in_height, tile_x, tile_y, ref_idx, cus_stride, col_stride, reserved;
+} flat_inter_params_t;
+typedef struct { uint8_t dir, ref[2], pad; int16_t mv[2][2]; } flat_merge_t;
+
+static void flat_to_cu(const flat_cu_t *f, cu_info_t *c)
+{
+  memset(c, 0, sizeof(*c));
+  c->type = f->type; c->depth = f->depth; c->part_size = f->part_size; c->tr_depth = f->tr_depth; c->qp = f->qp;
+  if (f->type == CU_INTER) {
+    memcpy(c->inter.mv, f->mv, sizeof(c->inter.mv));
+    c->inter.mv_ref[0] = f->mv_ref[0]; c->inter.mv_ref[1] = f->mv_ref[1];
+    c->inter.mv_dir = f->mv_dir;
+  }
+}
+
+static cu_array_t *flat_to_cua(const flat_cu_t *map, int stride, int rows)
+{
+  cu_array_t *a = calloc(1, sizeof(*a));
+  a->data = calloc((size_t)stride * rows, sizeof(cu_info_t));
+  a->width = stride * 4; a->height = rows * 4; a->stride = stride * 4; a->refcount = 1;
+  for (int i = 0; i < stride * rows; ++i) flat_to_cu(&map[i], &a->data[i]);
+  return a;
+}
+
+void ref_inter_candidates(const flat_cu_t *cus, const flat_cu_t *col_cus, const flat_cu_t *ref_cus, const flat_inter_params_t *p,
+                          rec_pu_t *pus, size_t count, flat_merge_t *merge_out)
+{
+  static encoder_control_t ctrl;
+  static encoder_state_t state;
+  static encoder_state_config_frame_t frame;
+  static encoder_state_config_tile_t tile;
+  static videoframe_t vframe;
+  static image_list_t refs;
+  static kvz_picture pics[16];
+  static kvz_picture *pic_ptr[16];
+  static cu_array_t *cuas[16];
+  static int32_t pocs[16];
+  static uint8_t ref_LXs[16][2][16];
+  memset(&ctrl, 0, sizeof(ctrl)); memset(&state, 0, sizeof(state)); memset(&frame, 0, sizeof(frame));
+  memset(&tile, 0, sizeof(tile)); memset(&vframe, 0, sizeof(vframe)); memset(&refs, 0, sizeof(refs));
+  memset(pics, 0, sizeof(pics)); memset(ref_LXs, 0, sizeof(ref_LXs));
+  ctrl.cfg.tmvp_enable = p->tmvp_enable;
+  ctrl.in.width = p->in_width; ctrl.in.height = p->in_height;
+  state.encoder_control = &ctrl; state.frame = &frame; state.tile = &tile;
+  tile.frame = &vframe; tile.offset_x = p->tile_x; tile.offset_y = p->tile_y;
+  vframe.width = p->pic_width; vframe.height = p->pic_height;
+  frame.poc = p->poc;
+  frame.slicetype = p->slice_is_b ? KVZ_SLICE_B : KVZ_SLICE_P;
+  memcpy(frame.ref_LX, p->ref_LX, sizeof(frame.ref_LX));
+  frame.ref_LX_size[0] = p->ref_LX_size[0]; frame.ref_LX_size[1] = p->ref_LX_size[1];
+  frame.ref = &refs;
+  refs.images = pic_ptr; refs.cu_arrays = cuas; refs.pocs = pocs; refs.ref_LXs = ref_LXs;
+  refs.size = 16; refs.used_size = (uint32_t)p->num_refs;
+  const int col_rows = ((p->in_height + 63) / 64) * 16;
+  const int col_pic = p->ref_LX_size[0] ? p->ref_LX[0][0] : -1;
+  cu_array_t *col_a = col_cus ? flat_to_cua(col_cus, p->col_stride, col_rows) : NULL;
+  cu_array_t *ref_a = ref_cus ? flat_to_cua(ref_cus, p->col_stride, col_rows) : NULL;
+  cu_array_t *empty = calloc(1, sizeof(*empty));
+  empty->data = calloc((size_t)p->col_stride * col_rows, sizeof(cu_info_t));
+  empty->width = p->col_stride * 4; empty->height = col_rows * 4; empty->stride = empty->width;
+  for (int i = 0; i < 16; ++i) {
+    pic_ptr[i] = &pics[i]; pocs[i] = p->ref_pocs[i];
+    cuas[i] = empty;
+  }
+  if (col_pic >= 0) {
+    if (col_a) cuas[col_pic] = col_a;
+    memcpy(pics[col_pic].ref_pocs, p->col_ref_pocs, sizeof(pics[col_pic].ref_pocs));
+    memcpy(ref_LXs[col_pic], p->col_ref_LX, sizeof(ref_LXs[col_pic]));
+  }
+  if (ref_a && p->ref_idx >= 0 && p->ref_idx < 16 && !(p->ref_idx == col_pic && col_a)) cuas[p->ref_idx] = ref_a;
+
+  /* search_pu_inter_ref :1143-1166 */
+  int8_t ref_list = -1, LX_idx;
+  const int8_t lx_max = MAX(frame.ref_LX_size[0], frame.ref_LX_size[1]);
+  for (LX_idx = 0; LX_idx < lx_max; LX_idx++) {
+    if (LX_idx < frame.ref_LX_size[0] && frame.ref_LX[0][LX_idx] == p->ref_idx) { ref_list = 0; break; }
+    if (LX_idx < frame.ref_LX_size[1] && frame.ref_LX[1][LX_idx] == p->ref_idx) { ref_list = 1; break; }
+  }
+
+  lcu_t *lcu = calloc(1, sizeof(lcu_t));
+  const int map_rows = (p->pic_height + 3) / 4;
+  for (size_t n = 0; n < count; ++n) {
+    rec_pu_t *u = &pus[n];
+    const int x = u->x, y = u->y, w = u->width, h = u->height;
+    const int ox = (x / LCU_WIDTH) * 16, oy = (y / LCU_WIDTH) * 16;     /* the LCU's first SCU */
+    memset(lcu->cu, 0, sizeof(lcu->cu));
+    for (int sy = -1; sy < 16; ++sy)
+      for (int sx = -1; sx < 16; ++sx) {
+        const int fx = ox + sx, fy = oy + sy;
+        if (fx < 0 || fy < 0 || fx >= p->cus_stride || fy >= map_rows) continue;
+        flat_to_cu(&cus[fy * p->cus_stride + fx], &lcu->cu[LCU_CU_OFFSET + sx + sy * LCU_T_CU_WIDTH]);
+      }
+    if (oy > 0 && ox + 16 < p->cus_stride) flat_to_cu(&cus[(oy - 1) * p->cus_stride + ox + 16], LCU_GET_TOP_RIGHT_CU(lcu));
+    cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
+
+    inter_merge_cand_t merge[MRG_MAX_NUM_CANDS];
+    memset(merge, 0, sizeof(merge));
+    const int n_merge = kvz_inter_get_merge_cand(&state, x, y, w, h, !(u->pad & 1), !(u->pad & 2), merge, lcu);
+    u->num_merge_cand = (int16_t)n_merge;
+    memset(u->merge, 0, sizeof(u->merge));
+    for (int i = 0; i < n_merge; ++i) {
+      const int dir = merge[i].dir;
+      u->merge[i].usable = dir != 3;
+      if (dir != 3) {
+        u->merge[i].mv[0] = merge[i].mv[dir - 1][0]; u->merge[i].mv[1] = merge[i].mv[dir - 1][1];
+        u->merge[i].same_ref = frame.ref_LX[dir - 1][merge[i].ref[dir - 1]] == p->ref_idx;
+      }
+    }
+    if (merge_out)
+      for (int i = 0; i < 5; ++i) {
+        flat_merge_t *o = &merge_out[5 * n + i];
+        memset(o, 0, sizeof(*o));
+        o->dir = merge[i].dir; o->ref[0] = merge[i].ref[0]; o->ref[1] = merge[i].ref[1];
+        memcpy(o->mv, merge[i].mv, sizeof(o->mv));
+      }
+    memset(u->mv_cand, 0, sizeof(u->mv_cand));
+    if (ref_list >= 0) {
+      cur_cu->inter.mv_ref[ref_list] = LX_idx;
+      kvz_inter_get_mv_cand(&state, x, y, w, h, u->mv_cand, cur_cu, lcu, ref_list);
+    }
+    u->extra_mv[0] = u->extra_mv[1] = 0;
+    if (ref_cus && p->ref_idx >= 0 && p->ref_idx < p->num_refs) {
+      const cu_info_t *ref_cu = kvz_cu_array_at_const(refs.cu_arrays[p->ref_idx], p->tile_x + x + (w >> 1), p->tile_y + y + (h >> 1));
+      if (ref_cu->type == CU_INTER) {
+        const int l = (ref_cu->inter.mv_dir & 1) ? 0 : 1;
+        u->extra_mv[0] = ref_cu->inter.mv[l][0]; u->extra_mv[1] = ref_cu->inter.mv[l][1];
+      }
+    }
+  }
+  free(lcu);
+  if (col_a) { free(col_a->data); free(col_a); }
+  if (ref_a) { free(ref_a->data); free(ref_a); }
+  free(empty->data); free(empty);
+}

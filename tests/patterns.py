@@ -394,3 +394,136 @@ def front_groups(meta):
     order = np.argsort(key, kind="stable")
     cuts = np.flatnonzero(np.diff(key[order])) + 1
     return np.split(order, cuts)
+
+
+# ---- AMVP / merge candidate derivation (inter.c:1209-1446): flattened encoder state ----
+INTER_PARAMS = np.dtype([("poc", "<i4"), ("slice_is_b", "<i4"), ("tmvp_enable", "<i4"), ("num_refs", "<i4"), ("ref_pocs", "<i4", (16,)),
+                         ("ref_LX", "u1", (2, 16)), ("ref_LX_size", "u1", (2,)), ("pad", "u1", (2,)), ("col_ref_pocs", "<i4", (16,)),
+                         ("col_ref_LX", "u1", (2, 16)), ("pic_width", "<i4"), ("pic_height", "<i4"), ("in_width", "<i4"),
+                         ("in_height", "<i4"), ("tile_x", "<i4"), ("tile_y", "<i4"), ("ref_idx", "<i4"), ("cus_stride", "<i4"),
+                         ("col_stride", "<i4"), ("reserved", "<i4")])
+MERGE_CAND = np.dtype([("dir", "u1"), ("ref", "u1", (2,)), ("pad", "u1"), ("mv", "<i2", (2, 2))])
+assert INTER_PARAMS.itemsize == 252 and MERGE_CAND.itemsize == 12
+
+
+def inter_params(w, h, poc=8, ref_pocs=(7,), l0=(0,), l1=(), slice_is_b=0, tmvp=1, ref_idx=0, col_ref_pocs=(6,), col_l0=(0,), col_l1=(),
+                 tile=(0, 0)):
+    """state->frame / state->tile / cfg fields kvz_inter_get_mv_cand and kvz_inter_get_merge_cand read.  ref_pocs = the pictures
+    of state->frame->ref, l0 / l1 = state->frame->ref_LX as indices into them; col_* describe the collocated picture
+    (ref_LX[0][0]): the POCs of ITS references and its two lists.  SCU maps are ceil(w / 64) * 16 records wide."""
+    p = np.zeros(1, dtype=INTER_PARAMS)
+    p["poc"], p["slice_is_b"], p["tmvp_enable"], p["num_refs"] = poc, slice_is_b, tmvp, len(ref_pocs)
+    p["ref_pocs"][0, :len(ref_pocs)] = ref_pocs
+    p["ref_LX"][0, 0, :len(l0)] = l0
+    p["ref_LX"][0, 1, :len(l1)] = l1
+    p["ref_LX_size"][0] = (len(l0), len(l1))
+    p["col_ref_pocs"][0, :len(col_ref_pocs)] = col_ref_pocs
+    p["col_ref_LX"][0, 0, :len(col_l0)] = col_l0
+    p["col_ref_LX"][0, 1, :len(col_l1)] = col_l1
+    p["pic_width"], p["pic_height"], p["in_width"], p["in_height"] = w, h, tile[0] + w, tile[1] + h
+    p["tile_x"], p["tile_y"], p["ref_idx"] = tile[0], tile[1], ref_idx
+    p["cus_stride"] = p["col_stride"] = ((tile[0] + w + 63) // 64) * 16
+    return p
+
+
+def inter_cu_map(w, h, seed, n_l0=1, n_l1=0, intra_share=0.2, unset_share=0.05):
+    """-> (cus [ceil(h/64)*16, ceil(w/64)*16] CU_INFO, PUs): a random quadtree of CUs 64..8 with every inter partition mode; each
+    PU carries its own motion (quarter-pel vectors from a small pool so that duplicates and equal AMVP candidates occur, and from a
+    wide range so that the POC scaling saturates), reference indices within the two list lengths; some CUs intra, some not set.
+    PUs = ME_PU records (x, y, width, height, pad = the barred merge neighbour of a CU's second PU) of every inter PU."""
+    g = np.random.default_rng(seed)
+    rows, stride = ((h + 63) // 64) * 16, ((w + 63) // 64) * 16
+    cus = np.zeros((rows, stride), dtype=CU_INFO)
+    pool = [(0, 0), (4, 0), (-5, 7), (12, -9), (-3, 1), (260, -120), (-32768, 32767), (32767, -32768)]
+    pus = []
+
+    def leaf(x, y, size, depth):
+        r = g.random()
+        if r < unset_share:
+            return
+        intra = r < unset_share + intra_share
+        part = 0
+        if not intra:
+            opts = [0, 0, 1, 2] + ([4, 5, 6, 7] if size >= 16 else [])
+            part = int(opts[int(g.integers(0, len(opts)))])
+        n_parts = (1, 2, 2, 4, 2, 2, 2, 2)[part]
+        offs = (((0, 0),), ((0, 0), (0, 2)), ((0, 0), (2, 0)), ((0, 0), (2, 0), (0, 2), (2, 2)), ((0, 0), (0, 1)), ((0, 0), (0, 3)),
+                ((0, 0), (1, 0)), ((0, 0), (3, 0)))[part]
+        sizes = (((4, 4),), ((4, 2), (4, 2)), ((2, 4), (2, 4)), ((2, 2),) * 4, ((4, 1), (4, 3)), ((4, 3), (4, 1)), ((1, 4), (3, 4)),
+                 ((3, 4), (1, 4)))[part]
+        for i in range(n_parts):
+            px, py = x + offs[i][0] * size // 4, y + offs[i][1] * size // 4
+            pw, ph = sizes[i][0] * size // 4, sizes[i][1] * size // 4
+            blk = cus[py // 4:(py + ph) // 4, px // 4:(px + pw) // 4]
+            blk["type"] = 1 if intra else 2
+            blk["depth"], blk["part_size"] = depth, part
+            if intra:
+                continue
+            d = int(g.integers(1, 4)) if n_l1 else 1
+            blk["mv_dir"] = d
+            for l, n in ((0, n_l0), (1, n_l1)):
+                mv = pool[int(g.integers(0, len(pool)))] if g.random() < 0.6 else tuple(int(v) for v in g.integers(-400, 401, 2))
+                blk["mv"][..., l, :] = mv                       # the unused list keeps a vector too: the derivation must ignore it
+                blk["mv_ref"][..., l] = int(g.integers(0, max(n, 1)))
+            if px + pw <= w and py + ph <= h:
+                barred = 0
+                if i > 0 and n_parts == 2:
+                    barred = 1 if pw < ph else 2            # second PU: A1 barred for the vertical splits, B1 for the horizontal ones
+                pus.append((px, py, pw, ph, barred))
+
+    def split(x, y, size, depth):
+        if x >= w or y >= h:
+            return
+        must = x + size > w or y + size > h
+        if size > 8 and (must or g.random() < (0.85, 0.6, 0.4)[depth]):
+            half = size // 2
+            for dy in (0, half):
+                for dx in (0, half):
+                    split(x + dx, y + dy, half, depth + 1)
+        else:
+            leaf(x, y, size, depth)
+
+    for ly in range(0, h, 64):
+        for lx in range(0, w, 64):
+            split(lx, ly, 64, 0)
+    out = np.zeros(len(pus), dtype=ME_PU)
+    for i, (px, py, pw, ph, barred) in enumerate(pus):
+        out[i]["x"], out[i]["y"], out[i]["width"], out[i]["height"], out[i]["pad"] = px, py, pw, ph, barred
+    return cus, out
+
+
+# (name, picture size, inter_params keywords, list lengths of the current and of the collocated picture's CUs)
+INTER_CAND_CONFIGS = [
+    ("p_one_ref", (168, 136), dict(poc=8, ref_pocs=(7,), l0=(0,), col_ref_pocs=(6,), col_l0=(0,)), (1, 0), (1, 0)),
+    ("p_no_tmvp", (128, 64), dict(poc=3, ref_pocs=(2,), l0=(0,), tmvp=0), (1, 0), (1, 0)),
+    ("p_second_frame", (72, 72), dict(poc=1, ref_pocs=(0,), l0=(0,), col_ref_pocs=(), col_l0=()), (1, 0), (0, 0)),
+    ("p_three_refs", (192, 136), dict(poc=12, ref_pocs=(11, 9, 4), l0=(0, 1, 2), ref_idx=1, col_ref_pocs=(9, 4, 2), col_l0=(0, 1, 2)), (3, 0), (3, 0)),
+    ("p_three_refs_far", (136, 128), dict(poc=200, ref_pocs=(199, 60, 2), l0=(0, 1, 2), ref_idx=2, col_ref_pocs=(60, 2), col_l0=(0, 1)), (3, 0), (2, 0)),
+    ("b_two_sided", (192, 136), dict(poc=4, ref_pocs=(0, 8), l0=(0, 1), l1=(1, 0), slice_is_b=1, ref_idx=1, col_ref_pocs=(8,), col_l0=(0,), col_l1=(0,)), (2, 2), (1, 1)),
+    ("b_lowdelay", (168, 72), dict(poc=9, ref_pocs=(8, 7, 4), l0=(0, 1, 2), l1=(0, 1, 2), slice_is_b=1, ref_idx=0, col_ref_pocs=(7, 4), col_l0=(0, 1), col_l1=(0, 1)), (3, 3), (2, 2)),
+    ("b_hier", (136, 136), dict(poc=6, ref_pocs=(4, 8, 0, 16), l0=(0, 2, 1), l1=(1, 3, 0), slice_is_b=1, ref_idx=3, col_ref_pocs=(0, 8), col_l0=(0, 1), col_l1=(1, 0)), (3, 3), (2, 2)),
+    ("p_tile", (128, 72), dict(poc=5, ref_pocs=(4,), l0=(0,), col_ref_pocs=(3,), col_l0=(0,), tile=(64, 64)), (1, 0), (1, 0)),
+]
+
+
+def inter_cand_case(name, seed=0):
+    """-> (params, cus, col_cus, ref_cus, pus): one configuration of INTER_CAND_CONFIGS with seeded random CU maps"""
+    for (n, (w, h), kw, cur_lists, col_lists) in INTER_CAND_CONFIGS:
+        if n != name:
+            continue
+        p = inter_params(w, h, **kw)
+        tile = kw.get("tile", (0, 0))
+        cus, pus = inter_cu_map(w, h, 9000 + seed, cur_lists[0], cur_lists[1])
+        full_w, full_h = tile[0] + w, tile[1] + h
+        # a collocated picture without references is an intra picture (a vector in it would make the reference divide by zero)
+        col, _ = inter_cu_map(full_w, full_h, 9100 + seed, max(col_lists[0], 1), col_lists[1],
+                              intra_share=0.3 if col_lists[0] else 1.0, unset_share=0.1)
+        if int(p["ref_idx"][0]) == int(p["ref_LX"][0, 0, 0]):
+            refm = col
+        else:
+            refm, _ = inter_cu_map(full_w, full_h, 9200 + seed, 1, 0, intra_share=0.3)
+        # the current picture's map has the stride of the whole picture's like the collocated ones
+        wide = np.zeros((cus.shape[0], int(p["cus_stride"][0])), dtype=CU_INFO)
+        wide[:, :cus.shape[1]] = cus
+        return p, wide, col, refm, pus
+    raise KeyError(name)

@@ -568,3 +568,18 @@ def deblock_frame(y, u, v, cus, prm):
     L.ref_deblock_frame(y.ctypes.data, y.shape[1], u.ctypes.data if u is not None else None, v.ctypes.data if v is not None else None,
                         u.shape[1] if u is not None else 0, y.shape[1], y.shape[0], cus.ctypes.data, prm.ctypes.data)
     return y, u, v
+
+
+# ---- AMVP / merge candidate derivation: the reference's kvz_inter_get_merge_cand / kvz_inter_get_mv_cand (oracle/ref_harness.c) ----
+def inter_candidates(params, cus, col_cus, ref_cus, pus):
+    from patterns import MERGE_CAND
+    L = lib()
+    L.ref_inter_candidates.restype = None
+    L.ref_inter_candidates.argtypes = [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
+    cus, col_cus = np.ascontiguousarray(cus), np.ascontiguousarray(col_cus)
+    ref_cus = None if ref_cus is None else np.ascontiguousarray(ref_cus)
+    pus = np.ascontiguousarray(pus).copy()
+    out = np.zeros((len(pus), 5), dtype=MERGE_CAND)
+    L.ref_inter_candidates(cus.ctypes.data, col_cus.ctypes.data, None if ref_cus is None else ref_cus.ctypes.data,
+                           np.ascontiguousarray(params).ctypes.data, pus.ctypes.data, len(pus), out.ctypes.data)
+    return pus, out

@@ -98,6 +98,16 @@ def test_golden_intra_ref(api):
             np.testing.assert_array_equal(got, d["refs%d_c%d" % (lg, color)], err_msg="color %d log2 %d" % (color, lg))
 
 
+def test_golden_inter_candidates(api):
+    from patterns import INTER_CAND_CONFIGS, inter_cand_case
+    d = gold("inter_cand.npz")
+    for (name, *_rest) in INTER_CAND_CONFIGS:
+        p, cus, col, refm, pus = inter_cand_case(name, 0)
+        got_pus, got_merge = api.inter_candidates_batch(p, cus, col, refm, pus)
+        np.testing.assert_array_equal(got_pus.ravel(), d[name + "_out_pus"].view(np.uint8).ravel(), err_msg=name)
+        np.testing.assert_array_equal(got_merge.ravel(), d[name + "_out_merge"].view(np.uint8).ravel(), err_msg=name)
+
+
 def test_golden_sao(api):
     d = gold("sao.npz")
     for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):

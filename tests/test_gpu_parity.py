@@ -1153,3 +1153,79 @@ def test_transform_skip_kinds(api, n):
         want = np.clip((back.astype(np.int32) + pred).astype(np.int16), 0, 255).astype(np.uint8)
         nz = (q != 0).any(axis=1)
         np.testing.assert_array_equal(rec[nz], want[nz])
+
+
+# ---- AMVP / merge candidate derivation (the driver half) ----
+from patterns import INTER_CAND_CONFIGS, ME_PU as ME_PU_DT, inter_cand_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", [c[0] for c in INTER_CAND_CONFIGS])
+def test_inter_candidates(api, name):
+    """every inter PU of seeded random CU maps: completed search descriptors and merge lists, byte for byte"""
+    for seed in range(1, 5):
+        p, cus, col, refm, pus = inter_cand_case(name, seed)
+        want_pus, want_merge = O.inter_candidates(p, cus, col, refm, pus)
+        got_pus, got_merge = api.inter_candidates_batch(p, cus, col, refm, pus)
+        np.testing.assert_array_equal(got_pus.view(ME_PU_DT).ravel(), want_pus, err_msg="%s seed %d" % (name, seed))
+        np.testing.assert_array_equal(got_merge.ravel(), want_merge.view(np.uint8).ravel(), err_msg="%s seed %d" % (name, seed))
+    # without the searched picture's CU array the start vector stays zero, everything else is unchanged
+    got2, _ = api.inter_candidates_batch(p, cus, col, None, pus)
+    want2 = want_pus.copy()
+    want2["extra_mv"] = 0
+    np.testing.assert_array_equal(got2.view(ME_PU_DT).ravel(), want2)
+
+
+def test_inter_candidates_bad_descriptors_and_arguments(api):
+    from kvazaar_amd._lib import KvzHipError
+    p, cus, col, refm, pus = inter_cand_case("p_one_ref", 0)
+    bad = pus[:6].copy()
+    bad["x"][0] = -8
+    bad["y"][1] = 2
+    bad["width"][2] = 0
+    bad["x"][3], bad["width"][3] = 160, 16                 # leaves the 168-wide picture
+    bad["height"][4] = 68
+    got, merge = api.inter_candidates_batch(p, cus, col, refm, bad)
+    got = got.view(ME_PU_DT).ravel()
+    assert (got["num_merge_cand"][:5] == -1).all() and got["num_merge_cand"][5] == 5
+    assert not merge[:5].any() and not got["mv_cand"][:5].any()
+    want, _ = O.inter_candidates(p, cus, col, refm, pus[5:6])
+    np.testing.assert_array_equal(got[5:6], want)
+    for field, value in (("num_refs", 17), ("ref_idx", 16), ("pic_width", 0), ("cus_stride", 8), ("in_width", 64)):
+        q = p.copy()
+        q[field] = value
+        with pytest.raises(KvzHipError):
+            api.inter_candidates_batch(q, cus, col, refm, pus)
+    q = p.copy()
+    q["ref_LX"][0, 1, 3] = 16
+    with pytest.raises(KvzHipError):
+        api.inter_candidates_batch(q, cus, col, refm, pus)
+    with pytest.raises(KvzHipError):
+        api.inter_candidates_batch(p, cus, None, refm, pus)         # tmvp on, references present: the collocated CUs are needed
+    assert api.inter_candidates_batch(p, cus, col, refm, pus[:0])[0].shape == (0, 64)
+
+
+def test_candidates_feed_the_search_on_the_device(api):
+    """derive -> search chained on one stream through device buffers only: the descriptors never visit the host between the two
+    entries; same vectors and costs as the oracle's search on the oracle's candidates"""
+    from kvazaar_amd import _lib
+    from kvazaar_amd.api import DeviceBuffer, check
+    L = _lib.init()
+    p, cus, col, refm, pus = inter_cand_case("p_one_ref", 7)
+    w, h = int(p["pic_width"][0]), int(p["pic_height"][0])
+    keep = [i for i in range(len(pus)) if (pus[i]["width"] % 8 == 0 or pus[i]["height"] % 8 == 0)]      # not 4x4-mod-8 in both (kvz_hip_me_pu)
+    pus = pus[keep]
+    cur, ref = me_frames(w, h, 31)
+    prm = me_params(lambda_cost=22)
+    d_cus, d_col, d_pus = DeviceBuffer.from_numpy(cus), DeviceBuffer.from_numpy(col), DeviceBuffer.from_numpy(pus)
+    d_cur, d_ref = DeviceBuffer.from_numpy(cur), DeviceBuffer.from_numpy(ref)
+    d_res = DeviceBuffer(32 * len(pus))
+    st = L.kvz_hip_stream_create()
+    try:
+        check(L.kvz_hip_inter_candidates_batch(d_cus.ptr, d_col.ptr, d_col.ptr, np.ascontiguousarray(p).ctypes.data, d_pus.ptr, len(pus), None, st), "candidates")
+        check(L.kvz_hip_search_pu_batch(d_cur.ptr, w, w, h, d_ref.ptr, w, w, h, d_pus.ptr, len(pus), np.ascontiguousarray(prm).ctypes.data, d_res.ptr, st), "search")
+        got = d_res.to_numpy(np.int32, (len(pus), 8), stream=st)
+    finally:
+        L.kvz_hip_stream_destroy(st)
+    want_pus, _ = O.inter_candidates(p, cus, col, col, pus)
+    want = O.search_pu_batch(cur, ref, want_pus, prm)
+    np.testing.assert_array_equal(got, np.asarray(want).view(np.int32).reshape(len(pus), 8))

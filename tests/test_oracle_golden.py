@@ -156,6 +156,17 @@ def test_golden_intra_ref():
             np.testing.assert_array_equal(got, d["refs%d_c%d" % (lg, color)], err_msg="color %d log2 %d" % (color, lg))
 
 
+def test_golden_inter_candidates():
+    """inputs are regenerated from the seeds (patterns.inter_cand_case), the fixture holds what the reference derived from them"""
+    from patterns import INTER_CAND_CONFIGS, inter_cand_case
+    d = gold("inter_cand.npz")
+    for (name, *_rest) in INTER_CAND_CONFIGS:
+        p, cus, col, refm, pus = inter_cand_case(name, 0)
+        got_pus, got_merge = O.inter_candidates(p, cus, col, refm, pus)
+        np.testing.assert_array_equal(got_pus.view(np.uint8), d[name + "_out_pus"].view(np.uint8), err_msg=name)
+        np.testing.assert_array_equal(got_merge.view(np.uint8), d[name + "_out_merge"].view(np.uint8), err_msg=name)
+
+
 def test_golden_sao():
     d = gold("sao.npz")
     for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):

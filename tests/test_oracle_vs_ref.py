@@ -551,3 +551,27 @@ def test_search_pu_mv_rdo(cfg):
         est = dict(MV_RDO_CONFIGS[cfg]); est.pop("mv_rdo")
         differs += int((O.search_pu_batch(pic, ref, pus, me_params(**est))["bitcost"] != a["bitcost"]).sum())
     assert differs > 60          # the CABAC bit counts are not the exp-Golomb estimate
+
+
+# ---- AMVP / merge candidate derivation (the driver half): inter.c:1209-1446 ----
+from patterns import INTER_CAND_CONFIGS, inter_cand_case  # noqa: E402
+
+
+@pytest.mark.parametrize("name", [c[0] for c in INTER_CAND_CONFIGS])
+def test_inter_candidates(name):
+    """every inter PU of random CU maps (all partition modes, intra and unset neighbours, vectors at the int16 limits): the merge
+    list, the AMVP pair for the searched picture, the start vector and the flattened merge view of the search descriptor"""
+    total, seed = 0, 0
+    while total < 400:
+        p, cus, col, refm, pus = inter_cand_case(name, seed)
+        seed += 1
+        want_pus, want_merge = R.inter_candidates(p, cus, col, refm, pus)
+        got_pus, got_merge = O.inter_candidates(p, cus, col, refm, pus)
+        for i in range(len(pus)):
+            where = "%s seed %d PU %s" % (name, seed - 1, tuple(int(pus[i][k]) for k in ("x", "y", "width", "height", "pad")))
+            assert got_pus[i]["num_merge_cand"] == want_pus[i]["num_merge_cand"] == 5, where
+            np.testing.assert_array_equal(got_merge[i], want_merge[i], err_msg=where)
+            np.testing.assert_array_equal(got_pus[i]["mv_cand"], want_pus[i]["mv_cand"], err_msg=where)
+            np.testing.assert_array_equal(got_pus[i]["extra_mv"], want_pus[i]["extra_mv"], err_msg=where)
+        np.testing.assert_array_equal(got_pus, want_pus)
+        total += len(pus)
