@@ -181,6 +181,19 @@ def inter_cand():
     np.savez_compressed(os.path.join(OUT, "inter_cand.npz"), **d)
 
 
+def recorded_cand():
+    """What the reference ENCODER's candidate derivation read and produced during a real encode (harness recorder with snapshots,
+    oracle/ref_harness.c): for 600 of the 2Nx2N inter searches of four 192 x 128 frames the lcu->cu array as it stood, the collocated
+    picture's CU array and POC tables per frame, and the search descriptor the encoder's kvz_inter_get_merge_cand /
+    kvz_inter_get_mv_cand calls filled"""
+    frames = R.synthetic_sequence(192, 128, 4, seed=11)
+    rec = R.record_inter_searches(frames, 192, 128, "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=30,threads=0,smp=0,amp=0,period=0", snapshots=4000)
+    pick = np.linspace(0, len(rec["snap_index"]) - 1, 600).astype(np.int64)
+    idx = rec["snap_index"][pick]
+    np.savez_compressed(os.path.join(OUT, "recorded_cand.npz"), snap_cus=rec["snap_cus"][pick], meta=rec["meta"][idx], pus=rec["pus"][idx],
+                        snap_col=rec["snap_col"], snap_params=rec["snap_params"])
+
+
 def sao():
     g = rng(SEED + 5)
     d = {}
@@ -286,7 +299,7 @@ if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, intra_ref=intra_ref, inter_cand=inter_cand, sao=sao, me=me, deblock=deblock, fronts=fronts)
+    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, intra_ref=intra_ref, inter_cand=inter_cand, recorded_cand=recorded_cand, sao=sao, me=me, deblock=deblock, fronts=fronts)
     for name in (sys.argv[1:] or list(groups)):          # python oracle/gen_golden.py [group ...]
         groups[name]()
     for f in sorted(os.listdir(OUT)):

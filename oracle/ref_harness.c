@@ -725,6 +725,9 @@ static struct {
 } g_rec;
 
 void __real_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost);
+/* optional snapshots of what the candidate derivation read (defined with the flat CU types below) */
+static void rec_snapshot_search(const encoder_state_t *state, const lcu_t *lcu, int record_index);
+static void rec_snapshot_frame(const encoder_state_t *state, int frame_index);
 
 static void rec_copy_plane(kvz_pixel *dst, const kvz_picture *p, int w, int h)
 {
@@ -745,6 +748,7 @@ void __wrap_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int
   rec_pu_t pu; memset(&pu, 0, sizeof(pu));
   pu.x = x; pu.y = y; pu.width = width; pu.height = width;
   cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
+  rec_snapshot_search(state, lcu, g_rec.count);          /* before the derivation below touches the neighbours */
   /* search_pu_inter :1492-1500 */
   inter_merge_cand_t merge[MRG_MAX_NUM_CANDS];
   const int n_merge = kvz_inter_get_merge_cand(state, x, y, width, width, true, true, merge, lcu);
@@ -780,6 +784,7 @@ void __wrap_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int
     rec_copy_plane(g_rec.pic + off, state->tile->frame->source, g_rec.w, g_rec.h);
     rec_copy_plane(g_rec.ref + off, state->frame->ref->images[0], g_rec.w, g_rec.h);
     g_rec.frame_poc[g_rec.n_frames++] = poc;
+    rec_snapshot_frame(state, g_rec.n_frames - 1);
     g_rec.cur_lcu_x = g_rec.cur_lcu_y = -1;
     rec_params_t *p = &g_rec.params;
     memset(p, 0, sizeof(*p));
@@ -1006,4 +1011,99 @@ void ref_inter_candidates(const flat_cu_t *cus, const flat_cu_t *col_cus, const 
   if (col_a) { free(col_a->data); free(col_a); }
   if (ref_a) { free(ref_a->data); free(ref_a); }
   free(empty->data); free(empty);
+}
+
+
+/* ------------------------------------------------------------------------
+ * Snapshots for the recorder above: what kvz_inter_get_merge_cand / kvz_inter_get_mv_cand READ when the encoder derived the
+ * recorded candidates -- lcu->cu as it stood (the 17 x 17 + 1 records of cu.h:324: decided neighbours, work-tree leftovers)
+ * and, per frame, the collocated picture's CU array with the POC tables.  The candidate derivation of the oracle and of
+ * the GPU entry is then checked against the candidates the encoder really used, on the states a real encode goes through.
+ * ------------------------------------------------------------------------ */
+static struct {
+  int max, count;
+  int32_t *index;                               /* record index of each snapshot */
+  flat_cu_t *cu;                                /* [max][LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1] */
+  int max_frames, col_stride, col_rows;
+  flat_cu_t *col;                               /* [frames][col_rows][col_stride] */
+  flat_inter_params_t *params;                  /* [frames] */
+} g_snap;
+
+static void cu_to_flat(const cu_info_t *c, flat_cu_t *f)
+{
+  memset(f, 0, sizeof(*f));
+  f->type = c->type; f->depth = c->depth; f->part_size = c->part_size; f->tr_depth = c->tr_depth; f->qp = c->qp;
+  if (c->type == CU_INTER) {
+    f->mv_dir = c->inter.mv_dir;
+    memcpy(f->mv, c->inter.mv, sizeof(f->mv));
+    f->mv_ref[0] = c->inter.mv_ref[0]; f->mv_ref[1] = c->inter.mv_ref[1];
+  }
+}
+
+int ref_record_snapshots(int max_snapshots)
+{
+  memset(&g_snap, 0, sizeof(g_snap));
+  if (!g_rec.on) return -1;
+  g_snap.max = max_snapshots;
+  g_snap.max_frames = g_rec.max_frames;
+  g_snap.col_stride = ((g_rec.w + 63) / 64) * 16; g_snap.col_rows = ((g_rec.h + 63) / 64) * 16;
+  g_snap.index = calloc((size_t)max_snapshots, sizeof(int32_t));
+  g_snap.cu = calloc((size_t)max_snapshots * (LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1), sizeof(flat_cu_t));
+  g_snap.col = calloc((size_t)g_snap.max_frames * g_snap.col_rows * g_snap.col_stride, sizeof(flat_cu_t));
+  g_snap.params = calloc((size_t)g_snap.max_frames, sizeof(flat_inter_params_t));
+  return (g_snap.index && g_snap.cu && g_snap.col && g_snap.params) ? 0 : -1;
+}
+
+static void rec_snapshot_search(const encoder_state_t *state, const lcu_t *lcu, int record_index)
+{
+  (void)state;
+  if (!g_snap.cu || g_snap.count >= g_snap.max) return;
+  if (g_snap.count && g_snap.index[g_snap.count - 1] == record_index) --g_snap.count;      /* a search that ended unrecorded */
+  const int n = LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1;
+  g_snap.index[g_snap.count] = record_index;
+  for (int i = 0; i < n; ++i) cu_to_flat(&lcu->cu[i], &g_snap.cu[(size_t)g_snap.count * n + i]);
+  ++g_snap.count;
+}
+
+static void rec_snapshot_frame(const encoder_state_t *state, int f)
+{
+  if (!g_snap.col || f >= g_snap.max_frames) return;
+  const encoder_state_config_frame_t *fr = state->frame;
+  flat_inter_params_t *p = &g_snap.params[f];
+  memset(p, 0, sizeof(*p));
+  p->poc = fr->poc; p->slice_is_b = fr->slicetype == KVZ_SLICE_B; p->tmvp_enable = state->encoder_control->cfg.tmvp_enable;
+  p->num_refs = (int32_t)fr->ref->used_size;
+  for (int i = 0; i < p->num_refs && i < 16; ++i) p->ref_pocs[i] = fr->ref->pocs[i];
+  memcpy(p->ref_LX, fr->ref_LX, sizeof(p->ref_LX));
+  p->ref_LX_size[0] = fr->ref_LX_size[0]; p->ref_LX_size[1] = fr->ref_LX_size[1];
+  p->pic_width = state->tile->frame->width; p->pic_height = state->tile->frame->height;
+  p->in_width = state->encoder_control->in.width; p->in_height = state->encoder_control->in.height;
+  p->tile_x = state->tile->offset_x; p->tile_y = state->tile->offset_y;
+  p->ref_idx = 0;
+  p->cus_stride = g_snap.col_stride; p->col_stride = g_snap.col_stride;
+  if (fr->ref_LX_size[0] > 0) {
+    const int c = fr->ref_LX[0][0];
+    memcpy(p->col_ref_pocs, fr->ref->images[c]->ref_pocs, sizeof(p->col_ref_pocs));
+    memcpy(p->col_ref_LX, fr->ref->ref_LXs[c], sizeof(p->col_ref_LX));
+    const cu_array_t *a = fr->ref->cu_arrays[c];
+    flat_cu_t *dst = g_snap.col + (size_t)f * g_snap.col_rows * g_snap.col_stride;
+    for (int y = 0; y < g_snap.col_rows && y * 4 < a->height; ++y)
+      for (int x = 0; x < g_snap.col_stride && x * 4 < a->width; ++x)
+        cu_to_flat(&a->data[x + y * (a->stride >> 2)], &dst[y * g_snap.col_stride + x]);
+  }
+}
+
+/* copies the snapshots out (call BEFORE ref_record_end); returns their count.  dims[0..1] = rows, stride of a col map */
+int ref_record_snapshots_get(int32_t *index, void *cu, void *col, void *params, int *dims)
+{
+  const int n = g_snap.count;
+  const size_t per = LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1;
+  if (index) memcpy(index, g_snap.index, (size_t)n * sizeof(int32_t));
+  if (cu) memcpy(cu, g_snap.cu, (size_t)n * per * sizeof(flat_cu_t));
+  if (col) memcpy(col, g_snap.col, (size_t)g_rec.n_frames * g_snap.col_rows * g_snap.col_stride * sizeof(flat_cu_t));
+  if (params) memcpy(params, g_snap.params, (size_t)g_rec.n_frames * sizeof(flat_inter_params_t));
+  if (dims) { dims[0] = g_snap.col_rows; dims[1] = g_snap.col_stride; }
+  free(g_snap.index); free(g_snap.cu); free(g_snap.col); free(g_snap.params);
+  memset(&g_snap, 0, sizeof(g_snap));
+  return n;
 }

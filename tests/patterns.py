@@ -527,3 +527,37 @@ def inter_cand_case(name, seed=0):
         wide[:, :cus.shape[1]] = cus
         return p, wide, col, refm, pus
     raise KeyError(name)
+
+
+def place_lcu_snapshot(cu_map, snap, lcu_x, lcu_y):
+    """writes the 290 records of one lcu->cu snapshot (cu.h:324-344: 17 x 17 records = the LCU's 16 x 16 SCUs with the row above,
+    the column to the left and the corner at index 0, then the top-right SCU) where they belong in a picture's SCU map"""
+    rows, stride = cu_map.shape
+    grid = snap[:289].reshape(17, 17)
+    oy, ox = lcu_y * 16, lcu_x * 16
+    y0, x0 = max(oy - 1, 0), max(ox - 1, 0)
+    y1, x1 = min(oy + 16, rows), min(ox + 16, stride)
+    cu_map[y0:y1, x0:x1] = grid[y0 - (oy - 1):y1 - (oy - 1), x0 - (ox - 1):x1 - (ox - 1)]
+    if oy > 0 and ox + 16 < stride:
+        cu_map[oy - 1, ox + 16] = snap[289]
+
+
+def recorded_cand_fixture(d, derive, seed=5):
+    """tests/golden/recorded_cand.npz (oracle/gen_golden.py: recorded_cand): every snapshot's lcu->cu put back into a picture-sized SCU
+    map whose other records are noise; `derive(params, cus, col, ref_cus, pus)` completes the descriptor.  -> (derived, recorded)"""
+    g = np.random.default_rng(seed)
+    meta, want = d["meta"], d["pus"]
+    noise = np.zeros(d["snap_col"][0].shape, dtype=CU_INFO)
+    noise["type"], noise["mv_dir"] = 2, 1
+    noise["mv"] = g.integers(-500, 500, noise["mv"].shape)
+    got = []
+    for k in range(len(want)):
+        f = int(meta[k, 0])
+        cus = noise.copy()
+        place_lcu_snapshot(cus, d["snap_cus"][k].view(CU_INFO).reshape(-1), int(meta[k, 1]), int(meta[k, 2]))
+        pu = np.zeros(1, dtype=ME_PU)
+        for fld in ("x", "y", "width", "height"):
+            pu[fld] = want[k][fld]
+        col = d["snap_col"][f].view(CU_INFO).reshape(noise.shape)
+        got.append(derive(d["snap_params"][f:f + 1].view(INTER_PARAMS), cus, col, col, pu))
+    return np.concatenate(got), want.view(ME_PU).reshape(-1)

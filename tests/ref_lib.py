@@ -358,12 +358,15 @@ def encode(frames, w, h, opts, strategy=None, cap=1 << 22):
     return out[:n].tobytes(), inst.value
 
 
-def record_inter_searches(frames, w, h, opts, max_records=400000):
+def record_inter_searches(frames, w, h, opts, max_records=400000, snapshots=0):
     """Runs the reference encoder over the frames with the harness recorder on: every 2Nx2N inter search the encoder
     itself performed on a single-reference P frame, with the candidates the encoder derived for it and what the
     reference search decided.  -> dict(pus [n] ME_PU, results [n] ME_RESULT, meta [n] (frame, lcu_x, lcu_y, seq, lambda_cost,
-    depth), params ME_PARAMS (lambda_cost 0: per record), pic / ref uint8 [frames, h, w], skipped)."""
-    from patterns import ME_PARAMS, ME_PU, ME_RESULT
+    depth), params ME_PARAMS (lambda_cost 0: per record), pic / ref uint8 [frames, h, w], skipped).
+    snapshots > 0 also keeps, for the first that many searches, what the encoder's candidate derivation read: snap_index [m] (record
+    of each snapshot), snap_cus [m, 290] CU_INFO (lcu->cu, cu.h:324), and per frame snap_col [frames, rows, stride] CU_INFO (the
+    collocated picture's CU array) and snap_params [frames] INTER_PARAMS."""
+    from patterns import CU_INFO, INTER_PARAMS, ME_PARAMS, ME_PU, ME_RESULT
     L = lib()
     L.ref_record_begin.restype = C.c_int
     L.ref_record_begin.argtypes = [C.c_int] * 4
@@ -371,9 +374,26 @@ def record_inter_searches(frames, w, h, opts, max_records=400000):
     L.ref_record_end.argtypes = [C.c_void_p] * 6 + [C.POINTER(C.c_int)]
     nf = len(frames)
     assert L.ref_record_begin(max_records, nf, w, h) == 0
+    snap = {}
+    if snapshots:
+        L.ref_record_snapshots.restype = C.c_int
+        L.ref_record_snapshots.argtypes = [C.c_int]
+        L.ref_record_snapshots_get.restype = C.c_int
+        L.ref_record_snapshots_get.argtypes = [C.c_void_p] * 4 + [C.POINTER(C.c_int)]
+        assert L.ref_record_snapshots(snapshots) == 0
     try:
         bitstream, _ = encode(frames, w, h, opts)
     finally:
+        if snapshots:
+            rows, stride = ((h + 63) // 64) * 16, ((w + 63) // 64) * 16
+            s_idx = np.zeros(snapshots, dtype=np.int32)
+            s_cu = np.zeros((snapshots, 290), dtype=CU_INFO)
+            s_col = np.zeros((nf, rows, stride), dtype=CU_INFO)
+            s_prm = np.zeros(nf, dtype=INTER_PARAMS)
+            dims = (C.c_int * 2)()
+            m = L.ref_record_snapshots_get(s_idx.ctypes.data, s_cu.ctypes.data, s_col.ctypes.data, s_prm.ctypes.data, dims)
+            assert (dims[0], dims[1]) == (rows, stride)
+            snap = dict(snap_index=s_idx[:m].copy(), snap_cus=s_cu[:m].copy(), snap_col=s_col, snap_params=s_prm)
         pus = np.zeros(max_records, dtype=ME_PU)
         res = np.zeros(max_records, dtype=ME_RESULT)
         meta = np.zeros((max_records, 6), dtype=np.int32)
@@ -382,8 +402,14 @@ def record_inter_searches(frames, w, h, opts, max_records=400000):
         ref = np.zeros((nf, h, w), dtype=np.uint8)
         info = (C.c_int * 2)()
         n = L.ref_record_end(pus.ctypes.data, res.ctypes.data, meta.ctypes.data, prm.ctypes.data, pic.ctypes.data, ref.ctypes.data, info)
-    return dict(pus=pus[:n].copy(), results=res[:n].copy(), meta=meta[:n].copy(), params=prm, pic=pic[:info[0]].copy(), ref=ref[:info[0]].copy(),
-                skipped=int(info[1]), bitstream=bitstream)
+    out = dict(pus=pus[:n].copy(), results=res[:n].copy(), meta=meta[:n].copy(), params=prm, pic=pic[:info[0]].copy(), ref=ref[:info[0]].copy(),
+               skipped=int(info[1]), bitstream=bitstream)
+    if snap:
+        keep = snap["snap_index"] < n                       # a last snapshot whose search was not recorded
+        snap["snap_index"], snap["snap_cus"] = snap["snap_index"][keep], snap["snap_cus"][keep]
+        snap["snap_col"], snap["snap_params"] = snap["snap_col"][:info[0]].copy(), snap["snap_params"][:info[0]].copy()
+        out.update(snap)
+    return out
 
 
 # ---- intra group ----

@@ -108,6 +108,14 @@ def test_golden_inter_candidates(api):
         np.testing.assert_array_equal(got_merge.ravel(), d[name + "_out_merge"].view(np.uint8).ravel(), err_msg=name)
 
 
+def test_golden_recorded_candidates(api):
+    """candidates the reference encoder derived during a real encode, re-derived on the device from snapshots of the state"""
+    from patterns import ME_PU, recorded_cand_fixture
+    got, want = recorded_cand_fixture(gold("recorded_cand.npz"), lambda *a: api.inter_candidates_batch(*a)[0].view(ME_PU).reshape(-1))
+    for fld in ("num_merge_cand", "merge", "mv_cand", "extra_mv"):
+        np.testing.assert_array_equal(got[fld], want[fld], err_msg=fld)
+
+
 def test_golden_sao(api):
     d = gold("sao.npz")
     for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):

@@ -167,6 +167,14 @@ def test_golden_inter_candidates():
         np.testing.assert_array_equal(got_merge.view(np.uint8), d[name + "_out_merge"].view(np.uint8), err_msg=name)
 
 
+def test_golden_recorded_candidates():
+    """candidates the reference encoder derived during a real encode, from snapshots of the state its functions read"""
+    from patterns import recorded_cand_fixture
+    got, want = recorded_cand_fixture(gold("recorded_cand.npz"), lambda *a: O.inter_candidates(*a)[0])
+    for fld in ("num_merge_cand", "merge", "mv_cand", "extra_mv"):
+        np.testing.assert_array_equal(got[fld], want[fld], err_msg=fld)
+
+
 def test_golden_sao():
     d = gold("sao.npz")
     for (bw, bh) in ((64, 64), (32, 32), (64, 40), (8, 16)):

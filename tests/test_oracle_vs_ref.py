@@ -575,3 +575,47 @@ def test_inter_candidates(name):
             np.testing.assert_array_equal(got_pus[i]["extra_mv"], want_pus[i]["extra_mv"], err_msg=where)
         np.testing.assert_array_equal(got_pus, want_pus)
         total += len(pus)
+
+
+def recorded_candidate_case(w=192, h=128, n_frames=4, opts="preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=30,threads=0,smp=0,amp=0,period=0",
+                            snapshots=4000, seed=11):
+    frames = R.synthetic_sequence(w, h, n_frames, seed=seed)
+    return R.record_inter_searches(frames, w, h, opts, snapshots=snapshots)
+
+
+def candidates_from_snapshots(rec, derive):
+    """for every snapshot: lcu->cu put back into a picture-sized SCU map whose other records are noise, the candidates derived by
+    `derive(params, cus, col, ref_cus, pus)` -> completed descriptors; returns (derived, recorded) descriptor arrays"""
+    from patterns import CU_INFO, place_lcu_snapshot
+    g = rng(5)
+    m, prm = rec["meta"], rec["snap_params"]
+    got, want = [], []
+    noise = None
+    for k, r in enumerate(rec["snap_index"]):
+        f = int(m[r, 0])
+        col = rec["snap_col"][f]
+        if noise is None:
+            noise = np.zeros(col.shape, dtype=CU_INFO)
+            noise["type"], noise["mv_dir"] = 2, 1
+            noise["mv"] = g.integers(-500, 500, noise["mv"].shape)
+        cus = noise.copy()
+        place_lcu_snapshot(cus, rec["snap_cus"][k], int(m[r, 1]), int(m[r, 2]))
+        pu = rec["pus"][r:r + 1].copy()
+        for fld in ("mv_cand", "extra_mv", "num_merge_cand", "merge"):
+            pu[fld] = 0
+        got.append(derive(prm[f:f + 1], cus, col, col, pu)[0])
+        want.append(rec["pus"][r])
+    return np.array(got), np.array(want)
+
+
+def test_candidates_on_recorded_encoder_states():
+    """the candidates the reference ENCODER derived during real encodes (P frames, TMVP on: POC 1..3) against the oracle's
+    derivation from snapshots of what the encoder's functions read -- lcu->cu with its work-tree leftovers, the collocated
+    picture's CU array, the POC tables"""
+    rec = recorded_candidate_case()
+    assert len(rec["snap_index"]) >= 1000 and rec["skipped"] == 0
+    got, want = candidates_from_snapshots(rec, lambda *a: O.inter_candidates(*a)[0])
+    for fld in ("num_merge_cand", "merge", "mv_cand", "extra_mv"):
+        np.testing.assert_array_equal(got[fld], want[fld], err_msg=fld)
+    # the states are not trivial: spatial / temporal candidates and non-zero predictors occur
+    assert (np.abs(want["mv_cand"]).sum(axis=(1, 2)) > 0).mean() > 0.3 and (np.abs(want["extra_mv"]).sum(axis=1) > 0).any()

@@ -188,6 +188,29 @@ def main():
                       lambda lg=lg, cnt=cnt, refs_d=refs_d, costs_d=costs_d: L.kvz_hip_intra_rough_batch(
                           lg, 3, refs_d.data_ptr(), a8.data_ptr(), cnt, costs_d.data_ptr(), None, st)))
 
+    # candidate derivation + intra reference building of one 1080p frame's 8x8 PUs (the glue kernels between dependency fronts)
+    from patterns import ME_PU, inter_cu_map, inter_params
+    ip = inter_params(1920, 1080, poc=8, ref_pocs=(7,), l0=(0,), col_ref_pocs=(6,), col_l0=(0,))
+    cu_now, _ = inter_cu_map(1920, 1080, 1)
+    cu_col, _ = inter_cu_map(1920, 1080, 2)
+    grid = np.zeros(32400, dtype=ME_PU)
+    grid["x"], grid["y"] = (np.arange(32400) % 240) * 8, (np.arange(32400) // 240) * 8
+    grid["width"] = grid["height"] = 8
+    cu_now_d = torch.from_numpy(cu_now.view(np.uint8).copy()).to(dev)
+    cu_col_d = torch.from_numpy(cu_col.view(np.uint8).copy()).to(dev)
+    grid_d = torch.from_numpy(grid.view(np.uint8).copy()).to(dev)
+    merge_d = torch.empty(32400 * 60, dtype=torch.uint8, device=dev)
+    ip_host = np.ascontiguousarray(ip)
+    cases.append(("inter_candidates_8x8(PUs)", 32400, 64 + 60 + 7 * 20,
+                  lambda: L.kvz_hip_inter_candidates_batch(cu_now_d.data_ptr(), cu_col_d.data_ptr(), cu_col_d.data_ptr(), ip_host.ctypes.data,
+                                                           grid_d.data_ptr(), 32400, merge_d.data_ptr(), st)))
+    pos = np.stack([grid["x"], grid["y"]], axis=1).astype(np.int32)
+    pos_d = torch.from_numpy(pos.copy()).to(dev)
+    rec_d = torch.randint(0, 256, (1080 * 1920,), dtype=torch.uint8, device=dev, generator=g)
+    refs8_d = torch.empty(32400 * 130, dtype=torch.uint8, device=dev)
+    cases.append(("intra_build_reference_8x8(PUs)", 32400, 130 + 33,
+                  lambda: L.kvz_hip_intra_build_reference_batch(3, 0, rec_d.data_ptr(), 1920, 1920, 1080, pos_d.data_ptr(), 32400, refs8_d.data_ptr(), st)))
+
     tune_key, tune_vals = None, [None]
     if args.tune:
         tune_key, vals = args.tune.split("=")

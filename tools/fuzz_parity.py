@@ -97,6 +97,20 @@ def main():
                   "%dx%d color %d log2 %d" % (pw, ph, color, lg))
     print("intra ok (%.0f s)" % (time.time() - t0))
 
+    # AMVP / merge candidate derivation: every configuration with fresh seeds
+    from patterns import INTER_CAND_CONFIGS, ME_PU, inter_cand_case
+    n = 0
+    for (name, *_rest) in INTER_CAND_CONFIGS:
+        for _ in range(2 * a.scale):
+            sd = int(g.integers(0, 1 << 20))
+            p, cus, col, refm, pus = inter_cand_case(name, sd)
+            want_pus, want_merge = O.inter_candidates(p, cus, col, refm, pus)
+            got_pus, got_merge = api.inter_candidates_batch(p, cus, col, refm, pus)
+            check("inter_candidates.pus", np.array_equal(got_pus.view(ME_PU).ravel(), want_pus), "%s seed %d" % (name, sd))
+            check("inter_candidates.merge", np.array_equal(got_merge.ravel(), want_merge.view(np.uint8).ravel()), "%s seed %d" % (name, sd))
+            n += len(pus)
+    print("inter candidates: %d PUs ok (%.0f s)" % (n, time.time() - t0))
+
     # fused TU: random qp / flags / sizes, with the rd=0 costs
     for it in range(40 * a.scale):
         w = int(g.choice([4, 8, 16, 32]))
