@@ -296,8 +296,9 @@ extern "C" int kvz_hip_inter_candidates_batch(const kvz_hip_cu_info *cus, const 
   bool ok = p.num_refs >= 0 && p.num_refs <= 16 && p.ref_LX_size[0] <= 16 && p.ref_LX_size[1] <= 16 && p.pic_width > 0 && p.pic_height > 0 &&
             p.tile_x >= 0 && p.tile_y >= 0 && p.in_width >= p.tile_x + p.pic_width && p.in_height >= p.tile_y + p.pic_height &&
             p.cus_stride * 4 >= p.pic_width && p.col_stride * 4 >= p.in_width && p.ref_idx >= 0 && p.ref_idx < 16;
+  // entries past a list's length are whatever the encoder left there (the reference never reads them; the kernel masks its indices)
   for (int l = 0; l < 2 && ok; ++l)
-    for (int i = 0; i < 16; ++i) if (p.ref_LX[l][i] > 15 || p.col_ref_LX[l][i] > 15) ok = false;
+    for (int i = 0; i < p.ref_LX_size[l]; ++i) if (p.ref_LX[l][i] > 15) ok = false;
   if (!ok) {
     set_error_msg("kvz_hip_inter_candidates_batch: at most 16 references, list entries 0..15, the tile inside the input picture, strides covering the pictures");
     return KVZ_HIP_ERR_INVALID;

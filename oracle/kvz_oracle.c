@@ -1942,7 +1942,7 @@ static int temporal_mv(const orc_inter_params *p, const cand_view *c, int cur_re
   for (int i = 0; i < p->num_refs; ++i) if (p->ref_pocs[i] > p->poc) { l = 1; break; }
   if (!(c->dir & (l + 1))) l = 1 - l;
   out[0] = c->mv[l][0]; out[1] = c->mv[l][1];
-  scale_mv(p->poc, p->ref_pocs[cur_ref], p->ref_pocs[col_pic], p->col_ref_pocs[p->col_ref_LX[l][c->ref[l] & 15]], out);
+  scale_mv(p->poc, p->ref_pocs[cur_ref & 15], p->ref_pocs[col_pic & 15], p->col_ref_pocs[p->col_ref_LX[l][c->ref[l] & 15] & 15], out);
   return 1;
 }
 
@@ -1956,7 +1956,7 @@ static int mvp_from(const orc_inter_params *p, const cand_view *c, int reflist, 
     const int nb_pic = p->ref_LX[l][c->ref[l] & 15];
     if (scaling) {
       out[0] = c->mv[l][0]; out[1] = c->mv[l][1];
-      scale_mv(p->poc, p->ref_pocs[cur_pic], p->poc, p->ref_pocs[nb_pic], out);
+      scale_mv(p->poc, p->ref_pocs[cur_pic & 15], p->poc, p->ref_pocs[nb_pic & 15], out);
       return 1;
     }
     if (nb_pic == cur_pic) { out[0] = c->mv[l][0]; out[1] = c->mv[l][1]; return 1; }

@@ -1196,9 +1196,12 @@ def test_inter_candidates_bad_descriptors_and_arguments(api):
         with pytest.raises(KvzHipError):
             api.inter_candidates_batch(q, cus, col, refm, pus)
     q = p.copy()
-    q["ref_LX"][0, 1, 3] = 16
+    q["ref_LX"][0, 0, 0] = 16
     with pytest.raises(KvzHipError):
         api.inter_candidates_batch(q, cus, col, refm, pus)
+    q = p.copy()
+    q["ref_LX"][0, 0, 1:], q["ref_LX"][0, 1, :], q["col_ref_LX"][0, :, 1:] = 255, 255, 255     # past the lists' ends: never read
+    np.testing.assert_array_equal(api.inter_candidates_batch(q, cus, col, refm, pus)[0], api.inter_candidates_batch(p, cus, col, refm, pus)[0])
     with pytest.raises(KvzHipError):
         api.inter_candidates_batch(p, cus, None, refm, pus)         # tmvp on, references present: the collocated CUs are needed
     assert api.inter_candidates_batch(p, cus, col, refm, pus[:0])[0].shape == (0, 64)
