@@ -32,16 +32,34 @@ __device__ __forceinline__ cand_t no_cand()
   return c;
 }
 
-__device__ __forceinline__ cand_t cand_at(const kvz_hip_cu_info *__restrict__ map, int stride, int x, int y)
+// list l of a candidate without indexing its arrays by a run-time value (which would move every candidate to scratch memory)
+__device__ __forceinline__ int cand_mvx(const cand_t &c, int l) { return l ? c.mv[1][0] : c.mv[0][0]; }
+__device__ __forceinline__ int cand_mvy(const cand_t &c, int l) { return l ? c.mv[1][1] : c.mv[0][1]; }
+__device__ __forceinline__ int cand_ref(const cand_t &c, int l) { return l ? c.ref[1] : c.ref[0]; }
+
+// a fetched record as a candidate; `want` = the position passed its availability tests
+__device__ __forceinline__ cand_t cand_of(const kvz_hip_cu_info &c, bool want)
 {
   cand_t v = no_cand();
-  const kvz_hip_cu_info *c = map + (size_t)(y >> 2) * stride + (x >> 2);
-  if (c->type != 2) return v;                           // inter.c:822-870: only inter CUs are candidates
-  v.ok = true; v.dir = c->mv_dir;
+  if (!want || c.type != 2) return v;                   // inter.c:822-870: only inter CUs are candidates
+  v.ok = true; v.dir = c.mv_dir;
 #pragma unroll
   for (int l = 0; l < 2; ++l)
-    if ((c->mv_dir >> l) & 1) { v.mv[l][0] = c->mv[l][0]; v.mv[l][1] = c->mv[l][1]; v.ref[l] = c->mv_ref[l]; }
+    if ((c.mv_dir >> l) & 1) { v.mv[l][0] = c.mv[l][0]; v.mv[l][1] = c.mv[l][1]; v.ref[l] = c.mv_ref[l]; }
   return v;
+}
+
+// one record of a CU array as five dwords (records are 20 bytes, 4-byte aligned)
+__device__ __forceinline__ kvz_hip_cu_info fetch_cu(const kvz_hip_cu_info *__restrict__ map, int stride, int x, int y, bool want)
+{
+  const size_t at = want ? (size_t)(y >> 2) * stride + (x >> 2) : 0;    // a position that failed its tests reads record 0 and is dropped
+  const u32 *q = reinterpret_cast<const u32 *>(map + at);
+  u32 w[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) w[k] = q[k];
+  kvz_hip_cu_info r;
+  __builtin_memcpy(&r, w, sizeof(r));
+  return r;
 }
 
 // position of a 4x4 unit in the coding order of its LCU (bits of its coordinates interleaved)
@@ -63,36 +81,39 @@ __device__ __forceinline__ bool corner_unit_coded(int nx, int ny, int sx, int sy
 
 struct cand_set { cand_t a[2], b[3]; };
 
-// get_spatial_merge_candidates (inter.c:799-875)
-__device__ __forceinline__ void spatial_cands(const kvz_hip_cu_info *__restrict__ cus, const kvz_hip_inter_params &p, int x, int y, int w, int h, cand_set &s)
+// get_spatial_merge_candidates (inter.c:799-875), get_temporal_merge_candidates (inter.c:713-780; every caller passes
+// list 1, index 0: H below-right of the PU unless that opens a new LCU row, else the centre C3, both on the 16x16 grid of
+// the collocated picture) and the CU of the searched picture under the PU's centre (search_inter.c:1190-1206).
+// All eight records are requested before any is looked at: the availability tests need only the geometry, so the
+// fetches are independent and one memory round trip serves the PU (as a chain of conditional lookups the kernel took
+// 12 us for 480 PUs).
+__device__ __forceinline__ void gather_cands(const kvz_hip_cu_info *__restrict__ cus, const kvz_hip_cu_info *__restrict__ col,
+                                             const kvz_hip_cu_info *__restrict__ ref_cus, const kvz_hip_inter_params &p,
+                                             int x, int y, int w, int h, cand_set &s, cand_t &tmp, cand_t &centre)
 {
   const int lw = w & -w, lh = h & -h, side = lw < lh ? lw : lh;
   const int xl = x & 63, yl = y & 63;
-  s.a[0] = s.a[1] = s.b[0] = s.b[1] = s.b[2] = no_cand();
-  if (x != 0) {
-    s.a[1] = cand_at(cus, p.cus_stride, x - 1, y + h - 1);
-    if (yl + h < 64 && y + h < p.pic_height && corner_unit_coded(x - 1, y + h, x, y + h - side))
-      s.a[0] = cand_at(cus, p.cus_stride, x - 1, y + h);
-  }
-  if (y != 0) {
-    if (x + w < p.pic_width && (xl + w < 64 || yl == 0) && corner_unit_coded(x + w, y - 1, x + w - side, y))
-      s.b[0] = cand_at(cus, p.cus_stride, x + w, y - 1);
-    s.b[1] = cand_at(cus, p.cus_stride, x + w - 1, y - 1);
-    if (x != 0) s.b[2] = cand_at(cus, p.cus_stride, x - 1, y - 1);
-  }
-}
-
-// get_temporal_merge_candidates (inter.c:713-780; every caller passes list 1, index 0): H below-right of the PU unless
-// that opens a new LCU row, else the centre C3, both on the 16x16 grid of the collocated picture
-__device__ __forceinline__ cand_t temporal_cand(const kvz_hip_cu_info *__restrict__ col, const kvz_hip_inter_params &p, int x, int y, int w, int h)
-{
-  cand_t hh = no_cand(), c3 = no_cand();
-  if (!p.num_refs || p.ref_LX_size[0] == 0 || !col) return hh;
+  const bool left = x != 0, top = y != 0;
+  const bool want_a0 = left && yl + h < 64 && y + h < p.pic_height && corner_unit_coded(x - 1, y + h, x, y + h - side);
+  const bool want_b0 = top && x + w < p.pic_width && (xl + w < 64 || yl == 0) && corner_unit_coded(x + w, y - 1, x + w - side, y);
+  const bool have_col = p.num_refs && p.ref_LX_size[0] != 0 && col != nullptr;
   const int bx = x + w, by = y + h, cx = x + w / 2, cy = y + h / 2;
-  if (bx < p.in_width && by < p.in_height && (by & 63) != 0) hh = cand_at(col, p.col_stride, bx & ~15, by & ~15);
-  if (hh.ok) return hh;
-  if (cx < p.in_width && cy < p.in_height) c3 = cand_at(col, p.col_stride, cx & ~15, cy & ~15);
-  return c3;
+  const bool want_h = have_col && bx < p.in_width && by < p.in_height && (by & 63) != 0;
+  const bool want_c3 = have_col && cx < p.in_width && cy < p.in_height;
+  const bool want_ctr = ref_cus != nullptr;
+  const kvz_hip_cu_info r_a0 = fetch_cu(cus, p.cus_stride, x - 1, y + h, want_a0);
+  const kvz_hip_cu_info r_a1 = fetch_cu(cus, p.cus_stride, x - 1, y + h - 1, left);
+  const kvz_hip_cu_info r_b0 = fetch_cu(cus, p.cus_stride, x + w, y - 1, want_b0);
+  const kvz_hip_cu_info r_b1 = fetch_cu(cus, p.cus_stride, x + w - 1, y - 1, top);
+  const kvz_hip_cu_info r_b2 = fetch_cu(cus, p.cus_stride, x - 1, y - 1, left && top);
+  const kvz_hip_cu_info r_h = fetch_cu(have_col ? col : cus, p.col_stride, bx & ~15, by & ~15, want_h);
+  const kvz_hip_cu_info r_c3 = fetch_cu(have_col ? col : cus, p.col_stride, cx & ~15, cy & ~15, want_c3);
+  const kvz_hip_cu_info r_ctr = fetch_cu(want_ctr ? ref_cus : cus, p.col_stride, p.tile_x + x + (w >> 1), p.tile_y + y + (h >> 1), want_ctr);
+  s.a[0] = cand_of(r_a0, want_a0); s.a[1] = cand_of(r_a1, left);
+  s.b[0] = cand_of(r_b0, want_b0); s.b[1] = cand_of(r_b1, top); s.b[2] = cand_of(r_b2, left && top);
+  const cand_t hh = cand_of(r_h, want_h);
+  tmp = hh.ok ? hh : cand_of(r_c3, want_c3);
+  centre = cand_of(r_ctr, want_ctr);
 }
 
 // apply_mv_scaling_pocs + get_scaled_mv (inter.c:955-980); C integer division (towards zero) and arithmetic shifts
@@ -119,8 +140,8 @@ __device__ __forceinline__ bool temporal_mv(const kvz_hip_inter_params &p, const
   int l = reflist;
   for (int i = 0; i < p.num_refs; ++i) if (p.ref_pocs[i] > p.poc) { l = 1; break; }
   if (!(c.dir & (l + 1))) l = 1 - l;
-  out[0] = c.mv[l][0]; out[1] = c.mv[l][1];
-  scale_mv(p.poc, p.ref_pocs[cur_pic & 15], p.ref_pocs[col_pic], p.col_ref_pocs[p.col_ref_LX[l][c.ref[l] & 15] & 15], out);
+  out[0] = cand_mvx(c, l); out[1] = cand_mvy(c, l);
+  scale_mv(p.poc, p.ref_pocs[cur_pic & 15], p.ref_pocs[col_pic], p.col_ref_pocs[p.col_ref_LX[l][cand_ref(c, l) & 15] & 15], out);
   return true;
 }
 
@@ -132,34 +153,49 @@ __device__ __forceinline__ bool mvp_from(const kvz_hip_inter_params &p, const ca
   for (int i = 0; i < 2; ++i) {
     const int l = i == 0 ? reflist : 1 - reflist;
     if (!(c.dir & (1 << l))) continue;
-    const int nb_pic = p.ref_LX[l][c.ref[l] & 15];
+    const int nb_pic = p.ref_LX[l][cand_ref(c, l) & 15];
     if (scaling) {
-      out[0] = c.mv[l][0]; out[1] = c.mv[l][1];
+      out[0] = cand_mvx(c, l); out[1] = cand_mvy(c, l);
       scale_mv(p.poc, p.ref_pocs[cur_pic & 15], p.poc, p.ref_pocs[nb_pic & 15], out);
       return true;
     }
-    if (nb_pic == cur_pic) { out[0] = c.mv[l][0]; out[1] = c.mv[l][1]; return true; }
+    if (nb_pic == cur_pic) { out[0] = cand_mvx(c, l); out[1] = cand_mvy(c, l); return true; }
   }
   return false;
 }
 
-// get_mv_cand_from_candidates (inter.c:1102-1195)
+// get_mv_cand_from_candidates (inter.c:1102-1195).  The list position n is data dependent: entries are written through
+// selects over the three slots so that everything stays in registers.
 __device__ __forceinline__ void amvp(const kvz_hip_inter_params &p, const cand_set &s, const cand_t &tmp, int reflist, int lx_idx, int16_t mv_cand[2][2])
 {
   const int cur_pic = p.ref_LX[reflist][lx_idx & 15];
-  int mv[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } }, n = 0;
-  for (int sc = 0; sc < 2 && n == 0; ++sc)
-    for (int i = 0; i < 2; ++i) if (mvp_from(p, s.a[i], reflist, cur_pic, sc != 0, mv[n])) { ++n; break; }
+  int mvx[3] = { 0, 0, 0 }, mvy[3] = { 0, 0, 0 }, n = 0, v[2];
+  auto put = [&](int at) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (k == at) { mvx[k] = v[0]; mvy[k] = v[1]; }
+  };
+  // left: the first of A0, A1 that points at the same picture, else the first that has a vector at all, scaled
+  bool got = false;
+#pragma unroll
+  for (int sc = 0; sc < 2; ++sc)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (!got && mvp_from(p, s.a[i], reflist, cur_pic, sc != 0, v)) { put(n); ++n; got = true; }
+  // above: the first of B0, B1, B2 pointing at the same picture ...
   int above = 0;
-  for (int i = 0; i < 3; ++i) if (mvp_from(p, s.b[i], reflist, cur_pic, false, mv[n])) { above = 1; break; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (!above && mvp_from(p, s.b[i], reflist, cur_pic, false, v)) { put(n); above = 1; }
   n += above;
+  // ... and a scaled one only when there is no left neighbour at all and the list is still short
   if (s.a[0].ok || s.a[1].ok) above = 1; else if (n != 2) above = 0;
-  if (!above)
-    for (int i = 0; i < 3; ++i) if (mvp_from(p, s.b[i], reflist, cur_pic, true, mv[n])) { ++n; break; }
-  if (n == 2 && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) n = 1;
-  if (p.tmvp_enable && p.poc > 1 && p.num_refs && n < 2 && tmp.ok && temporal_mv(p, tmp, cur_pic, reflist, mv[n])) ++n;
-  for (; n < 2; ++n) mv[n][0] = mv[n][1] = 0;
-  for (int i = 0; i < 2; ++i) { mv_cand[i][0] = (int16_t)mv[i][0]; mv_cand[i][1] = (int16_t)mv[i][1]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (!above && mvp_from(p, s.b[i], reflist, cur_pic, true, v)) { put(n); ++n; above = 1; }
+  if (n == 2 && mvx[0] == mvx[1] && mvy[0] == mvy[1]) n = 1;
+  if (p.tmvp_enable && p.poc > 1 && p.num_refs && n < 2 && tmp.ok && temporal_mv(p, tmp, cur_pic, reflist, v)) { put(n); ++n; }
+  mv_cand[0][0] = (int16_t)(n > 0 ? mvx[0] : 0); mv_cand[0][1] = (int16_t)(n > 0 ? mvy[0] : 0);
+  mv_cand[1][0] = (int16_t)(n > 1 ? mvx[1] : 0); mv_cand[1][1] = (int16_t)(n > 1 ? mvy[1] : 0);
 }
 
 // is_duplicate_candidate (inter.c:1262-1278)
@@ -241,18 +277,31 @@ __device__ __forceinline__ int merge_list(const kvz_hip_inter_params &p, cand_se
 }
 
 __global__ __launch_bounds__(64) void inter_candidates_kernel(const kvz_hip_cu_info *__restrict__ cus, const kvz_hip_cu_info *__restrict__ col_cus,
-                                                              const kvz_hip_cu_info *__restrict__ ref_cus, kvz_hip_inter_params p, int reflist, int lx_idx,
+                                                              const kvz_hip_cu_info *__restrict__ ref_cus, kvz_hip_inter_params p_arg, int reflist, int lx_idx,
                                                               kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_merge_cand *__restrict__ merge_out)
 {
+  // The POC and list tables are indexed with per-lane values and a merge list is filled at a per-lane position: both
+  // live in LDS (as kernel arguments / registers the compiler had moved them to 288 bytes of scratch memory per lane,
+  // several dependent memory round trips on a kernel that is nothing but latency).
+  __shared__ kvz_hip_inter_params p;
+  __shared__ kvz_hip_merge_cand s_mc[64][5];
+  if (threadIdx.x == 0) {
+    const u32 *src = reinterpret_cast<const u32 *>(&p_arg);
+    u32 *dst = reinterpret_cast<u32 *>(&p);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(p) / 4); ++k) dst[k] = src[k];
+  }
+  __syncthreads();
   const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= count) return;
+  kvz_hip_merge_cand *mc = s_mc[threadIdx.x];
   kvz_hip_me_pu u = pus[i];
   const int x = u.x, y = u.y, w = u.width, h = u.height;
-  kvz_hip_merge_cand mc[5];
   // a descriptor outside the picture or off the 4-pixel grid: num_merge_cand -1, nothing read
   const bool ok = x >= 0 && y >= 0 && w >= 4 && h >= 4 && w <= 64 && h <= 64 && ((x | y | w | h) & 3) == 0 && x + w <= p.pic_width && y + h <= p.pic_height;
   u.extra_mv[0] = u.extra_mv[1] = 0;
   u.mv_cand[0][0] = u.mv_cand[0][1] = u.mv_cand[1][0] = u.mv_cand[1][1] = 0;
+#pragma unroll
   for (int k = 0; k < 5; ++k) { u.merge[k].mv[0] = u.merge[k].mv[1] = 0; u.merge[k].usable = 0; u.merge[k].same_ref = 0; }
   if (!ok) {
     u.num_merge_cand = -1;
@@ -261,12 +310,14 @@ __global__ __launch_bounds__(64) void inter_candidates_kernel(const kvz_hip_cu_i
     return;
   }
   cand_set s;
-  spatial_cands(cus, p, x, y, w, h, s);
-  const cand_t tmp = temporal_cand(col_cus, p, x, y, w, h);
+  cand_t tmp, centre;
+  gather_cands(cus, col_cus, ref_cus, p, x, y, w, h, s, tmp, centre);
   // search_pu_inter (search_inter.c:1470-1500): the merge list, as calc_mvd_cost / the merge match read it
   const int n = merge_list(p, s, tmp, !(u.pad & 1), !(u.pad & 2), mc);
   u.num_merge_cand = (int16_t)n;
-  for (int k = 0; k < n; ++k) {
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    if (k >= n) continue;
     u.merge[k].usable = mc[k].dir != 3;
     if (mc[k].dir != 3) {
       const int l = mc[k].dir - 1;
@@ -277,10 +328,7 @@ __global__ __launch_bounds__(64) void inter_candidates_kernel(const kvz_hip_cu_i
   if (merge_out) for (int k = 0; k < 5; ++k) merge_out[5 * i + k] = mc[k];
   // search_pu_inter_ref (search_inter.c:1168-1206): the AMVP pair of the picture searched, the collocated CU's vector
   if (reflist >= 0) amvp(p, s, tmp, reflist, lx_idx, u.mv_cand);
-  if (ref_cus) {
-    const cand_t c = cand_at(ref_cus, p.col_stride, p.tile_x + x + (w >> 1), p.tile_y + y + (h >> 1));
-    if (c.ok) { const int l = (c.dir & 1) ? 0 : 1; u.extra_mv[0] = (int16_t)c.mv[l][0]; u.extra_mv[1] = (int16_t)c.mv[l][1]; }
-  }
+  if (centre.ok) { const int l = (centre.dir & 1) ? 0 : 1; u.extra_mv[0] = (int16_t)cand_mvx(centre, l); u.extra_mv[1] = (int16_t)cand_mvy(centre, l); }
   pus[i] = u;
 }
 

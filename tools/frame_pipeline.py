@@ -43,6 +43,13 @@ def build_stages(L, dev):
     keep += [cur, ref, pred]
     stages = {"me": [], "intra": [], "tu": [], "sao": []}      # "sao": the in-loop filter stage, deblocking + SAO statistics
 
+    # the CU arrays the candidate derivation reads: this frame's (as if every neighbour were decided) and the collocated one's
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from patterns import inter_cu_map, inter_params
+    ip = np.ascontiguousarray(inter_params(W, H, poc=8, ref_pocs=(7,), l0=(0,), col_ref_pocs=(6,), col_l0=(0,)))
+    cu_now = torch.from_numpy(inter_cu_map(W, H, 1)[0].view(np.uint8).copy()).to(dev)
+    cu_col = torch.from_numpy(inter_cu_map(W, H, 2)[0].view(np.uint8).copy()).to(dev)
+    keep += [ip, cu_now, cu_col]
     me_prm = np.zeros(22, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
     for n in (8, 16, 32, 64):
         xy = [(x, y) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)]
@@ -52,6 +59,9 @@ def build_stages(L, dev):
         res_d = torch.empty((len(xy), 8), dtype=torch.int32, device=dev)
         prm = me_prm.copy(); prm[10] = 1 if n <= 16 else (2 if n <= 32 else 4)
         keep += [pus_d, res_d, prm]
+        stages["me"].append(("inter_candidates_%dx%d" % (n, n), len(xy),
+                             lambda s, pus_d=pus_d, k=len(xy): L.kvz_hip_inter_candidates_batch(
+                                 cu_now.data_ptr(), cu_col.data_ptr(), cu_col.data_ptr(), ip.ctypes.data, pus_d.data_ptr(), k, None, s)))
         stages["me"].append(("search_pu_%dx%d" % (n, n), len(xy),
                              lambda s, pus_d=pus_d, res_d=res_d, k=len(xy), prm=prm: L.kvz_hip_search_pu_batch(
                                  cur.data_ptr(), W, W, H, ref.data_ptr(), W, W, H, pus_d.data_ptr(), k, prm.ctypes.data, res_d.data_ptr(), s)))
@@ -60,9 +70,13 @@ def build_stages(L, dev):
     for lg in (2, 3, 4, 5):
         n = 1 << lg
         cnt = (W // n) * (H // n)
-        refs_d = torch.randint(0, 256, (cnt * 130,), dtype=torch.uint8, device=dev, generator=g)
+        refs_d = torch.empty(cnt * 130, dtype=torch.uint8, device=dev)
         costs_d = torch.empty(cnt * 35, dtype=torch.int32, device=dev)
-        keep += [refs_d, costs_d]
+        pos_d = torch.tensor([(x, y) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)], dtype=torch.int32, device=dev)
+        keep += [refs_d, costs_d, pos_d]
+        stages["intra"].append(("intra_build_reference_%dx%d" % (n, n), cnt,
+                                lambda s, lg=lg, cnt=cnt, refs_d=refs_d, pos_d=pos_d: L.kvz_hip_intra_build_reference_batch(
+                                    lg, 0, pred.data_ptr(), W, W, H, pos_d.data_ptr(), cnt, refs_d.data_ptr(), s)))
         stages["intra"].append(("intra_rough_%dx%d" % (n, n), cnt,
                                 lambda s, lg=lg, cnt=cnt, refs_d=refs_d, costs_d=costs_d: L.kvz_hip_intra_rough_batch(
                                     lg, 3, refs_d.data_ptr(), flat_cur.data_ptr(), cnt, costs_d.data_ptr(), None, s)))
@@ -94,7 +108,6 @@ def build_stages(L, dev):
                               lambda s, n=n, cnt=cnt, band=band: L.kvz_hip_sao_band_stats_batch(
                                   flat_cur.data_ptr(), flat_pred.data_ptr(), n, n, cnt, band.data_ptr(), s)))
     # deblocking of the reconstructed frame (1088 coded rows), both passes
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from patterns import deblock_case, deblock_params
     DH = 1088
     ty, tu, tv, tcus = deblock_case(256, 128, 11, qp=36)
@@ -123,7 +136,9 @@ def enqueue_serial(stages, s):
 def by_launch(stages):
     """finer branches: every motion-search launch on its own (they are latency bound and, at 480..8040 PUs, none of the
     larger sizes fills the chip), the other three stages as before"""
-    out = {name: [(name, units, fn)] for name, units, fn in stages["me"]}
+    out = {}
+    for name, units, fn in stages["me"]:                 # a size's candidate derivation and its search stay on one branch, in order
+        out.setdefault(name.rsplit("_", 1)[1], []).append((name, units, fn))
     out.update({k: v for k, v in stages.items() if k != "me"})
     return out
 
