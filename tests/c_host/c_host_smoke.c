@@ -111,6 +111,50 @@ int main(void)
   CHECK(kvz_hip_memcpy_d2h(h_cost, d_cost, N * sizeof(uint32_t), NULL) == KVZ_HIP_OK, "d2h");
   for (int i = 0; i < N; ++i) CHECK(h_cost[i] == 64u * 5u, "NULL-stream sad_8x8[%d] = %u", i, h_cost[i]);
 
+  /* ---- the glue between dependency fronts, on the device: intra references from a reconstruction plane, merge / AMVP
+   * candidates from a CU array, both with answers known by construction ---- */
+  {
+    enum { PW = 64, PH = 64 };
+    uint8_t *d_rec = kvz_hip_malloc(PW * PH);
+    kvz_hip_intra_pos h_pos[2] = { { 0, 0 }, { 8, 8 } }, *d_pos = kvz_hip_malloc(sizeof(h_pos));
+    kvz_hip_intra_ref h_refs[2], *d_refs = kvz_hip_malloc(sizeof(h_refs));
+    CHECK(d_rec && d_pos && d_refs, "kvz_hip_malloc");
+    CHECK(kvz_hip_memset(d_rec, 77, PW * PH, st) == KVZ_HIP_OK && kvz_hip_memcpy_h2d(d_pos, h_pos, sizeof(h_pos), st) == KVZ_HIP_OK, "plane");
+    CHECK(kvz_hip_intra_build_reference_batch(3, 0, d_rec, PW, PW, PH, d_pos, 2, d_refs, st) == KVZ_HIP_OK, "intra_build_reference: %s", kvz_hip_last_error());
+    CHECK(kvz_hip_memcpy_d2h(h_refs, d_refs, sizeof(h_refs), st) == KVZ_HIP_OK, "d2h");
+    for (int k = 0; k <= 16; ++k) {
+      CHECK(h_refs[0].left[k] == 128 && h_refs[0].top[k] == 128, "picture corner: mid grey, got %d / %d at %d", h_refs[0].left[k], h_refs[0].top[k], k);
+      CHECK(h_refs[1].left[k] == 77 && h_refs[1].top[k] == 77, "inside a flat plane: its value, got %d / %d at %d", h_refs[1].left[k], h_refs[1].top[k], k);
+    }
+    /* a 64 x 64 picture whose left half is one inter CU with vector (12, -8): the 8x8 PU at (32, 0) sees it as A1 */
+    kvz_hip_cu_info h_cus[16 * 16];
+    memset(h_cus, 0, sizeof(h_cus));
+    for (int y = 0; y < 16; ++y) for (int x = 0; x < 8; ++x) {
+      kvz_hip_cu_info *c = &h_cus[y * 16 + x];
+      c->type = 2; c->mv_dir = 1; c->mv[0][0] = 12; c->mv[0][1] = -8;
+    }
+    kvz_hip_cu_info *d_cus = kvz_hip_malloc(sizeof(h_cus));
+    kvz_hip_me_pu h_pu, *d_pu = kvz_hip_malloc(sizeof(h_pu));
+    kvz_hip_merge_cand h_mc[5], *d_mc = kvz_hip_malloc(sizeof(h_mc));
+    memset(&h_pu, 0, sizeof(h_pu));
+    h_pu.x = 32; h_pu.y = 0; h_pu.width = 8; h_pu.height = 8;
+    kvz_hip_inter_params ip;
+    memset(&ip, 0, sizeof(ip));
+    ip.poc = 1; ip.num_refs = 1; ip.ref_pocs[0] = 0; ip.ref_LX_size[0] = 1;
+    ip.pic_width = ip.in_width = PW; ip.pic_height = ip.in_height = PH; ip.cus_stride = ip.col_stride = 16;
+    CHECK(d_cus && d_pu && d_mc, "kvz_hip_malloc");
+    CHECK(kvz_hip_memcpy_h2d(d_cus, h_cus, sizeof(h_cus), st) == KVZ_HIP_OK && kvz_hip_memcpy_h2d(d_pu, &h_pu, sizeof(h_pu), st) == KVZ_HIP_OK, "h2d");
+    CHECK(kvz_hip_inter_candidates_batch(d_cus, NULL, NULL, &ip, d_pu, 1, d_mc, st) == KVZ_HIP_OK, "inter_candidates: %s", kvz_hip_last_error());
+    CHECK(kvz_hip_memcpy_d2h(&h_pu, d_pu, sizeof(h_pu), st) == KVZ_HIP_OK && kvz_hip_memcpy_d2h(h_mc, d_mc, sizeof(h_mc), st) == KVZ_HIP_OK, "d2h");
+    CHECK(h_pu.num_merge_cand == 5 && h_mc[0].dir == 1 && h_mc[0].mv[0][0] == 12 && h_mc[0].mv[0][1] == -8 && h_mc[0].ref[0] == 0,
+          "merge candidate 0 = A1's motion, got dir %d mv (%d, %d)", h_mc[0].dir, h_mc[0].mv[0][0], h_mc[0].mv[0][1]);
+    CHECK(h_mc[1].dir == 1 && h_mc[1].mv[0][0] == 0 && h_mc[1].mv[0][1] == 0, "merge candidate 1 = the zero vector");
+    CHECK(h_pu.mv_cand[0][0] == 12 && h_pu.mv_cand[0][1] == -8 && h_pu.mv_cand[1][0] == 0 && h_pu.mv_cand[1][1] == 0,
+          "AMVP = (A1, zero), got (%d, %d) (%d, %d)", h_pu.mv_cand[0][0], h_pu.mv_cand[0][1], h_pu.mv_cand[1][0], h_pu.mv_cand[1][1]);
+    CHECK(h_pu.merge[0].usable == 1 && h_pu.merge[0].same_ref == 1 && h_pu.merge[0].mv[0] == 12, "the search's view of merge candidate 0");
+    kvz_hip_free(d_rec); kvz_hip_free(d_pos); kvz_hip_free(d_refs); kvz_hip_free(d_cus); kvz_hip_free(d_pu); kvz_hip_free(d_mc);
+  }
+
   /* ---- several contexts in one process: every visible device gets a context; a second init of another index is a
    * second context, an index beyond the device count is refused; two pthreads drive (up to) two devices at once ---- */
   const int ndev = kvz_hip_device_count();
