@@ -728,6 +728,8 @@ void __real_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int
 /* optional snapshots of what the candidate derivation read (defined with the flat CU types below) */
 static void rec_snapshot_search(const encoder_state_t *state, const lcu_t *lcu, int record_index);
 static void rec_snapshot_frame(const encoder_state_t *state, int frame_index);
+/* optional: the search served by the GPU chain instead of the reference's (defined at the end of the file) */
+static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost);
 
 static void rec_copy_plane(kvz_pixel *dst, const kvz_picture *p, int w, int h)
 {
@@ -736,6 +738,7 @@ static void rec_copy_plane(kvz_pixel *dst, const kvz_picture *p, int w, int h)
 
 void __wrap_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
 {
+  if (gpu_search_serve(state, x, y, depth, lcu, inter_cost, inter_bitcost)) return;
   const encoder_control_t *ctrl = state->encoder_control;
   const int usable = g_rec.on && state->frame->ref->used_size == 1 && state->frame->slicetype == KVZ_SLICE_P &&
                      !ctrl->cfg.mv_rdo && state->tile->offset_x == 0 && state->tile->offset_y == 0;
@@ -1106,4 +1109,198 @@ int ref_record_snapshots_get(int32_t *index, void *cu, void *col, void *params, 
   free(g_snap.index); free(g_snap.cu); free(g_snap.col); free(g_snap.params);
   memset(&g_snap, 0, sizeof(g_snap));
   return n;
+}
+
+
+/* ------------------------------------------------------------------------
+ * The encoder's 2Nx2N inter searches SERVED BY THE GPU CHAIN (tests only): with ref_gpu_search_begin, the wrapper of
+ * kvz_search_cu_inter above does not run the reference's search_pu_inter at all for the searches it can express
+ * (single-reference P slices, rd < 2, no mv-rdo, one tile) but
+ *   1. copies what the candidate derivation would read -- lcu->cu -- into the picture's CU array on the device
+ *      (the frame's planes and the collocated picture's CU array go up once per frame),
+ *   2. runs kvz_hip_inter_candidates_batch and kvz_hip_search_pu_batch back to back on one stream,
+ *   3. writes the decision into cur_cu and the two cost outputs exactly where search_pu_inter_ref does
+ *      (search_inter.c:1275-1290, :1497-1499).
+ * The encode must then produce the bitstream of the untouched encoder: every later decision of the encoder consumes
+ * these results.  One PU per launch -- a correctness path, the throughput form is a front of PUs per launch.
+ * ------------------------------------------------------------------------ */
+static struct {
+  int on, w, h, stride, rows, poc_loaded, have_frame;
+  void *lib;
+  int (*init)(int);
+  void *(*dmalloc)(size_t);
+  void (*dfree)(void *);
+  int (*h2d)(void *, const void *, size_t, kvz_hip_stream);
+  int (*d2h)(void *, const void *, size_t, kvz_hip_stream);
+  int (*cand)(const kvz_hip_cu_info *, const kvz_hip_cu_info *, const kvz_hip_cu_info *, const kvz_hip_inter_params *, kvz_hip_me_pu *, size_t,
+              kvz_hip_merge_cand *, kvz_hip_stream);
+  int (*search)(const kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_me_pu *, size_t,
+                const kvz_hip_me_params *, kvz_hip_me_result *, kvz_hip_stream);
+  const char *(*last_error)(void);
+  uint8_t *d_pic, *d_ref, *h_plane;
+  kvz_hip_cu_info *d_cus, *d_col, *h_cus, *h_col;
+  kvz_hip_me_pu *d_pu;
+  kvz_hip_me_result *d_res;
+  kvz_hip_inter_params ip;
+  kvz_hip_me_params mp;
+  long served, passed_on, failed;
+} g_gpu;
+
+int ref_gpu_search_begin(const char *lib_path, int w, int h)
+{
+  memset(&g_gpu, 0, sizeof(g_gpu));
+  void *l = dlopen(lib_path, RTLD_NOW | RTLD_GLOBAL);
+  if (!l) { fprintf(stderr, "dlopen %s: %s\n", lib_path, dlerror()); return -1; }
+  g_gpu.lib = l;
+  *(void **)&g_gpu.init = dlsym(l, "kvz_hip_init");
+  *(void **)&g_gpu.dmalloc = dlsym(l, "kvz_hip_malloc");
+  *(void **)&g_gpu.dfree = dlsym(l, "kvz_hip_free");
+  *(void **)&g_gpu.h2d = dlsym(l, "kvz_hip_memcpy_h2d");
+  *(void **)&g_gpu.d2h = dlsym(l, "kvz_hip_memcpy_d2h");
+  *(void **)&g_gpu.cand = dlsym(l, "kvz_hip_inter_candidates_batch");
+  *(void **)&g_gpu.search = dlsym(l, "kvz_hip_search_pu_batch");
+  *(void **)&g_gpu.last_error = dlsym(l, "kvz_hip_last_error");
+  if (!g_gpu.init || !g_gpu.dmalloc || !g_gpu.dfree || !g_gpu.h2d || !g_gpu.d2h || !g_gpu.cand || !g_gpu.search || !g_gpu.last_error) return -1;
+  if (g_gpu.init(-1) != KVZ_HIP_OK) { fprintf(stderr, "kvz_hip_init: %s\n", g_gpu.last_error()); return -1; }
+  g_gpu.w = w; g_gpu.h = h;
+  g_gpu.stride = ((w + 63) / 64) * 16; g_gpu.rows = ((h + 63) / 64) * 16;
+  const size_t map_bytes = (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info);
+  g_gpu.d_pic = g_gpu.dmalloc((size_t)w * h); g_gpu.d_ref = g_gpu.dmalloc((size_t)w * h);
+  g_gpu.d_cus = g_gpu.dmalloc(map_bytes); g_gpu.d_col = g_gpu.dmalloc(map_bytes);
+  g_gpu.d_pu = g_gpu.dmalloc(sizeof(kvz_hip_me_pu)); g_gpu.d_res = g_gpu.dmalloc(sizeof(kvz_hip_me_result));
+  g_gpu.h_plane = malloc((size_t)w * h);
+  g_gpu.h_cus = calloc(1, map_bytes); g_gpu.h_col = calloc(1, map_bytes);
+  if (!g_gpu.d_pic || !g_gpu.d_ref || !g_gpu.d_cus || !g_gpu.d_col || !g_gpu.d_pu || !g_gpu.d_res || !g_gpu.h_plane || !g_gpu.h_cus || !g_gpu.h_col) return -1;
+  g_gpu.poc_loaded = -1;
+  g_gpu.on = 1;
+  return 0;
+}
+
+/* out[0..2] = searches served by the GPU chain, searches passed on to the reference, GPU calls that failed */
+void ref_gpu_search_end(long *out)
+{
+  if (out) { out[0] = g_gpu.served; out[1] = g_gpu.passed_on; out[2] = g_gpu.failed; }
+  if (g_gpu.lib) {
+    g_gpu.dfree(g_gpu.d_pic); g_gpu.dfree(g_gpu.d_ref); g_gpu.dfree(g_gpu.d_cus); g_gpu.dfree(g_gpu.d_col);
+    g_gpu.dfree(g_gpu.d_pu); g_gpu.dfree(g_gpu.d_res);
+  }
+  free(g_gpu.h_plane); free(g_gpu.h_cus); free(g_gpu.h_col);
+  memset(&g_gpu, 0, sizeof(g_gpu));
+}
+
+static void cu_to_hip(const cu_info_t *c, kvz_hip_cu_info *f)
+{
+  memset(f, 0, sizeof(*f));
+  f->type = c->type; f->depth = c->depth; f->part_size = c->part_size; f->tr_depth = c->tr_depth; f->qp = c->qp;
+  if (c->type == CU_INTER) {
+    f->mv_dir = c->inter.mv_dir;
+    memcpy(f->mv, c->inter.mv, sizeof(f->mv));
+    f->mv_ref[0] = c->inter.mv_ref[0]; f->mv_ref[1] = c->inter.mv_ref[1];
+  }
+}
+
+static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
+{
+  if (!g_gpu.on) return 0;
+  const encoder_control_t *ctrl = state->encoder_control;
+  const encoder_state_config_frame_t *fr = state->frame;
+  const int can = fr->ref->used_size == 1 && fr->slicetype == KVZ_SLICE_P && fr->ref_LX_size[0] == 1 && fr->ref_LX[0][0] == 0 &&
+                  !ctrl->cfg.mv_rdo && ctrl->cfg.rdo < 2 && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
+                  state->tile->frame->width == g_gpu.w && state->tile->frame->height == g_gpu.h;
+  if (!can) { ++g_gpu.passed_on; return 0; }
+  const int w = g_gpu.w, h = g_gpu.h;
+  int bad = 0;
+  if (g_gpu.poc_loaded != fr->poc) {
+    /* per frame: the two luma planes, the collocated picture's CU array, the state both entries read */
+    const kvz_picture *src = state->tile->frame->source, *ref = fr->ref->images[0];
+    for (int r = 0; r < h; ++r) memcpy(g_gpu.h_plane + (size_t)r * w, src->y + (size_t)r * src->stride, (size_t)w);
+    bad |= g_gpu.h2d(g_gpu.d_pic, g_gpu.h_plane, (size_t)w * h, NULL);
+    for (int r = 0; r < h; ++r) memcpy(g_gpu.h_plane + (size_t)r * w, ref->y + (size_t)r * ref->stride, (size_t)w);
+    bad |= g_gpu.h2d(g_gpu.d_ref, g_gpu.h_plane, (size_t)w * h, NULL);
+    const cu_array_t *a = fr->ref->cu_arrays[0];
+    memset(g_gpu.h_col, 0, (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info));
+    for (int sy = 0; sy < g_gpu.rows && sy * 4 < a->height; ++sy)
+      for (int sx = 0; sx < g_gpu.stride && sx * 4 < a->width; ++sx)
+        cu_to_hip(&a->data[sx + sy * (a->stride >> 2)], &g_gpu.h_col[sy * g_gpu.stride + sx]);
+    bad |= g_gpu.h2d(g_gpu.d_col, g_gpu.h_col, (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info), NULL);
+    kvz_hip_inter_params *ip = &g_gpu.ip;
+    memset(ip, 0, sizeof(*ip));
+    ip->poc = fr->poc; ip->slice_is_b = 0; ip->tmvp_enable = ctrl->cfg.tmvp_enable; ip->num_refs = 1;
+    ip->ref_pocs[0] = fr->ref->pocs[0];
+    memcpy(ip->ref_LX, fr->ref_LX, sizeof(ip->ref_LX));
+    ip->ref_LX_size[0] = 1; ip->ref_LX_size[1] = 0;
+    memcpy(ip->col_ref_pocs, fr->ref->images[0]->ref_pocs, sizeof(ip->col_ref_pocs));
+    memcpy(ip->col_ref_LX, fr->ref->ref_LXs[0], sizeof(ip->col_ref_LX));
+    ip->pic_width = w; ip->pic_height = h; ip->in_width = ctrl->in.width; ip->in_height = ctrl->in.height;
+    ip->ref_idx = 0; ip->cus_stride = g_gpu.stride; ip->col_stride = g_gpu.stride;
+    kvz_hip_me_params *p = &g_gpu.mp;
+    memset(p, 0, sizeof(*p));
+    p->early_termination = ctrl->cfg.me_early_termination;
+    p->max_steps = ctrl->cfg.me_max_steps;
+    p->fme_level = ctrl->cfg.fme_level;
+    p->wpp_owf = ctrl->cfg.owf && ctrl->cfg.wpp;
+    p->ref_delay_px = ctrl->cfg.sao_type ? SAO_DELAY_PX : (ctrl->cfg.deblock_enable ? DEBLOCK_DELAY_PX : 0);
+    p->max_ref_lcu_down = ctrl->max_inter_ref_lcu.down; p->max_ref_lcu_right = ctrl->max_inter_ref_lcu.right;
+    switch (ctrl->cfg.ime_algorithm) {
+      case KVZ_IME_DIA: p->algorithm = 1; break;
+      case KVZ_IME_TZ: p->algorithm = 2; break;
+      case KVZ_IME_FULL64: p->algorithm = 3; p->search_range = 64; break;
+      case KVZ_IME_FULL32: case KVZ_IME_FULL: p->algorithm = 3; p->search_range = 32; break;
+      case KVZ_IME_FULL16: p->algorithm = 3; p->search_range = 16; break;
+      case KVZ_IME_FULL8: p->algorithm = 3; p->search_range = 8; break;
+      default: p->algorithm = 0; break;
+    }
+    p->mv_constraint = ctrl->cfg.mv_constraint;
+    g_gpu.poc_loaded = fr->poc;
+  }
+  /* 1. lcu->cu into the picture's CU array: the LCU's 16 x 16 SCUs, the row above, the column to the left, the corner,
+   *    the top-right SCU (cu.h:324-344); the rows that changed go to the device in one copy */
+  const int ox = (x / LCU_WIDTH) * 16, oy = (y / LCU_WIDTH) * 16;
+  for (int sy = -1; sy < 16; ++sy)
+    for (int sx = -1; sx < 16; ++sx) {
+      const int fx = ox + sx, fy = oy + sy;
+      if (fx < 0 || fy < 0 || fx >= g_gpu.stride || fy >= g_gpu.rows) continue;
+      cu_to_hip(&lcu->cu[LCU_CU_OFFSET + sx + sy * LCU_T_CU_WIDTH], &g_gpu.h_cus[fy * g_gpu.stride + fx]);
+    }
+  if (oy > 0 && ox + 16 < g_gpu.stride) cu_to_hip(LCU_GET_TOP_RIGHT_CU(lcu), &g_gpu.h_cus[(oy - 1) * g_gpu.stride + ox + 16]);
+  const int r0 = oy > 0 ? oy - 1 : 0, r1 = oy + 16 < g_gpu.rows ? oy + 16 : g_gpu.rows;
+  bad |= g_gpu.h2d(g_gpu.d_cus + (size_t)r0 * g_gpu.stride, g_gpu.h_cus + (size_t)r0 * g_gpu.stride,
+                   (size_t)(r1 - r0) * g_gpu.stride * sizeof(kvz_hip_cu_info), NULL);
+  /* 2. derive + search */
+  const int width = LCU_WIDTH >> depth;
+  kvz_hip_me_pu pu;
+  memset(&pu, 0, sizeof(pu));
+  pu.x = x; pu.y = y; pu.width = width; pu.height = width;
+  kvz_hip_me_params mp = g_gpu.mp;
+  mp.lambda_cost = (int32_t)(state->lambda_sqrt + 0.5);
+  mp.size_classes = width <= 16 ? 1 : (width <= 32 ? 2 : 4);
+  kvz_hip_me_result res;
+  memset(&res, 0, sizeof(res));
+  bad |= g_gpu.h2d(g_gpu.d_pu, &pu, sizeof(pu), NULL);
+  bad |= g_gpu.cand(g_gpu.d_cus, g_gpu.d_col, g_gpu.d_col, &g_gpu.ip, g_gpu.d_pu, 1, NULL, NULL);
+  bad |= g_gpu.search(g_gpu.d_pic, (uint32_t)w, w, h, g_gpu.d_ref, (uint32_t)w, w, h, g_gpu.d_pu, 1, &mp, g_gpu.d_res, NULL);
+  bad |= g_gpu.d2h(&res, g_gpu.d_res, sizeof(res), NULL);
+  if (bad || res.reserved == -1) {
+    if (g_gpu.failed++ == 0) fprintf(stderr, "gpu_search_serve: %s\n", g_gpu.last_error());
+    return 0;                                            /* the reference's own search takes over */
+  }
+  /* 3. what search_pu_inter / search_pu_inter_ref leave behind (search_inter.c:1460-1461, :1497-1499, :1275-1290) */
+  cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
+  *inter_cost = MAX_INT;
+  *inter_bitcost = MAX_INT;
+  CU_SET_MV_CAND(cur_cu, 0, 0);
+  CU_SET_MV_CAND(cur_cu, 1, 0);
+  if (res.cost != 0xffffffffu) {
+    cur_cu->inter.mv_dir = 1;
+    cur_cu->merged = (uint8_t)res.merged;
+    cur_cu->merge_idx = (uint8_t)res.merge_idx;
+    cur_cu->inter.mv_ref[0] = 0;
+    cur_cu->inter.mv[0][0] = (int16_t)res.mv[0];
+    cur_cu->inter.mv[0][1] = (int16_t)res.mv[1];
+    CU_SET_MV_CAND(cur_cu, 0, res.mv_cand);
+    *inter_cost = res.cost;
+    *inter_bitcost = res.bitcost;
+  }
+  ++g_gpu.served;
+  return 1;
 }

@@ -609,3 +609,21 @@ def inter_candidates(params, cus, col_cus, ref_cus, pus):
     L.ref_inter_candidates(cus.ctypes.data, col_cus.ctypes.data, None if ref_cus is None else ref_cus.ctypes.data,
                            np.ascontiguousarray(params).ctypes.data, pus.ctypes.data, len(pus), out.ctypes.data)
     return pus, out
+
+
+def encode_with_gpu_search(frames, w, h, opts, lib_path):
+    """ref_encode with the harness serving the encoder's 2Nx2N single-reference P searches through the GPU chain
+    (kvz_hip_inter_candidates_batch + kvz_hip_search_pu_batch; oracle/ref_harness.c: gpu_search_serve).
+    -> (bitstream, searches served by the GPU, searches passed on to the reference, failed GPU calls)"""
+    L = lib()
+    L.ref_gpu_search_begin.restype = C.c_int
+    L.ref_gpu_search_begin.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.ref_gpu_search_end.restype = None
+    L.ref_gpu_search_end.argtypes = [C.POINTER(C.c_long)]
+    assert L.ref_gpu_search_begin(lib_path.encode(), w, h) == 0
+    out = (C.c_long * 3)()
+    try:
+        bitstream, _ = encode(frames, w, h, opts)
+    finally:
+        L.ref_gpu_search_end(out)
+    return bitstream, int(out[0]), int(out[1]), int(out[2])

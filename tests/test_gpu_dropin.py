@@ -362,3 +362,27 @@ def test_get_extended_block_through_registry(hip):
     a, _, _ = R.get_extended_block(frame, 3, 4, 0, 0, 8, 9, 9, off_x=16, off_y=8, name="hip")      # tile offsets (search_inter.c:1007-1012)
     b, _, _ = R.get_extended_block(frame, 3, 4, 0, 0, 8, 9, 9, off_x=16, off_y=8, name="generic")
     np.testing.assert_array_equal(a, b)
+
+
+GPU_SEARCH_CONFIGS = [
+    # single-reference P frames; everything else about the encode is the preset's (RDOQ, SAO, deblocking, TMVP, WPP)
+    (192, 128, 4, "preset=medium,ref=1,bipred=0,gop=0,qp=30,threads=0,period=0"),
+    (192, 128, 4, "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=24,threads=0,me=tz,me-early-termination=sensitive,mv-constraint=frametilemargin,period=0"),
+    (128, 128, 5, "preset=fast,ref=1,bipred=0,gop=0,rdoq=0,qp=37,threads=0,me=dia,subme=2,deblock=1,sao=off,owf=0,wpp=0,period=0"),
+    (168, 104, 4, "preset=veryfast,ref=1,bipred=0,gop=0,qp=33,threads=0,tmvp=0,period=0"),       # ragged LCUs, no temporal candidates
+    (128, 64, 6, "preset=slow,ref=1,bipred=0,gop=0,rdoq=0,qp=27,threads=0,smp=1,amp=1,period=0"),   # SMP / AMP searches stay the reference's
+]
+
+
+@pytest.mark.parametrize("w,h,n,opts", GPU_SEARCH_CONFIGS)
+def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, n, opts):
+    """The batched entries inside a live encode: every 2Nx2N inter search of the reference encoder is answered by
+    kvz_hip_inter_candidates_batch (candidates from the encoder's lcu->cu, copied into a device CU array) followed by
+    kvz_hip_search_pu_batch, and the encoder carries on with that decision -- mode decision, reconstruction, the neighbours'
+    candidates, the next frame's temporal candidates all consume it.  The bitstream must be the untouched encoder's."""
+    frames = R.synthetic_sequence(w, h, n, seed=5)
+    plain, _ = R.encode(frames, w, h, opts)
+    served_bs, served, passed_on, failed = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"))
+    print("searches served by the GPU chain: %d, left to the reference: %d" % (served, passed_on))
+    assert failed == 0 and served >= 40 * (n - 1)
+    assert served_bs == plain, "bitstreams differ (%d vs %d bytes)" % (len(served_bs), len(plain))
