@@ -371,6 +371,7 @@ GPU_SEARCH_CONFIGS = [
     (128, 128, 5, "preset=fast,ref=1,bipred=0,gop=0,rdoq=0,qp=37,threads=0,me=dia,subme=2,deblock=1,sao=off,owf=0,wpp=0,period=0"),
     (168, 104, 4, "preset=veryfast,ref=1,bipred=0,gop=0,qp=33,threads=0,tmvp=0,period=0"),       # ragged LCUs, no temporal candidates
     (128, 64, 6, "preset=slow,ref=1,bipred=0,gop=0,rdoq=0,qp=27,threads=0,smp=1,amp=1,period=0"),   # SMP / AMP searches stay the reference's
+    (1920, 1080, 2, "preset=medium,ref=1,bipred=0,gop=0,qp=32,threads=0,period=0"),                 # one 1080p P frame: ~43 000 searches
 ]
 
 
