@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential run of the batched entries against the oracle, larger than the test suite
-(development tool; run on the GPU box: python tools/fuzz_parity.py --seed 1 --scale 1)."""
+(a checker, not collected by pytest; run on the GPU box: python tests/fuzz_parity.py --seed 1 --scale 1)."""
 import argparse
 import os
 import sys

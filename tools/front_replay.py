@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """Search-only timing of kvz_hip_search_pu_batch on searches RECORDED from real encodes of the reference encoder, issued front
 by front in the encoder's dependency order (tools/front_replay.c does the timed loop in C; this script prepares its input
-from tests/golden/fronts.npz -- or from a fresh recording with --live when oracle/_ref is present -- builds the C program and
-prints its JSON line).  Not an encoder: labelled "search only, fronts" wherever it is quoted.
+from tests/golden/fronts.npz -- recorded by oracle/gen_golden.py, group `fronts` -- builds the C program and prints its JSON line).  Not an encoder: labelled "search only, fronts" wherever it is quoted.
 
-  python3 tools/front_replay.py [--live FRAMES] [--repeats N] [--sessions 2,4,8,16]"""
+  python3 tools/front_replay.py [--repeats N] [--sessions 2,4,8,16]"""
 import argparse
 import os
 import struct
@@ -40,7 +39,6 @@ def write_case(path, pic, ref, pus, res, meta, prm):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--live", type=int, default=0, help="record a fresh 1080p encode of this many frames with oracle/_ref instead of the fixture")
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--keep-case", default="", help="also leave the first frame's input file here (to run tools/front_replay under rocprofv3)")
     ap.add_argument("--sessions", default="", help="comma list, e.g. 2,4,8,16: also replay with that many host threads at once")
@@ -48,19 +46,8 @@ def main():
     from patterns import fronts_fixture
     exe = build()
     cases = []
-    if args.live:
-        import ref_lib as R
-        w, h = 1920, 1080
-        rec = R.record_inter_searches(R.synthetic_sequence(w, h, args.live), w, h,
-                                      "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=32,threads=0,smp=0,amp=0,period=0", max_records=60000 * args.live)
-        m = rec["meta"]
-        for fr in range(len(rec["pic"])):
-            sel = np.where(m[:, 0] == fr)[0]
-            prm = rec["params"].copy(); prm["lambda_cost"] = m[sel[0], 4]
-            cases.append((rec["pic"][fr], rec["ref"][fr], rec["pus"][sel], rec["results"][sel], m[sel], prm))
-    else:
-        d = np.load(os.path.join(ROOT, "tests", "golden", "fronts.npz"))
-        cases = fronts_fixture(d, "hd")
+    d = np.load(os.path.join(ROOT, "tests", "golden", "fronts.npz"))
+    cases = fronts_fixture(d, "hd")
     for i, c in enumerate(cases):
         path = "/tmp/kvz_front_case_%d.bin" % i
         write_case(path, *c)
