@@ -78,7 +78,8 @@ KVZ_HIP_API const char *kvz_hip_last_error(void);    /* text of the calling thre
 KVZ_HIP_API const char *kvz_hip_device_name(void);   /* of the calling thread's current device */
 /* Version of this header's ABI as the library was built (layouts of the kvz_hip_* structs, entry signatures); a host
  * compares it with the KVZ_HIP_ABI_VERSION it was compiled against before it registers the strategies. */
-#define KVZ_HIP_ABI_VERSION 2   /* 2: per-device contexts, kvz_hip_me_params with tile / mv-constraint / mv-rdo fields */
+#define KVZ_HIP_ABI_VERSION 3   /* 2: per-device contexts, kvz_hip_me_params with tile / mv-constraint / mv-rdo fields;
+                                   3: kvz_hip_me_params.cost_to_beat (96 bytes), candidate derivation and intra reference entries */
 KVZ_HIP_API int kvz_hip_abi_version(void);
 
 /* Launch-geometry / kernel-selection knobs for A/B runs (tools/bench_all.py --tune key=v1,v2);
@@ -390,7 +391,12 @@ typedef struct {
   int32_t refs_before;           /* mv_rdo: pictures of state->frame->ref with poc < current poc (rdo.c:990-998); ref_idx is coded when > 1 */
   int32_t reserved;
   const kvz_hip_me_cabac *cabac; /* mv_rdo: DEVICE array of snapshots, indexed by kvz_hip_me_pu.reserved; else unused (NULL) */
-} kvz_hip_me_params;             /* 88 bytes */
+  const uint32_t *cost_to_beat;  /* NULL, or a DEVICE array with one entry per PU: *inter_cost as search_pu_inter_ref finds it
+                                    (search_inter.c:1239), i.e. the best cost of the reference pictures searched before this one
+                                    (MAX_INT for the first).  A PU whose integer search does not get below it skips the fractional
+                                    search and is scored like fme_level 0 (:1242-1252), exactly as the reference's loop over
+                                    the pictures of a multi-reference frame does */
+} kvz_hip_me_params;             /* 96 bytes */
 typedef struct {
   int32_t mv[2];                 /* info->best_mv, quarter-pel */
   uint32_t cost, bitcost;        /* info->best_cost, info->best_bitcost; cost 0xFFFFFFFF: nothing allowed / bad descriptor */

@@ -338,17 +338,22 @@ def inter_candidates_batch(params, cus, col_cus, ref_cus, pus):
 
 
 # ---- motion search of whole PUs ----
-def search_pu_batch(pic, ref, pus, params, cabac=None):
-    """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (88 bytes).
+def search_pu_batch(pic, ref, pus, params, cabac=None, cost_to_beat=None):
+    """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (96 bytes).
+    cabac: kvz_hip_me_cabac snapshots (--mv-rdo); cost_to_beat: uint32 per PU (the best cost of the pictures searched before).
     Returns the raw results as int32 [count, 8] (= kvz_hip_me_result)."""
     L = _lib.init()
     pic = np.ascontiguousarray(pic, dtype=np.uint8)
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     pus = np.ascontiguousarray(pus)
     params = np.ascontiguousarray(params)
-    assert pus.dtype.itemsize == 64 and params.nbytes == 88
+    assert pus.dtype.itemsize == 64 and params.nbytes == 96
     count = pus.shape[0]
-    cb = None
+    cb = tb = None
+    if cost_to_beat is not None:
+        tb = DeviceBuffer.from_numpy(np.ascontiguousarray(cost_to_beat, dtype=np.uint32))
+        params = params.copy()
+        params.view(np.uint8).reshape(-1)[88:96] = np.frombuffer(np.uint64(tb.ptr).tobytes(), dtype=np.uint8)
     if cabac is not None:                       # --mv-rdo: kvz_hip_me_cabac snapshots, staged to the device
         cb = DeviceBuffer.from_numpy(np.ascontiguousarray(cabac).view(np.uint8))
         params = params.copy()

@@ -284,7 +284,7 @@ struct me_shared { u32 sad[ME_GROUP]; int cx[ME_GROUP], cy[ME_GROUP]; };
 template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0, bool RDO = false, bool CONSTR = true>
 __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, const u8 *__restrict__ pic, u32 pic_stride,
                                                const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm,
-                                               kvz_hip_me_result *__restrict__ out)
+                                               kvz_hip_me_result *__restrict__ out, size_t pu_index)
 {
   typedef frac_geom<MAXW> G;
   u8 *s_cur = lds + G::P_BYTES;                        // same place search_frac_core keeps the current block
@@ -647,9 +647,12 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   if (best_cost != 0xffffffffu) {
     sync();
     const kvz_hip_block_pair d = { pu.x, pu.y, pu.x + best_x, pu.y + best_y, w, h };
-    const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model_t<RDO, CONSTR>, FW, FH>(tid, lds, pic, pic_stride, ref, d, prm.fme_level, mvc, (u32 *)nullptr, (i32 *)nullptr);
+    // :1239: the fractional search only if the integer result beats what the pictures searched before reached
+    const u32 beat = prm.cost_to_beat ? prm.cost_to_beat[pu_index] : 0xffffffffu;
+    const int level = __builtin_amdgcn_readfirstlane(best_cost < beat ? prm.fme_level : 0);   // the same in every lane: keep the level's branches scalar
+    const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model_t<RDO, CONSTR>, FW, FH>(tid, lds, pic, pic_stride, ref, d, level, mvc, (u32 *)nullptr, (i32 *)nullptr);
     best_cost = fr.cost;                               // level 0: satd + bits(int mv) * lambda, the same bits as best_bits
-    if (prm.fme_level > 0) { mv_x = fr.mvx; mv_y = fr.mvy; best_bits = fr.bitcost; }
+    if (level > 0) { mv_x = fr.mvx; mv_y = fr.mvy; best_bits = fr.bitcost; }
   }
 
   if (tid == 0) {
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__
     if (pu_orphan(cls, 4, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
     return;
   }
-  search_pu_core<64, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  search_pu_core<64, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x, blockIdx.x);
 }
 
 // --mv-rdo (cfg.mv_rdo, off in every preset): MV bits from the CABAC model.  One workgroup per PU for every size -- a
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(256) void search_pu_rdo_kernel(const u8 *__restrict
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];
   if (!pu_ok(pu, pic_w, pic_h) || pu.reserved < 0) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
-  search_pu_core<64, 256, false, 0, 0, true>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  search_pu_core<64, 256, false, 0, 0, true>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x, blockIdx.x);
 }
 
 // PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier.  The register budget is held at
@@ -739,9 +742,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (pu_orphan(cls, 1, prm.size_classes) && lane == 0) flag_bad(out + i);
     return;
   }
-  if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
-  else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
-  else search_pu_core<16, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  if (pu.width == 8 && pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i, i);
+  else if (pu.width == 16 && pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i, i);
+  else search_pu_core<16, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i, i);
 }
 
 // PUs up to 32x32 that are not the small kernel's: one wave per PU as well (two per workgroup: 15 KiB of LDS each).
@@ -764,8 +767,8 @@ __global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restr
     if (pu_orphan(cls, 2, prm.size_classes) && lane == 0) flag_bad(out + i);
     return;
   }
-  if (pu.width == 32 && pu.height == 32) search_pu_core<32, 64, true, 32, 32, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
-  else search_pu_core<32, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i);
+  if (pu.width == 32 && pu.height == 32) search_pu_core<32, 64, true, 32, 32, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i, i);
+  else search_pu_core<32, 64, true, 0, 0, false, CONSTR>(lane, lds[wv], &sh[wv], pic, pic_stride, ref, pu, prm, out + i, i);
 }
 
 // The same class with one workgroup of T threads per PU: lower latency per search (more lanes on each step, barriers
@@ -784,8 +787,8 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
     if (pu_orphan(cls, 2, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
     return;
   }
-  if (pu.width == 32 && pu.height == 32) search_pu_core<32, T, false, 32, 32, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
-  else search_pu_core<32, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x);
+  if (pu.width == 32 && pu.height == 32) search_pu_core<32, T, false, 32, 32, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x, blockIdx.x);
+  else search_pu_core<32, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x, blockIdx.x);
 }
 
 }  // namespace

@@ -1242,9 +1242,25 @@ static void me_hexagon(me_info *in)
   for (int i = 1; i < 9; ++i) me_check(in, mvx + small[i][0], mvy + small[i][1]);
 }
 
-/* the hexbs path of search_pu_inter_ref (:1134-1300) for one reference picture */
+/* the hexbs path of search_pu_inter_ref (:1134-1300) for one reference picture; inter_cost = *inter_cost on entry */
+static void search_pu_against(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
+                              const orc_me_pu *pu, const orc_me_params *prm, unsigned inter_cost, orc_me_result *res);
+
 void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
                    const orc_me_pu *pu, const orc_me_params *prm, orc_me_result *res)
+{
+  search_pu_against(pic, pic_stride, ref, ref_w, ref_h, pu, prm, 0xffffffffu, res);      /* the first picture searched: MAX_INT (:1456) */
+}
+
+void orc_search_pu_many(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
+                        const orc_me_pu *pus, size_t count, const orc_me_params *prm, orc_me_result *res)
+{
+  for (size_t i = 0; i < count; ++i)
+    search_pu_against(pic, pic_stride, ref, ref_w, ref_h, &pus[i], prm, prm->cost_to_beat ? prm->cost_to_beat[i] : 0xffffffffu, &res[i]);
+}
+
+static void search_pu_against(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
+                              const orc_me_pu *pu, const orc_me_params *prm, unsigned inter_cost, orc_me_result *res)
 {
   me_info in;
   memset(&in, 0, sizeof(in));
@@ -1259,7 +1275,7 @@ void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, i
   else if (prm->algorithm == 2) me_tz(&in);
   else if (prm->algorithm == 3) me_full(&in, prm->search_range);
   else me_hexagon(&in);
-  if (prm->fme_level > 0 && in.best_cost < 0xffffffffu) {   /* inter_cost starts at its maximum (:1456) */
+  if (prm->fme_level > 0 && in.best_cost < inter_cost) {    /* :1239 */
     int mv[2] = { in.best_mv[0] >> 2, in.best_mv[1] >> 2 };
     frac_search(pic, pic_stride, ref, ref_w, ref_h, pu->x, pu->y, pu->width, pu->height, mv, &in.mc, prm->fme_level,
                 NULL, NULL, &in.best_cost, &in.best_bitcost);

@@ -219,7 +219,8 @@ typedef struct {
   int32_t refs_before;           /* pictures of state->frame->ref with poc < the current poc (rdo.c:990-998) */
   int32_t reserved;
   const struct orc_me_cabac *cabac;   /* mv_rdo: snapshots of state->cabac; a PU uses entry pu->reserved */
-} orc_me_params;                 /* 88 bytes */
+  const uint32_t *cost_to_beat;  /* NULL, or one entry per PU of a batch: *inter_cost on entry to search_pu_inter_ref (:1239) */
+} orc_me_params;                 /* 96 bytes */
 typedef struct orc_me_cabac {    /* what kvz_calc_mvd_cost_cabac reads of cabac_data_t (cabac.h:41-88) */
   uint16_t range;                /* .range */
   uint8_t ctx[8];                /* uc_state of cu_merge_flag_ext_model, cu_merge_idx_ext_model, cu_ref_pic_model[0], [1],
@@ -235,6 +236,9 @@ typedef struct {
 } orc_me_result;
 void orc_search_pu(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
                    const orc_me_pu *pu, const orc_me_params *prm, orc_me_result *res);
+/* a batch: PU i is searched with prm->cost_to_beat[i] as the cost to beat (orc_search_pu alone: none) */
+void orc_search_pu_many(const orc_pixel *pic, int pic_stride, const orc_pixel *ref, int ref_w, int ref_h,
+                        const orc_me_pu *pus, size_t count, const orc_me_params *prm, orc_me_result *res);
 
 /* ---- SAO group: src/strategies/generic/sao-generic.c, src/sao.c.  SURVEY.md section 8(f) row 4.
  * Blocks are contiguous (stride = block_width), as the callers in sao.c blit them. ---- */

@@ -712,6 +712,7 @@ typedef struct {                              /* = kvz_hip_me_params / orc_me_pa
   int32_t tile_x, tile_y, tile_w, tile_h;
   int32_t mv_rdo, ref_idx, refs_before, reserved;
   const void *cabac;
+  const void *cost_to_beat;
 } rec_params_t;
 
 static struct {
@@ -1115,17 +1116,20 @@ int ref_record_snapshots_get(int32_t *index, void *cu, void *col, void *params, 
 /* ------------------------------------------------------------------------
  * The encoder's 2Nx2N inter searches SERVED BY THE GPU CHAIN (tests only): with ref_gpu_search_begin, the wrapper of
  * kvz_search_cu_inter above does not run the reference's search_pu_inter at all for the searches it can express
- * (single-reference P slices, rd < 2, no mv-rdo, one tile) but
+ * (P and B slices with any number of reference pictures, uni-prediction, rd < 2, no mv-rdo, one tile) but
  *   1. copies what the candidate derivation would read -- lcu->cu -- into the picture's CU array on the device
- *      (the frame's planes and the collocated picture's CU array go up once per frame),
- *   2. runs kvz_hip_inter_candidates_batch and kvz_hip_search_pu_batch back to back on one stream,
+ *      (the frame's planes and the reference pictures' CU arrays go up once per frame),
+ *   2. for every reference picture in turn, as search_pu_inter does (search_inter.c:1502-1507), runs
+ *      kvz_hip_inter_candidates_batch and kvz_hip_search_pu_batch back to back on one stream, the best cost so far
+ *      as the cost to beat (search_inter.c:1239),
  *   3. writes the decision into cur_cu and the two cost outputs exactly where search_pu_inter_ref does
  *      (search_inter.c:1275-1290, :1497-1499).
  * The encode must then produce the bitstream of the untouched encoder: every later decision of the encoder consumes
  * these results.  One PU per launch -- a correctness path, the throughput form is a front of PUs per launch.
  * ------------------------------------------------------------------------ */
+#define GPU_MAX_REFS 16
 static struct {
-  int on, w, h, stride, rows, poc_loaded, have_frame;
+  int on, w, h, stride, rows, poc_loaded;
   void *lib;
   int (*init)(int);
   void *(*dmalloc)(size_t);
@@ -1137,13 +1141,14 @@ static struct {
   int (*search)(const kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_me_pu *, size_t,
                 const kvz_hip_me_params *, kvz_hip_me_result *, kvz_hip_stream);
   const char *(*last_error)(void);
-  uint8_t *d_pic, *d_ref, *h_plane;
-  kvz_hip_cu_info *d_cus, *d_col, *h_cus, *h_col;
+  uint8_t *d_pic, *d_ref[GPU_MAX_REFS], *h_plane;
+  kvz_hip_cu_info *d_cus, *d_refcus[GPU_MAX_REFS], *h_cus, *h_col;
   kvz_hip_me_pu *d_pu;
   kvz_hip_me_result *d_res;
+  uint32_t *d_beat;
   kvz_hip_inter_params ip;
   kvz_hip_me_params mp;
-  long served, passed_on, failed;
+  long served, passed_on, failed, launches;
 } g_gpu;
 
 int ref_gpu_search_begin(const char *lib_path, int w, int h)
@@ -1165,24 +1170,26 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   g_gpu.w = w; g_gpu.h = h;
   g_gpu.stride = ((w + 63) / 64) * 16; g_gpu.rows = ((h + 63) / 64) * 16;
   const size_t map_bytes = (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info);
-  g_gpu.d_pic = g_gpu.dmalloc((size_t)w * h); g_gpu.d_ref = g_gpu.dmalloc((size_t)w * h);
-  g_gpu.d_cus = g_gpu.dmalloc(map_bytes); g_gpu.d_col = g_gpu.dmalloc(map_bytes);
+  g_gpu.d_pic = g_gpu.dmalloc((size_t)w * h);
+  g_gpu.d_cus = g_gpu.dmalloc(map_bytes);
   g_gpu.d_pu = g_gpu.dmalloc(sizeof(kvz_hip_me_pu)); g_gpu.d_res = g_gpu.dmalloc(sizeof(kvz_hip_me_result));
+  g_gpu.d_beat = g_gpu.dmalloc(sizeof(uint32_t));
   g_gpu.h_plane = malloc((size_t)w * h);
   g_gpu.h_cus = calloc(1, map_bytes); g_gpu.h_col = calloc(1, map_bytes);
-  if (!g_gpu.d_pic || !g_gpu.d_ref || !g_gpu.d_cus || !g_gpu.d_col || !g_gpu.d_pu || !g_gpu.d_res || !g_gpu.h_plane || !g_gpu.h_cus || !g_gpu.h_col) return -1;
+  if (!g_gpu.d_pic || !g_gpu.d_cus || !g_gpu.d_pu || !g_gpu.d_res || !g_gpu.d_beat || !g_gpu.h_plane || !g_gpu.h_cus || !g_gpu.h_col) return -1;
   g_gpu.poc_loaded = -1;
   g_gpu.on = 1;
   return 0;
 }
 
-/* out[0..2] = searches served by the GPU chain, searches passed on to the reference, GPU calls that failed */
+/* out[0..3] = searches served by the GPU chain, searches passed on to the reference, GPU calls that failed,
+ * (candidates + search) launch pairs issued (one per reference picture of a served search) */
 void ref_gpu_search_end(long *out)
 {
-  if (out) { out[0] = g_gpu.served; out[1] = g_gpu.passed_on; out[2] = g_gpu.failed; }
+  if (out) { out[0] = g_gpu.served; out[1] = g_gpu.passed_on; out[2] = g_gpu.failed; out[3] = g_gpu.launches; }
   if (g_gpu.lib) {
-    g_gpu.dfree(g_gpu.d_pic); g_gpu.dfree(g_gpu.d_ref); g_gpu.dfree(g_gpu.d_cus); g_gpu.dfree(g_gpu.d_col);
-    g_gpu.dfree(g_gpu.d_pu); g_gpu.dfree(g_gpu.d_res);
+    g_gpu.dfree(g_gpu.d_pic); g_gpu.dfree(g_gpu.d_cus); g_gpu.dfree(g_gpu.d_pu); g_gpu.dfree(g_gpu.d_res); g_gpu.dfree(g_gpu.d_beat);
+    for (int i = 0; i < GPU_MAX_REFS; ++i) { g_gpu.dfree(g_gpu.d_ref[i]); g_gpu.dfree(g_gpu.d_refcus[i]); }
   }
   free(g_gpu.h_plane); free(g_gpu.h_cus); free(g_gpu.h_col);
   memset(&g_gpu, 0, sizeof(g_gpu));
@@ -1199,60 +1206,79 @@ static void cu_to_hip(const cu_info_t *c, kvz_hip_cu_info *f)
   }
 }
 
+/* per frame: the luma planes, the reference pictures' CU arrays, the state both entries read */
+static int gpu_load_frame(const encoder_state_t *state)
+{
+  const encoder_control_t *ctrl = state->encoder_control;
+  const encoder_state_config_frame_t *fr = state->frame;
+  const int w = g_gpu.w, h = g_gpu.h, nref = (int)fr->ref->used_size;
+  const size_t map_bytes = (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info);
+  int bad = 0;
+  const kvz_picture *src = state->tile->frame->source;
+  for (int r = 0; r < h; ++r) memcpy(g_gpu.h_plane + (size_t)r * w, src->y + (size_t)r * src->stride, (size_t)w);
+  bad |= g_gpu.h2d(g_gpu.d_pic, g_gpu.h_plane, (size_t)w * h, NULL);
+  for (int i = 0; i < nref; ++i) {
+    if (!g_gpu.d_ref[i]) { g_gpu.d_ref[i] = g_gpu.dmalloc((size_t)w * h); g_gpu.d_refcus[i] = g_gpu.dmalloc(map_bytes); }
+    if (!g_gpu.d_ref[i] || !g_gpu.d_refcus[i]) return 1;
+    const kvz_picture *ref = fr->ref->images[i];
+    for (int r = 0; r < h; ++r) memcpy(g_gpu.h_plane + (size_t)r * w, ref->y + (size_t)r * ref->stride, (size_t)w);
+    bad |= g_gpu.h2d(g_gpu.d_ref[i], g_gpu.h_plane, (size_t)w * h, NULL);
+    const cu_array_t *a = fr->ref->cu_arrays[i];
+    memset(g_gpu.h_col, 0, map_bytes);
+    for (int sy = 0; sy < g_gpu.rows && sy * 4 < a->height; ++sy)
+      for (int sx = 0; sx < g_gpu.stride && sx * 4 < a->width; ++sx)
+        cu_to_hip(&a->data[sx + sy * (a->stride >> 2)], &g_gpu.h_col[sy * g_gpu.stride + sx]);
+    bad |= g_gpu.h2d(g_gpu.d_refcus[i], g_gpu.h_col, map_bytes, NULL);
+  }
+  kvz_hip_inter_params *ip = &g_gpu.ip;
+  memset(ip, 0, sizeof(*ip));
+  ip->poc = fr->poc; ip->slice_is_b = fr->slicetype == KVZ_SLICE_B; ip->tmvp_enable = ctrl->cfg.tmvp_enable; ip->num_refs = nref;
+  for (int i = 0; i < nref; ++i) ip->ref_pocs[i] = fr->ref->pocs[i];
+  memcpy(ip->ref_LX, fr->ref_LX, sizeof(ip->ref_LX));
+  ip->ref_LX_size[0] = fr->ref_LX_size[0]; ip->ref_LX_size[1] = fr->ref_LX_size[1];
+  if (fr->ref_LX_size[0] > 0) {
+    const int c = fr->ref_LX[0][0];
+    memcpy(ip->col_ref_pocs, fr->ref->images[c]->ref_pocs, sizeof(ip->col_ref_pocs));
+    memcpy(ip->col_ref_LX, fr->ref->ref_LXs[c], sizeof(ip->col_ref_LX));
+  }
+  ip->pic_width = w; ip->pic_height = h; ip->in_width = ctrl->in.width; ip->in_height = ctrl->in.height;
+  ip->cus_stride = g_gpu.stride; ip->col_stride = g_gpu.stride;
+  kvz_hip_me_params *p = &g_gpu.mp;
+  memset(p, 0, sizeof(*p));
+  p->early_termination = ctrl->cfg.me_early_termination;
+  p->max_steps = ctrl->cfg.me_max_steps;
+  p->fme_level = ctrl->cfg.fme_level;
+  p->wpp_owf = ctrl->cfg.owf && ctrl->cfg.wpp;
+  p->ref_delay_px = ctrl->cfg.sao_type ? SAO_DELAY_PX : (ctrl->cfg.deblock_enable ? DEBLOCK_DELAY_PX : 0);
+  p->max_ref_lcu_down = ctrl->max_inter_ref_lcu.down; p->max_ref_lcu_right = ctrl->max_inter_ref_lcu.right;
+  switch (ctrl->cfg.ime_algorithm) {
+    case KVZ_IME_DIA: p->algorithm = 1; break;
+    case KVZ_IME_TZ: p->algorithm = 2; break;
+    case KVZ_IME_FULL64: p->algorithm = 3; p->search_range = 64; break;
+    case KVZ_IME_FULL32: case KVZ_IME_FULL: p->algorithm = 3; p->search_range = 32; break;
+    case KVZ_IME_FULL16: p->algorithm = 3; p->search_range = 16; break;
+    case KVZ_IME_FULL8: p->algorithm = 3; p->search_range = 8; break;
+    default: p->algorithm = 0; break;
+  }
+  p->mv_constraint = ctrl->cfg.mv_constraint;
+  p->cost_to_beat = g_gpu.d_beat;
+  return bad;
+}
+
 static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
 {
   if (!g_gpu.on) return 0;
   const encoder_control_t *ctrl = state->encoder_control;
   const encoder_state_config_frame_t *fr = state->frame;
-  const int can = fr->ref->used_size == 1 && fr->slicetype == KVZ_SLICE_P && fr->ref_LX_size[0] == 1 && fr->ref_LX[0][0] == 0 &&
+  const int nref = (int)fr->ref->used_size;
+  const int can = nref >= 1 && nref <= GPU_MAX_REFS && fr->slicetype != KVZ_SLICE_I &&
+                  !(ctrl->cfg.bipred && fr->slicetype == KVZ_SLICE_B) &&      /* search_pu_inter_bipred stays the reference's */
                   !ctrl->cfg.mv_rdo && ctrl->cfg.rdo < 2 && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
                   state->tile->frame->width == g_gpu.w && state->tile->frame->height == g_gpu.h;
   if (!can) { ++g_gpu.passed_on; return 0; }
   const int w = g_gpu.w, h = g_gpu.h;
   int bad = 0;
-  if (g_gpu.poc_loaded != fr->poc) {
-    /* per frame: the two luma planes, the collocated picture's CU array, the state both entries read */
-    const kvz_picture *src = state->tile->frame->source, *ref = fr->ref->images[0];
-    for (int r = 0; r < h; ++r) memcpy(g_gpu.h_plane + (size_t)r * w, src->y + (size_t)r * src->stride, (size_t)w);
-    bad |= g_gpu.h2d(g_gpu.d_pic, g_gpu.h_plane, (size_t)w * h, NULL);
-    for (int r = 0; r < h; ++r) memcpy(g_gpu.h_plane + (size_t)r * w, ref->y + (size_t)r * ref->stride, (size_t)w);
-    bad |= g_gpu.h2d(g_gpu.d_ref, g_gpu.h_plane, (size_t)w * h, NULL);
-    const cu_array_t *a = fr->ref->cu_arrays[0];
-    memset(g_gpu.h_col, 0, (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info));
-    for (int sy = 0; sy < g_gpu.rows && sy * 4 < a->height; ++sy)
-      for (int sx = 0; sx < g_gpu.stride && sx * 4 < a->width; ++sx)
-        cu_to_hip(&a->data[sx + sy * (a->stride >> 2)], &g_gpu.h_col[sy * g_gpu.stride + sx]);
-    bad |= g_gpu.h2d(g_gpu.d_col, g_gpu.h_col, (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info), NULL);
-    kvz_hip_inter_params *ip = &g_gpu.ip;
-    memset(ip, 0, sizeof(*ip));
-    ip->poc = fr->poc; ip->slice_is_b = 0; ip->tmvp_enable = ctrl->cfg.tmvp_enable; ip->num_refs = 1;
-    ip->ref_pocs[0] = fr->ref->pocs[0];
-    memcpy(ip->ref_LX, fr->ref_LX, sizeof(ip->ref_LX));
-    ip->ref_LX_size[0] = 1; ip->ref_LX_size[1] = 0;
-    memcpy(ip->col_ref_pocs, fr->ref->images[0]->ref_pocs, sizeof(ip->col_ref_pocs));
-    memcpy(ip->col_ref_LX, fr->ref->ref_LXs[0], sizeof(ip->col_ref_LX));
-    ip->pic_width = w; ip->pic_height = h; ip->in_width = ctrl->in.width; ip->in_height = ctrl->in.height;
-    ip->ref_idx = 0; ip->cus_stride = g_gpu.stride; ip->col_stride = g_gpu.stride;
-    kvz_hip_me_params *p = &g_gpu.mp;
-    memset(p, 0, sizeof(*p));
-    p->early_termination = ctrl->cfg.me_early_termination;
-    p->max_steps = ctrl->cfg.me_max_steps;
-    p->fme_level = ctrl->cfg.fme_level;
-    p->wpp_owf = ctrl->cfg.owf && ctrl->cfg.wpp;
-    p->ref_delay_px = ctrl->cfg.sao_type ? SAO_DELAY_PX : (ctrl->cfg.deblock_enable ? DEBLOCK_DELAY_PX : 0);
-    p->max_ref_lcu_down = ctrl->max_inter_ref_lcu.down; p->max_ref_lcu_right = ctrl->max_inter_ref_lcu.right;
-    switch (ctrl->cfg.ime_algorithm) {
-      case KVZ_IME_DIA: p->algorithm = 1; break;
-      case KVZ_IME_TZ: p->algorithm = 2; break;
-      case KVZ_IME_FULL64: p->algorithm = 3; p->search_range = 64; break;
-      case KVZ_IME_FULL32: case KVZ_IME_FULL: p->algorithm = 3; p->search_range = 32; break;
-      case KVZ_IME_FULL16: p->algorithm = 3; p->search_range = 16; break;
-      case KVZ_IME_FULL8: p->algorithm = 3; p->search_range = 8; break;
-      default: p->algorithm = 0; break;
-    }
-    p->mv_constraint = ctrl->cfg.mv_constraint;
-    g_gpu.poc_loaded = fr->poc;
-  }
+  if (g_gpu.poc_loaded != fr->poc) { bad |= gpu_load_frame(state); g_gpu.poc_loaded = fr->poc; }
   /* 1. lcu->cu into the picture's CU array: the LCU's 16 x 16 SCUs, the row above, the column to the left, the corner,
    *    the top-right SCU (cu.h:324-344); the rows that changed go to the device in one copy */
   const int ox = (x / LCU_WIDTH) * 16, oy = (y / LCU_WIDTH) * 16;
@@ -1266,41 +1292,59 @@ static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu
   const int r0 = oy > 0 ? oy - 1 : 0, r1 = oy + 16 < g_gpu.rows ? oy + 16 : g_gpu.rows;
   bad |= g_gpu.h2d(g_gpu.d_cus + (size_t)r0 * g_gpu.stride, g_gpu.h_cus + (size_t)r0 * g_gpu.stride,
                    (size_t)(r1 - r0) * g_gpu.stride * sizeof(kvz_hip_cu_info), NULL);
-  /* 2. derive + search */
+  /* 2. + 3.: search_pu_inter (search_inter.c:1456-1507) with the two entries in place of search_pu_inter_ref's middle */
   const int width = LCU_WIDTH >> depth;
-  kvz_hip_me_pu pu;
-  memset(&pu, 0, sizeof(pu));
-  pu.x = x; pu.y = y; pu.width = width; pu.height = width;
+  cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
+  const cu_info_t saved = *cur_cu;
+  double cost = MAX_INT;
+  uint32_t bitcost = MAX_INT;
+  CU_SET_MV_CAND(cur_cu, 0, 0);
+  CU_SET_MV_CAND(cur_cu, 1, 0);
   kvz_hip_me_params mp = g_gpu.mp;
   mp.lambda_cost = (int32_t)(state->lambda_sqrt + 0.5);
   mp.size_classes = width <= 16 ? 1 : (width <= 32 ? 2 : 4);
-  kvz_hip_me_result res;
-  memset(&res, 0, sizeof(res));
-  bad |= g_gpu.h2d(g_gpu.d_pu, &pu, sizeof(pu), NULL);
-  bad |= g_gpu.cand(g_gpu.d_cus, g_gpu.d_col, g_gpu.d_col, &g_gpu.ip, g_gpu.d_pu, 1, NULL, NULL);
-  bad |= g_gpu.search(g_gpu.d_pic, (uint32_t)w, w, h, g_gpu.d_ref, (uint32_t)w, w, h, g_gpu.d_pu, 1, &mp, g_gpu.d_res, NULL);
-  bad |= g_gpu.d2h(&res, g_gpu.d_res, sizeof(res), NULL);
-  if (bad || res.reserved == -1) {
+  const int8_t lx_max = MAX(fr->ref_LX_size[0], fr->ref_LX_size[1]);
+  for (int ref_idx = 0; ref_idx < nref && !bad; ++ref_idx) {
+    int8_t ref_list = -1, LX_idx;                      /* :1143-1166 */
+    for (LX_idx = 0; LX_idx < lx_max; LX_idx++) {
+      if (LX_idx < fr->ref_LX_size[0] && fr->ref_LX[0][LX_idx] == ref_idx) { ref_list = 0; break; }
+      if (LX_idx < fr->ref_LX_size[1] && fr->ref_LX[1][LX_idx] == ref_idx) { ref_list = 1; break; }
+    }
+    if (ref_list < 0) { bad = 1; break; }
+    kvz_hip_me_pu pu;
+    memset(&pu, 0, sizeof(pu));
+    pu.x = x; pu.y = y; pu.width = width; pu.height = width;
+    const uint32_t beat = (uint32_t)cost;               /* *inter_cost as search_pu_inter_ref finds it (:1239) */
+    kvz_hip_me_result res;
+    memset(&res, 0, sizeof(res));
+    g_gpu.ip.ref_idx = ref_idx;
+    const int c = fr->ref_LX_size[0] > 0 ? fr->ref_LX[0][0] : 0;
+    bad |= g_gpu.h2d(g_gpu.d_pu, &pu, sizeof(pu), NULL);
+    bad |= g_gpu.h2d(g_gpu.d_beat, &beat, sizeof(beat), NULL);
+    bad |= g_gpu.cand(g_gpu.d_cus, g_gpu.d_refcus[c], g_gpu.d_refcus[ref_idx], &g_gpu.ip, g_gpu.d_pu, 1, NULL, NULL);
+    bad |= g_gpu.search(g_gpu.d_pic, (uint32_t)w, w, h, g_gpu.d_ref[ref_idx], (uint32_t)w, w, h, g_gpu.d_pu, 1, &mp, g_gpu.d_res, NULL);
+    bad |= g_gpu.d2h(&res, g_gpu.d_res, sizeof(res), NULL);
+    ++g_gpu.launches;
+    if (bad || res.reserved == -1) { bad = 1; break; }
+    if (res.cost != 0xffffffffu && res.cost < cost) {  /* :1275-1290 */
+      cur_cu->inter.mv_dir = ref_list + 1;
+      cur_cu->merged = (uint8_t)res.merged;
+      cur_cu->merge_idx = (uint8_t)res.merge_idx;
+      cur_cu->inter.mv_ref[ref_list] = LX_idx;
+      cur_cu->inter.mv[ref_list][0] = (int16_t)res.mv[0];
+      cur_cu->inter.mv[ref_list][1] = (int16_t)res.mv[1];
+      CU_SET_MV_CAND(cur_cu, ref_list, res.mv_cand);
+      cost = res.cost;
+      bitcost = res.bitcost + cur_cu->inter.mv_dir - 1 + LX_idx;
+    }
+  }
+  if (bad) {
     if (g_gpu.failed++ == 0) fprintf(stderr, "gpu_search_serve: %s\n", g_gpu.last_error());
+    *cur_cu = saved;
     return 0;                                            /* the reference's own search takes over */
   }
-  /* 3. what search_pu_inter / search_pu_inter_ref leave behind (search_inter.c:1460-1461, :1497-1499, :1275-1290) */
-  cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
-  *inter_cost = MAX_INT;
-  *inter_bitcost = MAX_INT;
-  CU_SET_MV_CAND(cur_cu, 0, 0);
-  CU_SET_MV_CAND(cur_cu, 1, 0);
-  if (res.cost != 0xffffffffu) {
-    cur_cu->inter.mv_dir = 1;
-    cur_cu->merged = (uint8_t)res.merged;
-    cur_cu->merge_idx = (uint8_t)res.merge_idx;
-    cur_cu->inter.mv_ref[0] = 0;
-    cur_cu->inter.mv[0][0] = (int16_t)res.mv[0];
-    cur_cu->inter.mv[0][1] = (int16_t)res.mv[1];
-    CU_SET_MV_CAND(cur_cu, 0, res.mv_cand);
-    *inter_cost = res.cost;
-    *inter_bitcost = res.bitcost;
-  }
+  *inter_cost = cost;
+  *inter_bitcost = bitcost;
   ++g_gpu.served;
   return 1;
 }

@@ -35,6 +35,7 @@ typedef struct {
   int32_t tile_x, tile_y, tile_w, tile_h;
   int32_t mv_rdo, ref_idx, refs_before, reserved;
   const struct me_cabac_s *cabac;
+  const uint32_t *cost_to_beat;               /* the caller points it at THIS PU's entry (or NULL) */
 } me_params_t;
 typedef struct me_cabac_s { uint16_t range; uint8_t ctx[8]; uint8_t pad[6]; } me_cabac_t;
 typedef struct { int32_t mv[2]; uint32_t cost, bitcost; int32_t merged, merge_idx, mv_cand, reserved; } me_result_t;
@@ -129,7 +130,8 @@ void ref_me_search_pu(const kvz_pixel *pic_y, const kvz_pixel *ref_y, int frame_
   else if (prm->algorithm == 2) tz_search(&info, extra);
   else if (prm->algorithm == 3) search_mv_full(&info, prm->search_range, extra);
   else hexagon_search(&info, extra, prm->max_steps);
-  if (prm->fme_level > 0 && info.best_cost < UINT32_MAX) {
+  const double inter_cost = prm->cost_to_beat ? (double)*prm->cost_to_beat : (double)MAX_INT;      /* *inter_cost, search_inter.c:1239, :1456 */
+  if (prm->fme_level > 0 && info.best_cost < inter_cost) {
     search_frac(&info);
   } else if (info.best_cost < UINT32_MAX) {
     info.best_cost = kvz_image_calc_satd(&pic, &ref, info.origin.x, info.origin.y, tx + info.origin.x + (info.best_mv.x >> 2),

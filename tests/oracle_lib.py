@@ -442,22 +442,25 @@ def intra_rough_costs_batch(refs, log2_width, orig, filter_boundary=1):
 
 
 # ---- motion search ----
-def search_pu_batch(pic, ref, pus, params, cabac=None):
-    """orc_search_pu over a structured array of patterns.ME_PU; returns patterns.ME_RESULT array"""
+def search_pu_batch(pic, ref, pus, params, cabac=None, cost_to_beat=None):
+    """orc_search_pu_many over a structured array of patterns.ME_PU; returns patterns.ME_RESULT array"""
     from patterns import ME_RESULT
     L = lib()
-    L.orc_search_pu.restype = None
-    L.orc_search_pu.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_search_pu_many.restype = None
+    L.orc_search_pu_many.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     pic, ref = _u8(pic), _u8(ref)
     pus = np.ascontiguousarray(pus)
     params = np.ascontiguousarray(params).copy()
+    assert params.nbytes == 96
     if cabac is not None:                       # --mv-rdo: ME_CABAC snapshots; pus["reserved"] indexes them
         cabac = np.ascontiguousarray(cabac)
         params["cabac"] = cabac.ctypes.data
+    if cost_to_beat is not None:
+        cost_to_beat = np.ascontiguousarray(cost_to_beat, dtype=np.uint32)
+        params["cost_to_beat"] = cost_to_beat.ctypes.data
     out = np.zeros(len(pus), dtype=ME_RESULT)
-    for i in range(len(pus)):
-        L.orc_search_pu(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0],
-                        pus.ctypes.data + 64 * i, params.ctypes.data, out.ctypes.data + 32 * i)
+    L.orc_search_pu_many(_p(pic, u8p), pic.shape[1], _p(ref, u8p), ref.shape[1], ref.shape[0], pus.ctypes.data, len(pus),
+                         params.ctypes.data, out.ctypes.data)
     return out
 
 

@@ -138,11 +138,12 @@ ME_PARAMS = np.dtype([("lambda_cost", "<i4"), ("early_termination", "<i4"), ("ma
                       ("wpp_owf", "<i4"), ("ref_delay_px", "<i4"), ("max_ref_lcu_down", "<i4"), ("max_ref_lcu_right", "<i4"),
                       ("algorithm", "<i4"), ("search_range", "<i4"), ("size_classes", "<i4"), ("mv_constraint", "<i4"),
                       ("tile_x", "<i4"), ("tile_y", "<i4"), ("tile_w", "<i4"), ("tile_h", "<i4"),
-                      ("mv_rdo", "<i4"), ("ref_idx", "<i4"), ("refs_before", "<i4"), ("reserved", "<i4"), ("cabac", "<u8")])
+                      ("mv_rdo", "<i4"), ("ref_idx", "<i4"), ("refs_before", "<i4"), ("reserved", "<i4"), ("cabac", "<u8"),
+                      ("cost_to_beat", "<u8")])
 ME_CABAC = np.dtype([("range", "<u2"), ("ctx", "u1", (8,)), ("pad", "u1", (6,))])
 ME_RESULT = np.dtype([("mv", "<i4", (2,)), ("cost", "<u4"), ("bitcost", "<u4"), ("merged", "<i4"), ("merge_idx", "<i4"),
                       ("mv_cand", "<i4"), ("reserved", "<i4")])
-assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 88 and ME_RESULT.itemsize == 32 and ME_CABAC.itemsize == 16
+assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 96 and ME_RESULT.itemsize == 32 and ME_CABAC.itemsize == 16
 
 
 def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_level=4, wpp_owf=0, ref_delay_px=0,
@@ -561,3 +562,15 @@ def recorded_cand_fixture(d, derive, seed=5):
         col = d["snap_col"][f].view(CU_INFO).reshape(noise.shape)
         got.append(derive(d["snap_params"][f:f + 1].view(INTER_PARAMS), cus, col, col, pu))
     return np.concatenate(got), want.view(ME_PU).reshape(-1)
+
+
+def cost_to_beat_case(integer_costs, seed):
+    """per PU *inter_cost values around the integer-stage cost of an unconstrained search (fme_level 0 reports bits * lambda +
+    SATD, close to but not the SAD-based integer cost the test is made on): far above, just above, equal, just below, zero,
+    and the MAX_INT the first picture of a frame starts from"""
+    g = np.random.default_rng(seed)
+    c = np.asarray(integer_costs, dtype=np.int64)
+    pick = g.integers(0, 6, len(c))
+    out = np.where(pick == 0, c * 4 + 1000, np.where(pick == 1, c + g.integers(1, 40, len(c)), np.where(pick == 2, c, np.where(
+        pick == 3, np.maximum(c - g.integers(1, 400, len(c)), 0), np.where(pick == 4, 0, 0x7fffffff)))))
+    return np.clip(out, 0, 0xffffffff).astype(np.uint32)

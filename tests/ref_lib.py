@@ -497,7 +497,7 @@ def intra_build_reference_from_plane(log2_width, color, plane, pic_w, pic_h, x, 
 
 
 # ---- motion search: the reference's static hexagon_search + search_frac (oracle/ref_me_harness.c) ----
-def search_pu_batch(pic, ref, pus, params, cabac=None):
+def search_pu_batch(pic, ref, pus, params, cabac=None, cost_to_beat=None):
     from patterns import ME_RESULT
     L = lib()
     L.ref_me_search_pu.restype = None
@@ -509,8 +509,13 @@ def search_pu_batch(pic, ref, pus, params, cabac=None):
     if cabac is not None:                       # --mv-rdo: ME_CABAC snapshots; pus["reserved"] indexes them
         cabac = np.ascontiguousarray(cabac)
         params["cabac"] = cabac.ctypes.data
+    assert params.nbytes == 96
+    if cost_to_beat is not None:
+        cost_to_beat = np.ascontiguousarray(cost_to_beat, dtype=np.uint32)
     out = np.zeros(len(pus), dtype=ME_RESULT)
     for i in range(len(pus)):
+        if cost_to_beat is not None:
+            params["cost_to_beat"] = cost_to_beat.ctypes.data + 4 * i          # the harness reads this PU's entry
         L.ref_me_search_pu(_p(pic, u8p), _p(ref, u8p), pic.shape[1], pic.shape[0],
                            pus.ctypes.data + 64 * i, params.ctypes.data, out.ctypes.data + 32 * i)
     return out
@@ -614,16 +619,16 @@ def inter_candidates(params, cus, col_cus, ref_cus, pus):
 def encode_with_gpu_search(frames, w, h, opts, lib_path):
     """ref_encode with the harness serving the encoder's 2Nx2N single-reference P searches through the GPU chain
     (kvz_hip_inter_candidates_batch + kvz_hip_search_pu_batch; oracle/ref_harness.c: gpu_search_serve).
-    -> (bitstream, searches served by the GPU, searches passed on to the reference, failed GPU calls)"""
+    -> (bitstream, searches served by the GPU, searches passed on to the reference, failed GPU calls, launch pairs)"""
     L = lib()
     L.ref_gpu_search_begin.restype = C.c_int
     L.ref_gpu_search_begin.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.ref_gpu_search_end.restype = None
     L.ref_gpu_search_end.argtypes = [C.POINTER(C.c_long)]
     assert L.ref_gpu_search_begin(lib_path.encode(), w, h) == 0
-    out = (C.c_long * 3)()
+    out = (C.c_long * 4)()
     try:
         bitstream, _ = encode(frames, w, h, opts)
     finally:
         L.ref_gpu_search_end(out)
-    return bitstream, int(out[0]), int(out[1]), int(out[2])
+    return bitstream, int(out[0]), int(out[1]), int(out[2]), int(out[3])

@@ -372,6 +372,11 @@ GPU_SEARCH_CONFIGS = [
     (168, 104, 4, "preset=veryfast,ref=1,bipred=0,gop=0,qp=33,threads=0,tmvp=0,period=0"),       # ragged LCUs, no temporal candidates
     (128, 64, 6, "preset=slow,ref=1,bipred=0,gop=0,rdoq=0,qp=27,threads=0,smp=1,amp=1,period=0"),   # SMP / AMP searches stay the reference's
     (1920, 1080, 2, "preset=medium,ref=1,bipred=0,gop=0,qp=32,threads=0,period=0"),                 # one 1080p P frame: ~43 000 searches
+    # several reference pictures: every picture searched in turn, the best cost so far as the cost to beat (search_inter.c:1239)
+    (192, 128, 7, "preset=medium,ref=3,bipred=0,gop=0,qp=29,threads=0,period=0"),
+    # preset medium as it is: B slices in a GOP of 8, four reference pictures in two lists, uni-prediction
+    (192, 128, 10, "preset=medium,qp=30,threads=0"),
+    (128, 128, 9, "preset=fast,gop=lp-g4d3t1,qp=34,threads=0,rdoq=0"),                               # low-delay P GOP
 ]
 
 
@@ -386,10 +391,10 @@ def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, 
     t0 = time.perf_counter()
     plain, _ = R.encode(frames, w, h, opts)
     t1 = time.perf_counter()
-    served_bs, served, passed_on, failed = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"))
+    served_bs, served, passed_on, failed, launches = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"))
     t2 = time.perf_counter()
     # one search per launch and three host round trips each: a correctness path, its time is printed for the record only
-    print("%dx%d x %d frames: searches served by the GPU chain: %d, left to the reference: %d; whole encode %.2f s untouched, %.2f s served"
-          % (w, h, n, served, passed_on, t1 - t0, t2 - t1))
+    print("%dx%d x %d frames: searches served by the GPU chain: %d (%d candidate + search launch pairs), left to the reference: %d; "
+          "whole encode %.2f s untouched, %.2f s served" % (w, h, n, served, launches, passed_on, t1 - t0, t2 - t1))
     assert failed == 0 and served >= 40 * (n - 1)
     assert served_bs == plain, "bitstreams differ (%d vs %d bytes)" % (len(served_bs), len(plain))

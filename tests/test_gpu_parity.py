@@ -1114,7 +1114,7 @@ def test_contexts_per_device_and_thread_binding(api):
     assert ndev >= 1
     assert L.kvz_hip_init(ndev) == -2 and b"out of range" in L.kvz_hip_last_error()
     assert L.kvz_hip_init(0) == 0 and L.kvz_hip_get_device() == 0
-    assert L.kvz_hip_abi_version() == 2
+    assert L.kvz_hip_abi_version() == 3
     errs = []
 
     def work(seed, device):
@@ -1232,3 +1232,24 @@ def test_candidates_feed_the_search_on_the_device(api):
     want_pus, _ = O.inter_candidates(p, cus, col, col, pus)
     want = O.search_pu_batch(cur, ref, want_pus, prm)
     np.testing.assert_array_equal(got, np.asarray(want).view(np.int32).reshape(len(pus), 8))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 4, 8, 11, 14, 19])
+def test_search_pu_with_a_cost_to_beat(api, cfg):
+    """kvz_hip_me_params.cost_to_beat: the later pictures of a multi-reference frame (search_inter.c:1239-1252), every size class"""
+    from patterns import cost_to_beat_case
+    prm = me_params(**ME_CONFIGS[cfg])
+    for k, motion in enumerate(((3, -2), (-7, 5))):
+        pic, ref = me_frames(192, 128, 910 + k, motion)
+        pus = me_pus_in_tile(me_random_pus(192, 128, 120, 177 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1])), prm)
+        free = O.search_pu_batch(pic, ref, pus, prm)
+        beat = cost_to_beat_case(free["cost"], 3 * cfg + k)
+        want = O.search_pu_batch(pic, ref, pus, prm, cost_to_beat=beat)
+        got = api.search_pu_batch(pic, ref, pus, prm, cost_to_beat=beat)
+        np.testing.assert_array_equal(got, np.asarray(want).view(np.int32).reshape(len(pus), 8), err_msg="cfg %d motion %s" % (cfg, motion))
+        for hint in (1, 2, 4):                               # one class per launch: the limit is indexed by the PU's place in the batch
+            q = prm.copy()
+            q["size_classes"] = hint
+            sel = [i for i in range(len(pus)) if (1 if max(pus[i]["width"], pus[i]["height"]) <= 16 else 2 if max(pus[i]["width"], pus[i]["height"]) <= 32 else 4) == hint]
+            got_h = api.search_pu_batch(pic, ref, pus, q, cost_to_beat=beat)
+            np.testing.assert_array_equal(got_h[sel], got[sel])

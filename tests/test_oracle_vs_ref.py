@@ -364,6 +364,25 @@ def test_search_pu(cfg):
     np.testing.assert_array_equal(a.view(np.int32), b.view(np.int32))
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 4, 8, 11, 14, 19])
+def test_search_pu_with_a_cost_to_beat(cfg):
+    """search_pu_inter_ref for the second and later pictures of a multi-reference frame (search_inter.c:1239-1252): the fractional
+    search runs only if the integer result beats *inter_cost, else the integer vector is re-scored with SATD"""
+    from patterns import cost_to_beat_case
+    prm = me_params(**ME_CONFIGS[cfg])
+    changed = 0
+    for k, motion in enumerate(((3, -2), (-7, 5), (0, 0))):
+        pic, ref = me_frames(192, 128, 910 + k, motion)
+        pus = me_pus_in_tile(me_random_pus(192, 128, 40, 177 + 10 * cfg + k, hint=(-4 * motion[0] + 2, -4 * motion[1])), prm)
+        free = O.search_pu_batch(pic, ref, pus, prm)
+        beat = cost_to_beat_case(free["cost"], 3 * cfg + k)
+        a, b = O.search_pu_batch(pic, ref, pus, prm, cost_to_beat=beat), R.search_pu_batch(pic, ref, pus, prm, cost_to_beat=beat)
+        for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
+            np.testing.assert_array_equal(a[f], b[f], err_msg="%s cfg %d motion %s" % (f, cfg, motion))
+        changed += int((a["mv"] != free["mv"]).any(axis=1).sum())
+    assert changed > 5 or int(prm["fme_level"][0]) == 0          # the limit did change searches
+
+
 AMP_SMP_SHAPES = ((8, 4), (4, 8), (16, 4), (4, 16), (16, 12), (12, 16), (8, 8), (16, 16))
 
 

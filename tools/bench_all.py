@@ -128,7 +128,7 @@ def main():
                           picf.data_ptr(), W, reff.data_ptr(), W, W, F * H, prs_d.data_ptr(), k, co.data_ptr(), be.data_ptr(), st)))
 
     # whole-PU motion search (hexagon + fractional, with MV costs): every n x n PU of 4 frames
-    me_prm = np.zeros(22, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
+    me_prm = np.zeros(24, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
     for n in (8, 16, 32, 64):
         rows = [(x, f * H + y) for f in range(4) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)]
         pus = np.zeros((len(rows), 16), dtype=np.int32)

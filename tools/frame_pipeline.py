@@ -50,7 +50,7 @@ def build_stages(L, dev):
     cu_now = torch.from_numpy(inter_cu_map(W, H, 1)[0].view(np.uint8).copy()).to(dev)
     cu_col = torch.from_numpy(inter_cu_map(W, H, 2)[0].view(np.uint8).copy()).to(dev)
     keep += [ip, cu_now, cu_col]
-    me_prm = np.zeros(22, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
+    me_prm = np.zeros(24, dtype=np.int32); me_prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1)
     for n in (8, 16, 32, 64):
         xy = [(x, y) for y in range(0, H - n + 1, n) for x in range(0, W - n + 1, n)]
         pus = np.zeros((len(xy), 16), dtype=np.int32)

@@ -21,7 +21,7 @@ for n in (8, 16, 32, 64):
 allp = np.concatenate([lists[n] for n in (64, 32, 16, 8)])
 def run(pus, cls):
     d = torch.from_numpy(pus).to(dev); out = torch.empty((len(pus), 8), dtype=torch.int32, device=dev)
-    prm = np.zeros(22, dtype=np.int32); prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1); prm[10] = cls
+    prm = np.zeros(24, dtype=np.int32); prm[:8] = (20, 1, -1, 4, 0, 0, 1, 1); prm[10] = cls
     torch.cuda.synchronize()
     return min(timed(L, st, lambda: _lib.check(L.kvz_hip_search_pu_batch(pic.data_ptr(), W, W, H, ref.data_ptr(), W, W, H, d.data_ptr(), len(pus),
                                                                         prm.ctypes.data, out.data_ptr(), st), "x")) for _ in range(3)) * 1e3

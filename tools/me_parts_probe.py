@@ -18,6 +18,6 @@ for n in (8, 16):
                        ("no early term", (20, 0, -1, 4, 0, 0, 1, 1, 0, 0, 1, 0)), ("fme0 + no ET", (20, 0, -1, 0, 0, 0, 1, 1, 0, 0, 1, 0)),
                        ("max_steps 0, fme0, no ET", (20, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 0)), ("dia", (20, 1, -1, 4, 0, 0, 1, 1, 1, 0, 1, 0)),
                        ("fme2", (20, 1, -1, 2, 0, 0, 1, 1, 0, 0, 1, 0))):
-        p = np.array(prm, dtype=np.int32)
+        p = np.zeros(24, dtype=np.int32); p[:len(prm)] = prm          # kvz_hip_me_params is 96 bytes
         ms = min(timed(L, st, lambda: _lib.check(L.kvz_hip_search_pu_batch(picf.data_ptr(), W, W, F * H, reff.data_ptr(), W, W, F * H, pus_d.data_ptr(), len(rows), p.ctypes.data, res_d.data_ptr(), st), "x")) for _ in range(3))
         print("%2dx%-2d %-26s %8.1f M/s  %6.1f us" % (n, n, label, len(rows) / ms / 1e3, ms * 1e3))
