@@ -377,6 +377,7 @@ GPU_SEARCH_CONFIGS = [
     # preset medium as it is: B slices in a GOP of 8, four reference pictures in two lists, uni-prediction
     (192, 128, 10, "preset=medium,qp=30,threads=0"),
     (128, 128, 9, "preset=fast,gop=lp-g4d3t1,qp=34,threads=0,rdoq=0"),                               # low-delay P GOP
+    (1920, 1080, 4, "preset=medium,qp=32,threads=0"),                                                # BASELINE's 1080p medium, three B pictures
 ]
 
 
