@@ -6,6 +6,7 @@
  * strategy registry (src/strategyselector.h:86-87, tests/test_strategies.c:29-52
  * is the model for walking the registry).
  */
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1149,7 +1150,16 @@ static struct {
   kvz_hip_inter_params ip;
   kvz_hip_me_params mp;
   long served, passed_on, failed, launches;
+  /* intra: the LCU's surroundings as a small picture, one PU's original block, its references and 35 + 35 costs */
+  int (*build_ref)(int, int, const kvz_hip_pixel *, int, int, int, const kvz_hip_intra_pos *, size_t, kvz_hip_intra_ref *, kvz_hip_stream);
+  int (*rough)(int, int, const kvz_hip_intra_ref *, const kvz_hip_pixel *, size_t, uint32_t *, uint32_t *, kvz_hip_stream);
+  uint8_t *d_vplane, *d_orig, *h_vplane;
+  kvz_hip_intra_pos *d_pos;
+  kvz_hip_intra_ref *d_iref;
+  uint32_t *d_icost;
+  long intra_served, intra_passed_on;
 } g_gpu;
+enum { VPLANE_W = 192, VPLANE_H = 128 };
 
 int ref_gpu_search_begin(const char *lib_path, int w, int h)
 {
@@ -1165,7 +1175,10 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   *(void **)&g_gpu.cand = dlsym(l, "kvz_hip_inter_candidates_batch");
   *(void **)&g_gpu.search = dlsym(l, "kvz_hip_search_pu_batch");
   *(void **)&g_gpu.last_error = dlsym(l, "kvz_hip_last_error");
-  if (!g_gpu.init || !g_gpu.dmalloc || !g_gpu.dfree || !g_gpu.h2d || !g_gpu.d2h || !g_gpu.cand || !g_gpu.search || !g_gpu.last_error) return -1;
+  *(void **)&g_gpu.build_ref = dlsym(l, "kvz_hip_intra_build_reference_batch");
+  *(void **)&g_gpu.rough = dlsym(l, "kvz_hip_intra_rough_batch");
+  if (!g_gpu.init || !g_gpu.dmalloc || !g_gpu.dfree || !g_gpu.h2d || !g_gpu.d2h || !g_gpu.cand || !g_gpu.search || !g_gpu.last_error ||
+      !g_gpu.build_ref || !g_gpu.rough) return -1;
   if (g_gpu.init(-1) != KVZ_HIP_OK) { fprintf(stderr, "kvz_hip_init: %s\n", g_gpu.last_error()); return -1; }
   g_gpu.w = w; g_gpu.h = h;
   g_gpu.stride = ((w + 63) / 64) * 16; g_gpu.rows = ((h + 63) / 64) * 16;
@@ -1176,22 +1189,28 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   g_gpu.d_beat = g_gpu.dmalloc(sizeof(uint32_t));
   g_gpu.h_plane = malloc((size_t)w * h);
   g_gpu.h_cus = calloc(1, map_bytes); g_gpu.h_col = calloc(1, map_bytes);
-  if (!g_gpu.d_pic || !g_gpu.d_cus || !g_gpu.d_pu || !g_gpu.d_res || !g_gpu.d_beat || !g_gpu.h_plane || !g_gpu.h_cus || !g_gpu.h_col) return -1;
+  g_gpu.d_vplane = g_gpu.dmalloc(VPLANE_W * VPLANE_H); g_gpu.h_vplane = calloc(1, VPLANE_W * VPLANE_H);
+  g_gpu.d_orig = g_gpu.dmalloc(32 * 32); g_gpu.d_pos = g_gpu.dmalloc(sizeof(kvz_hip_intra_pos));
+  g_gpu.d_iref = g_gpu.dmalloc(sizeof(kvz_hip_intra_ref)); g_gpu.d_icost = g_gpu.dmalloc(70 * sizeof(uint32_t));
+  if (!g_gpu.d_pic || !g_gpu.d_cus || !g_gpu.d_pu || !g_gpu.d_res || !g_gpu.d_beat || !g_gpu.h_plane || !g_gpu.h_cus || !g_gpu.h_col ||
+      !g_gpu.d_vplane || !g_gpu.h_vplane || !g_gpu.d_orig || !g_gpu.d_pos || !g_gpu.d_iref || !g_gpu.d_icost) return -1;
   g_gpu.poc_loaded = -1;
   g_gpu.on = 1;
   return 0;
 }
 
-/* out[0..3] = searches served by the GPU chain, searches passed on to the reference, GPU calls that failed,
- * (candidates + search) launch pairs issued (one per reference picture of a served search) */
+/* out[0..5] = inter searches served by the GPU chain, inter searches passed on to the reference, GPU calls that failed,
+ * (candidates + search) launch pairs issued (one per reference picture of a served search), intra searches served, passed on */
 void ref_gpu_search_end(long *out)
 {
-  if (out) { out[0] = g_gpu.served; out[1] = g_gpu.passed_on; out[2] = g_gpu.failed; out[3] = g_gpu.launches; }
+  if (out) { out[0] = g_gpu.served; out[1] = g_gpu.passed_on; out[2] = g_gpu.failed; out[3] = g_gpu.launches;
+             out[4] = g_gpu.intra_served; out[5] = g_gpu.intra_passed_on; }
   if (g_gpu.lib) {
+    g_gpu.dfree(g_gpu.d_vplane); g_gpu.dfree(g_gpu.d_orig); g_gpu.dfree(g_gpu.d_pos); g_gpu.dfree(g_gpu.d_iref); g_gpu.dfree(g_gpu.d_icost);
     g_gpu.dfree(g_gpu.d_pic); g_gpu.dfree(g_gpu.d_cus); g_gpu.dfree(g_gpu.d_pu); g_gpu.dfree(g_gpu.d_res); g_gpu.dfree(g_gpu.d_beat);
     for (int i = 0; i < GPU_MAX_REFS; ++i) { g_gpu.dfree(g_gpu.d_ref[i]); g_gpu.dfree(g_gpu.d_refcus[i]); }
   }
-  free(g_gpu.h_plane); free(g_gpu.h_cus); free(g_gpu.h_col);
+  free(g_gpu.h_plane); free(g_gpu.h_cus); free(g_gpu.h_col); free(g_gpu.h_vplane);
   memset(&g_gpu, 0, sizeof(g_gpu));
 }
 
@@ -1347,4 +1366,148 @@ static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu
   *inter_bitcost = bitcost;
   ++g_gpu.served;
   return 1;
+}
+
+
+/* ------------------------------------------------------------------------
+ * The encoder's intra mode searches served the same way (tests only; -Wl,--wrap=kvz_search_cu_intra).  For the searches
+ * that consist of the rough search alone (rd < 2, depth > 0: search_intra.c:840-883) the wrapper
+ *   1. lays what kvz_intra_build_reference would read -- lcu->rec.y with lcu->top_ref.y / left_ref.y around it -- out as
+ *      a small picture on the device (the LCU at (64, 64), or at 0 where the real picture ends, so that every
+ *      availability test sees the distances to the picture edges it would see in the real one),
+ *   2. runs kvz_hip_intra_build_reference_batch and kvz_hip_intra_rough_batch back to back: 35 SATD (and SAD) costs,
+ *   3. walks that table in the order of search_intra_rough (search_intra.c:404-545: coarse grid, halving refinement
+ *      around the best, the three predicted modes + DC + planar, lambda * mode bits) -- the host half the header of
+ *      kvz_hip_intra_rough_batch describes -- and returns mode and cost like kvz_search_cu_intra.
+ * ------------------------------------------------------------------------ */
+void __real_kvz_search_cu_intra(encoder_state_t * const state, const int x_px, const int y_px, const int depth, lcu_t *lcu,
+                                int8_t *mode_out, double *cost_out);
+
+#ifndef TRSKIP_RATIO
+# define TRSKIP_RATIO 1.7                      /* search_intra.c:39-41 */
+#endif
+
+static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth, lcu_t *lcu, int8_t *mode_out, double *cost_out)
+{
+  if (!g_gpu.on) return 0;
+  const encoder_control_t *ctrl = state->encoder_control;
+  const kvz_config *cfg = &ctrl->cfg;
+  if (depth == 0 || cfg->rdo >= 2 || state->tile->frame->width != g_gpu.w || state->tile->frame->height != g_gpu.h) {
+    ++g_gpu.intra_passed_on;                  /* search_intra_rdo is part of these: the reference's */
+    return 0;
+  }
+  const vector2d_t lcu_px = { SUB_SCU(x_px), SUB_SCU(y_px) };
+  const int log2_width = LOG2_LCU_WIDTH - depth, width = 1 << log2_width;
+  cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, lcu_px.x, lcu_px.y);
+  cu_info_t *left_cu = NULL, *above_cu = NULL;                    /* search_intra.c:814-825 */
+  if (x_px >= SCU_WIDTH) left_cu = LCU_GET_CU_AT_PX(lcu, lcu_px.x - 1, lcu_px.y);
+  if (y_px >= SCU_WIDTH && lcu_px.y > 0) above_cu = LCU_GET_CU_AT_PX(lcu, lcu_px.x, lcu_px.y - 1);
+  int8_t intra_preds[3];
+  kvz_intra_get_dir_luma_predictor(x_px, y_px, intra_preds, cur_cu, left_cu, above_cu);
+
+  /* 1. the LCU and its borders as a picture */
+  const int lcu_x0 = x_px - lcu_px.x, lcu_y0 = y_px - lcu_px.y;
+  const int ox = lcu_x0 > 0 ? 64 : 0, oy = lcu_y0 > 0 ? 64 : 0;
+  const int vw = ox + MIN(g_gpu.w - lcu_x0, 128), vh = oy + MIN(g_gpu.h - lcu_y0, 64);
+  uint8_t *v = g_gpu.h_vplane;
+  for (int y = 0; y < 64; ++y) memcpy(v + (size_t)(oy + y) * VPLANE_W + ox, lcu->rec.y + y * LCU_WIDTH, 64);
+  if (oy > 0) {
+    memcpy(v + (size_t)(oy - 1) * VPLANE_W + ox, &lcu->top_ref.y[1], LCU_REF_PX_WIDTH);
+    if (ox > 0) v[(size_t)(oy - 1) * VPLANE_W + ox - 1] = lcu->left_ref.y[0];
+  }
+  if (ox > 0) for (int y = 0; y < 64; ++y) v[(size_t)(oy + y) * VPLANE_W + ox - 1] = lcu->left_ref.y[1 + y];
+  const int r0 = oy > 0 ? oy - 1 : 0;
+  int bad = g_gpu.h2d(g_gpu.d_vplane + (size_t)r0 * VPLANE_W, v + (size_t)r0 * VPLANE_W, (size_t)(oy + 64 - r0) * VPLANE_W, NULL);
+  uint8_t orig_block[32 * 32];
+  for (int y = 0; y < width; ++y) memcpy(orig_block + y * width, &lcu->ref.y[lcu_px.x + (lcu_px.y + y) * LCU_WIDTH], (size_t)width);
+  bad |= g_gpu.h2d(g_gpu.d_orig, orig_block, (size_t)width * width, NULL);
+  const kvz_hip_intra_pos pos = { ox + lcu_px.x, oy + lcu_px.y };
+  bad |= g_gpu.h2d(g_gpu.d_pos, &pos, sizeof(pos), NULL);
+  /* 2. references and the 35-mode cost table */
+  const bool filter_boundary = !(cfg->lossless && cfg->implicit_rdpcm);
+  uint32_t table[70];
+  bad |= g_gpu.build_ref(log2_width, 0, g_gpu.d_vplane, VPLANE_W, vw, vh, g_gpu.d_pos, 1, g_gpu.d_iref, NULL);
+  bad |= g_gpu.rough(log2_width, KVZ_HIP_INTRA_LUMA | (filter_boundary ? KVZ_HIP_INTRA_FILTER_BOUNDARY : 0), g_gpu.d_iref, g_gpu.d_orig, 1,
+                     g_gpu.d_icost, g_gpu.d_icost + 35, NULL);
+  bad |= g_gpu.d2h(table, g_gpu.d_icost, sizeof(table), NULL);
+  if (bad) {
+    if (g_gpu.failed++ == 0) fprintf(stderr, "gpu_intra_serve: %s\n", g_gpu.last_error());
+    return 0;
+  }
+  /* get_cost / get_cost_dual (search_intra.c:99-172) from the table */
+  const bool trskip = TRSKIP_RATIO != 0 && width == 4 && cfg->trskip_enable;
+  double trskip_bits = 0;
+  if (trskip) {
+    const cabac_ctx_t *ctx = &state->cabac.ctx.transform_skip_model_luma;
+    trskip_bits = CTX_ENTROPY_FBITS(ctx, 1) - CTX_ENTROPY_FBITS(ctx, 0);
+    if (ctrl->chroma_format != KVZ_CSP_400) {
+      ctx = &state->cabac.ctx.transform_skip_model_chroma;
+      trskip_bits += 2.0 * (CTX_ENTROPY_FBITS(ctx, 1) - CTX_ENTROPY_FBITS(ctx, 0));
+    }
+  }
+#define MODE_COST(m, out) do {                                                                      \
+    double c__ = (double)table[(m)];                                                                \
+    if (trskip) {                                                                                   \
+      const double s__ = TRSKIP_RATIO * (double)table[35 + (m)] + state->lambda_sqrt * trskip_bits; \
+      if (s__ < c__) c__ = s__;                                                                     \
+    }                                                                                               \
+    (out) = c__;                                                                                    \
+  } while (0)
+  /* 3. search_intra_rough's walk (search_intra.c:430-540) */
+  int8_t modes[35];
+  double costs[35];
+  int8_t n = 0;
+  unsigned min_cost = UINT_MAX, max_cost = 0;
+  int offset;
+  if (cfg->full_intra_search) offset = 1;
+  else { static const int8_t offsets[4] = { 2, 4, 8, 8 }; offset = offsets[log2_width - 2]; }
+  for (int mode = 2; mode <= 34; mode += 2 * offset)
+    for (int i = 0; i < 2; ++i)
+      if (mode + i * offset <= 34) {
+        MODE_COST(mode + i * offset, costs[n]);
+        modes[n] = (int8_t)(mode + i * offset);
+        min_cost = MIN(min_cost, costs[n]);
+        max_cost = MAX(max_cost, costs[n]);
+        ++n;
+      }
+  int best_i = 0;
+  for (int i = 1; i < n; ++i) if (costs[i] < costs[best_i]) best_i = i;
+  int8_t best_mode = modes[best_i];
+  double best_cost = min_cost;
+  if (min_cost != max_cost) {
+    while (offset > 1) {
+      offset >>= 1;
+      const int8_t test_modes[2] = { (int8_t)(best_mode - offset), (int8_t)(best_mode + offset) };
+      for (int i = 0; i < 2; ++i)
+        if (test_modes[i] >= 2 && test_modes[i] <= 34) {
+          MODE_COST(test_modes[i], costs[n]);
+          modes[n] = test_modes[i];
+          if (costs[n] < best_cost) { best_cost = costs[n]; best_mode = modes[n]; }
+          ++n;
+        }
+    }
+  }
+  const int8_t add_modes[5] = { intra_preds[0], intra_preds[1], intra_preds[2], 0, 1 };
+  for (int k = 0; k < 5; ++k) {
+    bool has = false;
+    for (int i = 0; i < n; ++i) if (modes[i] == add_modes[k]) { has = true; break; }
+    if (!has) { MODE_COST(add_modes[k], costs[n]); modes[n] = add_modes[k]; ++n; }
+  }
+  const int lambda_cost = (int)(state->lambda_sqrt + 0.5);
+  for (int i = 0; i < n; ++i) costs[i] += lambda_cost * kvz_luma_mode_bits(state, modes[i], intra_preds);
+#undef MODE_COST
+  kvz_lcu_set_trdepth(lcu, x_px, y_px, depth, depth);            /* search_intra.c:856 */
+  best_i = 0;
+  for (int i = 1; i < n; ++i) if (costs[i] < costs[best_i]) best_i = i;
+  *mode_out = modes[best_i];
+  *cost_out = costs[best_i];
+  ++g_gpu.intra_served;
+  return 1;
+}
+
+void __wrap_kvz_search_cu_intra(encoder_state_t * const state, const int x_px, const int y_px, const int depth, lcu_t *lcu,
+                                int8_t *mode_out, double *cost_out)
+{
+  if (gpu_intra_serve(state, x_px, y_px, depth, lcu, mode_out, cost_out)) return;
+  __real_kvz_search_cu_intra(state, x_px, y_px, depth, lcu, mode_out, cost_out);
 }

@@ -378,24 +378,31 @@ GPU_SEARCH_CONFIGS = [
     (192, 128, 10, "preset=medium,qp=30,threads=0"),
     (128, 128, 9, "preset=fast,gop=lp-g4d3t1,qp=34,threads=0,rdoq=0"),                               # low-delay P GOP
     (1920, 1080, 4, "preset=medium,qp=32,threads=0"),                                                # BASELINE's 1080p medium, three B pictures
+    # intra pictures only; 4x4 transform skip (its SAD test in get_cost); every mode in the first pass
+    (192, 128, 3, "preset=medium,period=1,qp=27,threads=0"),
+    (128, 128, 3, "preset=fast,period=1,transform-skip=1,rd=1,qp=24,threads=0"),
+    (168, 104, 3, "preset=medium,period=1,full-intra-search=1,qp=35,threads=0"),
 ]
 
 
 @pytest.mark.parametrize("w,h,n,opts", GPU_SEARCH_CONFIGS)
 def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, n, opts):
-    """The batched entries inside a live encode: every 2Nx2N inter search of the reference encoder is answered by
+    """The batched entries inside a live encode.  Every 2Nx2N inter search of the reference encoder is answered by
     kvz_hip_inter_candidates_batch (candidates from the encoder's lcu->cu, copied into a device CU array) followed by
-    kvz_hip_search_pu_batch, and the encoder carries on with that decision -- mode decision, reconstruction, the neighbours'
-    candidates, the next frame's temporal candidates all consume it.  The bitstream must be the untouched encoder's."""
+    kvz_hip_search_pu_batch, once per reference picture; every rough intra search by kvz_hip_intra_build_reference_batch (from
+    lcu->rec and its borders laid out as a picture) followed by kvz_hip_intra_rough_batch, the harness walking the 35-cost table in
+    search_intra_rough's order.  The encoder carries on with those decisions -- mode decision, reconstruction, the neighbours'
+    candidates, the next pictures' temporal candidates all consume them.  The bitstream must be the untouched encoder's."""
     import time
     frames = R.synthetic_sequence(w, h, n, seed=5)
     t0 = time.perf_counter()
     plain, _ = R.encode(frames, w, h, opts)
     t1 = time.perf_counter()
-    served_bs, served, passed_on, failed, launches = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"))
+    served_bs, c = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"))
     t2 = time.perf_counter()
     # one search per launch and three host round trips each: a correctness path, its time is printed for the record only
-    print("%dx%d x %d frames: searches served by the GPU chain: %d (%d candidate + search launch pairs), left to the reference: %d; "
-          "whole encode %.2f s untouched, %.2f s served" % (w, h, n, served, launches, passed_on, t1 - t0, t2 - t1))
-    assert failed == 0 and served >= 40 * (n - 1)
+    print("%dx%d x %d frames: inter searches served by the GPU chain: %d (%d candidate + search launch pairs), left to the reference: %d; "
+          "intra searches served: %d, left to the reference: %d; whole encode %.2f s untouched, %.2f s served"
+          % (w, h, n, c["inter_served"], c["launch_pairs"], c["inter_passed_on"], c["intra_served"], c["intra_passed_on"], t1 - t0, t2 - t1))
+    assert c["failed"] == 0 and c["inter_served"] + c["intra_served"] >= 40 * (n - 1) and c["intra_served"] > 0
     assert served_bs == plain, "bitstreams differ (%d vs %d bytes)" % (len(served_bs), len(plain))
