@@ -692,6 +692,8 @@ int ref_sizeof_sao_info(void) { return (int)sizeof(sao_info_t); }
  * Nothing here changes what the encoder does; without ref_record_begin the wrapper is a plain call-through.
  * ------------------------------------------------------------------------ */
 #include "search_inter.h"
+#include "search_intra.h"
+#include "search.h"
 #include "inter.h"
 
 typedef struct { int16_t mv[2]; uint8_t usable; uint8_t same_ref; } rec_merge_t;
@@ -1496,6 +1498,27 @@ static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth
   const int lambda_cost = (int)(state->lambda_sqrt + 0.5);
   for (int i = 0; i < n; ++i) costs[i] += lambda_cost * kvz_luma_mode_bits(state, modes[i], intra_preds);
 #undef MODE_COST
+  if (getenv("KVZ_GPU_SERVE_CHECK")) {                           /* debugging aid: the table against the reference's own functions */
+    static int shown = 0;
+    kvz_intra_references refs;
+    const vector2d_t luma_px = { x_px, y_px }, pic_px = { state->tile->frame->width, state->tile->frame->height };
+    kvz_intra_build_reference(log2_width, COLOR_Y, &luma_px, &pic_px, lcu, &refs);
+    kvz_hip_intra_ref got;
+    g_gpu.d2h(&got, g_gpu.d_iref, sizeof(got), NULL);
+    const int refs_equal = !memcmp(got.left, refs.ref.left, 2 * width + 1) && !memcmp(got.top, refs.ref.top, 2 * width + 1);
+    kvz_pixel pred[32 * 32 + 64];
+    kvz_pixel *pp = (kvz_pixel *)(((uintptr_t)pred + 31) & ~(uintptr_t)31);
+    for (int m = 0; m < 35 && shown < 12; ++m) {
+      kvz_intra_predict(&refs, log2_width, m, COLOR_Y, pp, filter_boundary);
+      const unsigned want = kvz_pixels_get_satd_func(width)(pp, orig_block);
+      if (want != table[m] || !refs_equal) {
+        fprintf(stderr, "intra table mismatch at (%d, %d) log2 %d mode %d: table %u, reference satd %u, references %s, lambda_cost %d\n",
+                x_px, y_px, log2_width, m, table[m], want, refs_equal ? "equal" : "DIFFER", lambda_cost);
+        ++shown;
+        break;
+      }
+    }
+  }
   kvz_lcu_set_trdepth(lcu, x_px, y_px, depth, depth);            /* search_intra.c:856 */
   best_i = 0;
   for (int i = 1; i < n; ++i) if (costs[i] < costs[best_i]) best_i = i;
@@ -1508,6 +1531,16 @@ static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth
 void __wrap_kvz_search_cu_intra(encoder_state_t * const state, const int x_px, const int y_px, const int depth, lcu_t *lcu,
                                 int8_t *mode_out, double *cost_out)
 {
-  if (gpu_intra_serve(state, x_px, y_px, depth, lcu, mode_out, cost_out)) return;
+  if (gpu_intra_serve(state, x_px, y_px, depth, lcu, mode_out, cost_out)) {
+    if (getenv("KVZ_GPU_SERVE_CHECK")) {                 /* debugging aid: the reference's answer next to the served one */
+      int8_t m = -1; double c = -1;
+      static int shown = 0;
+      __real_kvz_search_cu_intra(state, x_px, y_px, depth, lcu, &m, &c);
+      if ((m != *mode_out || c != *cost_out) && shown++ < 10)
+        fprintf(stderr, "intra serve mismatch at (%d, %d) depth %d poc %d: served mode %d cost %.3f, reference mode %d cost %.3f\n",
+                x_px, y_px, depth, state->frame->poc, *mode_out, *cost_out, m, c);
+    }
+    return;
+  }
   __real_kvz_search_cu_intra(state, x_px, y_px, depth, lcu, mode_out, cost_out);
 }
