@@ -1286,17 +1286,25 @@ static int gpu_load_frame(const encoder_state_t *state)
   return bad;
 }
 
-static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
+/* which searches the two entries can answer */
+static int gpu_can_serve_inter(const encoder_state_t *state)
 {
-  if (!g_gpu.on) return 0;
   const encoder_control_t *ctrl = state->encoder_control;
   const encoder_state_config_frame_t *fr = state->frame;
   const int nref = (int)fr->ref->used_size;
-  const int can = nref >= 1 && nref <= GPU_MAX_REFS && fr->slicetype != KVZ_SLICE_I &&
-                  !(ctrl->cfg.bipred && fr->slicetype == KVZ_SLICE_B) &&      /* search_pu_inter_bipred stays the reference's */
-                  !ctrl->cfg.mv_rdo && ctrl->cfg.rdo < 2 && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
-                  state->tile->frame->width == g_gpu.w && state->tile->frame->height == g_gpu.h;
-  if (!can) { ++g_gpu.passed_on; return 0; }
+  return nref >= 1 && nref <= GPU_MAX_REFS && fr->slicetype != KVZ_SLICE_I &&
+         !(ctrl->cfg.bipred && fr->slicetype == KVZ_SLICE_B) &&      /* search_pu_inter_bipred stays the reference's */
+         !ctrl->cfg.mv_rdo && ctrl->cfg.rdo < 2 && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
+         state->tile->frame->width == g_gpu.w && state->tile->frame->height == g_gpu.h;
+}
+
+/* search_pu_inter (search_inter.c:1451-1520) for one PU of any shape, the two entries in place of search_pu_inter_ref's
+ * middle.  Returns 0 when a GPU call failed (nothing of the encoder's state is changed then). */
+static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int height, int merge_a1, int merge_b1, lcu_t *lcu,
+                        double *inter_cost, uint32_t *inter_bitcost)
+{
+  const encoder_state_config_frame_t *fr = state->frame;
+  const int nref = (int)fr->ref->used_size;
   const int w = g_gpu.w, h = g_gpu.h;
   int bad = 0;
   if (g_gpu.poc_loaded != fr->poc) { bad |= gpu_load_frame(state); g_gpu.poc_loaded = fr->poc; }
@@ -1313,8 +1321,7 @@ static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu
   const int r0 = oy > 0 ? oy - 1 : 0, r1 = oy + 16 < g_gpu.rows ? oy + 16 : g_gpu.rows;
   bad |= g_gpu.h2d(g_gpu.d_cus + (size_t)r0 * g_gpu.stride, g_gpu.h_cus + (size_t)r0 * g_gpu.stride,
                    (size_t)(r1 - r0) * g_gpu.stride * sizeof(kvz_hip_cu_info), NULL);
-  /* 2. + 3.: search_pu_inter (search_inter.c:1456-1507) with the two entries in place of search_pu_inter_ref's middle */
-  const int width = LCU_WIDTH >> depth;
+  /* 2. + 3.: every reference picture in turn (search_inter.c:1502-1507) */
   cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
   const cu_info_t saved = *cur_cu;
   double cost = MAX_INT;
@@ -1323,7 +1330,8 @@ static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu
   CU_SET_MV_CAND(cur_cu, 1, 0);
   kvz_hip_me_params mp = g_gpu.mp;
   mp.lambda_cost = (int32_t)(state->lambda_sqrt + 0.5);
-  mp.size_classes = width <= 16 ? 1 : (width <= 32 ? 2 : 4);
+  const int longer = width > height ? width : height;
+  mp.size_classes = longer <= 16 ? 1 : (longer <= 32 ? 2 : 4);
   const int8_t lx_max = MAX(fr->ref_LX_size[0], fr->ref_LX_size[1]);
   for (int ref_idx = 0; ref_idx < nref && !bad; ++ref_idx) {
     int8_t ref_list = -1, LX_idx;                      /* :1143-1166 */
@@ -1334,7 +1342,8 @@ static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu
     if (ref_list < 0) { bad = 1; break; }
     kvz_hip_me_pu pu;
     memset(&pu, 0, sizeof(pu));
-    pu.x = x; pu.y = y; pu.width = width; pu.height = width;
+    pu.x = x; pu.y = y; pu.width = width; pu.height = height;
+    pu.pad = (int16_t)((merge_a1 ? 0 : 1) | (merge_b1 ? 0 : 2));
     const uint32_t beat = (uint32_t)cost;               /* *inter_cost as search_pu_inter_ref finds it (:1239) */
     kvz_hip_me_result res;
     memset(&res, 0, sizeof(res));
@@ -1360,16 +1369,90 @@ static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu
     }
   }
   if (bad) {
-    if (g_gpu.failed++ == 0) fprintf(stderr, "gpu_search_serve: %s\n", g_gpu.last_error());
+    if (g_gpu.failed++ == 0) fprintf(stderr, "gpu_serve_pu: %s\n", g_gpu.last_error());
     *cur_cu = saved;
-    return 0;                                            /* the reference's own search takes over */
+    return 0;
   }
   *inter_cost = cost;
   *inter_bitcost = bitcost;
+  return 1;
+}
+
+/* kvz_search_cu_inter (search_inter.c:1587-1608) for rd < 2: the 2Nx2N PU */
+static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
+{
+  if (!g_gpu.on) return 0;
+  if (!gpu_can_serve_inter(state)) { ++g_gpu.passed_on; return 0; }
+  const int width = LCU_WIDTH >> depth;
+  if (!gpu_serve_pu(state, x, y, width, width, 1, 1, lcu, inter_cost, inter_bitcost)) return 0;   /* the reference's own search takes over */
   ++g_gpu.served;
   return 1;
 }
 
+/* kvz_search_cu_smp (search_inter.c:1626-1718) for rd < 2: the PUs of a SMP / AMP partition one after the other, each
+ * seeing its predecessor's decision in lcu->cu (-Wl,--wrap=kvz_search_cu_smp) */
+void __real_kvz_search_cu_smp(encoder_state_t * const state, int x, int y, int depth, part_mode_t part_mode, lcu_t *lcu,
+                              double *inter_cost, uint32_t *inter_bitcost);
+
+void __wrap_kvz_search_cu_smp(encoder_state_t * const state, int x, int y, int depth, part_mode_t part_mode, lcu_t *lcu,
+                              double *inter_cost, uint32_t *inter_bitcost)
+{
+  if (!g_gpu.on || !gpu_can_serve_inter(state)) {
+    if (g_gpu.on) ++g_gpu.passed_on;
+    __real_kvz_search_cu_smp(state, x, y, depth, part_mode, lcu, inter_cost, inter_bitcost);
+    return;
+  }
+  const int num_pu = kvz_part_mode_num_parts[part_mode];
+  const int width = LCU_WIDTH >> depth;
+  const int x_local = SUB_SCU(x), y_local = SUB_SCU(y);
+  /* a failed GPU call hands the whole CU back to the reference, from the state it started with */
+  cu_info_t keep[LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1];
+  memcpy(keep, lcu->cu, sizeof(keep));
+  *inter_cost = 0;
+  *inter_bitcost = 0;
+  for (int i = 0; i < num_pu; ++i) {
+    const int x_pu = PU_GET_X(part_mode, width, x_local, i), y_pu = PU_GET_Y(part_mode, width, y_local, i);
+    const int width_pu = PU_GET_W(part_mode, width, i), height_pu = PU_GET_H(part_mode, width, i);
+    cu_info_t *cur_pu = LCU_GET_CU_AT_PX(lcu, x_pu, y_pu);
+    cur_pu->type = CU_INTER;
+    cur_pu->part_size = part_mode;
+    cur_pu->depth = depth;
+    cur_pu->qp = state->qp;
+    double cost = MAX_INT;
+    uint32_t bitcost = MAX_INT;
+    /* search_pu_inter :1463-1475: the PU in picture coordinates, the merge neighbour barred for a second PU */
+    const int xp = PU_GET_X(part_mode, width, x, i), yp = PU_GET_Y(part_mode, width, y, i);
+    const int merge_a1 = i == 0 || width_pu >= height_pu, merge_b1 = i == 0 || width_pu <= height_pu;
+    if (!gpu_serve_pu(state, xp, yp, width_pu, height_pu, merge_a1, merge_b1, lcu, &cost, &bitcost)) {
+      memcpy(lcu->cu, keep, sizeof(keep));
+      __real_kvz_search_cu_smp(state, x, y, depth, part_mode, lcu, inter_cost, inter_bitcost);
+      return;
+    }
+    ++g_gpu.served;
+    if (cost >= MAX_INT) {                               /* no vector found */
+      *inter_cost = MAX_INT;
+      *inter_bitcost = MAX_INT;
+      return;
+    }
+    *inter_cost += cost;
+    *inter_bitcost += bitcost;
+    for (int yy = y_pu; yy < y_pu + height_pu; yy += SCU_WIDTH)
+      for (int xx = x_pu; xx < x_pu + width_pu; xx += SCU_WIDTH) {
+        cu_info_t *scu = LCU_GET_CU_AT_PX(lcu, xx, yy);
+        scu->type = CU_INTER;
+        scu->inter = cur_pu->inter;
+      }
+  }
+  /* the partition mode's own bits (:1702-1716; rd < 2 here) */
+  int smp_extra_bits = 1;
+  if (state->encoder_control->cfg.amp_enable) {
+    smp_extra_bits += 1;
+    if (part_mode != SIZE_2NxN && part_mode != SIZE_Nx2N) smp_extra_bits += 1;
+  }
+  smp_extra_bits += 6;
+  *inter_cost += state->lambda_sqrt * smp_extra_bits;
+  *inter_bitcost += smp_extra_bits;
+}
 
 /* ------------------------------------------------------------------------
  * The encoder's intra mode searches served the same way (tests only; -Wl,--wrap=kvz_search_cu_intra).  For the searches

@@ -370,7 +370,8 @@ GPU_SEARCH_CONFIGS = [
     (192, 128, 4, "preset=medium,ref=1,bipred=0,gop=0,rdoq=0,qp=24,threads=0,me=tz,me-early-termination=sensitive,mv-constraint=frametilemargin,period=0"),
     (128, 128, 5, "preset=fast,ref=1,bipred=0,gop=0,rdoq=0,qp=37,threads=0,me=dia,subme=2,deblock=1,sao=off,owf=0,wpp=0,period=0"),
     (168, 104, 4, "preset=veryfast,ref=1,bipred=0,gop=0,qp=33,threads=0,tmvp=0,period=0"),       # ragged LCUs, no temporal candidates
-    (128, 64, 6, "preset=slow,ref=1,bipred=0,gop=0,rdoq=0,qp=27,threads=0,smp=1,amp=1,period=0"),   # SMP / AMP searches stay the reference's
+    (128, 64, 6, "preset=slow,ref=1,bipred=0,gop=0,rdoq=0,qp=27,threads=0,smp=1,amp=1,period=0"),   # + every SMP / AMP PU (kvz_search_cu_smp)
+    (192, 128, 6, "preset=medium,smp=1,amp=1,qp=31,threads=0"),                                      # SMP / AMP in B slices with four references
     (1920, 1080, 2, "preset=medium,ref=1,bipred=0,gop=0,qp=32,threads=0,period=0"),                 # one 1080p P frame: ~43 000 searches
     # several reference pictures: every picture searched in turn, the best cost so far as the cost to beat (search_inter.c:1239)
     (192, 128, 7, "preset=medium,ref=3,bipred=0,gop=0,qp=29,threads=0,period=0"),
@@ -387,7 +388,7 @@ GPU_SEARCH_CONFIGS = [
 
 @pytest.mark.parametrize("w,h,n,opts", GPU_SEARCH_CONFIGS)
 def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, n, opts):
-    """The batched entries inside a live encode.  Every 2Nx2N inter search of the reference encoder is answered by
+    """The batched entries inside a live encode.  Every inter search of the reference encoder (2Nx2N, and the PUs of the SMP / AMP partitions) is answered by
     kvz_hip_inter_candidates_batch (candidates from the encoder's lcu->cu, copied into a device CU array) followed by
     kvz_hip_search_pu_batch, once per reference picture; every rough intra search by kvz_hip_intra_build_reference_batch (from
     lcu->rec and its borders laid out as a picture) followed by kvz_hip_intra_rough_batch, the harness walking the 35-cost table in
