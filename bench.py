@@ -363,6 +363,9 @@ def shard_search_leg(env, sh, steps, warmup, frames):
     return dt, ex_ms, se_ms, sums
 
 
+SHARD_LEG_LIMIT_S = 300
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -380,6 +383,63 @@ def main():
 
     dt, ms, blocks = headline_leg(env, args.steps, args.warmup, F)
     torch.cuda.empty_cache()
+
+    def emit(shard_out):
+        """rank 0: the one JSON line (the headline numbers are final before the shard leg starts)"""
+        total_blocks = (2 * blocks["sad_8x8"] + blocks["dct_32x32"]) * world * args.steps
+        kern = kernel_stats(ms, blocks)
+        dom = max(NAMES, key=lambda k: kern[k]["avg_launch_ms"])
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from separate rocprofv3 --pmc passes of this command
+        if os.path.exists(tfile) and F == 128:                          # the PMC passes were taken at the default batch size
+            try:
+                t = json.load(open(tfile))
+                cap = t.get("_captured", {})
+                if cap.get("kernel_sources_sha1_16") == kernel_sources_digest():
+                    traffic = t.get(dom)
+                    traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (bytes per "
+                                   "launch), captured %s at commit %s on these kernel sources" % (cap.get("date"), cap.get("commit")))
+                else:
+                    traffic_src = "profiles/pmc_traffic.json was captured on other kernel sources (%s): not quoted" % cap.get("commit")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mblocks/s (SAD8/SATD8/DCT32) per GPU",
+            "value": round(total_blocks / dt / 1e6, 1),
+            "unit": "Mblocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1080p CTU grid x %d frames per launch per GPU: sad_8x8 + satd_8x8 on %d 8x8 block pairs, "
+                                   "dct_32x32 on %d int16 residual blocks, via the kvz_hip C ABI (batched 'hip' strategy entries)"
+                                   % (F, blocks["sad_8x8"], blocks["dct_32x32"]),
+                       "frames_per_batch": F, "parallelism": "independent batches per GPU, no data-path collective (value); "
+                                                             "CTU-row shards of one fixed 4K batch + RCCL halo exchange (shard_4k)"},
+            "kernels": kern,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_src},
+        }
+        if shard_out is not None:
+            out["shard_4k"] = shard_out
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+    # The shard leg exchanges halo rows between ranks; should a collective ever hang, the headline line is still printed: a
+    # watchdog emits it (with the failure noted) and ends the process.
+    watchdog = None
+    if not args.no_shard_leg and world > 1:
+        import threading
+
+        def give_up():
+            sys.stderr.write("rank %d: shard_4k leg exceeded %d s, giving up on it\n" % (rank, SHARD_LEG_LIMIT_S))
+            if rank == 0:
+                emit({"error": "timed out after %d s" % SHARD_LEG_LIMIT_S, "note": "the shard_4k leg hung; `value` (headline leg) is unaffected"})
+            os._exit(0)
+        watchdog = threading.Timer(SHARD_LEG_LIMIT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
 
     shard_out = None
     if not args.no_shard_leg:
@@ -438,46 +498,10 @@ def main():
                 },
             }
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        total_blocks = (2 * blocks["sad_8x8"] + blocks["dct_32x32"]) * world * args.steps
-        kern = kernel_stats(ms, blocks)
-        dom = max(NAMES, key=lambda k: kern[k]["avg_launch_ms"])
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")      # written from separate rocprofv3 --pmc passes of this command
-        if os.path.exists(tfile) and F == 128:                          # the PMC passes were taken at the default batch size
-            try:
-                t = json.load(open(tfile))
-                cap = t.get("_captured", {})
-                if cap.get("kernel_sources_sha1_16") == kernel_sources_digest():
-                    traffic = t.get(dom)
-                    traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (bytes per "
-                                   "launch), captured %s at commit %s on these kernel sources" % (cap.get("date"), cap.get("commit")))
-                else:
-                    traffic_src = "profiles/pmc_traffic.json was captured on other kernel sources (%s): not quoted" % cap.get("commit")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "Mblocks/s (SAD8/SATD8/DCT32) per GPU",
-            "value": round(total_blocks / dt / 1e6, 1),
-            "unit": "Mblocks/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1080p CTU grid x %d frames per launch per GPU: sad_8x8 + satd_8x8 on %d 8x8 block pairs, "
-                                   "dct_32x32 on %d int16 residual blocks, via the kvz_hip C ABI (batched 'hip' strategy entries)"
-                                   % (F, blocks["sad_8x8"], blocks["dct_32x32"]),
-                       "frames_per_batch": F, "parallelism": "independent batches per GPU, no data-path collective (value); "
-                                                             "CTU-row shards of one fixed 4K batch + RCCL halo exchange (shard_4k)"},
-            "kernels": kern,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kern[dom]["frac_of_hbm_peak"], "traffic": traffic, "traffic_source": traffic_src},
-        }
-        if shard_out is not None:
-            out["shard_4k"] = shard_out
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        emit(shard_out)
     if env.dist:
         env.dist.barrier()
         env.dist.destroy_process_group()
