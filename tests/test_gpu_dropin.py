@@ -407,3 +407,15 @@ def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, 
           % (w, h, n, c["inter_served"], c["launch_pairs"], c["inter_passed_on"], c["intra_served"], c["intra_passed_on"], t1 - t0, t2 - t1))
     assert c["failed"] == 0 and c["inter_served"] + c["intra_served"] >= 40 * (n - 1) and c["intra_served"] > 0
     assert served_bs == plain, "bitstreams differ (%d vs %d bytes)" % (len(served_bs), len(plain))
+
+
+def test_reference_encoder_with_searches_served_and_hip_strategies_installed(hip):
+    """both halves of the boundary at once: the per-call "hip" strategies in the encoder's function table (SAD / SATD, transforms,
+    quantisation, interpolation, intra prediction, SAO) AND the inter / intra searches served by the batched entries -- the
+    encoder then does none of SURVEY 8(a)'s arithmetic on the host, and its bitstream is still the generic C encoder's"""
+    w, h, n, opts = 192, 128, 5, "preset=medium,qp=29,threads=0"
+    frames = R.synthetic_sequence(w, h, n, seed=9)
+    gen, _ = R.encode(frames, w, h, opts, "generic")
+    both, c = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"), strategy="hip")
+    assert c["failed"] == 0 and c["inter_served"] > 500 and c["intra_served"] > 500
+    assert both == gen, "bitstreams differ (%d vs %d bytes)" % (len(both), len(gen))
