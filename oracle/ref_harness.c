@@ -1143,7 +1143,13 @@ static struct {
               kvz_hip_merge_cand *, kvz_hip_stream);
   int (*search)(const kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_me_pu *, size_t,
                 const kvz_hip_me_params *, kvz_hip_me_result *, kvz_hip_stream);
+  int (*bipred)(const kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_pixel *, uint32_t, const kvz_hip_pixel *, uint32_t, int, int,
+                const kvz_hip_bipred_cand *, size_t, uint32_t *, kvz_hip_stream);
   const char *(*last_error)(void);
+  kvz_hip_merge_cand *d_merge;
+  kvz_hip_bipred_cand *d_bcand;
+  uint32_t *d_bcost;
+  long bipred_pairs;
   uint8_t *d_pic, *d_ref[GPU_MAX_REFS], *h_plane;
   kvz_hip_cu_info *d_cus, *d_refcus[GPU_MAX_REFS], *h_cus, *h_col;
   kvz_hip_me_pu *d_pu;
@@ -1177,10 +1183,11 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   *(void **)&g_gpu.cand = dlsym(l, "kvz_hip_inter_candidates_batch");
   *(void **)&g_gpu.search = dlsym(l, "kvz_hip_search_pu_batch");
   *(void **)&g_gpu.last_error = dlsym(l, "kvz_hip_last_error");
+  *(void **)&g_gpu.bipred = dlsym(l, "kvz_hip_bipred_cost_batch");
   *(void **)&g_gpu.build_ref = dlsym(l, "kvz_hip_intra_build_reference_batch");
   *(void **)&g_gpu.rough = dlsym(l, "kvz_hip_intra_rough_batch");
   if (!g_gpu.init || !g_gpu.dmalloc || !g_gpu.dfree || !g_gpu.h2d || !g_gpu.d2h || !g_gpu.cand || !g_gpu.search || !g_gpu.last_error ||
-      !g_gpu.build_ref || !g_gpu.rough) return -1;
+      !g_gpu.build_ref || !g_gpu.rough || !g_gpu.bipred) return -1;
   if (g_gpu.init(-1) != KVZ_HIP_OK) { fprintf(stderr, "kvz_hip_init: %s\n", g_gpu.last_error()); return -1; }
   g_gpu.w = w; g_gpu.h = h;
   g_gpu.stride = ((w + 63) / 64) * 16; g_gpu.rows = ((h + 63) / 64) * 16;
@@ -1189,11 +1196,14 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   g_gpu.d_cus = g_gpu.dmalloc(map_bytes);
   g_gpu.d_pu = g_gpu.dmalloc(sizeof(kvz_hip_me_pu)); g_gpu.d_res = g_gpu.dmalloc(sizeof(kvz_hip_me_result));
   g_gpu.d_beat = g_gpu.dmalloc(sizeof(uint32_t));
+  g_gpu.d_merge = g_gpu.dmalloc(5 * sizeof(kvz_hip_merge_cand)); g_gpu.d_bcand = g_gpu.dmalloc(sizeof(kvz_hip_bipred_cand));
+  g_gpu.d_bcost = g_gpu.dmalloc(sizeof(uint32_t));
   g_gpu.h_plane = malloc((size_t)w * h);
   g_gpu.h_cus = calloc(1, map_bytes); g_gpu.h_col = calloc(1, map_bytes);
   g_gpu.d_vplane = g_gpu.dmalloc(VPLANE_W * VPLANE_H); g_gpu.h_vplane = calloc(1, VPLANE_W * VPLANE_H);
   g_gpu.d_orig = g_gpu.dmalloc(32 * 32); g_gpu.d_pos = g_gpu.dmalloc(sizeof(kvz_hip_intra_pos));
   g_gpu.d_iref = g_gpu.dmalloc(sizeof(kvz_hip_intra_ref)); g_gpu.d_icost = g_gpu.dmalloc(70 * sizeof(uint32_t));
+  if (!g_gpu.d_merge || !g_gpu.d_bcand || !g_gpu.d_bcost) return -1;
   if (!g_gpu.d_pic || !g_gpu.d_cus || !g_gpu.d_pu || !g_gpu.d_res || !g_gpu.d_beat || !g_gpu.h_plane || !g_gpu.h_cus || !g_gpu.h_col ||
       !g_gpu.d_vplane || !g_gpu.h_vplane || !g_gpu.d_orig || !g_gpu.d_pos || !g_gpu.d_iref || !g_gpu.d_icost) return -1;
   g_gpu.poc_loaded = -1;
@@ -1201,13 +1211,14 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   return 0;
 }
 
-/* out[0..5] = inter searches served by the GPU chain, inter searches passed on to the reference, GPU calls that failed,
+/* out[0..6] (out[6] = bi-prediction candidate pairs scored by kvz_hip_bipred_cost_batch); out[0..5] = inter searches served by the GPU chain, inter searches passed on to the reference, GPU calls that failed,
  * (candidates + search) launch pairs issued (one per reference picture of a served search), intra searches served, passed on */
 void ref_gpu_search_end(long *out)
 {
   if (out) { out[0] = g_gpu.served; out[1] = g_gpu.passed_on; out[2] = g_gpu.failed; out[3] = g_gpu.launches;
-             out[4] = g_gpu.intra_served; out[5] = g_gpu.intra_passed_on; }
+             out[4] = g_gpu.intra_served; out[5] = g_gpu.intra_passed_on; out[6] = g_gpu.bipred_pairs; }
   if (g_gpu.lib) {
+    g_gpu.dfree(g_gpu.d_merge); g_gpu.dfree(g_gpu.d_bcand); g_gpu.dfree(g_gpu.d_bcost);
     g_gpu.dfree(g_gpu.d_vplane); g_gpu.dfree(g_gpu.d_orig); g_gpu.dfree(g_gpu.d_pos); g_gpu.dfree(g_gpu.d_iref); g_gpu.dfree(g_gpu.d_icost);
     g_gpu.dfree(g_gpu.d_pic); g_gpu.dfree(g_gpu.d_cus); g_gpu.dfree(g_gpu.d_pu); g_gpu.dfree(g_gpu.d_res); g_gpu.dfree(g_gpu.d_beat);
     for (int i = 0; i < GPU_MAX_REFS; ++i) { g_gpu.dfree(g_gpu.d_ref[i]); g_gpu.dfree(g_gpu.d_refcus[i]); }
@@ -1286,6 +1297,10 @@ static int gpu_load_frame(const encoder_state_t *state)
   return bad;
 }
 
+uint32_t refme_calc_mvd_cost(const encoder_state_t *state, int x, int y, int mv_shift, int16_t mv_cand[2][2], uint32_t *bitcost);
+int refme_select_mv_cand(const encoder_state_t *state, int16_t mv_cand[2][2], int32_t mv_x, int32_t mv_y);
+int refme_fracmv_within_tile(const encoder_state_t *state, int origin_x, int origin_y, int width, int height, int mv_x, int mv_y);
+
 /* which searches the two entries can answer */
 static int gpu_can_serve_inter(const encoder_state_t *state)
 {
@@ -1293,7 +1308,6 @@ static int gpu_can_serve_inter(const encoder_state_t *state)
   const encoder_state_config_frame_t *fr = state->frame;
   const int nref = (int)fr->ref->used_size;
   return nref >= 1 && nref <= GPU_MAX_REFS && fr->slicetype != KVZ_SLICE_I &&
-         !(ctrl->cfg.bipred && fr->slicetype == KVZ_SLICE_B) &&      /* search_pu_inter_bipred stays the reference's */
          !ctrl->cfg.mv_rdo && ctrl->cfg.rdo < 2 && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
          state->tile->frame->width == g_gpu.w && state->tile->frame->height == g_gpu.h;
 }
@@ -1351,7 +1365,7 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
     const int c = fr->ref_LX_size[0] > 0 ? fr->ref_LX[0][0] : 0;
     bad |= g_gpu.h2d(g_gpu.d_pu, &pu, sizeof(pu), NULL);
     bad |= g_gpu.h2d(g_gpu.d_beat, &beat, sizeof(beat), NULL);
-    bad |= g_gpu.cand(g_gpu.d_cus, g_gpu.d_refcus[c], g_gpu.d_refcus[ref_idx], &g_gpu.ip, g_gpu.d_pu, 1, NULL, NULL);
+    bad |= g_gpu.cand(g_gpu.d_cus, g_gpu.d_refcus[c], g_gpu.d_refcus[ref_idx], &g_gpu.ip, g_gpu.d_pu, 1, g_gpu.d_merge, NULL);
     bad |= g_gpu.search(g_gpu.d_pic, (uint32_t)w, w, h, g_gpu.d_ref[ref_idx], (uint32_t)w, w, h, g_gpu.d_pu, 1, &mp, g_gpu.d_res, NULL);
     bad |= g_gpu.d2h(&res, g_gpu.d_res, sizeof(res), NULL);
     ++g_gpu.launches;
@@ -1366,6 +1380,64 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
       CU_SET_MV_CAND(cur_cu, ref_list, res.mv_cand);
       cost = res.cost;
       bitcost = res.bitcost + cur_cu->inter.mv_dir - 1 + LX_idx;
+    }
+  }
+  /* search_pu_inter_bipred (search_inter.c:1304-1440): pairs of an L0 and an L1 merge candidate, each scored by
+   * kvz_hip_bipred_cost_batch (the blended prediction's SATD) + the reference's own MV bit costs (:1509-1516) */
+  if (!bad && fr->slicetype == KVZ_SLICE_B && state->encoder_control->cfg.bipred && width + height >= 16) {
+    kvz_hip_merge_cand mc[5];
+    kvz_hip_me_pu last;
+    bad |= g_gpu.d2h(mc, g_gpu.d_merge, sizeof(mc), NULL);
+    bad |= g_gpu.d2h(&last, g_gpu.d_pu, sizeof(last), NULL);        /* info->mv_cand as the last picture's search left it */
+    int16_t mv_cand[2][2];
+    memcpy(mv_cand, last.mv_cand, sizeof(mv_cand));
+    static const uint8_t first[12] = { 0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3 }, second[12] = { 1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2 };
+    const int n_merge = last.num_merge_cand;
+    const unsigned pairs = MIN(n_merge * (n_merge - 1), 12);
+    for (unsigned idx = 0; idx < pairs && !bad; ++idx) {
+      const int i = first[idx], j = second[idx];
+      if (i >= n_merge || j >= n_merge) break;
+      if (!(mc[i].dir & 1) || !(mc[j].dir & 2)) continue;
+      if (fr->ref_LX[0][mc[i].ref[0]] == fr->ref_LX[1][mc[j].ref[1]] && mc[i].mv[0][0] == mc[j].mv[1][0] && mc[i].mv[0][1] == mc[j].mv[1][1]) continue;
+      int16_t mv[2][2] = { { mc[i].mv[0][0], mc[i].mv[0][1] }, { mc[j].mv[1][0], mc[j].mv[1][1] } };
+      if (!refme_fracmv_within_tile(state, x, y, width, height, mv[0][0], mv[0][1]) ||
+          !refme_fracmv_within_tile(state, x, y, width, height, mv[1][0], mv[1][1])) continue;
+      kvz_hip_bipred_cand bc;
+      memset(&bc, 0, sizeof(bc));
+      bc.x = x; bc.y = y; bc.width = width; bc.height = height;
+      bc.mv0[0] = mv[0][0]; bc.mv0[1] = mv[0][1]; bc.mv1[0] = mv[1][0]; bc.mv1[1] = mv[1][1];
+      uint32_t pair_cost = 0;
+      bad |= g_gpu.h2d(g_gpu.d_bcand, &bc, sizeof(bc), NULL);
+      bad |= g_gpu.bipred(g_gpu.d_pic, (uint32_t)w, w, h, g_gpu.d_ref[fr->ref_LX[0][mc[i].ref[0]]], (uint32_t)w,
+                          g_gpu.d_ref[fr->ref_LX[1][mc[j].ref[1]]], (uint32_t)w, w, h, g_gpu.d_bcand, 1, g_gpu.d_bcost, NULL);
+      bad |= g_gpu.d2h(&pair_cost, g_gpu.d_bcost, sizeof(pair_cost), NULL);
+      ++g_gpu.bipred_pairs;
+      if (bad || pair_cost == 0xffffffffu) { bad = 1; break; }
+      uint32_t bits[2] = { 0, 0 };
+      pair_cost += refme_calc_mvd_cost(state, mc[i].mv[0][0], mc[i].mv[0][1], 0, mv_cand, &bits[0]);
+      pair_cost += refme_calc_mvd_cost(state, mc[i].mv[1][0], mc[i].mv[1][1], 0, mv_cand, &bits[1]);     /* [i], as :1379-1386 has it */
+      const int extra_bits = mc[i].ref[0] + mc[j].ref[1] + 2;
+      pair_cost += state->lambda_sqrt * extra_bits + 0.5;
+      if (pair_cost < cost) {
+        cur_cu->inter.mv_dir = 3;
+        cur_cu->inter.mv_ref[0] = mc[i].ref[0];
+        cur_cu->inter.mv_ref[1] = mc[j].ref[1];
+        memcpy(cur_cu->inter.mv, mv, sizeof(mv));
+        cur_cu->merged = 0;
+        for (int m = 0; m < n_merge; ++m)
+          if (mc[m].mv[0][0] == mv[0][0] && mc[m].mv[0][1] == mv[0][1] && mc[m].mv[1][0] == mv[1][0] && mc[m].mv[1][1] == mv[1][1] &&
+              mc[m].ref[0] == cur_cu->inter.mv_ref[0] && mc[m].ref[1] == cur_cu->inter.mv_ref[1]) {
+            cur_cu->merged = 1;
+            cur_cu->merge_idx = m;
+            break;
+          }
+        for (int reflist = 0; reflist < 2; reflist++) {   /* each vector has its own candidate; mv_cand stays the last list's (:1424-1433) */
+          kvz_inter_get_mv_cand(state, x, y, width, height, mv_cand, cur_cu, lcu, reflist);
+          CU_SET_MV_CAND(cur_cu, reflist, refme_select_mv_cand(state, mv_cand, cur_cu->inter.mv[reflist][0], cur_cu->inter.mv[reflist][1]));
+        }
+        cost = pair_cost;
+        bitcost = bits[0] + bits[1] + extra_bits;
+      }
     }
   }
   if (bad) {

@@ -182,3 +182,22 @@ unsigned ref_bipred_luma_satd(const kvz_pixel *pic_y, const kvz_pixel *ref0_y, c
   free(lcu);
   return cost;
 }
+
+/* The reference's file-local helpers of the bi-prediction search (search_pu_inter_bipred, search_inter.c:1304-1440), for the
+ * harness code that serves that search from the GPU entry inside a live encode (oracle/ref_harness.c: gpu_serve_pu): the
+ * MV bit cost, the AMVP choice and the MV constraint test are the reference's own. */
+uint32_t refme_calc_mvd_cost(const encoder_state_t *state, int x, int y, int mv_shift, int16_t mv_cand[2][2], uint32_t *bitcost)
+{
+  return calc_mvd_cost(state, x, y, mv_shift, mv_cand, NULL, 0, 0, bitcost);
+}
+
+int refme_select_mv_cand(const encoder_state_t *state, int16_t mv_cand[2][2], int32_t mv_x, int32_t mv_y)
+{
+  return select_mv_cand(state, mv_cand, mv_x, mv_y, NULL);
+}
+
+int refme_fracmv_within_tile(const encoder_state_t *state, int origin_x, int origin_y, int width, int height, int mv_x, int mv_y)
+{
+  inter_search_info_t info = { .state = (encoder_state_t *)state, .origin = { origin_x, origin_y }, .width = width, .height = height };
+  return fracmv_within_tile(&info, mv_x, mv_y);
+}

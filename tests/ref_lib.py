@@ -620,16 +620,17 @@ def encode_with_gpu_search(frames, w, h, opts, lib_path, strategy=None):
     """ref_encode with the harness serving the encoder's 2Nx2N inter searches (kvz_hip_inter_candidates_batch +
     kvz_hip_search_pu_batch; oracle/ref_harness.c: gpu_search_serve) and its rough intra searches
     (kvz_hip_intra_build_reference_batch + kvz_hip_intra_rough_batch; gpu_intra_serve) through the GPU chain.
-    -> (bitstream, dict(inter_served, inter_passed_on, failed, launch_pairs, intra_served, intra_passed_on))"""
+    -> (bitstream, dict(inter_served, inter_passed_on, failed, launch_pairs, intra_served, intra_passed_on, bipred_pairs))"""
     L = lib()
     L.ref_gpu_search_begin.restype = C.c_int
     L.ref_gpu_search_begin.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.ref_gpu_search_end.restype = None
     L.ref_gpu_search_end.argtypes = [C.POINTER(C.c_long)]
     assert L.ref_gpu_search_begin(lib_path.encode(), w, h) == 0
-    out = (C.c_long * 6)()
+    out = (C.c_long * 7)()
     try:
         bitstream, _ = encode(frames, w, h, opts, strategy)
     finally:
         L.ref_gpu_search_end(out)
-    return bitstream, dict(zip(("inter_served", "inter_passed_on", "failed", "launch_pairs", "intra_served", "intra_passed_on"), (int(v) for v in out)))
+    return bitstream, dict(zip(("inter_served", "inter_passed_on", "failed", "launch_pairs", "intra_served", "intra_passed_on", "bipred_pairs"),
+                               (int(v) for v in out)))

@@ -379,6 +379,9 @@ GPU_SEARCH_CONFIGS = [
     (192, 128, 10, "preset=medium,qp=30,threads=0"),
     (128, 128, 9, "preset=fast,gop=lp-g4d3t1,qp=34,threads=0,rdoq=0"),                               # low-delay P GOP
     (1920, 1080, 4, "preset=medium,qp=32,threads=0"),                                                # BASELINE's 1080p medium, three B pictures
+    # bi-prediction: pairs of merge candidates scored by kvz_hip_bipred_cost_batch (search_pu_inter_bipred)
+    (192, 128, 10, "preset=medium,bipred=1,qp=30,threads=0"),
+    (128, 128, 9, "preset=slow,qp=26,threads=0"),
     # intra pictures only; 4x4 transform skip (its SAD test in get_cost); every mode in the first pass
     (192, 128, 3, "preset=medium,period=1,qp=27,threads=0"),
     (128, 128, 3, "preset=fast,period=1,transform-skip=1,rd=1,qp=24,threads=0"),
@@ -403,8 +406,10 @@ def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, 
     t2 = time.perf_counter()
     # one search per launch and three host round trips each: a correctness path, its time is printed for the record only
     print("%dx%d x %d frames: inter searches served by the GPU chain: %d (%d candidate + search launch pairs), left to the reference: %d; "
-          "intra searches served: %d, left to the reference: %d; whole encode %.2f s untouched, %.2f s served"
-          % (w, h, n, c["inter_served"], c["launch_pairs"], c["inter_passed_on"], c["intra_served"], c["intra_passed_on"], t1 - t0, t2 - t1))
+          "bi-prediction pairs scored: %d; intra searches served: %d, left to the reference: %d; whole encode %.2f s untouched, %.2f s served"
+          % (w, h, n, c["inter_served"], c["launch_pairs"], c["inter_passed_on"], c["bipred_pairs"], c["intra_served"], c["intra_passed_on"],
+             t1 - t0, t2 - t1))
+    assert c["bipred_pairs"] > 100 or "bipred=1" not in opts
     assert c["failed"] == 0 and c["inter_served"] + c["intra_served"] >= 40 * (n - 1) and c["intra_served"] > 0
     assert served_bs == plain, "bitstreams differ (%d vs %d bytes)" % (len(served_bs), len(plain))
 
