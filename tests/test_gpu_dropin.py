@@ -410,6 +410,11 @@ def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, 
           % (w, h, n, c["inter_served"], c["launch_pairs"], c["inter_passed_on"], c["bipred_pairs"], c["intra_served"], c["intra_passed_on"],
              t1 - t0, t2 - t1))
     assert c["bipred_pairs"] > 100 or "bipred=1" not in opts
+    if (w, h) == (1920, 1080) and n >= 4:
+        # for the record beside it: the untouched encoder with its thread pool on this host (BASELINE's "encoder fps 1080p medium")
+        t3 = time.perf_counter()
+        R.encode(frames, w, h, opts.replace("threads=0", "threads=16"))
+        print("%dx%d x %d frames, untouched encoder with threads=16: %.2f s (%.1f frames/s)" % (w, h, n, time.perf_counter() - t3, n / (time.perf_counter() - t3)))
     assert c["failed"] == 0 and c["inter_served"] + c["intra_served"] >= 40 * (n - 1) and c["intra_served"] > 0
     assert served_bs == plain, "bitstreams differ (%d vs %d bytes)" % (len(served_bs), len(plain))
 
