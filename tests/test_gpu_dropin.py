@@ -379,6 +379,7 @@ GPU_SEARCH_CONFIGS = [
     (192, 128, 10, "preset=medium,qp=30,threads=0"),
     (128, 128, 9, "preset=fast,gop=lp-g4d3t1,qp=34,threads=0,rdoq=0"),                               # low-delay P GOP
     (1920, 1080, 4, "preset=medium,qp=32,threads=0"),                                                # BASELINE's 1080p medium, three B pictures
+    (3840, 2160, 2, "preset=medium,ref=1,bipred=0,gop=0,qp=34,threads=0,period=0"),                 # BASELINE's largest picture: one 4K P frame
     # bi-prediction: pairs of merge candidates scored by kvz_hip_bipred_cost_batch (search_pu_inter_bipred)
     (192, 128, 10, "preset=medium,bipred=1,qp=30,threads=0"),
     (128, 128, 9, "preset=slow,qp=26,threads=0"),
