@@ -342,7 +342,7 @@ def synthetic_sequence(w, h, n, seed=5):
     return frames
 
 
-def encode(frames, w, h, opts, strategy=None, cap=1 << 22):
+def encode(frames, w, h, opts, strategy=None, cap=None):
     """Run the reference encoder (kvz_api) over the frames; strategy=None keeps the selector's own choice,
     otherwise every type registered under that name is installed.  Returns (bitstream bytes, n installed)."""
     L = lib()
@@ -350,6 +350,8 @@ def encode(frames, w, h, opts, strategy=None, cap=1 << 22):
     L.ref_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_long,
                              C.POINTER(C.c_int)]
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    if cap is None:
+        cap = max(1 << 22, 2 * w * h * frames.shape[0])          # noise-like test sequences compress badly
     out = np.zeros(cap, dtype=np.uint8)
     inst = C.c_int(0)
     n = L.ref_encode(frames.ctypes.data, w, h, frames.shape[0], opts.encode(), strategy.encode() if strategy else None,
