@@ -372,7 +372,6 @@ GPU_SEARCH_CONFIGS = [
     (168, 104, 4, "preset=veryfast,ref=1,bipred=0,gop=0,qp=33,threads=0,tmvp=0,period=0"),       # ragged LCUs, no temporal candidates
     (128, 64, 6, "preset=slow,ref=1,bipred=0,gop=0,rdoq=0,qp=27,threads=0,smp=1,amp=1,period=0"),   # + every SMP / AMP PU (kvz_search_cu_smp)
     (192, 128, 6, "preset=medium,smp=1,amp=1,qp=31,threads=0"),                                      # SMP / AMP in B slices with four references
-    (1920, 1080, 2, "preset=medium,ref=1,bipred=0,gop=0,qp=32,threads=0,period=0"),                 # one 1080p P frame: ~43 000 searches
     # several reference pictures: every picture searched in turn, the best cost so far as the cost to beat (search_inter.c:1239)
     (192, 128, 7, "preset=medium,ref=3,bipred=0,gop=0,qp=29,threads=0,period=0"),
     # preset medium as it is: B slices in a GOP of 8, four reference pictures in two lists, uni-prediction
