@@ -1301,6 +1301,8 @@ uint32_t refme_calc_mvd_cost(const encoder_state_t *state, int x, int y, int mv_
 int refme_select_mv_cand(const encoder_state_t *state, int16_t mv_cand[2][2], int32_t mv_x, int32_t mv_y);
 int refme_fracmv_within_tile(const encoder_state_t *state, int origin_x, int origin_y, int width, int height, int mv_x, int mv_y);
 
+static void gpu_flush_deblock(const encoder_state_t *state);
+
 /* which searches the two entries can answer */
 static int gpu_can_serve_inter(const encoder_state_t *state)
 {
@@ -1454,6 +1456,7 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
 static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
 {
   if (!g_gpu.on) return 0;
+  gpu_flush_deblock(state);
   if (!gpu_can_serve_inter(state)) { ++g_gpu.passed_on; return 0; }
   const int width = LCU_WIDTH >> depth;
   if (!gpu_serve_pu(state, x, y, width, width, 1, 1, lcu, inter_cost, inter_bitcost)) return 0;   /* the reference's own search takes over */
@@ -1469,6 +1472,7 @@ void __real_kvz_search_cu_smp(encoder_state_t * const state, int x, int y, int d
 void __wrap_kvz_search_cu_smp(encoder_state_t * const state, int x, int y, int depth, part_mode_t part_mode, lcu_t *lcu,
                               double *inter_cost, uint32_t *inter_bitcost)
 {
+  if (g_gpu.on) gpu_flush_deblock(state);
   if (!g_gpu.on || !gpu_can_serve_inter(state)) {
     if (g_gpu.on) ++g_gpu.passed_on;
     __real_kvz_search_cu_smp(state, x, y, depth, part_mode, lcu, inter_cost, inter_bitcost);
@@ -1547,6 +1551,7 @@ void __real_kvz_search_cu_intra(encoder_state_t * const state, const int x_px, c
 static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth, lcu_t *lcu, int8_t *mode_out, double *cost_out)
 {
   if (!g_gpu.on) return 0;
+  gpu_flush_deblock(state);
   const encoder_control_t *ctrl = state->encoder_control;
   const kvz_config *cfg = &ctrl->cfg;
   if (depth == 0 || cfg->rdo >= 2 || state->tile->frame->width != g_gpu.w || state->tile->frame->height != g_gpu.h) {
@@ -1698,4 +1703,107 @@ void __wrap_kvz_search_cu_intra(encoder_state_t * const state, const int x_px, c
     return;
   }
   __real_kvz_search_cu_intra(state, x_px, y_px, depth, lcu, mode_out, cost_out);
+}
+
+
+/* ------------------------------------------------------------------------
+ * The deblocking filter of a whole picture in one call (tests only; -Wl,--wrap=kvz_filter_deblock_lcu).  With
+ * ref_gpu_serve_deblock(1) the per-LCU calls of the encoder (encoderstate.c:635-637) do nothing but remember the
+ * picture; when the encoder first touches the NEXT picture, the remembered one -- complete, unfiltered, with its final CU
+ * array -- is filtered by kvz_hip_deblock_frame in place.  Nothing reads a picture's filtered pixels before that when SAO is
+ * off (the intra borders are the unfiltered copies of hor_buf / ver_buf), so the encode must produce the untouched
+ * encoder's bitstream: every later picture predicts from the pixels the GPU filtered.
+ * ------------------------------------------------------------------------ */
+void __real_kvz_filter_deblock_lcu(encoder_state_t * const state, int x_px, int y_px);
+
+static struct {
+  int on;
+  int (*deblock)(kvz_hip_pixel *, uint32_t, kvz_hip_pixel *, kvz_hip_pixel *, uint32_t, int, int, const kvz_hip_cu_info *,
+                 const kvz_hip_deblock_params *, kvz_hip_stream);
+  kvz_picture *pic;                            /* the picture waiting to be filtered (a reference is held) */
+  cu_array_t *cua;
+  kvz_hip_deblock_params prm;
+  long frames, lcus_skipped;
+} g_dbk;
+
+int ref_gpu_serve_deblock(int on)
+{
+  memset(&g_dbk, 0, sizeof(g_dbk));
+  if (!on) return 0;
+  if (!g_gpu.on) return -1;
+  *(void **)&g_dbk.deblock = dlsym(g_gpu.lib, "kvz_hip_deblock_frame");
+  if (!g_dbk.deblock) return -1;
+  g_dbk.on = 1;
+  return 0;
+}
+
+/* out[0..1] = pictures filtered by kvz_hip_deblock_frame, per-LCU filter calls of the encoder that were skipped for them */
+void ref_gpu_serve_deblock_end(long *out)
+{
+  if (g_dbk.on) gpu_flush_deblock(NULL);
+  if (out) { out[0] = g_dbk.frames; out[1] = g_dbk.lcus_skipped; }
+  memset(&g_dbk, 0, sizeof(g_dbk));
+}
+
+static void gpu_flush_deblock(const encoder_state_t *state)
+{
+  if (!g_dbk.on || !g_dbk.pic) return;
+  if (state && state->tile->frame->rec == g_dbk.pic) return;          /* still the picture being coded */
+  kvz_picture *pic = g_dbk.pic;
+  cu_array_t *cua = g_dbk.cua;
+  const int w = pic->width, h = pic->height, sy = pic->stride, sc = pic->stride / 2;
+  const int has_chroma = g_dbk.prm.chroma;
+  const int cstride = (w + 3) / 4, crows = (h + 3) / 4;
+  kvz_hip_cu_info *map = calloc((size_t)cstride * crows, sizeof(*map));
+  for (int y = 0; y < crows; ++y)
+    for (int x = 0; x < cstride; ++x) {
+      const cu_info_t *cu = kvz_cu_array_at_const(cua, x * 4, y * 4);
+      kvz_hip_cu_info *o = &map[y * cstride + x];
+      cu_to_hip(cu, o);
+      o->cbf_y = cbf_is_set(cu->cbf, cu->tr_depth, COLOR_Y);
+    }
+  uint8_t *d_y = g_gpu.dmalloc((size_t)sy * h), *d_u = NULL, *d_v = NULL;
+  kvz_hip_cu_info *d_map = g_gpu.dmalloc((size_t)cstride * crows * sizeof(*map));
+  int bad = !d_y || !d_map;
+  if (has_chroma) { d_u = g_gpu.dmalloc((size_t)sc * (h / 2)); d_v = g_gpu.dmalloc((size_t)sc * (h / 2)); bad |= !d_u || !d_v; }
+  if (!bad) {
+    bad |= g_gpu.h2d(d_y, pic->y, (size_t)sy * h, NULL);
+    if (has_chroma) { bad |= g_gpu.h2d(d_u, pic->u, (size_t)sc * (h / 2), NULL); bad |= g_gpu.h2d(d_v, pic->v, (size_t)sc * (h / 2), NULL); }
+    bad |= g_gpu.h2d(d_map, map, (size_t)cstride * crows * sizeof(*map), NULL);
+    bad |= g_dbk.deblock(d_y, (uint32_t)sy, d_u, d_v, (uint32_t)sc, w, h, d_map, &g_dbk.prm, NULL);
+    bad |= g_gpu.d2h(pic->y, d_y, (size_t)sy * h, NULL);
+    if (has_chroma) { bad |= g_gpu.d2h(pic->u, d_u, (size_t)sc * (h / 2), NULL); bad |= g_gpu.d2h(pic->v, d_v, (size_t)sc * (h / 2), NULL); }
+  }
+  if (bad) { fprintf(stderr, "gpu_flush_deblock: %s\n", g_gpu.last_error()); ++g_gpu.failed; }
+  else ++g_dbk.frames;
+  g_gpu.dfree(d_y); g_gpu.dfree(d_u); g_gpu.dfree(d_v); g_gpu.dfree(d_map);
+  free(map);
+  kvz_image_free(pic);
+  kvz_cu_array_free(&cua);
+  g_dbk.pic = NULL; g_dbk.cua = NULL;
+}
+
+void __wrap_kvz_filter_deblock_lcu(encoder_state_t * const state, int x_px, int y_px)
+{
+  const encoder_control_t *ctrl = state->encoder_control;
+  if (!g_dbk.on || ctrl->cfg.sao_type || ctrl->cfg.lossless || state->tile->offset_x || state->tile->offset_y ||
+      state->tile->frame->width != state->tile->frame->rec->width) {
+    __real_kvz_filter_deblock_lcu(state, x_px, y_px);
+    return;
+  }
+  kvz_picture *rec = state->tile->frame->rec;
+  if (g_dbk.pic != rec) {
+    gpu_flush_deblock(state);                            /* an earlier picture nobody searched after */
+    g_dbk.pic = kvz_image_copy_ref(rec);
+    g_dbk.cua = kvz_cu_array_copy_ref(state->tile->frame->cu_array);
+    kvz_hip_deblock_params *p = &g_dbk.prm;
+    memset(p, 0, sizeof(*p));
+    p->beta_offset_div2 = ctrl->cfg.deblock_beta; p->tc_offset_div2 = ctrl->cfg.deblock_tc;
+    p->qp = state->qp; p->frame_qp = state->frame->QP;
+    p->per_cu_qp = ctrl->max_qp_delta_depth >= 0;
+    p->slice_is_b = state->frame->slicetype == KVZ_SLICE_B;
+    p->chroma = ctrl->chroma_format != KVZ_CSP_400;
+    memcpy(p->ref_LX, state->frame->ref_LX, sizeof(p->ref_LX));
+  }
+  ++g_dbk.lcus_skipped;
 }

@@ -618,21 +618,32 @@ def inter_candidates(params, cus, col_cus, ref_cus, pus):
     return pus, out
 
 
-def encode_with_gpu_search(frames, w, h, opts, lib_path, strategy=None):
+def encode_with_gpu_search(frames, w, h, opts, lib_path, strategy=None, deblock=False):
     """ref_encode with the harness serving the encoder's 2Nx2N inter searches (kvz_hip_inter_candidates_batch +
     kvz_hip_search_pu_batch; oracle/ref_harness.c: gpu_search_serve) and its rough intra searches
     (kvz_hip_intra_build_reference_batch + kvz_hip_intra_rough_batch; gpu_intra_serve) through the GPU chain.
-    -> (bitstream, dict(inter_served, inter_passed_on, failed, launch_pairs, intra_served, intra_passed_on, bipred_pairs))"""
+    deblock=True: the per-LCU deblocking calls are skipped as well and every picture is filtered by one kvz_hip_deblock_frame call
+    before the next picture is searched (gpu_flush_deblock; SAO must be off).
+    -> (bitstream, dict(inter_served, inter_passed_on, failed, launch_pairs, intra_served, intra_passed_on, bipred_pairs,
+    deblocked_pictures, deblock_lcu_calls_skipped))"""
     L = lib()
     L.ref_gpu_search_begin.restype = C.c_int
     L.ref_gpu_search_begin.argtypes = [C.c_char_p, C.c_int, C.c_int]
     L.ref_gpu_search_end.restype = None
     L.ref_gpu_search_end.argtypes = [C.POINTER(C.c_long)]
+    L.ref_gpu_serve_deblock.restype = C.c_int
+    L.ref_gpu_serve_deblock.argtypes = [C.c_int]
+    L.ref_gpu_serve_deblock_end.restype = None
+    L.ref_gpu_serve_deblock_end.argtypes = [C.POINTER(C.c_long)]
     assert L.ref_gpu_search_begin(lib_path.encode(), w, h) == 0
-    out = (C.c_long * 7)()
+    assert L.ref_gpu_serve_deblock(1 if deblock else 0) == 0
+    out, dbk = (C.c_long * 7)(), (C.c_long * 2)()
     try:
         bitstream, _ = encode(frames, w, h, opts, strategy)
     finally:
+        L.ref_gpu_serve_deblock_end(dbk)               # filters a last pending picture: before the device buffers go
         L.ref_gpu_search_end(out)
-    return bitstream, dict(zip(("inter_served", "inter_passed_on", "failed", "launch_pairs", "intra_served", "intra_passed_on", "bipred_pairs"),
-                               (int(v) for v in out)))
+    c = dict(zip(("inter_served", "inter_passed_on", "failed", "launch_pairs", "intra_served", "intra_passed_on", "bipred_pairs"),
+                 (int(v) for v in out)))
+    c["deblocked_pictures"], c["deblock_lcu_calls_skipped"] = int(dbk[0]), int(dbk[1])
+    return bitstream, c

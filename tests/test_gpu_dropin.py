@@ -429,3 +429,21 @@ def test_reference_encoder_with_searches_served_and_hip_strategies_installed(hip
     both, c = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"), strategy="hip")
     assert c["failed"] == 0 and c["inter_served"] > 500 and c["intra_served"] > 500
     assert both == gen, "bitstreams differ (%d vs %d bytes)" % (len(both), len(gen))
+
+
+@pytest.mark.parametrize("w,h,n,opts", [
+    (192, 128, 6, "preset=medium,sao=off,deblock=1,qp=34,threads=0"),                                   # B slices, four references
+    (168, 104, 5, "preset=fast,ref=2,bipred=0,gop=0,sao=off,deblock=-2:3,qp=38,threads=0,period=0"),     # ragged LCUs, filter offsets
+    (1920, 1080, 3, "preset=ultrafast,ref=1,gop=0,sao=off,deblock=1,qp=36,threads=0,period=0"),
+])
+def test_reference_encoder_with_pictures_deblocked_by_one_gpu_call(hip, w, h, n, opts):
+    """the in-loop filter as a whole-picture entry inside a live encode: the encoder's per-LCU kvz_filter_deblock_lcu calls are
+    skipped and each picture is filtered by ONE kvz_hip_deblock_frame call (from the encoder's own CU array: TU / PU edges, cbf,
+    QPs, vectors) before the next picture is searched; every later picture predicts from those pixels.  Searches served as well."""
+    frames = R.synthetic_sequence(w, h, n, seed=13)
+    plain, _ = R.encode(frames, w, h, opts)
+    served_bs, c = R.encode_with_gpu_search(frames, w, h, opts, os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so"), deblock=True)
+    print("%dx%d x %d frames: %d pictures deblocked by one GPU call each (%d per-LCU calls skipped), inter / intra searches served: %d / %d"
+          % (w, h, n, c["deblocked_pictures"], c["deblock_lcu_calls_skipped"], c["inter_served"], c["intra_served"]))
+    assert c["failed"] == 0 and c["deblocked_pictures"] == n and c["deblock_lcu_calls_skipped"] == n * ((w + 63) // 64) * ((h + 63) // 64)
+    assert served_bs == plain, "bitstreams differ (%d vs %d bytes)" % (len(served_bs), len(plain))
