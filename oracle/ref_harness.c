@@ -1807,3 +1807,18 @@ void __wrap_kvz_filter_deblock_lcu(encoder_state_t * const state, int x_px, int 
   }
   ++g_dbk.lcus_skipped;
 }
+
+/* the decoded picture hash SEI (encoder_state-bitstream.c:905-930) is taken from the finished picture: a pending filter
+ * pass has to run before it (with --hash=none the pass waits for the next picture's first search) */
+void __real_kvz_image_checksum(const kvz_picture *im, unsigned char checksum_out[][SEI_HASH_MAX_LENGTH], const uint8_t bitdepth);
+void __real_kvz_image_md5(const kvz_picture *im, unsigned char checksum_out[][SEI_HASH_MAX_LENGTH], const uint8_t bitdepth);
+void __wrap_kvz_image_checksum(const kvz_picture *im, unsigned char checksum_out[][SEI_HASH_MAX_LENGTH], const uint8_t bitdepth)
+{
+  if (g_dbk.on && g_dbk.pic == im) gpu_flush_deblock(NULL);
+  __real_kvz_image_checksum(im, checksum_out, bitdepth);
+}
+void __wrap_kvz_image_md5(const kvz_picture *im, unsigned char checksum_out[][SEI_HASH_MAX_LENGTH], const uint8_t bitdepth)
+{
+  if (g_dbk.on && g_dbk.pic == im) gpu_flush_deblock(NULL);
+  __real_kvz_image_md5(im, checksum_out, bitdepth);
+}
