@@ -1814,11 +1814,11 @@ void __real_kvz_image_checksum(const kvz_picture *im, unsigned char checksum_out
 void __real_kvz_image_md5(const kvz_picture *im, unsigned char checksum_out[][SEI_HASH_MAX_LENGTH], const uint8_t bitdepth);
 void __wrap_kvz_image_checksum(const kvz_picture *im, unsigned char checksum_out[][SEI_HASH_MAX_LENGTH], const uint8_t bitdepth)
 {
-  if (g_dbk.on && g_dbk.pic == im) gpu_flush_deblock(NULL);
+  if (g_dbk.on && g_dbk.pic && g_dbk.pic->y == im->y) gpu_flush_deblock(NULL);      /* the tile's picture is a view of the frame's */
   __real_kvz_image_checksum(im, checksum_out, bitdepth);
 }
 void __wrap_kvz_image_md5(const kvz_picture *im, unsigned char checksum_out[][SEI_HASH_MAX_LENGTH], const uint8_t bitdepth)
 {
-  if (g_dbk.on && g_dbk.pic == im) gpu_flush_deblock(NULL);
+  if (g_dbk.on && g_dbk.pic && g_dbk.pic->y == im->y) gpu_flush_deblock(NULL);
   __real_kvz_image_md5(im, checksum_out, bitdepth);
 }
