@@ -1149,7 +1149,7 @@ static struct {
   kvz_hip_merge_cand *d_merge;
   kvz_hip_bipred_cand *d_bcand;
   uint32_t *d_bcost;
-  long bipred_pairs;
+  long bipred_pairs, bipred_launches;
   uint8_t *d_pic, *d_ref[GPU_MAX_REFS], *h_plane;
   kvz_hip_cu_info *d_cus, *d_refcus[GPU_MAX_REFS], *h_cus, *h_col;
   kvz_hip_me_pu *d_pu;
@@ -1196,8 +1196,8 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   g_gpu.d_cus = g_gpu.dmalloc(map_bytes);
   g_gpu.d_pu = g_gpu.dmalloc(sizeof(kvz_hip_me_pu)); g_gpu.d_res = g_gpu.dmalloc(sizeof(kvz_hip_me_result));
   g_gpu.d_beat = g_gpu.dmalloc(sizeof(uint32_t));
-  g_gpu.d_merge = g_gpu.dmalloc(5 * sizeof(kvz_hip_merge_cand)); g_gpu.d_bcand = g_gpu.dmalloc(sizeof(kvz_hip_bipred_cand));
-  g_gpu.d_bcost = g_gpu.dmalloc(sizeof(uint32_t));
+  g_gpu.d_merge = g_gpu.dmalloc(5 * sizeof(kvz_hip_merge_cand)); g_gpu.d_bcand = g_gpu.dmalloc(12 * sizeof(kvz_hip_bipred_cand));
+  g_gpu.d_bcost = g_gpu.dmalloc(12 * sizeof(uint32_t));
   g_gpu.h_plane = malloc((size_t)w * h);
   g_gpu.h_cus = calloc(1, map_bytes); g_gpu.h_col = calloc(1, map_bytes);
   g_gpu.d_vplane = g_gpu.dmalloc(VPLANE_W * VPLANE_H); g_gpu.h_vplane = calloc(1, VPLANE_W * VPLANE_H);
@@ -1211,12 +1211,12 @@ int ref_gpu_search_begin(const char *lib_path, int w, int h)
   return 0;
 }
 
-/* out[0..6] (out[6] = bi-prediction candidate pairs scored by kvz_hip_bipred_cost_batch); out[0..5] = inter searches served by the GPU chain, inter searches passed on to the reference, GPU calls that failed,
+/* out[0..7] (out[6] = bi-prediction candidate pairs scored by kvz_hip_bipred_cost_batch, out[7] = in that many calls); out[0..5] = inter searches served by the GPU chain, inter searches passed on to the reference, GPU calls that failed,
  * (candidates + search) launch pairs issued (one per reference picture of a served search), intra searches served, passed on */
 void ref_gpu_search_end(long *out)
 {
   if (out) { out[0] = g_gpu.served; out[1] = g_gpu.passed_on; out[2] = g_gpu.failed; out[3] = g_gpu.launches;
-             out[4] = g_gpu.intra_served; out[5] = g_gpu.intra_passed_on; out[6] = g_gpu.bipred_pairs; }
+             out[4] = g_gpu.intra_served; out[5] = g_gpu.intra_passed_on; out[6] = g_gpu.bipred_pairs; out[7] = g_gpu.bipred_launches; }
   if (g_gpu.lib) {
     g_gpu.dfree(g_gpu.d_merge); g_gpu.dfree(g_gpu.d_bcand); g_gpu.dfree(g_gpu.d_bcost);
     g_gpu.dfree(g_gpu.d_vplane); g_gpu.dfree(g_gpu.d_orig); g_gpu.dfree(g_gpu.d_pos); g_gpu.dfree(g_gpu.d_iref); g_gpu.dfree(g_gpu.d_icost);
@@ -1396,25 +1396,49 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
     static const uint8_t first[12] = { 0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3 }, second[12] = { 1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2 };
     const int n_merge = last.num_merge_cand;
     const unsigned pairs = MIN(n_merge * (n_merge - 1), 12);
-    for (unsigned idx = 0; idx < pairs && !bad; ++idx) {
+    /* which pairs the loop of :1326-1350 scores, and their pictures */
+    int valid[12], pic0[12], pic1[12];
+    uint32_t satd[12];
+    kvz_hip_bipred_cand bc[12];
+    unsigned stop = pairs;
+    for (unsigned idx = 0; idx < pairs; ++idx) {
       const int i = first[idx], j = second[idx];
-      if (i >= n_merge || j >= n_merge) break;
+      valid[idx] = 0;
+      if (i >= n_merge || j >= n_merge) { stop = idx; break; }
       if (!(mc[i].dir & 1) || !(mc[j].dir & 2)) continue;
       if (fr->ref_LX[0][mc[i].ref[0]] == fr->ref_LX[1][mc[j].ref[1]] && mc[i].mv[0][0] == mc[j].mv[1][0] && mc[i].mv[0][1] == mc[j].mv[1][1]) continue;
+      if (!refme_fracmv_within_tile(state, x, y, width, height, mc[i].mv[0][0], mc[i].mv[0][1]) ||
+          !refme_fracmv_within_tile(state, x, y, width, height, mc[j].mv[1][0], mc[j].mv[1][1])) continue;
+      valid[idx] = 1;
+      pic0[idx] = fr->ref_LX[0][mc[i].ref[0]]; pic1[idx] = fr->ref_LX[1][mc[j].ref[1]];
+      memset(&bc[idx], 0, sizeof(bc[idx]));
+      bc[idx].x = x; bc[idx].y = y; bc[idx].width = width; bc[idx].height = height;
+      bc[idx].mv0[0] = mc[i].mv[0][0]; bc[idx].mv0[1] = mc[i].mv[0][1]; bc[idx].mv1[0] = mc[j].mv[1][0]; bc[idx].mv1[1] = mc[j].mv[1][1];
+    }
+    /* the blended predictions' SATDs do not depend on one another: every pair that shares its two pictures goes into ONE
+     * kvz_hip_bipred_cost_batch call */
+    int done[12] = { 0 };
+    for (unsigned a = 0; a < stop && !bad; ++a) {
+      if (!valid[a] || done[a]) continue;
+      kvz_hip_bipred_cand group[12];
+      unsigned member[12], n = 0;
+      for (unsigned b = a; b < stop; ++b)
+        if (valid[b] && !done[b] && pic0[b] == pic0[a] && pic1[b] == pic1[a]) { group[n] = bc[b]; member[n++] = b; done[b] = 1; }
+      uint32_t out[12];
+      bad |= g_gpu.h2d(g_gpu.d_bcand, group, n * sizeof(group[0]), NULL);
+      bad |= g_gpu.bipred(g_gpu.d_pic, (uint32_t)w, w, h, g_gpu.d_ref[pic0[a]], (uint32_t)w, g_gpu.d_ref[pic1[a]], (uint32_t)w, w, h,
+                          g_gpu.d_bcand, n, g_gpu.d_bcost, NULL);
+      bad |= g_gpu.d2h(out, g_gpu.d_bcost, n * sizeof(out[0]), NULL);
+      ++g_gpu.bipred_launches;
+      g_gpu.bipred_pairs += n;
+      for (unsigned k = 0; k < n; ++k) { satd[member[k]] = out[k]; if (out[k] == 0xffffffffu) bad = 1; }
+    }
+    /* the decisions in the reference's order: a winning pair changes info->mv_cand and with it the bit costs of the pairs after it */
+    for (unsigned idx = 0; idx < stop && !bad; ++idx) {
+      if (!valid[idx]) continue;
+      const int i = first[idx], j = second[idx];
       int16_t mv[2][2] = { { mc[i].mv[0][0], mc[i].mv[0][1] }, { mc[j].mv[1][0], mc[j].mv[1][1] } };
-      if (!refme_fracmv_within_tile(state, x, y, width, height, mv[0][0], mv[0][1]) ||
-          !refme_fracmv_within_tile(state, x, y, width, height, mv[1][0], mv[1][1])) continue;
-      kvz_hip_bipred_cand bc;
-      memset(&bc, 0, sizeof(bc));
-      bc.x = x; bc.y = y; bc.width = width; bc.height = height;
-      bc.mv0[0] = mv[0][0]; bc.mv0[1] = mv[0][1]; bc.mv1[0] = mv[1][0]; bc.mv1[1] = mv[1][1];
-      uint32_t pair_cost = 0;
-      bad |= g_gpu.h2d(g_gpu.d_bcand, &bc, sizeof(bc), NULL);
-      bad |= g_gpu.bipred(g_gpu.d_pic, (uint32_t)w, w, h, g_gpu.d_ref[fr->ref_LX[0][mc[i].ref[0]]], (uint32_t)w,
-                          g_gpu.d_ref[fr->ref_LX[1][mc[j].ref[1]]], (uint32_t)w, w, h, g_gpu.d_bcand, 1, g_gpu.d_bcost, NULL);
-      bad |= g_gpu.d2h(&pair_cost, g_gpu.d_bcost, sizeof(pair_cost), NULL);
-      ++g_gpu.bipred_pairs;
-      if (bad || pair_cost == 0xffffffffu) { bad = 1; break; }
+      uint32_t pair_cost = satd[idx];
       uint32_t bits[2] = { 0, 0 };
       pair_cost += refme_calc_mvd_cost(state, mc[i].mv[0][0], mc[i].mv[0][1], 0, mv_cand, &bits[0]);
       pair_cost += refme_calc_mvd_cost(state, mc[i].mv[1][0], mc[i].mv[1][1], 0, mv_cand, &bits[1]);     /* [i], as :1379-1386 has it */

@@ -637,13 +637,13 @@ def encode_with_gpu_search(frames, w, h, opts, lib_path, strategy=None, deblock=
     L.ref_gpu_serve_deblock_end.argtypes = [C.POINTER(C.c_long)]
     assert L.ref_gpu_search_begin(lib_path.encode(), w, h) == 0
     assert L.ref_gpu_serve_deblock(1 if deblock else 0) == 0
-    out, dbk = (C.c_long * 7)(), (C.c_long * 2)()
+    out, dbk = (C.c_long * 8)(), (C.c_long * 2)()
     try:
         bitstream, _ = encode(frames, w, h, opts, strategy)
     finally:
         L.ref_gpu_serve_deblock_end(dbk)               # filters a last pending picture: before the device buffers go
         L.ref_gpu_search_end(out)
-    c = dict(zip(("inter_served", "inter_passed_on", "failed", "launch_pairs", "intra_served", "intra_passed_on", "bipred_pairs"),
-                 (int(v) for v in out)))
+    c = dict(zip(("inter_served", "inter_passed_on", "failed", "launch_pairs", "intra_served", "intra_passed_on", "bipred_pairs",
+                  "bipred_launches"), (int(v) for v in out)))
     c["deblocked_pictures"], c["deblock_lcu_calls_skipped"] = int(dbk[0]), int(dbk[1])
     return bitstream, c

@@ -406,8 +406,8 @@ def test_reference_encoder_with_its_searches_served_by_the_gpu_chain(hip, w, h, 
     t2 = time.perf_counter()
     # one search per launch and three host round trips each: a correctness path, its time is printed for the record only
     print("%dx%d x %d frames: inter searches served by the GPU chain: %d (%d candidate + search launch pairs), left to the reference: %d; "
-          "bi-prediction pairs scored: %d; intra searches served: %d, left to the reference: %d; whole encode %.2f s untouched, %.2f s served"
-          % (w, h, n, c["inter_served"], c["launch_pairs"], c["inter_passed_on"], c["bipred_pairs"], c["intra_served"], c["intra_passed_on"],
+          "bi-prediction pairs scored: %d in %d calls; intra searches served: %d, left to the reference: %d; whole encode %.2f s untouched, %.2f s served"
+          % (w, h, n, c["inter_served"], c["launch_pairs"], c["inter_passed_on"], c["bipred_pairs"], c["bipred_launches"], c["intra_served"], c["intra_passed_on"],
              t1 - t0, t2 - t1))
     assert c["bipred_pairs"] > 100 or "bipred=1" not in opts
     if (w, h) == (1920, 1080) and n >= 4:
