@@ -518,7 +518,7 @@ typedef struct { int32_t x, y; } kvz_hip_intra_pos;
  * of that plane) of the reconstruction BEFORE deblocking -- what lcu->rec,
  * lcu->top_ref and lcu->left_ref are views of (init_lcu_t,
  * search.c:761-835).  pic_width / pic_height are pic_px, the luma size of
- * the (tile) picture.  Which neighbours count as coded follows from the PU's
+ * the (tile) picture (multiples of 8, as the encoder pads them).  Which neighbours count as coded follows from the PU's
  * place in the coding order of its LCU exactly as num_ref_pixels_top / _left
  * (intra.c:35-70) say, so pixels of CUs that come later are never read and may
  * hold anything.  Entries 0..2N of both arrays are the reference's, the rest
