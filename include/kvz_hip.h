@@ -89,7 +89,8 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * "intra_rough_waves" (4/8 waves per workgroup of the rough search), "pair_wave_kernel" (0/1: one wave per
  * descriptor for frame-level pair batches of up to 4096 descriptors), "wg_chunk_min_wgs" (the workgroup-per-descriptor
  * kernels of the sampling / fractional search entries take up to 64 descriptors per workgroup once the list would give
- * more workgroups than this; 0: always one).
+ * more workgroups than this; 0: always one), "pair_satd_threads" (128 / 256 / 512 threads per workgroup of the
+ * descriptor SATD kernel).
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
  * knobs at kvz_hip_init() for A/B runs of an unmodified host. */
 KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);
