@@ -147,6 +147,34 @@ def test_image_calc_sad_and_satd_edges(api):
         assert b == O.image_calc("satd", pic, ref, *p), p
 
 
+@pytest.mark.parametrize("threads", [128, 256, 512])
+def test_image_calc_satd_chunks_of_8x8_pairs(api, threads):
+    """the grid-stride descriptor kernel takes 64 descriptors per workgroup: chunks of nothing but 8x8 pairs are scored one pair
+    per lane (also across the frame's edges), a single other size in a chunk sends the whole chunk down the general split, the
+    last chunk is ragged -- for each workgroup size of the tuning knob"""
+    from kvazaar_amd import _lib
+    L = _lib.init(0)
+    g = rng(81)
+    pic = g.integers(0, 256, (96, 160), dtype=np.uint8)
+    ref = g.integers(0, 256, (96, 160), dtype=np.uint8)
+    pairs = []
+    for i in range(4096 + 64 * 9 + 37):                           # beyond the one-wave-per-descriptor limit; ragged tail
+        w, h = 8, 8
+        if 640 <= i < 704 and i % 7 == 0:
+            w, h = ((16, 16), (8, 16), (4, 4), (64, 64))[i % 4]    # one chunk with strangers in it
+        if 1024 <= i < 1088:
+            w, h = 16, 8                                          # one chunk without a single 8x8 pair
+        x1, y1 = int(g.integers(0, 160 - w + 1)), int(g.integers(0, 96 - h + 1))
+        dx, dy = (int(g.integers(-200, 200)), int(g.integers(-120, 120))) if i % 5 == 0 else (int(g.integers(-6, 7)), int(g.integers(-6, 7)))
+        pairs.append((x1, y1, x1 + dx, y1 + dy, w, h))
+    want = [O.image_calc("satd", pic, ref, *p) for p in pairs]
+    assert L.kvz_hip_set_tuning(b"pair_satd_threads", threads) == 0
+    try:
+        np.testing.assert_array_equal(api.image_calc_satd_batch(pic, ref, pairs), want)
+    finally:
+        L.kvz_hip_set_tuning(b"pair_satd_threads", -1)
+
+
 def test_pixels_calc_ssd(api):
     g = rng(6)
     a = g.integers(0, 256, (70, 70), dtype=np.uint8)
