@@ -435,23 +435,25 @@ __device__ __forceinline__ int intra_coded_above(int ux, int uy)
   return n < 64 ? n : 64;
 }
 
-// One wave per PU.  Lane l owns left[1 + l] and top[1 + l] (2N <= 64), lane 0 also the corner; entries past
-// 2N are written as zero so a record is a function of its inputs alone.  A position outside the picture, or
+// L = max(2N, 16) lanes per PU, 64 / L PUs per wave (a wave per PU spent 25 us on the 129 600 4x4 PUs of a frame: 129 600
+// waves for 18 useful bytes each).  Lane l < 2N of a PU's group owns left[1 + l] and top[1 + l], lane 0 also the corner;
+// entries past 2N are written as zero so a record is a function of its inputs alone.  A position outside the picture, or
 // off the 4-pixel grid, gives an all-zero record and reads nothing.
+template <int LOG2>
 __global__ __launch_bounds__(256) void intra_build_reference_kernel(const u8 *__restrict__ rec, int stride, int pic_w, int pic_h,
-                                                                    const kvz_hip_intra_pos *__restrict__ pus, size_t count, int log2_width,
+                                                                    const kvz_hip_intra_pos *__restrict__ pus, size_t count,
                                                                     int chroma, kvz_hip_intra_ref *__restrict__ refs)
 {
-  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int n2 = 2 << LOG2, L = n2 < 16 ? 16 : n2, PER_WAVE = 64 / L;
+  const int lane = threadIdx.x & 63, l = lane & (L - 1);
+  const size_t i = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PER_WAVE + lane / L;
   if (i >= count) return;
-  const int l = threadIdx.x & 63;
-  const int n2 = 2 << log2_width;
   const int lx = pus[i].x, ly = pus[i].y;
   u8 *out = reinterpret_cast<u8 *>(refs + i);
-  const int span = (1 << log2_width) << chroma;
+  const int span = (1 << LOG2) << chroma;
   const bool ok = lx >= 0 && ly >= 0 && ((lx | ly) & 3) == 0 && lx + span <= pic_w && ly + span <= pic_h;
   u8 left = 0, top = 0, corner = 0;
-  if (ok) {
+  if (ok && l < n2) {
     const int x = lx >> chroma, y = ly >> chroma;
     const int ux = (lx & 63) >> 2, uy = (ly & 63) >> 2;
     const bool has_left = lx > 0, has_top = ly > 0;
@@ -473,11 +475,13 @@ __global__ __launch_bounds__(256) void intra_build_reference_kernel(const u8 *__
       top = has_left ? rec[(size_t)y * stride + x - 1] : 128;
     }
     // intra.c:414-428 / :504-517; left[1] is the same value in every lane wherever it stands in for the corner
-    corner = (has_left && has_top) ? above[x - 1] : (has_left ? rec[(size_t)y * stride + x - 1] : left);
-    if (l >= n2) left = top = 0;
+    if (l == 0) corner = (has_left && has_top) ? above[x - 1] : (has_left ? rec[(size_t)y * stride + x - 1] : left);
   }
-  out[1 + l] = left;
-  out[65 + 1 + l] = top;
+  // entries 1 .. 64 of both arrays: the group's lanes stride over them (values for e < 2N, zeros behind)
+  for (int e = l; e < 64; e += L) {
+    out[1 + e] = e == l ? left : 0;
+    out[65 + 1 + e] = e == l ? top : 0;
+  }
   if (l == 0) { out[0] = corner; out[65] = corner; }
 }
 
@@ -502,8 +506,14 @@ int kvz_hip_intra_build_reference_batch(int log2_width, int color, const kvz_hip
   if (!rec || !pus || !refs) { set_error_msg("kvz_hip_intra_build_reference_batch: null buffer"); return KVZ_HIP_ERR_INVALID; }
   if (count > (size_t)0x7fffffff * 4) { set_error_msg("kvz_hip_intra_build_reference_batch: count too large"); return KVZ_HIP_ERR_INVALID; }
   hipStream_t st = ctx_stream(stream);
-  hipLaunchKernelGGL(intra_build_reference_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, rec, stride, pic_width, pic_height,
-                     pus, count, log2_width, chroma, refs);
+  const unsigned per_wg = 4u * (64u / (unsigned)((2 << log2_width) < 16 ? 16 : (2 << log2_width)));   // PUs per workgroup of four waves
+  const dim3 grid((unsigned)((count + per_wg - 1) / per_wg)), block(256);
+  switch (log2_width) {
+    case 2: hipLaunchKernelGGL(intra_build_reference_kernel<2>, grid, block, 0, st, rec, stride, pic_width, pic_height, pus, count, chroma, refs); break;
+    case 3: hipLaunchKernelGGL(intra_build_reference_kernel<3>, grid, block, 0, st, rec, stride, pic_width, pic_height, pus, count, chroma, refs); break;
+    case 4: hipLaunchKernelGGL(intra_build_reference_kernel<4>, grid, block, 0, st, rec, stride, pic_width, pic_height, pus, count, chroma, refs); break;
+    default: hipLaunchKernelGGL(intra_build_reference_kernel<5>, grid, block, 0, st, rec, stride, pic_width, pic_height, pus, count, chroma, refs); break;
+  }
   KVZ_CHECK_LAUNCH("intra_build_reference_kernel");
   return KVZ_HIP_OK;
 }
