@@ -112,3 +112,37 @@ def test_build_is_free_of_v_ashr_pk_u8_i32():
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     assert not hits, hits
+
+
+def test_python_record_layouts_match_the_header(tmp_path):
+    """the numpy record types the tests, tools and bench.py build descriptors with (tests/patterns.py) against sizeof / offsetof of
+    the structs of include/kvz_hip.h as a C compiler lays them out"""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import patterns as P
+    pairs = [("kvz_hip_me_pu", P.ME_PU), ("kvz_hip_me_params", P.ME_PARAMS), ("kvz_hip_me_result", P.ME_RESULT), ("kvz_hip_me_cabac", P.ME_CABAC),
+             ("kvz_hip_cu_info", P.CU_INFO), ("kvz_hip_deblock_params", P.DEBLOCK_PARAMS), ("kvz_hip_inter_params", P.INTER_PARAMS),
+             ("kvz_hip_merge_cand", P.MERGE_CAND)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kvz_hip.h"', 'int main(void) {']
+    for cname, dt in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field in dt.names:
+            if field in ("pad", "reserved"):
+                continue
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines += ['  printf("kvz_hip_intra_ref %zu\\n", sizeof(kvz_hip_intra_ref));', '  printf("kvz_hip_intra_pos %zu\\n", sizeof(kvz_hip_intra_pos));',
+              '  printf("kvz_hip_block_pair %zu\\n", sizeof(kvz_hip_block_pair));', '  printf("kvz_hip_bipred_cand %zu\\n", sizeof(kvz_hip_bipred_cand));',
+              '  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, dt in pairs:
+        assert int(got[cname]) == dt.itemsize, cname
+        for field in dt.names:
+            if field in ("pad", "reserved"):
+                continue
+            assert int(got["%s.%s" % (cname, field)]) == dt.fields[field][1], "%s.%s" % (cname, field)
+    assert (int(got["kvz_hip_intra_ref"]), int(got["kvz_hip_intra_pos"]), int(got["kvz_hip_block_pair"]), int(got["kvz_hip_bipred_cand"])) == (130, 8, 24, 24)
