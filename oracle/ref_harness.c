@@ -1846,3 +1846,9 @@ void __wrap_kvz_image_md5(const kvz_picture *im, unsigned char checksum_out[][SE
   if (g_dbk.on && g_dbk.pic && g_dbk.pic->y == im->y) gpu_flush_deblock(NULL);
   __real_kvz_image_md5(im, checksum_out, bitdepth);
 }
+
+/* the harness's own copies of the record layouts against the header's */
+_Static_assert(sizeof(flat_cu_t) == sizeof(kvz_hip_cu_info) && sizeof(flat_inter_params_t) == sizeof(kvz_hip_inter_params) &&
+               sizeof(flat_merge_t) == sizeof(kvz_hip_merge_cand) && sizeof(rec_pu_t) == sizeof(kvz_hip_me_pu) &&
+               sizeof(rec_params_t) == sizeof(kvz_hip_me_params) && sizeof(rec_result_t) == sizeof(kvz_hip_me_result),
+               "record layouts of include/kvz_hip.h");
