@@ -1310,7 +1310,7 @@ static int gpu_can_serve_inter(const encoder_state_t *state)
   const encoder_state_config_frame_t *fr = state->frame;
   const int nref = (int)fr->ref->used_size;
   return nref >= 1 && nref <= GPU_MAX_REFS && fr->slicetype != KVZ_SLICE_I &&
-         !ctrl->cfg.mv_rdo && ctrl->cfg.rdo < 2 && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
+         !ctrl->cfg.mv_rdo && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
          state->tile->frame->width == g_gpu.w && state->tile->frame->height == g_gpu.h;
 }
 
@@ -1476,7 +1476,7 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
   return 1;
 }
 
-/* kvz_search_cu_inter (search_inter.c:1587-1608) for rd < 2: the 2Nx2N PU */
+/* kvz_search_cu_inter (search_inter.c:1587-1608): the 2Nx2N PU */
 static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
 {
   if (!g_gpu.on) return 0;
@@ -1485,10 +1485,11 @@ static int gpu_search_serve(encoder_state_t *state, int x, int y, int depth, lcu
   const int width = LCU_WIDTH >> depth;
   if (!gpu_serve_pu(state, x, y, width, width, 1, 1, lcu, inter_cost, inter_bitcost)) return 0;   /* the reference's own search takes over */
   ++g_gpu.served;
+  if (state->encoder_control->cfg.rdo >= 2) kvz_cu_cost_inter_rd2(state, x, y, depth, lcu, inter_cost, inter_bitcost);   /* :1600-1607 */
   return 1;
 }
 
-/* kvz_search_cu_smp (search_inter.c:1626-1718) for rd < 2: the PUs of a SMP / AMP partition one after the other, each
+/* kvz_search_cu_smp (search_inter.c:1626-1718): the PUs of a SMP / AMP partition one after the other, each
  * seeing its predecessor's decision in lcu->cu (-Wl,--wrap=kvz_search_cu_smp) */
 void __real_kvz_search_cu_smp(encoder_state_t * const state, int x, int y, int depth, part_mode_t part_mode, lcu_t *lcu,
                               double *inter_cost, uint32_t *inter_bitcost);
@@ -1543,20 +1544,21 @@ void __wrap_kvz_search_cu_smp(encoder_state_t * const state, int x, int y, int d
         scu->inter = cur_pu->inter;
       }
   }
-  /* the partition mode's own bits (:1702-1716; rd < 2 here) */
+  if (state->encoder_control->cfg.rdo >= 2) kvz_cu_cost_inter_rd2(state, x, y, depth, lcu, inter_cost, inter_bitcost);   /* :1693-1700 */
+  /* the partition mode's own bits (:1702-1716) */
   int smp_extra_bits = 1;
   if (state->encoder_control->cfg.amp_enable) {
     smp_extra_bits += 1;
     if (part_mode != SIZE_2NxN && part_mode != SIZE_Nx2N) smp_extra_bits += 1;
   }
   smp_extra_bits += 6;
-  *inter_cost += state->lambda_sqrt * smp_extra_bits;
+  *inter_cost += (state->encoder_control->cfg.rdo >= 2 ? state->lambda : state->lambda_sqrt) * smp_extra_bits;
   *inter_bitcost += smp_extra_bits;
 }
 
 /* ------------------------------------------------------------------------
  * The encoder's intra mode searches served the same way (tests only; -Wl,--wrap=kvz_search_cu_intra).  For the searches
- * that consist of the rough search alone (rd < 2, depth > 0: search_intra.c:840-883) the wrapper
+ * that start with the rough search (rd < 3, depth > 0: search_intra.c:840-883) the wrapper
  *   1. lays what kvz_intra_build_reference would read -- lcu->rec.y with lcu->top_ref.y / left_ref.y around it -- out as
  *      a small picture on the device (the LCU at (64, 64), or at 0 where the real picture ends, so that every
  *      availability test sees the distances to the picture edges it would see in the real one),
@@ -1567,6 +1569,8 @@ void __wrap_kvz_search_cu_smp(encoder_state_t * const state, int x, int y, int d
  * ------------------------------------------------------------------------ */
 void __real_kvz_search_cu_intra(encoder_state_t * const state, const int x_px, const int y_px, const int depth, lcu_t *lcu,
                                 int8_t *mode_out, double *cost_out);
+int8_t refintra_refine(encoder_state_t *state, int x_px, int y_px, int depth, kvz_pixel *orig, int32_t origstride, int8_t *intra_preds,
+                       int modes_to_check, int8_t number_of_modes, int8_t modes[35], double costs[35], lcu_t *lcu);
 
 #ifndef TRSKIP_RATIO
 # define TRSKIP_RATIO 1.7                      /* search_intra.c:39-41 */
@@ -1578,8 +1582,8 @@ static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth
   gpu_flush_deblock(state);
   const encoder_control_t *ctrl = state->encoder_control;
   const kvz_config *cfg = &ctrl->cfg;
-  if (depth == 0 || cfg->rdo >= 2 || state->tile->frame->width != g_gpu.w || state->tile->frame->height != g_gpu.h) {
-    ++g_gpu.intra_passed_on;                  /* search_intra_rdo is part of these: the reference's */
+  if (depth == 0 || cfg->rdo >= 3 || state->tile->frame->width != g_gpu.w || state->tile->frame->height != g_gpu.h) {
+    ++g_gpu.intra_passed_on;                  /* no rough search in these (search_intra.c:840): the reference's */
     return 0;
   }
   const vector2d_t lcu_px = { SUB_SCU(x_px), SUB_SCU(y_px) };
@@ -1704,6 +1708,13 @@ static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth
     }
   }
   kvz_lcu_set_trdepth(lcu, x_px, y_px, depth, depth);            /* search_intra.c:856 */
+  if (cfg->rdo >= 2) {
+    /* rd 2: the best two (4x4: three) modes of the rough search re-scored by full reconstruction -- the reference's own
+     * search_intra_rdo (search_intra.c:857-878), which goes through the strategy table */
+    const int to_search = width == 4 ? 3 : 2;
+    n = refintra_refine(state, x_px, y_px, depth, &lcu->ref.y[lcu_px.x + lcu_px.y * LCU_WIDTH], LCU_WIDTH, intra_preds, MIN(n, to_search), n,
+                        modes, costs, lcu);
+  }
   best_i = 0;
   for (int i = 1; i < n; ++i) if (costs[i] < costs[best_i]) best_i = i;
   *mode_out = modes[best_i];

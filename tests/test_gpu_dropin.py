@@ -383,6 +383,9 @@ GPU_SEARCH_CONFIGS = [
     # bi-prediction: pairs of merge candidates scored by kvz_hip_bipred_cost_batch (search_pu_inter_bipred)
     (192, 128, 10, "preset=medium,bipred=1,qp=30,threads=0"),
     (128, 128, 9, "preset=slow,qp=26,threads=0"),
+    # rd 2: the searches are followed by the reference's own full-reconstruction refinements (kvz_cu_cost_inter_rd2, search_intra_rdo)
+    (128, 128, 6, "preset=medium,rd=2,qp=28,threads=0"),
+    (128, 64, 9, "preset=slower,qp=31,threads=0"),
     # intra pictures only; 4x4 transform skip (its SAD test in get_cost); every mode in the first pass
     (192, 128, 3, "preset=medium,period=1,qp=27,threads=0"),
     (128, 128, 3, "preset=fast,period=1,transform-skip=1,rd=1,qp=24,threads=0"),
