@@ -444,9 +444,11 @@ typedef struct {
   uint8_t pad[2];
   int32_t col_ref_pocs[16];      /* state->frame->ref->images[c]->ref_pocs, c = ref_LX[0][0]: the collocated picture (inter.c:1020-1055) */
   uint8_t col_ref_LX[2][16];     /* state->frame->ref->ref_LXs[c] */
-  int32_t pic_width, pic_height; /* state->tile->frame->width / height; PU coordinates are relative to this (tile) picture */
+  int32_t pic_width, pic_height; /* state->tile->frame->width / height: the (tile) picture the reference's functions see */
   int32_t in_width, in_height;   /* encoder_control->in.width / height: the bounds of the temporal neighbours (inter.c:747,763) */
-  int32_t tile_x, tile_y;        /* state->tile->offset_x / _y: added only by the start vector's lookup (search_inter.c:1193-1194) */
+  int32_t tile_x, tile_y;        /* state->tile->offset_x / _y.  Descriptors carry PICTURE coordinates (the search entry's
+                                    convention); the derivation subtracts the offset, cus is indexed tile-relative, col_cus /
+                                    ref_cus picture-wide (the start vector's lookup, search_inter.c:1193-1194, adds it back) */
   int32_t ref_idx;               /* info->ref_idx: the picture of state->frame->ref about to be searched */
   int32_t cus_stride;            /* records per row of cus */
   int32_t col_stride;            /* records per row of col_cus / ref_cus (cu_array_t: the picture width rounded up to whole LCUs, / 4) */
@@ -461,7 +463,7 @@ typedef struct {
 } kvz_hip_merge_cand;            /* 12 bytes */
 /* Completes the search descriptors of `count` PUs on the device -- everything search_pu_inter and
  * search_pu_inter_ref derive before the search of picture params->ref_idx (search_inter.c:1470-1500, :1143-1206):
- *   in : pus[i].x, y, width, height (any PU shape of the inter search) and pus[i].pad: bit 0 = merge candidate A1
+ *   in : pus[i].x, y (picture coordinates), width, height (any PU shape of the inter search) and pus[i].pad: bit 0 = merge candidate A1
  *        barred, bit 1 = B1 barred (the second PU of a two-PU CU, search_inter.c:1470-1475);
  *   out: pus[i].num_merge_cand and merge[] (kvz_inter_get_merge_cand, inter.c:1314-1446, seen as calc_mvd_cost sees
  *        it), mv_cand (kvz_inter_get_mv_cand, inter.c:1209-1240, for the list and index that hold ref_idx),

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(64) void inter_candidates_kernel(const kvz_hip_cu_i
   if (i >= count) return;
   kvz_hip_merge_cand *mc = s_mc[threadIdx.x];
   kvz_hip_me_pu u = pus[i];
-  const int x = u.x, y = u.y, w = u.width, h = u.height;
+  // descriptors carry PICTURE coordinates, like kvz_hip_search_pu_batch's; the reference's functions work in the tile's
+  const int x = u.x - p.tile_x, y = u.y - p.tile_y, w = u.width, h = u.height;
   // a descriptor outside the picture or off the 4-pixel grid: num_merge_cand -1, nothing read
   const bool ok = x >= 0 && y >= 0 && w >= 4 && h >= 4 && w <= 64 && h <= 64 && ((x | y | w | h) & 3) == 0 && x + w <= p.pic_width && y + h <= p.pic_height;
   u.extra_mv[0] = u.extra_mv[1] = 0;

@@ -2100,7 +2100,8 @@ void orc_inter_candidates(const orc_cu_info *cus, const orc_cu_info *col_cus, co
   for (size_t i = 0; i < count; ++i) {
     orc_me_pu *u = &pus[i];
     orc_merge_cand mc[5];
-    const int n = orc_inter_get_merge_cand(cus, col_cus, p, u->x, u->y, u->width, u->height, !(u->pad & 1), !(u->pad & 2), mc);
+    const int tx = u->x - p->tile_x, ty = u->y - p->tile_y;     /* descriptors carry picture coordinates, the derivation works in the tile's */
+    const int n = orc_inter_get_merge_cand(cus, col_cus, p, tx, ty, u->width, u->height, !(u->pad & 1), !(u->pad & 2), mc);
     u->num_merge_cand = (int16_t)n;
     for (int k = 0; k < 5; ++k) {
       memset(&u->merge[k], 0, sizeof(u->merge[k]));
@@ -2114,11 +2115,11 @@ void orc_inter_candidates(const orc_cu_info *cus, const orc_cu_info *col_cus, co
     }
     if (merge_out) memcpy(merge_out + 5 * i, mc, sizeof(mc));
     memset(u->mv_cand, 0, sizeof(u->mv_cand));
-    if (reflist >= 0) orc_inter_get_mv_cand(cus, col_cus, p, u->x, u->y, u->width, u->height, reflist, lx, u->mv_cand);
+    if (reflist >= 0) orc_inter_get_mv_cand(cus, col_cus, p, tx, ty, u->width, u->height, reflist, lx, u->mv_cand);
     /* the collocated CU's vector as one more start point (search_inter.c:1190-1206) */
     u->extra_mv[0] = u->extra_mv[1] = 0;
     if (ref_cus) {
-      const cand_view c = cand_at(ref_cus, p->col_stride, p->tile_x + u->x + (u->width >> 1), p->tile_y + u->y + (u->height >> 1));
+      const cand_view c = cand_at(ref_cus, p->col_stride, u->x + (u->width >> 1), u->y + (u->height >> 1));
       if (c.ok) { const int l = (c.dir & 1) ? 0 : 1; u->extra_mv[0] = (int16_t)c.mv[l][0]; u->extra_mv[1] = (int16_t)c.mv[l][1]; }
     }
   }

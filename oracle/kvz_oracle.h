@@ -333,8 +333,8 @@ void orc_inter_get_mv_cand(const orc_cu_info *cus, const orc_cu_info *col_cus, c
 /* kvz_inter_get_merge_cand; fields of `out` the reference leaves unwritten are zero */
 int orc_inter_get_merge_cand(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_inter_params *p,
                              int x, int y, int width, int height, int use_a1, int use_b1, orc_merge_cand out[5]);
-/* What search_pu_inter + search_pu_inter_ref derive before the search of picture p->ref_idx, for every PU: in = x, y,
- * width, height and pad (bit 0: A1 barred, bit 1: B1 barred -- the second PU of a two-PU CU, search_inter.c:1470-1475);
+/* What search_pu_inter + search_pu_inter_ref derive before the search of picture p->ref_idx, for every PU: in = x, y (PICTURE
+ * coordinates; the tile offset is subtracted here), width, height and pad (bit 0: A1 barred, bit 1: B1 barred -- the second PU of a two-PU CU, search_inter.c:1470-1475);
  * out = mv_cand, extra_mv (ref_cus = the SCU map of picture ref_idx, may be NULL), num_merge_cand, merge[] as
  * calc_mvd_cost reads them; merge_out (may be NULL) = the five inter_merge_cand_t per PU */
 void orc_inter_candidates(const orc_cu_info *cus, const orc_cu_info *col_cus, const orc_cu_info *ref_cus, const orc_inter_params *p,

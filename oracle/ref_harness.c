@@ -968,7 +968,7 @@ void ref_inter_candidates(const flat_cu_t *cus, const flat_cu_t *col_cus, const 
   const int map_rows = (p->pic_height + 3) / 4;
   for (size_t n = 0; n < count; ++n) {
     rec_pu_t *u = &pus[n];
-    const int x = u->x, y = u->y, w = u->width, h = u->height;
+    const int x = u->x - p->tile_x, y = u->y - p->tile_y, w = u->width, h = u->height;    /* descriptors carry picture coordinates */
     const int ox = (x / LCU_WIDTH) * 16, oy = (y / LCU_WIDTH) * 16;     /* the LCU's first SCU */
     memset(lcu->cu, 0, sizeof(lcu->cu));
     for (int sy = -1; sy < 16; ++sy)
@@ -1119,7 +1119,7 @@ int ref_record_snapshots_get(int32_t *index, void *cu, void *col, void *params, 
 /* ------------------------------------------------------------------------
  * The encoder's 2Nx2N inter searches SERVED BY THE GPU CHAIN (tests only): with ref_gpu_search_begin, the wrapper of
  * kvz_search_cu_inter above does not run the reference's search_pu_inter at all for the searches it can express
- * (P and B slices with any number of reference pictures, uni-prediction, rd < 2, no mv-rdo, one tile) but
+ * (P and B slices with any number of reference pictures, any number of tiles, no mv-rdo) but
  *   1. copies what the candidate derivation would read -- lcu->cu -- into the picture's CU array on the device
  *      (the frame's planes and the reference pictures' CU arrays go up once per frame),
  *   2. for every reference picture in turn, as search_pu_inter does (search_inter.c:1502-1507), runs
@@ -1246,7 +1246,7 @@ static int gpu_load_frame(const encoder_state_t *state)
   const int w = g_gpu.w, h = g_gpu.h, nref = (int)fr->ref->used_size;
   const size_t map_bytes = (size_t)g_gpu.stride * g_gpu.rows * sizeof(kvz_hip_cu_info);
   int bad = 0;
-  const kvz_picture *src = state->tile->frame->source;
+  const kvz_picture *src = state->tile->frame->source->base_image;     /* a tile's source is a view of the whole picture */
   for (int r = 0; r < h; ++r) memcpy(g_gpu.h_plane + (size_t)r * w, src->y + (size_t)r * src->stride, (size_t)w);
   bad |= g_gpu.h2d(g_gpu.d_pic, g_gpu.h_plane, (size_t)w * h, NULL);
   for (int i = 0; i < nref; ++i) {
@@ -1273,7 +1273,7 @@ static int gpu_load_frame(const encoder_state_t *state)
     memcpy(ip->col_ref_pocs, fr->ref->images[c]->ref_pocs, sizeof(ip->col_ref_pocs));
     memcpy(ip->col_ref_LX, fr->ref->ref_LXs[c], sizeof(ip->col_ref_LX));
   }
-  ip->pic_width = w; ip->pic_height = h; ip->in_width = ctrl->in.width; ip->in_height = ctrl->in.height;
+  ip->in_width = ctrl->in.width; ip->in_height = ctrl->in.height;      /* the tile's own fields are set per search */
   ip->cus_stride = g_gpu.stride; ip->col_stride = g_gpu.stride;
   kvz_hip_me_params *p = &g_gpu.mp;
   memset(p, 0, sizeof(*p));
@@ -1310,8 +1310,7 @@ static int gpu_can_serve_inter(const encoder_state_t *state)
   const encoder_state_config_frame_t *fr = state->frame;
   const int nref = (int)fr->ref->used_size;
   return nref >= 1 && nref <= GPU_MAX_REFS && fr->slicetype != KVZ_SLICE_I &&
-         !ctrl->cfg.mv_rdo && state->tile->offset_x == 0 && state->tile->offset_y == 0 &&
-         state->tile->frame->width == g_gpu.w && state->tile->frame->height == g_gpu.h;
+         !ctrl->cfg.mv_rdo && ctrl->in.width == g_gpu.w && ctrl->in.height == g_gpu.h;
 }
 
 /* search_pu_inter (search_inter.c:1451-1520) for one PU of any shape, the two entries in place of search_pu_inter_ref's
@@ -1344,7 +1343,13 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
   uint32_t bitcost = MAX_INT;
   CU_SET_MV_CAND(cur_cu, 0, 0);
   CU_SET_MV_CAND(cur_cu, 1, 0);
+  /* the tile: the CU array on the device is the current tile's (tile-relative, like lcu->cu), descriptors carry picture
+   * coordinates, the search and the candidate derivation are told where the tile lies */
+  const int tile_x = state->tile->offset_x, tile_y = state->tile->offset_y;
+  g_gpu.ip.pic_width = state->tile->frame->width; g_gpu.ip.pic_height = state->tile->frame->height;
+  g_gpu.ip.tile_x = tile_x; g_gpu.ip.tile_y = tile_y;
   kvz_hip_me_params mp = g_gpu.mp;
+  mp.tile_x = tile_x; mp.tile_y = tile_y; mp.tile_w = state->tile->frame->width; mp.tile_h = state->tile->frame->height;
   mp.lambda_cost = (int32_t)(state->lambda_sqrt + 0.5);
   const int longer = width > height ? width : height;
   mp.size_classes = longer <= 16 ? 1 : (longer <= 32 ? 2 : 4);
@@ -1358,7 +1363,7 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
     if (ref_list < 0) { bad = 1; break; }
     kvz_hip_me_pu pu;
     memset(&pu, 0, sizeof(pu));
-    pu.x = x; pu.y = y; pu.width = width; pu.height = height;
+    pu.x = tile_x + x; pu.y = tile_y + y; pu.width = width; pu.height = height;
     pu.pad = (int16_t)((merge_a1 ? 0 : 1) | (merge_b1 ? 0 : 2));
     const uint32_t beat = (uint32_t)cost;               /* *inter_cost as search_pu_inter_ref finds it (:1239) */
     kvz_hip_me_result res;
@@ -1412,7 +1417,7 @@ static int gpu_serve_pu(encoder_state_t *state, int x, int y, int width, int hei
       valid[idx] = 1;
       pic0[idx] = fr->ref_LX[0][mc[i].ref[0]]; pic1[idx] = fr->ref_LX[1][mc[j].ref[1]];
       memset(&bc[idx], 0, sizeof(bc[idx]));
-      bc[idx].x = x; bc[idx].y = y; bc[idx].width = width; bc[idx].height = height;
+      bc[idx].x = tile_x + x; bc[idx].y = tile_y + y; bc[idx].width = width; bc[idx].height = height;
       bc[idx].mv0[0] = mc[i].mv[0][0]; bc[idx].mv0[1] = mc[i].mv[0][1]; bc[idx].mv1[0] = mc[j].mv[1][0]; bc[idx].mv1[1] = mc[j].mv[1][1];
     }
     /* the blended predictions' SATDs do not depend on one another: every pair that shares its two pictures goes into ONE
@@ -1582,7 +1587,7 @@ static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth
   gpu_flush_deblock(state);
   const encoder_control_t *ctrl = state->encoder_control;
   const kvz_config *cfg = &ctrl->cfg;
-  if (depth == 0 || cfg->rdo >= 3 || state->tile->frame->width != g_gpu.w || state->tile->frame->height != g_gpu.h) {
+  if (depth == 0 || cfg->rdo >= 3 || ctrl->in.width != g_gpu.w || ctrl->in.height != g_gpu.h) {
     ++g_gpu.intra_passed_on;                  /* no rough search in these (search_intra.c:840): the reference's */
     return 0;
   }
@@ -1598,7 +1603,7 @@ static int gpu_intra_serve(encoder_state_t *state, int x_px, int y_px, int depth
   /* 1. the LCU and its borders as a picture */
   const int lcu_x0 = x_px - lcu_px.x, lcu_y0 = y_px - lcu_px.y;
   const int ox = lcu_x0 > 0 ? 64 : 0, oy = lcu_y0 > 0 ? 64 : 0;
-  const int vw = ox + MIN(g_gpu.w - lcu_x0, 128), vh = oy + MIN(g_gpu.h - lcu_y0, 64);
+  const int vw = ox + MIN(state->tile->frame->width - lcu_x0, 128), vh = oy + MIN(state->tile->frame->height - lcu_y0, 64);   /* the tile's picture */
   uint8_t *v = g_gpu.h_vplane;
   for (int y = 0; y < 64; ++y) memcpy(v + (size_t)(oy + y) * VPLANE_W + ox, lcu->rec.y + y * LCU_WIDTH, 64);
   if (oy > 0) {
@@ -1821,8 +1826,7 @@ static void gpu_flush_deblock(const encoder_state_t *state)
 void __wrap_kvz_filter_deblock_lcu(encoder_state_t * const state, int x_px, int y_px)
 {
   const encoder_control_t *ctrl = state->encoder_control;
-  if (!g_dbk.on || ctrl->cfg.sao_type || ctrl->cfg.lossless || state->tile->offset_x || state->tile->offset_y ||
-      state->tile->frame->width != state->tile->frame->rec->width) {
+  if (!g_dbk.on || ctrl->cfg.sao_type || ctrl->cfg.lossless || ctrl->cfg.tiles_width_count * ctrl->cfg.tiles_height_count > 1) {
     __real_kvz_filter_deblock_lcu(state, x_px, y_px);
     return;
   }

@@ -526,6 +526,8 @@ def inter_cand_case(name, seed=0):
         # the current picture's map has the stride of the whole picture's like the collocated ones
         wide = np.zeros((cus.shape[0], int(p["cus_stride"][0])), dtype=CU_INFO)
         wide[:, :cus.shape[1]] = cus
+        pus["x"] += tile[0]                    # descriptors carry picture coordinates; the CU map of the tile is tile-relative
+        pus["y"] += tile[1]
         return p, wide, col, refm, pus
     raise KeyError(name)
 

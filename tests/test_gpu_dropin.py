@@ -383,6 +383,11 @@ GPU_SEARCH_CONFIGS = [
     # bi-prediction: pairs of merge candidates scored by kvz_hip_bipred_cost_batch (search_pu_inter_bipred)
     (192, 128, 10, "preset=medium,bipred=1,qp=30,threads=0"),
     (128, 128, 9, "preset=slow,qp=26,threads=0"),
+    # tiles: the candidate derivation and the search work in the tile's picture, descriptors and reference planes in the whole one
+    (192, 128, 5, "preset=medium,tiles=2x2,qp=31,threads=0"),
+    # CTU-row tiles with vectors kept inside the tile: the partition bench.py's shard leg cuts a frame by, in a real encode
+    (256, 256, 5, "preset=medium,ref=2,bipred=0,gop=0,tiles=1x2,mv-constraint=frametilemargin,qp=29,threads=0,period=0"),
+    (1920, 1080, 2, "preset=medium,ref=1,bipred=0,gop=0,tiles=1x4,mv-constraint=frametilemargin,qp=33,threads=0,period=0,pu-depth-intra=2-3"),
     # rd 2: the searches are followed by the reference's own full-reconstruction refinements (kvz_cu_cost_inter_rd2, search_intra_rdo)
     (128, 128, 6, "preset=medium,rd=2,qp=28,threads=0"),
     (128, 64, 9, "preset=slower,qp=31,threads=0"),
