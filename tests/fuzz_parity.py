@@ -63,6 +63,9 @@ def main():
             kw = dict(cabac=cab)
         if len(pus) == 0:
             continue
+        if it % 2 == 1:                                  # a later picture of a multi-reference search: a cost to beat per PU
+            from patterns import cost_to_beat_case
+            kw["cost_to_beat"] = cost_to_beat_case(O.search_pu_batch(pic, ref, pus, prm, **kw)["cost"], int(g.integers(0, 1 << 30)))
         got = api.search_pu_batch(pic, ref, pus, prm, **kw).view(ME_RESULT).reshape(-1)
         want = O.search_pu_batch(pic, ref, pus, prm, **kw)
         for f in ("mv", "cost", "bitcost", "merged", "merge_idx", "mv_cand"):
