@@ -8,7 +8,9 @@
 #   3. the fused quantize_residual kernels under the SQ / TCC counter groups -> TAG_qr_pmc.txt
 #   4. the frame-level sampling / SATD kernels under the same groups -> TAG_frame_kernels_pmc.txt
 #   5. every entry of the ABI: TAG_bench_all_kernels.txt
-# The program always follows `--` directly (no env / bash -c hop).  usage: tools/gpu_profile_round.sh TAG COMMIT
+#   6. (third argument `all`) front replay, frame pipeline, served encodes: TAG_front_replay.json, TAG_front_replay_kernel_stats.csv,
+#      TAG_frame_pipeline.txt, TAG_gpu_served_encode.txt
+# The program always follows `--` directly (no env / bash -c hop).  usage: tools/gpu_profile_round.sh TAG COMMIT [all]
 set -e
 TAG=${1:-r02}
 COMMIT=${2:-unknown}
@@ -38,4 +40,15 @@ rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_prof/f4 -o p --output-format csv -- $F >
 for p in f1 f2 f3 f4; do python3 tools/pmc_filter.py $O/${TAG}_prof/$p $KS; done
 python3 tools/pmc_kernels.py $O/${TAG}_frame_kernels_pmc.txt $KS $O/${TAG}_prof/f1 $O/${TAG}_prof/f2 $O/${TAG}_prof/f3 $O/${TAG}_prof/f4 > /dev/null
 python3 tools/bench_all.py > $O/${TAG}_bench_all_kernels.txt 2>&1
+#   6. searches recorded from a real encode, front by front (+ S host threads), with the kernel statistics of that loop;
+#      one 1080p frame of every stage; the GPU-served encodes of the reference encoder (their printed summaries)
+if [ "${3:-}" = "all" ]; then
+  R=$PWD
+  python3 tools/front_replay.py --repeats 3 --sessions 2,4,8,16 --keep-case /tmp/kvz_case0.bin > $O/${TAG}_front_replay.json 2> $O/${TAG}_prof/front_replay.err
+  python3 tools/frame_pipeline.py > $O/${TAG}_frame_pipeline.txt 2>&1
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof/fr -o p -- $R/tools/front_replay /tmp/kvz_case0.bin 2 1 > $R/$O/${TAG}_prof/front_profiled.json 2> $R/$O/${TAG}_prof/front_prof.err)
+  cp $O/${TAG}_prof/fr/p_kernel_stats.csv $O/${TAG}_front_replay_kernel_stats.csv
+  rm -rf $O/${TAG}_prof/fr /tmp/kvz_case0.bin
+  python3 -m pytest tests/test_gpu_dropin.py -m gpu -q -s -k "served or deblocked_by_one" 2>&1 | grep -E "frames: |frames, untouched|passed|failed" > $O/${TAG}_gpu_served_encode.txt
+fi
 echo "profile set $TAG done"
