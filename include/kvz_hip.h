@@ -352,7 +352,8 @@ typedef struct {
   int16_t num_merge_cand;        /* 0..5 */
   int16_t reserved;              /* mv_rdo: index of this PU's snapshot in kvz_hip_me_params.cabac */
   kvz_hip_me_merge merge[5];
-  int16_t pad;
+  int16_t pad;                   /* bits 0-1: merge neighbours barred (kvz_hip_inter_candidates_batch); bits 2..: plane pair
+                                    (kvz_hip_search_pu_multi_batch); ignored by kvz_hip_search_pu_batch */
 } kvz_hip_me_pu;                 /* 64 bytes */
 /* The CABAC state kvz_calc_mvd_cost_cabac (rdo.c:908-1060, --mv-rdo) starts from: what it reads of state->cabac
  * (cabac_data_t, cabac.h:41-88).  The encoder's contexts change from LCU to LCU; a batch carries one snapshot per
@@ -417,6 +418,17 @@ KVZ_HIP_API int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_s
                                         const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
                                         const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
                                         kvz_hip_me_result *results, kvz_hip_stream s);
+/* The same search over SEVERAL pictures of one size in one launch: pics / refs are DEVICE arrays of n_planes plane pointers
+ * (all planes share the strides and sizes given), and a PU names its pair in kvz_hip_me_pu.pad >> 2 (bits 0 and 1 keep
+ * their meaning for kvz_hip_inter_candidates_batch).  This is how work that is independent by construction -- the same
+ * dependency front of several frames in flight (--owf), of several tiles, of several encoder instances -- shares a launch:
+ * a front of a dozen PUs leaves the chip idle, and host threads stop scaling at the runtime's launch rate, but fronts of
+ * many pictures merged into one launch cost what one does.  A plane index outside 0 .. n_planes - 1 flags the PU
+ * (reserved -1).  mv_rdo is not available here. */
+KVZ_HIP_API int kvz_hip_search_pu_multi_batch(const kvz_hip_pixel *const *pics, uint32_t pic_stride, int pic_w, int pic_h,
+                                              const kvz_hip_pixel *const *refs, uint32_t ref_stride, int ref_w, int ref_h, int n_planes,
+                                              const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
+                                              kvz_hip_me_result *results, kvz_hip_stream s);
 
 /* ---- candidate derivation next to the search: what a host derives between two dependency fronts ---- */
 /* One record per 4x4 SCU, row-major: the fields of cu_info_t (cu.h:117-153) the candidate derivation and the

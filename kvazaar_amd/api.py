@@ -365,6 +365,29 @@ def search_pu_batch(pic, ref, pus, params, cabac=None, cost_to_beat=None):
     return out.to_numpy(np.int32, (count, 8))
 
 
+def search_pu_multi_batch(pics, refs, pus, params):
+    """kvz_hip_search_pu_multi_batch: pics / refs = lists of equally sized 2-D planes, pus carry their pair in pad >> 2.
+    Returns int32 [count, 8]."""
+    L = _lib.init()
+    pics = [np.ascontiguousarray(p, dtype=np.uint8) for p in pics]
+    refs = [np.ascontiguousarray(r, dtype=np.uint8) for r in refs]
+    assert len(pics) == len(refs) and all(p.shape == pics[0].shape for p in pics) and all(r.shape == refs[0].shape for r in refs)
+    pus = np.ascontiguousarray(pus)
+    params = np.ascontiguousarray(params)
+    assert pus.dtype.itemsize == 64 and params.nbytes == 96
+    count = pus.shape[0]
+    dp, dr = [DeviceBuffer.from_numpy(p) for p in pics], [DeviceBuffer.from_numpy(r) for r in refs]
+    tp = DeviceBuffer.from_numpy(np.array([b.ptr for b in dp], dtype=np.uint64))
+    tr = DeviceBuffer.from_numpy(np.array([b.ptr for b in dr], dtype=np.uint64))
+    d = DeviceBuffer.from_numpy(pus.view(np.uint8))
+    out = DeviceBuffer(max(1, 32 * count))
+    h, w = pics[0].shape
+    rh, rw = refs[0].shape
+    check(L.kvz_hip_search_pu_multi_batch(tp.ptr, w, w, h, tr.ptr, rw, rw, rh, len(pics), d.ptr, count, params.ctypes.data, out.ptr, None),
+          "search_pu multi batch")
+    return out.to_numpy(np.int32, (count, 8))
+
+
 # ---- SAO group ----
 def sao_edge_stats_batch(orig, rec, bw, bh):
     """-> int32 [count, 4 classes, 2 (sum, count), 5 categories]"""

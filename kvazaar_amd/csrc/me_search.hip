@@ -690,8 +690,22 @@ __device__ __forceinline__ int pu_class(const kvz_hip_me_pu &pu)
 // no kernel: the kernel of the lowest class named flags it (cost 0xFFFFFFFF, reserved -1) on its way past.
 __device__ __forceinline__ bool pu_orphan(int cls, int mine, int hinted) { return !(hinted & cls) && mine == (hinted & -hinted); }
 
+// kvz_hip_search_pu_multi_batch: several pictures of one size in a launch (frames in flight, tiles' or instances' pictures).
+// The `pic` / `ref.p` arguments are then DEVICE TABLES of plane pointers, a PU names its pair in pad >> 2, the table length
+// travels in prm.reserved.  A template flag, so that the one-picture kernels compile exactly as before.
+template <bool MULTI>
+__device__ __forceinline__ bool pick_planes(const u8 *__restrict__ &pic, refplane_t &ref, const kvz_hip_me_pu &pu, int n_planes)
+{
+  if (!MULTI) return true;
+  const int k = pu.pad >> 2;
+  if (k < 0 || k >= n_planes) return false;
+  pic = reinterpret_cast<const u8 *const *>(pic)[k];
+  ref.p = reinterpret_cast<const u8 *const *>(ref.p)[k];
+  return true;
+}
+
 // PUs larger than 32x32 in either direction (and malformed descriptors, which are flagged): one workgroup (T threads) per PU
-template <int T, bool CONSTR>
+template <int T, bool CONSTR, bool MULTI = false>
 __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                             const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
                                                             kvz_hip_me_result *__restrict__ out)
@@ -699,7 +713,7 @@ __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__
   __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];            // uniform address: the compiler reads it with scalar loads
-  if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.reserved)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   const int cls = pu_class(pu);
   if (cls != 4) {                                       // the one-wave-per-PU kernels'
     if (pu_orphan(cls, 4, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
@@ -724,7 +738,7 @@ __global__ __launch_bounds__(256) void search_pu_rdo_kernel(const u8 *__restrict
 
 // PUs up to 16x16: one wave per PU, four PUs per workgroup, wave-private LDS, no barrier.  The register budget is held at
 // 6 waves per SIMD (80 VGPRs): at 82 the kernel dropped to 5 and lost 8 % (measured A/B on one box).
-template <bool CONSTR>
+template <bool CONSTR, bool MULTI = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void search_pu_small_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                               const kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_me_params prm,
                                                               kvz_hip_me_result *__restrict__ out)
@@ -736,7 +750,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   if (i >= count) return;
   const kvz_hip_me_pu &pu = pus[i];
   const int lane = threadIdx.x & 63;
-  if (!pu_ok(pu, pic_w, pic_h)) { if (lane == 0) flag_bad(out + i); return; }
+  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.reserved)) { if (lane == 0) flag_bad(out + i); return; }
   const int cls = pu_class(pu);
   if (cls != 1) {
     if (pu_orphan(cls, 1, prm.size_classes) && lane == 0) flag_bad(out + i);
@@ -773,7 +787,7 @@ __global__ __launch_bounds__(128) void search_pu_medium_kernel(const u8 *__restr
 
 // The same class with one workgroup of T threads per PU: lower latency per search (more lanes on each step, barriers
 // instead of wave-local fences), lower throughput -- for batches too small to fill the chip with one wave per PU.
-template <int T, bool CONSTR>
+template <int T, bool CONSTR, bool MULTI = false>
 __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__restrict__ pic, u32 pic_stride, int pic_w, int pic_h, refplane_t ref,
                                                                 const kvz_hip_me_pu *__restrict__ pus, kvz_hip_me_params prm,
                                                                 kvz_hip_me_result *__restrict__ out)
@@ -781,7 +795,7 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
   __shared__ __attribute__((aligned(16))) u8 lds[(frac_geom<32>::TOTAL + 15) & ~15];
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];
-  if (!pu_ok(pu, pic_w, pic_h)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.reserved)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   const int cls = pu_class(pu);
   if (cls != 2) {
     if (pu_orphan(cls, 2, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
@@ -793,23 +807,24 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
 
 }  // namespace
 
-template <bool CONSTR>
+template <bool CONSTR, bool MULTI>
 static void launch_classes(int classes, const u8 *pic, u32 pic_stride, int pic_w, int pic_h, const refplane_t &r, const kvz_hip_me_pu *pus,
                            size_t count, const kvz_hip_me_params &prm, kvz_hip_me_result *results, hipStream_t st)
 {
   // one launch per size class over the same descriptor list; each kernel takes its class and skips the rest
   if (classes == 7 || (classes & 4))
-    hipLaunchKernelGGL((search_pu_big_kernel<512, CONSTR>), dim3((unsigned)count), dim3(512), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, prm, results);
+    hipLaunchKernelGGL((search_pu_big_kernel<512, CONSTR, MULTI>), dim3((unsigned)count), dim3(512), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, prm, results);
   if (classes & 1)
-    hipLaunchKernelGGL((search_pu_small_kernel<CONSTR>), dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count, prm, results);
+    hipLaunchKernelGGL((search_pu_small_kernel<CONSTR, MULTI>), dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, count, prm, results);
   if (classes & 2)
-    hipLaunchKernelGGL((search_pu_medium_wg_kernel<128, CONSTR>), dim3((unsigned)count), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, prm, results);
+    hipLaunchKernelGGL((search_pu_medium_wg_kernel<128, CONSTR, MULTI>), dim3((unsigned)count), dim3(128), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, prm, results);
 }
 
-extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
-                                       const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
-                                       const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
-                                       kvz_hip_me_result *results, kvz_hip_stream s)
+// n_planes == 0: pic / ref are the planes; > 0: device tables of that many plane pointers (kvz_hip_search_pu_multi_batch)
+static int search_pu_launch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
+                            const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h, int n_planes,
+                            const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
+                            kvz_hip_me_result *results, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
   if (!pic || !ref || !pus || !params || !results || pic_w <= 0 || pic_h <= 0 || ref_w <= 0 || ref_h <= 0) {
@@ -841,6 +856,7 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   // one launch per size class over the same descriptor list; each kernel takes its class and skips the rest.  The big
   // kernel also flags malformed descriptors, so it only goes when the caller vouches for the classes it names.
   if (params->mv_rdo) {
+    if (n_planes) { set_error_msg("kvz_hip_search_pu_multi_batch: mv_rdo is a one-picture path"); return KVZ_HIP_ERR_INVALID; }
     if (!params->cabac || params->refs_before < 1 || params->refs_before > 16 || params->ref_idx < 0 || params->ref_idx >= 16) {
       set_error_msg("kvz_hip_search_pu_batch: mv_rdo needs the cabac snapshots (device array), refs_before 1..16 and ref_idx 0..15");
       return KVZ_HIP_ERR_INVALID;
@@ -853,11 +869,36 @@ extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_st
   // (pu_orphan: written by the kernels themselves -- a separate fill would be one more command per dependency front)
   const int classes = (params->size_classes & 7) ? (params->size_classes & 7) : 7;
   prm_v.size_classes = classes;
+  prm_v.reserved = n_planes;
   // thread counts are measured choices: > 32x32: 512 threads per PU 10.5 M/s (256: 9.5, 1024: 6.5); <= 32x32: 128 per PU 48.9 M/s
   // (256: 46.6, one wave: 42.6); <= 16x16: one wave per PU, four per workgroup
   const bool constrained = params->wpp_owf != 0 || params->mv_constraint != 0;
-  if (constrained) launch_classes<true>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
-  else launch_classes<false>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
+  if (n_planes) {
+    if (constrained) launch_classes<true, true>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
+    else launch_classes<false, true>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
+  } else {
+    if (constrained) launch_classes<true, false>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
+    else launch_classes<false, false>(classes, pic, pic_stride, pic_w, pic_h, r, pus, count, *params, results, st);
+  }
   KVZ_CHECK_LAUNCH("search_pu kernels");
   return KVZ_HIP_OK;
+}
+
+
+extern "C" int kvz_hip_search_pu_batch(const kvz_hip_pixel *pic, uint32_t pic_stride, int pic_w, int pic_h,
+                                       const kvz_hip_pixel *ref, uint32_t ref_stride, int ref_w, int ref_h,
+                                       const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
+                                       kvz_hip_me_result *results, kvz_hip_stream s)
+{
+  return search_pu_launch(pic, pic_stride, pic_w, pic_h, ref, ref_stride, ref_w, ref_h, 0, pus, count, params, results, s);
+}
+
+extern "C" int kvz_hip_search_pu_multi_batch(const kvz_hip_pixel *const *pics, uint32_t pic_stride, int pic_w, int pic_h,
+                                             const kvz_hip_pixel *const *refs, uint32_t ref_stride, int ref_w, int ref_h, int n_planes,
+                                             const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
+                                             kvz_hip_me_result *results, kvz_hip_stream s)
+{
+  if (n_planes < 1 || n_planes > 8192) { set_error_msg("kvz_hip_search_pu_multi_batch: 1 .. 8192 plane pairs"); return KVZ_HIP_ERR_INVALID; }
+  return search_pu_launch(reinterpret_cast<const kvz_hip_pixel *>(pics), pic_stride, pic_w, pic_h, reinterpret_cast<const kvz_hip_pixel *>(refs),
+                          ref_stride, ref_w, ref_h, n_planes, pus, count, params, results, s);
 }

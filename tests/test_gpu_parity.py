@@ -1281,3 +1281,31 @@ def test_search_pu_with_a_cost_to_beat(api, cfg):
             sel = [i for i in range(len(pus)) if (1 if max(pus[i]["width"], pus[i]["height"]) <= 16 else 2 if max(pus[i]["width"], pus[i]["height"]) <= 32 else 4) == hint]
             got_h = api.search_pu_batch(pic, ref, pus, q, cost_to_beat=beat)
             np.testing.assert_array_equal(got_h[sel], got[sel])
+
+
+@pytest.mark.parametrize("cfg", [0, 4, 8, 14, 19, 22])
+def test_search_pu_over_several_pictures_in_one_launch(api, cfg):
+    """kvz_hip_search_pu_multi_batch: PUs of five picture pairs interleaved in one launch (every size class, with and without the
+    hint) against one launch per pair; a plane index beyond the table flags its PU"""
+    prm = me_params(**ME_CONFIGS[cfg])
+    pairs = [me_frames(192, 128, 700 + k, motion) for k, motion in enumerate(((3, -2), (-7, 5), (0, 0), (11, 6), (-2, -9)))]
+    pus = me_pus_in_tile(me_random_pus(192, 128, 200, 55 + cfg, hint=(-10, 8)), prm)
+    owner = np.arange(len(pus)) % 5
+    pus["pad"] = (owner << 2) | (np.arange(len(pus)) % 4)            # bits 0-1 are the candidate entry's, ignored here
+    want = np.zeros((len(pus), 8), np.int32)
+    for k, (pic, ref) in enumerate(pairs):
+        sel = np.where(owner == k)[0]
+        want[sel] = api.search_pu_batch(pic, ref, pus[sel], prm)
+        np.testing.assert_array_equal(want[sel], np.asarray(O.search_pu_batch(pic, ref, pus[sel], prm)).view(np.int32).reshape(len(sel), 8))
+    pics, refs = [p for p, _ in pairs], [r for _, r in pairs]
+    np.testing.assert_array_equal(api.search_pu_multi_batch(pics, refs, pus, prm), want)
+    for hint in (1, 2, 4):
+        q = prm.copy()
+        q["size_classes"] = hint
+        sel = [i for i in range(len(pus)) if (1 if max(pus[i]["width"], pus[i]["height"]) <= 16 else 2 if max(pus[i]["width"], pus[i]["height"]) <= 32 else 4) == hint]
+        np.testing.assert_array_equal(api.search_pu_multi_batch(pics, refs, pus, q)[sel], want[sel])
+    bad = pus[:8].copy()
+    bad["pad"][3] = 5 << 2
+    bad["pad"][5] = -4
+    got = api.search_pu_multi_batch(pics, refs, bad, prm)
+    assert got[3, 7] == -1 and got[5, 7] == -1 and (got[[0, 1, 2, 4, 6, 7], 7] == 0).all()

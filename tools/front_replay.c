@@ -7,6 +7,8 @@
  * With a 4th argument S > 1 the program instead runs S host threads, each replaying the frame front by front on its own
  * stream, planes and pinned buffers -- S encoder instances (or S frames in flight under --owf, S tiles) of one process sharing
  * the GPU through the per-thread contexts of the C ABI -- and reports the aggregate rate.
+ * With a 5th argument M > 1 it runs ONE host thread that merges the same front of M sessions (M copies of the planes, as M
+ * frames in flight / tiles / instances would have) into one kvz_hip_search_pu_multi_batch launch per front.
  * Prints one JSON line; every replayed result is compared with the recorded one.  NOT an encoder: candidate derivation,
  * mode decision, reconstruction are not here. */
 #include <pthread.h>
@@ -101,12 +103,65 @@ static int run_sessions(int S, session_t proto)
   return (mism || failed) ? 1 : 0;
 }
 
+/* ---- M sessions merged into one launch per front ---- */
+static int run_merged(int M, int w, int h, int n, int ng, int repeats, const uint8_t *pic, const uint8_t *ref, const kvz_hip_me_params *prm,
+                      const kvz_hip_me_pu *pus, const kvz_hip_me_result *want, const int32_t *off)
+{
+  kvz_hip_stream st = kvz_hip_stream_create();
+  const uint8_t **h_pics = malloc((size_t)M * sizeof(*h_pics)), **h_refs = malloc((size_t)M * sizeof(*h_refs));
+  for (int m = 0; m < M; ++m) {
+    uint8_t *a = kvz_hip_malloc((size_t)w * h), *b = kvz_hip_malloc((size_t)w * h);
+    if (!a || !b || kvz_hip_memcpy_h2d(a, pic, (size_t)w * h, st) || kvz_hip_memcpy_h2d(b, ref, (size_t)w * h, st)) DIE("session planes");
+    h_pics[m] = a; h_refs[m] = b;
+  }
+  const uint8_t **d_pics = kvz_hip_malloc((size_t)M * sizeof(*d_pics)), **d_refs = kvz_hip_malloc((size_t)M * sizeof(*d_refs));
+  int max_front = 0;
+  for (int g = 0; g < ng; ++g) if (off[g + 1] - off[g] > max_front) max_front = off[g + 1] - off[g];
+  kvz_hip_me_pu *h_pus = kvz_hip_malloc_host((size_t)M * max_front * sizeof(*h_pus));
+  kvz_hip_me_result *h_res = kvz_hip_malloc_host((size_t)M * max_front * sizeof(*h_res));
+  if (!st || !d_pics || !d_refs || !h_pus || !h_res) DIE("allocation");
+  if (kvz_hip_memcpy_h2d(d_pics, h_pics, (size_t)M * sizeof(*d_pics), st) || kvz_hip_memcpy_h2d(d_refs, h_refs, (size_t)M * sizeof(*d_refs), st) ||
+      kvz_hip_stream_sync(st)) DIE("tables");
+  double best = 1e30;
+  long mismatches = 0;
+  for (int rep = 0; rep < repeats + 1; ++rep) {
+    const double t0 = now_s();
+    for (int g = 0; g < ng; ++g) {
+      const int a = off[g], c = off[g + 1] - off[g];
+      int classes = 0;
+      for (int m = 0; m < M; ++m)
+        for (int i = 0; i < c; ++i) {
+          kvz_hip_me_pu *u = &h_pus[(size_t)m * c + i];
+          *u = pus[a + i];                                 /* the host "derives" every session's descriptors */
+          u->pad = (int16_t)(m << 2);
+          const int sz = u->width > u->height ? u->width : u->height;
+          classes |= sz <= 16 ? 1 : (sz <= 32 ? 2 : 4);
+        }
+      kvz_hip_me_params fp = *prm;
+      fp.size_classes = classes;
+      if (kvz_hip_search_pu_multi_batch(d_pics, (uint32_t)w, w, h, d_refs, (uint32_t)w, w, h, M, h_pus, (size_t)M * c, &fp, h_res, st) ||
+          kvz_hip_stream_sync(st)) DIE("search (merged)");
+      for (int m = 0; m < M; ++m)
+        for (int i = 0; i < c; ++i)
+          if (memcmp(&h_res[(size_t)m * c + i], &want[a + i], 28) != 0) ++mismatches;      /* checked inside the loop: part of what a host does */
+    }
+    const double dt = now_s() - t0;
+    if (rep > 0 && dt < best) best = dt;
+  }
+  printf("{\"what\": \"search only, fronts, the same front of %d sessions merged into one launch (NOT an encoder)\", \"merged_sessions\": %d, "
+         "\"frame\": \"%dx%d\", \"searches_per_session\": %d, \"fronts\": %d, \"mismatches_vs_recorded\": %ld, \"ms_per_pass\": %.3f, "
+         "\"us_per_front\": %.2f, \"aggregate_frames_per_s\": %.2f, \"aggregate_searches_per_s\": %.0f, \"device\": \"%s\"}\n",
+         M, M, w, h, n, ng, mismatches, best * 1e3, best * 1e6 / ng, M / best, (double)M * n / best, kvz_hip_device_name());
+  return mismatches ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
-  if (argc < 2) { fprintf(stderr, "usage: front_replay FILE [repeats] [size-class hint 0/1] [sessions]\n"); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: front_replay FILE [repeats] [size-class hint 0/1] [sessions] [merged sessions]\n"); return 2; }
   const int repeats = argc > 2 ? atoi(argv[2]) : 3;
   const int hint = argc > 3 ? atoi(argv[3]) : 1;
   const int sessions = argc > 4 ? atoi(argv[4]) : 1;
+  const int merged = argc > 5 ? atoi(argv[5]) : 1;
   FILE *f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 2; }
   int32_t hdr[4];                                     /* width, height, PUs, fronts */
@@ -123,6 +178,10 @@ int main(int argc, char **argv)
   fclose(f);
 
   if (kvz_hip_init(-1) != KVZ_HIP_OK) DIE("kvz_hip_init");
+  if (merged > 1) {
+    if (merged > 2048 || repeats < 1) { fprintf(stderr, "merged sessions 2..2048, repeats >= 1\n"); return 2; }
+    return run_merged(merged, w, h, n, ng, repeats, pic, ref, &prm, pus, want, off);
+  }
   if (sessions > 1) {
     if (sessions > 64 || repeats < 1) { fprintf(stderr, "sessions 2..64, repeats >= 1\n"); return 2; }
     session_t proto = { w, h, n, ng, repeats, hint, 0, pic, ref, &prm, pus, want, off, NULL, 0.0, 0, 0 };

@@ -3,7 +3,7 @@
 by front in the encoder's dependency order (tools/front_replay.c does the timed loop in C; this script prepares its input
 from tests/golden/fronts.npz -- recorded by oracle/gen_golden.py, group `fronts` -- builds the C program and prints its JSON line).  Not an encoder: labelled "search only, fronts" wherever it is quoted.
 
-  python3 tools/front_replay.py [--repeats N] [--sessions 2,4,8,16]"""
+  python3 tools/front_replay.py [--repeats N] [--sessions 2,4,8,16] [--merged 4,16,64,256]"""
 import argparse
 import os
 import struct
@@ -41,6 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--keep-case", default="", help="also leave the first frame's input file here (to run tools/front_replay under rocprofv3)")
+    ap.add_argument("--merged", default="", help="comma list, e.g. 4,16,64: also replay with that many sessions merged into one launch per front")
     ap.add_argument("--sessions", default="", help="comma list, e.g. 2,4,8,16: also replay with that many host threads at once")
     args = ap.parse_args()
     from patterns import fronts_fixture
@@ -55,6 +56,9 @@ def main():
             sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats), str(hint)], text=True))
         for k in [int(v) for v in args.sessions.split(",") if v]:
             sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats), "1", str(k)], text=True))
+            sys.stdout.flush()
+        for k in [int(v) for v in args.merged.split(",") if v]:
+            sys.stdout.write(subprocess.check_output([exe, path, str(args.repeats), "1", "1", str(k)], text=True))
             sys.stdout.flush()
         if i == 0 and args.keep_case:
             os.replace(path, args.keep_case)
