@@ -44,7 +44,7 @@ python3 tools/bench_all.py > $O/${TAG}_bench_all_kernels.txt 2>&1
 #      one 1080p frame of every stage; the GPU-served encodes of the reference encoder (their printed summaries)
 if [ "${3:-}" = "all" ]; then
   R=$PWD
-  python3 tools/front_replay.py --repeats 3 --sessions 2,4,8,16 --keep-case /tmp/kvz_case0.bin > $O/${TAG}_front_replay.json 2> $O/${TAG}_prof/front_replay.err
+  python3 tools/front_replay.py --repeats 3 --sessions 2,4,8,16 --merged 2,8,32,128,512 --keep-case /tmp/kvz_case0.bin > $O/${TAG}_front_replay.json 2> $O/${TAG}_prof/front_replay.err
   python3 tools/frame_pipeline.py > $O/${TAG}_frame_pipeline.txt 2>&1
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/${TAG}_prof/fr -o p -- $R/tools/front_replay /tmp/kvz_case0.bin 2 1 > $R/$O/${TAG}_prof/front_profiled.json 2> $R/$O/${TAG}_prof/front_prof.err)
   cp $O/${TAG}_prof/fr/p_kernel_stats.csv $O/${TAG}_front_replay_kernel_stats.csv
