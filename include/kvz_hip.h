@@ -491,6 +491,18 @@ KVZ_HIP_API int kvz_hip_inter_candidates_batch(const kvz_hip_cu_info *cus, const
                                                const kvz_hip_inter_params *params, kvz_hip_me_pu *pus, size_t count,
                                                kvz_hip_merge_cand *merge_out, kvz_hip_stream s);
 
+/* The same derivation for PUs of SEVERAL pictures in one launch (cf. kvz_hip_search_pu_multi_batch): one record per picture
+ * in DEVICE memory, a PU names its picture in kvz_hip_me_pu.pad >> 2.  What the one-picture entry refuses as a bad
+ * argument (table sizes, strides, a missing collocated array) makes the PUs of that picture read num_merge_cand -1 here,
+ * as does a picture index outside 0 .. n_pictures - 1. */
+typedef struct {
+  const kvz_hip_cu_info *cus, *col_cus, *ref_cus;   /* as the arguments of kvz_hip_inter_candidates_batch */
+  kvz_hip_inter_params params;
+  int32_t reserved;
+} kvz_hip_inter_picture;         /* 280 bytes */
+KVZ_HIP_API int kvz_hip_inter_candidates_multi_batch(const kvz_hip_inter_picture *pictures, int n_pictures, kvz_hip_me_pu *pus, size_t count,
+                                                     kvz_hip_merge_cand *merge_out, kvz_hip_stream s);
+
 
 /* Bi-prediction candidate cost of search_pu_inter_bipred (search_inter.c:1304-1440): for candidate i the luma of
  * kvz_inter_recon_bipred (inter.c:430-477; a 14-bit quarter-pel sample per reference when its vector is fractional,

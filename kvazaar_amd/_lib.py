@@ -97,6 +97,7 @@ SIGNATURES = {
     "kvz_hip_search_pu_multi_batch": (_I, [_P, _U, _I, _I, _P, _U, _I, _I, _I, _P, _SZ, _P, _P, _P]),
     "kvz_hip_bipred_cost_batch": (_I, [_P, _U, _I, _I, _P, _U, _P, _U, _I, _I, _P, _SZ, _P, _P]),
     "kvz_hip_inter_candidates_batch": (_I, [_P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "kvz_hip_inter_candidates_multi_batch": (_I, [_P, _I, _P, _SZ, _P, _P]),
     "kvz_hip_intra_build_reference_batch": (_I, [_I, _I, _P, _I, _I, _I, _P, _SZ, _P, _P]),
     "kvz_hip_intra_predict_batch": (_I, [_I, _I, _P, _SZ, _P, _I, _P, _P]),
     "kvz_hip_intra_rough_batch": (_I, [_I, _I, _P, _P, _SZ, _P, _P, _P]),

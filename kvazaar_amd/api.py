@@ -337,6 +337,28 @@ def inter_candidates_batch(params, cus, col_cus, ref_cus, pus):
     return u.to_numpy(np.uint8, (count, 64)), m.to_numpy(np.uint8, (count, 5, 12))
 
 
+def inter_candidates_multi_batch(pictures, pus):
+    """kvz_hip_inter_candidates_multi_batch: pictures = list of (params, cus, col_cus, ref_cus) as inter_candidates_batch takes them;
+    pus carry their picture in pad >> 2.  Returns (descriptors as bytes [count, 64], merge lists as bytes [count, 5, 12])."""
+    import struct
+    L = _lib.init()
+    pus = np.ascontiguousarray(pus)
+    count = pus.shape[0]
+    keep, rec = [], b""
+    for (params, cus, col_cus, ref_cus) in pictures:
+        params = np.ascontiguousarray(params)
+        assert params.nbytes == 252
+        bufs = [DeviceBuffer.from_numpy(np.ascontiguousarray(m)) if m is not None else None for m in (cus, col_cus, ref_cus)]
+        keep += bufs
+        rec += struct.pack("<3Q", *[(b.ptr or 0) if b else 0 for b in bufs]) + params.tobytes() + struct.pack("<i", 0)
+    assert len(rec) == 280 * len(pictures)
+    table = DeviceBuffer.from_numpy(np.frombuffer(rec, dtype=np.uint8))
+    u = DeviceBuffer.from_numpy(pus)
+    m = DeviceBuffer(max(1, 60 * count))
+    check(L.kvz_hip_inter_candidates_multi_batch(table.ptr, len(pictures), u.ptr, count, m.ptr, None), "inter_candidates multi batch")
+    return u.to_numpy(np.uint8, (count, 64)), m.to_numpy(np.uint8, (count, 5, 12))
+
+
 # ---- motion search of whole PUs ----
 def search_pu_batch(pic, ref, pus, params, cabac=None, cost_to_beat=None):
     """pus: structured array laid out as kvz_hip_me_pu (64 bytes each), params: one kvz_hip_me_params record (96 bytes).

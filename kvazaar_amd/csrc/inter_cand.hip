@@ -15,7 +15,7 @@
 
 using namespace kvzhip;
 
-static_assert(sizeof(kvz_hip_inter_params) == 252 && sizeof(kvz_hip_merge_cand) == 12 && sizeof(kvz_hip_me_pu) == 64,
+static_assert(sizeof(kvz_hip_inter_params) == 252 && sizeof(kvz_hip_merge_cand) == 12 && sizeof(kvz_hip_me_pu) == 64 && sizeof(kvz_hip_inter_picture) == 280,
               "layouts of include/kvz_hip.h");
 
 namespace {
@@ -276,30 +276,19 @@ __device__ __forceinline__ int merge_list(const kvz_hip_inter_params &p, cand_se
   return n;
 }
 
-__global__ __launch_bounds__(64) void inter_candidates_kernel(const kvz_hip_cu_info *__restrict__ cus, const kvz_hip_cu_info *__restrict__ col_cus,
-                                                              const kvz_hip_cu_info *__restrict__ ref_cus, kvz_hip_inter_params p_arg, int reflist, int lx_idx,
-                                                              kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_merge_cand *__restrict__ merge_out)
+// everything of one PU, given its picture's arrays and parameters (p: LDS in the one-picture kernel, global memory in the
+// several-pictures one)
+__device__ __forceinline__ void derive_pu(const kvz_hip_cu_info *__restrict__ cus, const kvz_hip_cu_info *__restrict__ col_cus,
+                                          const kvz_hip_cu_info *__restrict__ ref_cus, const kvz_hip_inter_params &p, bool params_ok,
+                                          int reflist, int lx_idx, kvz_hip_me_pu *__restrict__ pus, size_t i, kvz_hip_merge_cand *mc,
+                                          kvz_hip_merge_cand *__restrict__ merge_out)
 {
-  // The POC and list tables are indexed with per-lane values and a merge list is filled at a per-lane position: both
-  // live in LDS (as kernel arguments / registers the compiler had moved them to 288 bytes of scratch memory per lane,
-  // several dependent memory round trips on a kernel that is nothing but latency).
-  __shared__ kvz_hip_inter_params p;
-  __shared__ kvz_hip_merge_cand s_mc[64][5];
-  if (threadIdx.x == 0) {
-    const u32 *src = reinterpret_cast<const u32 *>(&p_arg);
-    u32 *dst = reinterpret_cast<u32 *>(&p);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(p) / 4); ++k) dst[k] = src[k];
-  }
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= count) return;
-  kvz_hip_merge_cand *mc = s_mc[threadIdx.x];
   kvz_hip_me_pu u = pus[i];
   // descriptors carry PICTURE coordinates, like kvz_hip_search_pu_batch's; the reference's functions work in the tile's
   const int x = u.x - p.tile_x, y = u.y - p.tile_y, w = u.width, h = u.height;
   // a descriptor outside the picture or off the 4-pixel grid: num_merge_cand -1, nothing read
-  const bool ok = x >= 0 && y >= 0 && w >= 4 && h >= 4 && w <= 64 && h <= 64 && ((x | y | w | h) & 3) == 0 && x + w <= p.pic_width && y + h <= p.pic_height;
+  const bool ok = params_ok && x >= 0 && y >= 0 && w >= 4 && h >= 4 && w <= 64 && h <= 64 && ((x | y | w | h) & 3) == 0 &&
+                  x + w <= p.pic_width && y + h <= p.pic_height;
   u.extra_mv[0] = u.extra_mv[1] = 0;
   u.mv_cand[0][0] = u.mv_cand[0][1] = u.mv_cand[1][0] = u.mv_cand[1][1] = 0;
 #pragma unroll
@@ -331,6 +320,62 @@ __global__ __launch_bounds__(64) void inter_candidates_kernel(const kvz_hip_cu_i
   if (reflist >= 0) amvp(p, s, tmp, reflist, lx_idx, u.mv_cand);
   if (centre.ok) { const int l = (centre.dir & 1) ? 0 : 1; u.extra_mv[0] = (int16_t)cand_mvx(centre, l); u.extra_mv[1] = (int16_t)cand_mvy(centre, l); }
   pus[i] = u;
+}
+
+__global__ __launch_bounds__(64) void inter_candidates_kernel(const kvz_hip_cu_info *__restrict__ cus, const kvz_hip_cu_info *__restrict__ col_cus,
+                                                              const kvz_hip_cu_info *__restrict__ ref_cus, kvz_hip_inter_params p_arg, int reflist, int lx_idx,
+                                                              kvz_hip_me_pu *__restrict__ pus, size_t count, kvz_hip_merge_cand *__restrict__ merge_out)
+{
+  // The POC and list tables are indexed with per-lane values and a merge list is filled at a per-lane position: both
+  // live in LDS (as kernel arguments / registers the compiler had moved them to 288 bytes of scratch memory per lane,
+  // several dependent memory round trips on a kernel that is nothing but latency).
+  __shared__ kvz_hip_inter_params p;
+  __shared__ kvz_hip_merge_cand s_mc[64][5];
+  if (threadIdx.x == 0) {
+    const u32 *src = reinterpret_cast<const u32 *>(&p_arg);
+    u32 *dst = reinterpret_cast<u32 *>(&p);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(p) / 4); ++k) dst[k] = src[k];
+  }
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= count) return;
+  derive_pu(cus, col_cus, ref_cus, p, true, reflist, lx_idx, pus, i, s_mc[threadIdx.x], merge_out);
+}
+
+// which list holds picture ref_idx, and where (search_pu_inter_ref, search_inter.c:1143-1166); in neither: no AMVP pair
+__device__ __forceinline__ void find_list(const kvz_hip_inter_params &p, int &reflist, int &lx)
+{
+  reflist = -1;
+  const int lx_max = p.ref_LX_size[0] > p.ref_LX_size[1] ? p.ref_LX_size[0] : p.ref_LX_size[1];
+  for (lx = 0; lx < lx_max; ++lx) {
+    if (lx < p.ref_LX_size[0] && p.ref_LX[0][lx] == p.ref_idx) { reflist = 0; return; }
+    if (lx < p.ref_LX_size[1] && p.ref_LX[1][lx] == p.ref_idx) { reflist = 1; return; }
+  }
+}
+
+// kvz_hip_inter_candidates_multi_batch: every PU names its picture (pad >> 2); arrays and parameters come from that picture's
+// record in device memory.  The records cannot be checked on the host, so what the one-picture entry refuses is refused
+// per PU here (num_merge_cand -1).
+__global__ __launch_bounds__(64) void inter_candidates_multi_kernel(const kvz_hip_inter_picture *__restrict__ pictures, int n_pictures,
+                                                                    kvz_hip_me_pu *__restrict__ pus, size_t count,
+                                                                    kvz_hip_merge_cand *__restrict__ merge_out)
+{
+  __shared__ kvz_hip_merge_cand s_mc[64][5];
+  const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= count) return;
+  int k = pus[i].pad >> 2;
+  const bool known = k >= 0 && k < n_pictures;
+  if (!known) k = 0;
+  const kvz_hip_inter_picture &pc = pictures[k];
+  const kvz_hip_inter_params &p = pc.params;
+  bool ok = known && pc.cus != nullptr && p.num_refs >= 0 && p.num_refs <= 16 && p.ref_LX_size[0] <= 16 && p.ref_LX_size[1] <= 16 &&
+            p.pic_width > 0 && p.pic_height > 0 && p.tile_x >= 0 && p.tile_y >= 0 && p.in_width >= p.tile_x + p.pic_width &&
+            p.in_height >= p.tile_y + p.pic_height && p.cus_stride * 4 >= p.pic_width && p.col_stride * 4 >= p.in_width &&
+            p.ref_idx >= 0 && p.ref_idx < 16 && !(p.num_refs > 0 && p.tmvp_enable && pc.col_cus == nullptr);
+  int reflist = -1, lx = 0;
+  if (ok) find_list(p, reflist, lx);
+  derive_pu(pc.cus, pc.col_cus, pc.ref_cus, p, ok, reflist, lx, pus, i, s_mc[threadIdx.x], merge_out);
 }
 
 }  // namespace
@@ -368,5 +413,19 @@ extern "C" int kvz_hip_inter_candidates_batch(const kvz_hip_cu_info *cus, const 
   hipStream_t st = ctx_stream(stream);
   hipLaunchKernelGGL(inter_candidates_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, cus, col_cus, ref_cus, p, reflist, lx, pus, count, merge_out);
   KVZ_CHECK_LAUNCH("inter_candidates_kernel");
+  return KVZ_HIP_OK;
+}
+
+extern "C" int kvz_hip_inter_candidates_multi_batch(const kvz_hip_inter_picture *pictures, int n_pictures, kvz_hip_me_pu *pus, size_t count,
+                                                    kvz_hip_merge_cand *merge_out, kvz_hip_stream stream)
+{
+  KVZ_CHECK_CTX();
+  if (n_pictures < 1 || n_pictures > 8192) { set_error_msg("kvz_hip_inter_candidates_multi_batch: 1 .. 8192 pictures"); return KVZ_HIP_ERR_INVALID; }
+  if (count == 0) return KVZ_HIP_OK;
+  if (!pictures || !pus) { set_error_msg("kvz_hip_inter_candidates_multi_batch: null buffer"); return KVZ_HIP_ERR_INVALID; }
+  if (count > 0x7fffffffu) return kvzhip::invalid_arg(__func__);
+  hipStream_t st = ctx_stream(stream);
+  hipLaunchKernelGGL(inter_candidates_multi_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, pictures, n_pictures, pus, count, merge_out);
+  KVZ_CHECK_LAUNCH("inter_candidates_multi_kernel");
   return KVZ_HIP_OK;
 }

@@ -1309,3 +1309,34 @@ def test_search_pu_over_several_pictures_in_one_launch(api, cfg):
     bad["pad"][5] = -4
     got = api.search_pu_multi_batch(pics, refs, bad, prm)
     assert got[3, 7] == -1 and got[5, 7] == -1 and (got[[0, 1, 2, 4, 6, 7], 7] == 0).all()
+
+
+def test_inter_candidates_of_several_pictures_in_one_launch(api):
+    """kvz_hip_inter_candidates_multi_batch: PUs of six pictures (P and B slices, one to four references, a tile, different sizes)
+    interleaved in one launch against one launch per picture; a picture the one-picture entry would refuse, and an index beyond the
+    table, give num_merge_cand -1 for their PUs only"""
+    names = ["p_one_ref", "p_three_refs", "b_two_sided", "b_hier", "p_tile", "p_no_tmvp"]
+    cases = [inter_cand_case(n, 3) for n in names]
+    parts, owners, want_pus, want_merge = [], [], [], []
+    for k, (p, cus, col, refm, pus) in enumerate(cases):
+        pus = pus[:60].copy()
+        pus["pad"] = (k << 2) | (pus["pad"] & 3)
+        a, b = api.inter_candidates_batch(p, cus, col, refm, pus)
+        parts.append(pus); owners += [k] * len(pus); want_pus.append(a.view(ME_PU_DT).ravel()); want_merge.append(b)
+    order = np.random.default_rng(4).permutation(len(owners))
+    allpus = np.concatenate(parts)[order]
+    want_pus, want_merge = np.concatenate(want_pus)[order], np.concatenate(want_merge)[order]
+    pictures = [(p, cus, col, refm) for (p, cus, col, refm, _) in cases]
+    got_pus, got_merge = api.inter_candidates_multi_batch(pictures, allpus)
+    np.testing.assert_array_equal(got_pus.view(ME_PU_DT).ravel(), want_pus)
+    np.testing.assert_array_equal(got_merge, want_merge)
+    # picture 1 made unusable (17 references), one PU pointing past the table
+    broken = [(p.copy(), cus, col, refm) for (p, cus, col, refm) in pictures]
+    broken[1][0]["num_refs"] = 17
+    stray = allpus.copy()
+    stray["pad"][0] = 6 << 2
+    got2 = api.inter_candidates_multi_batch(broken, stray)[0].view(ME_PU_DT).ravel()
+    owner = np.array(owners)[order]
+    assert got2["num_merge_cand"][0] == -1 and (got2["num_merge_cand"][owner == 1] == -1).all()
+    keep = (owner != 1) & (np.arange(len(owner)) != 0)
+    np.testing.assert_array_equal(got2[keep], want_pus[keep])
