@@ -152,6 +152,21 @@ int main(void)
     CHECK(h_pu.mv_cand[0][0] == 12 && h_pu.mv_cand[0][1] == -8 && h_pu.mv_cand[1][0] == 0 && h_pu.mv_cand[1][1] == 0,
           "AMVP = (A1, zero), got (%d, %d) (%d, %d)", h_pu.mv_cand[0][0], h_pu.mv_cand[0][1], h_pu.mv_cand[1][0], h_pu.mv_cand[1][1]);
     CHECK(h_pu.merge[0].usable == 1 && h_pu.merge[0].same_ref == 1 && h_pu.merge[0].mv[0] == 12, "the search's view of merge candidate 0");
+    /* the same PU through the several-pictures entry: one record, picture 0 */
+    kvz_hip_inter_picture h_picrec, *d_picrec = kvz_hip_malloc(sizeof(h_picrec));
+    memset(&h_picrec, 0, sizeof(h_picrec));
+    h_picrec.cus = d_cus; h_picrec.params = ip;
+    memset(&h_pu, 0, sizeof(h_pu));
+    h_pu.x = 32; h_pu.y = 0; h_pu.width = 8; h_pu.height = 8;
+    CHECK(d_picrec && kvz_hip_memcpy_h2d(d_picrec, &h_picrec, sizeof(h_picrec), st) == KVZ_HIP_OK && kvz_hip_memcpy_h2d(d_pu, &h_pu, sizeof(h_pu), st) == KVZ_HIP_OK, "h2d");
+    CHECK(kvz_hip_inter_candidates_multi_batch(d_picrec, 1, d_pu, 1, NULL, st) == KVZ_HIP_OK, "inter_candidates_multi: %s", kvz_hip_last_error());
+    CHECK(kvz_hip_memcpy_d2h(&h_pu, d_pu, sizeof(h_pu), st) == KVZ_HIP_OK, "d2h");
+    CHECK(h_pu.num_merge_cand == 5 && h_pu.mv_cand[0][0] == 12 && h_pu.mv_cand[0][1] == -8 && h_pu.merge[0].mv[0] == 12, "several-pictures entry, picture 0");
+    h_pu.pad = 1 << 2;                                    /* a picture the table does not have */
+    CHECK(kvz_hip_memcpy_h2d(d_pu, &h_pu, sizeof(h_pu), st) == KVZ_HIP_OK, "h2d");
+    CHECK(kvz_hip_inter_candidates_multi_batch(d_picrec, 1, d_pu, 1, NULL, st) == KVZ_HIP_OK, "inter_candidates_multi");
+    CHECK(kvz_hip_memcpy_d2h(&h_pu, d_pu, sizeof(h_pu), st) == KVZ_HIP_OK && h_pu.num_merge_cand == -1, "unknown picture is flagged");
+    kvz_hip_free(d_picrec);
     kvz_hip_free(d_rec); kvz_hip_free(d_pos); kvz_hip_free(d_refs); kvz_hip_free(d_cus); kvz_hip_free(d_pu); kvz_hip_free(d_mc);
   }
 
