@@ -78,8 +78,9 @@ KVZ_HIP_API const char *kvz_hip_last_error(void);    /* text of the calling thre
 KVZ_HIP_API const char *kvz_hip_device_name(void);   /* of the calling thread's current device */
 /* Version of this header's ABI as the library was built (layouts of the kvz_hip_* structs, entry signatures); a host
  * compares it with the KVZ_HIP_ABI_VERSION it was compiled against before it registers the strategies. */
-#define KVZ_HIP_ABI_VERSION 3   /* 2: per-device contexts, kvz_hip_me_params with tile / mv-constraint / mv-rdo fields;
-                                   3: kvz_hip_me_params.cost_to_beat (96 bytes), candidate derivation and intra reference entries */
+#define KVZ_HIP_ABI_VERSION 4   /* 2: per-device contexts, kvz_hip_me_params with tile / mv-constraint / mv-rdo fields;
+                                   3: kvz_hip_me_params.cost_to_beat (96 bytes), candidate derivation and intra reference entries;
+                                   4: kvz_hip_me_params.n_cabac (was reserved), the search service, kvz_hip_halo_exchange */
 KVZ_HIP_API int kvz_hip_abi_version(void);
 
 /* Launch-geometry / kernel-selection knobs for A/B runs (tools/bench_all.py --tune key=v1,v2);
@@ -391,8 +392,9 @@ typedef struct {
                                     kvz_get_mvd_coding_cost_cabac in select_mv_cand) instead of the exp-Golomb estimate */
   int32_t ref_idx;               /* mv_rdo: info->ref_idx of the reference picture searched */
   int32_t refs_before;           /* mv_rdo: pictures of state->frame->ref with poc < current poc (rdo.c:990-998); ref_idx is coded when > 1 */
-  int32_t reserved;
-  const kvz_hip_me_cabac *cabac; /* mv_rdo: DEVICE array of snapshots, indexed by kvz_hip_me_pu.reserved; else unused (NULL) */
+  int32_t n_cabac;               /* mv_rdo: number of snapshots in cabac (>= 1); a PU whose kvz_hip_me_pu.reserved is not an index into it is
+                                    flagged (cost 0xFFFFFFFF, reserved -1) instead of searched.  Else unused (0) */
+  const kvz_hip_me_cabac *cabac; /* mv_rdo: DEVICE array of n_cabac snapshots, indexed by kvz_hip_me_pu.reserved; else unused (NULL) */
   const uint32_t *cost_to_beat;  /* NULL, or a DEVICE array with one entry per PU: *inter_cost as search_pu_inter_ref finds it
                                     (search_inter.c:1239), i.e. the best cost of the reference pictures searched before this one
                                     (MAX_INT for the first).  A PU whose integer search does not get below it skips the fractional
@@ -429,6 +431,61 @@ KVZ_HIP_API int kvz_hip_search_pu_multi_batch(const kvz_hip_pixel *const *pics, 
                                               const kvz_hip_pixel *const *refs, uint32_t ref_stride, int ref_w, int ref_h, int n_planes,
                                               const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
                                               kvz_hip_me_result *results, kvz_hip_stream s);
+
+/* ---- search service: the searches of MANY host threads in shared launches ---- */
+/* The reference runs one CTU job per threadqueue worker (encoderstate.c:777-828: WPP rows, frames in flight under
+ * --owf, tiles), and every worker reaches search_pu_inter (search_inter.c:1451-1520) with ONE PU at a time.  A launch per
+ * PU and per reference picture leaves the chip idle and pays the launch price every time; the service is the piece
+ * between those workers and the kernels of kvz_hip_search_pu_batch:
+ *   - the luma planes the searches read (source pictures, reconstructed pictures) stay resident on the device in
+ *     numbered slots, written rectangle by rectangle as the host produces them;
+ *   - kvz_hip_me_service_search() is called concurrently by the workers, each with one PU and ALL the reference pictures
+ *     of search_pu_inter's loop (:1502-1507).  Requests that are pending at the same time leave in one launch (one per
+ *     size class): whichever caller finds the launch path free takes everything that is queued -- its own request and
+ *     those of the callers that arrived while the previous launch was being issued -- so batches grow with the load and
+ *     an idle service adds no wait;
+ *   - the reference pictures of a PU are searched IN PARALLEL.  The loop of :1502-1507 is sequential only through
+ *     *inter_cost: a picture whose integer search does not get below it skips search_frac and is re-scored with SATD
+ *     (:1239-1252).  Every (PU, picture) unit therefore computes both outcomes -- the search with its fractional stage,
+ *     and the integer vector with the SATD cost, which is search_frac's own first candidate (:1019-1029) -- and the call
+ *     replays the sequential rule over the units before it returns.  results[i] is what search_pu_inter_ref leaves in
+ *     info for picture i when the pictures are visited in order, starting from cost_to_beat;
+ *   - descriptors are read, and results written, by the kernels in page-locked host memory: no copy commands, a caller
+ *     waits on its own results only.
+ * One service per device and picture size.  Thread-safe.  mv_rdo is not available here. */
+typedef struct kvz_hip_me_service kvz_hip_me_service;
+#define KVZ_HIP_SERVICE_MAX_REFS 16
+typedef struct {
+  int32_t width, height;        /* luma size of every picture of the service */
+  int32_t max_pictures;         /* slots, 1..256 */
+  int32_t max_threads;          /* host threads that will ever call kvz_hip_me_service_search (each gets its own result area), 1..1024 */
+  int32_t reserved[4];          /* 0 */
+} kvz_hip_me_service_config;
+typedef struct {
+  int32_t pic_slot;             /* the picture being coded */
+  int32_t n_refs;               /* 1..KVZ_HIP_SERVICE_MAX_REFS */
+  int32_t ref_slot[KVZ_HIP_SERVICE_MAX_REFS];
+  uint32_t cost_to_beat;        /* *inter_cost as search_pu_inter hands it to the first picture (MAX_INT, :1492) */
+  int32_t reserved;
+  kvz_hip_me_params params;     /* as for kvz_hip_search_pu_batch; cost_to_beat / cabac / mv_rdo / size_classes unused (NULL, 0) */
+  kvz_hip_me_pu pu[KVZ_HIP_SERVICE_MAX_REFS];   /* the PU as picture i sees it: mv_cand, extra_mv and merge[].same_ref differ per picture */
+} kvz_hip_me_request;
+typedef struct {
+  uint64_t requests, units;     /* searches asked for; (PU, picture) units searched */
+  uint64_t batches, launches;   /* times the queue was drained; kernel launches (up to three size classes per batch) */
+  uint64_t max_batch_units;
+  uint64_t rects, rect_bytes;   /* kvz_hip_me_service_put_rect calls and the bytes they moved */
+  uint64_t wait_ns;             /* summed over callers: time between posting a request and seeing its results */
+} kvz_hip_me_service_stats;
+KVZ_HIP_API kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *cfg);
+KVZ_HIP_API void kvz_hip_me_service_destroy(kvz_hip_me_service *svc);
+/* Copies a w x h rectangle of a host plane (host points at its top-left pixel) to (x, y) of slot's plane; complete on
+ * return, so a request posted afterwards by any thread reads it. */
+KVZ_HIP_API int kvz_hip_me_service_put_rect(kvz_hip_me_service *svc, int slot, const kvz_hip_pixel *host, uint32_t host_stride,
+                                            int x, int y, int w, int h);
+/* Blocks until the request's results[0 .. n_refs - 1] are there. */
+KVZ_HIP_API int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request *req, kvz_hip_me_result *results);
+KVZ_HIP_API int kvz_hip_me_service_get_stats(kvz_hip_me_service *svc, kvz_hip_me_service_stats *out);
 
 /* ---- candidate derivation next to the search: what a host derives between two dependency fronts ---- */
 /* One record per 4x4 SCU, row-major: the fields of cu_info_t (cu.h:117-153) the candidate derivation and the

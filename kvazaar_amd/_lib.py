@@ -95,6 +95,11 @@ SIGNATURES = {
     "kvz_hip_search_frac_batch": (_I, [_P, _U, _P, _U, _I, _I, _P, _SZ, _P, _P, _P]),
     "kvz_hip_search_pu_batch": (_I, [_P, _U, _I, _I, _P, _U, _I, _I, _P, _SZ, _P, _P, _P]),
     "kvz_hip_search_pu_multi_batch": (_I, [_P, _U, _I, _I, _P, _U, _I, _I, _I, _P, _SZ, _P, _P, _P]),
+    "kvz_hip_me_service_create": (_P, [_P]),
+    "kvz_hip_me_service_destroy": (None, [_P]),
+    "kvz_hip_me_service_put_rect": (_I, [_P, _I, _P, _U, _I, _I, _I, _I]),
+    "kvz_hip_me_service_search": (_I, [_P, _P, _P]),
+    "kvz_hip_me_service_get_stats": (_I, [_P, _P]),
     "kvz_hip_bipred_cost_batch": (_I, [_P, _U, _I, _I, _P, _U, _P, _U, _I, _I, _P, _SZ, _P, _P]),
     "kvz_hip_inter_candidates_batch": (_I, [_P, _P, _P, _P, _P, _SZ, _P, _P]),
     "kvz_hip_inter_candidates_multi_batch": (_I, [_P, _I, _P, _SZ, _P, _P]),

@@ -380,6 +380,8 @@ def search_pu_batch(pic, ref, pus, params, cabac=None, cost_to_beat=None):
         cb = DeviceBuffer.from_numpy(np.ascontiguousarray(cabac).view(np.uint8))
         params = params.copy()
         params.view(np.uint8).reshape(-1)[80:88] = np.frombuffer(np.uint64(cb.ptr).tobytes(), dtype=np.uint8)
+        if int(params.view(np.int32).reshape(-1)[19]) == 0:      # n_cabac: the number of snapshots handed over
+            params.view(np.int32).reshape(-1)[19] = len(cabac)
     a, b, d = DeviceBuffer.from_numpy(pic), DeviceBuffer.from_numpy(ref), DeviceBuffer.from_numpy(pus.view(np.uint8))
     out = DeviceBuffer(max(1, 32 * count))
     check(L.kvz_hip_search_pu_batch(a.ptr, pic.shape[1], pic.shape[1], pic.shape[0], b.ptr, ref.shape[1], ref.shape[1], ref.shape[0],
@@ -504,3 +506,53 @@ def deblock_frame(y, u, v, cus, prm):
     check(L.kvz_hip_deblock_frame(dy.ptr, y.shape[1], du.ptr if du else None, dv.ptr if dv else None, u.shape[1] if u is not None else 0,
                                   y.shape[1], y.shape[0], dc.ptr, prm.ctypes.data, None), "deblock_frame")
     return (dy.to_numpy(np.uint8, y.shape), du.to_numpy(np.uint8, u.shape) if du else None, dv.to_numpy(np.uint8, v.shape) if dv else None)
+
+
+# ---- search service: requests of many host threads in shared launches (include/kvz_hip.h, "search service") ----
+class MeService:
+    """kvz_hip_me_service: resident luma planes in numbered slots + kvz_hip_me_service_search, callable from many threads."""
+
+    def __init__(self, width, height, max_pictures=8, max_threads=64):
+        self.lib = _lib.init()
+        cfg = np.zeros(8, dtype=np.int32)
+        cfg[:4] = (width, height, max_pictures, max_threads)
+        self.w, self.h = int(width), int(height)
+        self.ptr = self.lib.kvz_hip_me_service_create(cfg.ctypes.data)
+        if not self.ptr:
+            raise KvzHipError("kvz_hip_me_service_create failed: %s" % self.lib.kvz_hip_last_error().decode())
+
+    def put_plane(self, slot, plane):
+        plane = np.ascontiguousarray(plane, dtype=np.uint8)
+        assert plane.shape == (self.h, self.w)
+        check(self.lib.kvz_hip_me_service_put_rect(self.ptr, slot, plane.ctypes.data, self.w, 0, 0, self.w, self.h), "me_service_put_rect")
+
+    def put_rect(self, slot, plane, x, y, w, h):
+        """rectangle (x, y, w, h) of a full host plane"""
+        plane = np.ascontiguousarray(plane, dtype=np.uint8)
+        check(self.lib.kvz_hip_me_service_put_rect(self.ptr, slot, plane.ctypes.data + y * plane.shape[1] + x, plane.shape[1], x, y, w, h),
+              "me_service_put_rect")
+
+    def search(self, request):
+        """request: one record laid out as kvz_hip_me_request (1200 bytes).  Returns int32 [n_refs, 8] (= kvz_hip_me_result)."""
+        request = np.ascontiguousarray(request)
+        assert request.nbytes == 1200
+        n = int(request.view(np.int32).reshape(-1)[1])
+        out = np.zeros((max(n, 1), 8), dtype=np.int32)
+        check(self.lib.kvz_hip_me_service_search(self.ptr, request.ctypes.data, out.ctypes.data), "me_service_search")
+        return out[:n]
+
+    def stats(self):
+        s = np.zeros(8, dtype=np.uint64)
+        check(self.lib.kvz_hip_me_service_get_stats(self.ptr, s.ctypes.data), "me_service_get_stats")
+        return dict(zip(("requests", "units", "batches", "launches", "max_batch_units", "rects", "rect_bytes", "wait_ns"), (int(v) for v in s)))
+
+    def close(self):
+        if self.ptr:
+            self.lib.kvz_hip_me_service_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

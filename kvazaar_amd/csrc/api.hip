@@ -144,7 +144,7 @@ int kvz_hip_init(int device)
     set_error_msg("kvz_hip_init: no HIP device visible (this library has no CPU fallback)");
     return KVZ_HIP_ERR_NO_DEVICE;
   }
-  if (device >= n || device >= KVZ_MAX_DEVICES) {
+  if (device < 0 || device >= n || device >= KVZ_MAX_DEVICES) {      // < 0: a negative $KVZ_HIP_DEVICE
     std::snprintf(g_err, sizeof(g_err), "kvz_hip_init: device index %d out of range (%d device(s) visible)", device, n);
     return KVZ_HIP_ERR_INVALID;
   }

@@ -100,7 +100,8 @@ struct frac_no_cost {
   __device__ __forceinline__ u32 cost(int, int, int, u32 &bits) const { bits = 0; return 0; }
   __device__ __forceinline__ bool within(int, int) const { return true; }
 };
-struct frac_result { int mvx, mvy; u32 cost, bitcost; };   // info->best_mv (quarter-pel), best_cost, best_bitcost
+struct frac_result { int mvx, mvy; u32 cost, bitcost; u32 cost0; };   // info->best_mv (quarter-pel), best_cost, best_bitcost; cost0: the integer position's
+                                                                   // SATD + MV cost (search_inter.c:1019-1029) = the re-score of :1242-1252
 
 // d: (x1, y1) block in pic, (x2, y2) its integer-pel position in ref.  fme_level = cfg.fme_level (number of filter
 // steps, 0..4).  out (17 raw SATD costs) and best (hpel / qpel indices) may be null.
@@ -381,6 +382,7 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
   u32 best_cost = s_cost[0];
   if (out && tid == 0) out[0] = best_cost;
   best_cost += mvc.cost(mx, my, 2, best_bitcost);
+  const u32 cost0 = best_cost;
   mx *= 2; my *= 2;                                    // half-pel precision (search_inter.c:1031-1032)
 
   if (fme_level > 0) hor_planes(0, 0, 2, 1);
@@ -429,7 +431,7 @@ __device__ __forceinline__ frac_result search_frac_core(int tid, u8 *lds, const 
     }
     sync();
   }
-  frac_result res = { mx, my, best_cost, best_bitcost };
+  frac_result res = { mx, my, best_cost, best_bitcost, cost0 };
   return res;
 }
 

@@ -42,6 +42,25 @@ int tuning(const char *key, int dflt);     // kvz_hip_set_tuning override or dfl
     }                                                        \
   } while (0)
 
+// ---- search service (serve.hip <-> me_search.hip) ----
+// One (PU, reference picture) unit of a batch, as the kernels read it from page-locked host memory.
+struct serve_unit {                       // 176 bytes
+  int32_t pic_slot, ref_slot;
+  void *result;                           // this unit's serve_result (page-locked host memory)
+  kvz_hip_me_pu pu;
+  kvz_hip_me_params prm;
+};
+struct serve_result {                     // 80 bytes
+  kvz_hip_me_result frac;                 // integer + fractional search: search_pu_inter_ref when info->best_cost < *inter_cost
+  kvz_hip_me_result integer;              // otherwise: the integer vector with its SATD cost (search_inter.c:1242-1252)
+  uint32_t integer_search_cost;           // info->best_cost after the integer search, what :1239 compares with *inter_cost
+  uint32_t done;                          // written last
+  uint32_t pad[2];
+};
+// `constrained`: some fracmv_within_tile rule is active in the batch (wpp_owf or an mv_constraint)
+int serve_launch(int cls, bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,
+                 const serve_unit *units, int count, hipStream_t st);
+
 // Grid sizing for streaming kernels: enough workgroups to fill 256 CUs several
 // times over, capped so that grid-stride loops amortise the launch.
 static inline unsigned stream_grid(size_t work_items, unsigned items_per_block, unsigned max_blocks_per_cu = 128)

@@ -281,7 +281,10 @@ struct me_shared { u32 sad[ME_GROUP]; int cx[ME_GROUP], cy[ME_GROUP]; };
 
 // One PU.  T threads (a wave with wave-private LDS, or the whole workgroup) share the work; every thread
 // carries the same search state, so all decisions are uniform across them.
-template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0, bool RDO = false, bool CONSTR = true>
+// BOTH (the search service, serve.hip): the fractional stage always runs and `out` is a serve_result that also receives the
+// outcome search_pu_inter_ref reaches when the integer search does not beat *inter_cost (:1239-1252), so that the pictures
+// of a PU can be searched in parallel and the sequential rule replayed afterwards.
+template <int MAXW, int T, bool WAVE, int FW = 0, int FH = 0, bool RDO = false, bool CONSTR = true, bool BOTH = false>
 __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, const u8 *__restrict__ pic, u32 pic_stride,
                                                const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm,
                                                kvz_hip_me_result *__restrict__ out, size_t pu_index)
@@ -644,15 +647,46 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
 
   // ---- search_frac, or the SATD re-cost of :1236-1248 when cfg.fme_level == 0 ----
   int mv_x = best_x * 4, mv_y = best_y * 4;
+  const u32 int_cost = best_cost, int_bits = best_bits;
+  u32 cost0 = 0xffffffffu;
   if (best_cost != 0xffffffffu) {
     sync();
     const kvz_hip_block_pair d = { pu.x, pu.y, pu.x + best_x, pu.y + best_y, w, h };
     // :1239: the fractional search only if the integer result beats what the pictures searched before reached
-    const u32 beat = prm.cost_to_beat ? prm.cost_to_beat[pu_index] : 0xffffffffu;
+    const u32 beat = (!BOTH && prm.cost_to_beat) ? prm.cost_to_beat[pu_index] : 0xffffffffu;
     const int level = __builtin_amdgcn_readfirstlane(best_cost < beat ? prm.fme_level : 0);   // the same in every lane: keep the level's branches scalar
     const frac_result fr = search_frac_core<MAXW, T, WAVE, me_cost_model_t<RDO, CONSTR>, FW, FH>(tid, lds, pic, pic_stride, ref, d, level, mvc, (u32 *)nullptr, (i32 *)nullptr);
     best_cost = fr.cost;                               // level 0: satd + bits(int mv) * lambda, the same bits as best_bits
+    cost0 = fr.cost0;
     if (level > 0) { mv_x = fr.mvx; mv_y = fr.mvy; best_bits = fr.bitcost; }
+  }
+
+  if (BOTH) {
+    if (tid == 0) {
+      serve_result *so = reinterpret_cast<serve_result *>(out);
+      kvz_hip_me_result r;
+      u32 unused;
+      r.mv[0] = mv_x; r.mv[1] = mv_y;
+      r.cost = best_cost; r.bitcost = best_bits;
+      int m = mvc.merge_match(mv_x, mv_y);
+      r.merged = m >= 0;
+      r.merge_idx = m >= 0 ? m : mvc.n_merge;
+      r.mv_cand = m >= 0 ? 0 : mvc.select_cand(mv_x, mv_y, unused);
+      r.reserved = 0;
+      so->frac = r;
+      r.mv[0] = best_x * 4; r.mv[1] = best_y * 4;          // :1242-1252: the integer vector, SATD + its bits
+      r.cost = cost0; r.bitcost = int_bits;
+      m = mvc.merge_match(best_x * 4, best_y * 4);
+      r.merged = m >= 0;
+      r.merge_idx = m >= 0 ? m : mvc.n_merge;
+      r.mv_cand = m >= 0 ? 0 : mvc.select_cand(best_x * 4, best_y * 4, unused);
+      so->integer = r;
+      so->integer_search_cost = int_cost;
+      // the caller polls `done` in page-locked host memory: results first, system-wide, then the flag
+      __threadfence_system();
+      __hip_atomic_store(&so->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
   }
 
   if (tid == 0) {
@@ -692,7 +726,7 @@ __device__ __forceinline__ bool pu_orphan(int cls, int mine, int hinted) { retur
 
 // kvz_hip_search_pu_multi_batch: several pictures of one size in a launch (frames in flight, tiles' or instances' pictures).
 // The `pic` / `ref.p` arguments are then DEVICE TABLES of plane pointers, a PU names its pair in pad >> 2, the table length
-// travels in prm.reserved.  A template flag, so that the one-picture kernels compile exactly as before.
+// travels in prm.n_cabac (unused without mv_rdo).  A template flag, so that the one-picture kernels compile exactly as before.
 template <bool MULTI>
 __device__ __forceinline__ bool pick_planes(const u8 *__restrict__ &pic, refplane_t &ref, const kvz_hip_me_pu &pu, int n_planes)
 {
@@ -713,7 +747,7 @@ __global__ __launch_bounds__(T) void search_pu_big_kernel(const u8 *__restrict__
   __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];            // uniform address: the compiler reads it with scalar loads
-  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.reserved)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.n_cabac)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   const int cls = pu_class(pu);
   if (cls != 4) {                                       // the one-wave-per-PU kernels'
     if (pu_orphan(cls, 4, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
@@ -732,7 +766,7 @@ __global__ __launch_bounds__(256) void search_pu_rdo_kernel(const u8 *__restrict
   __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];
-  if (!pu_ok(pu, pic_w, pic_h) || pu.reserved < 0) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  if (!pu_ok(pu, pic_w, pic_h) || pu.reserved < 0 || pu.reserved >= prm.n_cabac) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }   // a stale snapshot index is flagged, never dereferenced
   search_pu_core<64, 256, false, 0, 0, true>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x, blockIdx.x);
 }
 
@@ -750,7 +784,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   if (i >= count) return;
   const kvz_hip_me_pu &pu = pus[i];
   const int lane = threadIdx.x & 63;
-  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.reserved)) { if (lane == 0) flag_bad(out + i); return; }
+  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.n_cabac)) { if (lane == 0) flag_bad(out + i); return; }
   const int cls = pu_class(pu);
   if (cls != 1) {
     if (pu_orphan(cls, 1, prm.size_classes) && lane == 0) flag_bad(out + i);
@@ -795,7 +829,7 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
   __shared__ __attribute__((aligned(16))) u8 lds[(frac_geom<32>::TOTAL + 15) & ~15];
   __shared__ me_shared sh;
   const kvz_hip_me_pu &pu = pus[blockIdx.x];
-  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.reserved)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
+  if (!pu_ok(pu, pic_w, pic_h) || !pick_planes<MULTI>(pic, ref, pu, prm.n_cabac)) { if (threadIdx.x == 0) flag_bad(out + blockIdx.x); return; }
   const int cls = pu_class(pu);
   if (cls != 2) {
     if (pu_orphan(cls, 2, prm.size_classes) && threadIdx.x == 0) flag_bad(out + blockIdx.x);
@@ -805,7 +839,92 @@ __global__ __launch_bounds__(T) void search_pu_medium_wg_kernel(const u8 *__rest
   else search_pu_core<32, T, false, 0, 0, false, CONSTR>(threadIdx.x, lds, &sh, pic, pic_stride, ref, pu, prm, out + blockIdx.x, blockIdx.x);
 }
 
+// ---- the search service's kernels (serve.hip): one (PU, reference picture) unit each, descriptor + parameters read from
+// page-locked host memory ONCE into registers (every later access would be another trip over PCIe), planes resident in
+// slots of one device allocation, results written straight back to the caller's page-locked area ----
+__device__ __forceinline__ void serve_flag_bad(serve_result *so)
+{
+  kvz_hip_me_result r = { { 0, 0 }, 0xffffffffu, 0, 0, 0, 0, -1 };
+  so->frac = r; so->integer = r; so->integer_search_cost = 0xffffffffu;
+  __threadfence_system();
+  __hip_atomic_store(&so->done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool serve_unit_ok(const serve_unit &u, int pic_w, int pic_h, int n_slots)
+{
+  return pu_ok(u.pu, pic_w, pic_h) && u.pic_slot >= 0 && u.pic_slot < n_slots && u.ref_slot >= 0 && u.ref_slot < n_slots;
+}
+
+template <bool CONSTR>
+__global__ __launch_bounds__(256) void serve_small_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
+                                                          const serve_unit *__restrict__ units, int count)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[4][(frac_geom<16>::TOTAL + 15) & ~15];
+  __shared__ me_shared sh[4];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = (int)blockIdx.x * 4 + wv;
+  if (i >= count) return;
+  const serve_unit u = units[i];
+  const int lane = threadIdx.x & 63;
+  serve_result *so = reinterpret_cast<serve_result *>(u.result);
+  if (!serve_unit_ok(u, pic_w, pic_h, n_slots) || pu_class(u.pu) != 1) { if (lane == 0) serve_flag_bad(so); return; }
+  const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
+  const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
+  kvz_hip_me_result *out = reinterpret_cast<kvz_hip_me_result *>(so);
+  if (u.pu.width == 8 && u.pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR, true>(lane, lds[wv], &sh[wv], pic, stride, ref, u.pu, u.prm, out, 0);
+  else if (u.pu.width == 16 && u.pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, CONSTR, true>(lane, lds[wv], &sh[wv], pic, stride, ref, u.pu, u.prm, out, 0);
+  else search_pu_core<16, 64, true, 0, 0, false, CONSTR, true>(lane, lds[wv], &sh[wv], pic, stride, ref, u.pu, u.prm, out, 0);
+}
+
+template <int T, bool CONSTR>
+__global__ __launch_bounds__(T) void serve_medium_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
+                                                         const serve_unit *__restrict__ units, int count)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[(frac_geom<32>::TOTAL + 15) & ~15];
+  __shared__ me_shared sh;
+  const serve_unit u = units[blockIdx.x];
+  serve_result *so = reinterpret_cast<serve_result *>(u.result);
+  if (!serve_unit_ok(u, pic_w, pic_h, n_slots) || pu_class(u.pu) != 2) { if (threadIdx.x == 0) serve_flag_bad(so); return; }
+  const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
+  const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
+  kvz_hip_me_result *out = reinterpret_cast<kvz_hip_me_result *>(so);
+  if (u.pu.width == 32 && u.pu.height == 32) search_pu_core<32, T, false, 32, 32, false, CONSTR, true>(threadIdx.x, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+  else search_pu_core<32, T, false, 0, 0, false, CONSTR, true>(threadIdx.x, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+}
+
+template <int T, bool CONSTR>
+__global__ __launch_bounds__(T) void serve_big_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
+                                                      const serve_unit *__restrict__ units, int count)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
+  __shared__ me_shared sh;
+  const serve_unit u = units[blockIdx.x];
+  serve_result *so = reinterpret_cast<serve_result *>(u.result);
+  if (!serve_unit_ok(u, pic_w, pic_h, n_slots) || pu_class(u.pu) != 4) { if (threadIdx.x == 0) serve_flag_bad(so); return; }
+  const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
+  const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
+  search_pu_core<64, T, false, 0, 0, false, CONSTR, true>(threadIdx.x, lds, &sh, pic, stride, ref, u.pu, u.prm, reinterpret_cast<kvz_hip_me_result *>(so), 0);
+}
+
 }  // namespace
+
+// serve.hip's launch of one size class (1: up to 16x16, 2: up to 32x32, 4: larger) of a batch; `units` is device-visible host memory
+int kvzhip::serve_launch(int cls, bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,
+                         const serve_unit *units, int count, hipStream_t st)
+{
+  if (count <= 0) return KVZ_HIP_OK;
+  if (cls == 1) {
+    if (constrained) hipLaunchKernelGGL(serve_small_kernel<true>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+    else hipLaunchKernelGGL(serve_small_kernel<false>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  } else if (cls == 2) {
+    if (constrained) hipLaunchKernelGGL((serve_medium_kernel<128, true>), dim3((unsigned)count), dim3(128), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+    else hipLaunchKernelGGL((serve_medium_kernel<128, false>), dim3((unsigned)count), dim3(128), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  } else {
+    if (constrained) hipLaunchKernelGGL((serve_big_kernel<512, true>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+    else hipLaunchKernelGGL((serve_big_kernel<512, false>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  }
+  KVZ_CHECK_LAUNCH("search service kernels");
+  return KVZ_HIP_OK;
+}
 
 template <bool CONSTR, bool MULTI>
 static void launch_classes(int classes, const u8 *pic, u32 pic_stride, int pic_w, int pic_h, const refplane_t &r, const kvz_hip_me_pu *pus,
@@ -857,8 +976,8 @@ static int search_pu_launch(const kvz_hip_pixel *pic, uint32_t pic_stride, int p
   // kernel also flags malformed descriptors, so it only goes when the caller vouches for the classes it names.
   if (params->mv_rdo) {
     if (n_planes) { set_error_msg("kvz_hip_search_pu_multi_batch: mv_rdo is a one-picture path"); return KVZ_HIP_ERR_INVALID; }
-    if (!params->cabac || params->refs_before < 1 || params->refs_before > 16 || params->ref_idx < 0 || params->ref_idx >= 16) {
-      set_error_msg("kvz_hip_search_pu_batch: mv_rdo needs the cabac snapshots (device array), refs_before 1..16 and ref_idx 0..15");
+    if (!params->cabac || params->n_cabac < 1 || params->refs_before < 1 || params->refs_before > 16 || params->ref_idx < 0 || params->ref_idx >= 16) {
+      set_error_msg("kvz_hip_search_pu_batch: mv_rdo needs the cabac snapshots (device array of n_cabac >= 1), refs_before 1..16 and ref_idx 0..15");
       return KVZ_HIP_ERR_INVALID;
     }
     hipLaunchKernelGGL(search_pu_rdo_kernel, dim3((unsigned)count), dim3(256), 0, st, pic, pic_stride, pic_w, pic_h, r, pus, *params, results);
@@ -869,7 +988,7 @@ static int search_pu_launch(const kvz_hip_pixel *pic, uint32_t pic_stride, int p
   // (pu_orphan: written by the kernels themselves -- a separate fill would be one more command per dependency front)
   const int classes = (params->size_classes & 7) ? (params->size_classes & 7) : 7;
   prm_v.size_classes = classes;
-  prm_v.reserved = n_planes;
+  prm_v.n_cabac = n_planes;                             // the multi-picture kernels find the table length here (mv_rdo is a one-picture path)
   // thread counts are measured choices: > 32x32: 512 threads per PU 10.5 M/s (256: 9.5, 1024: 6.5); <= 32x32: 128 per PU 48.9 M/s
   // (256: 46.6, one wave: 42.6); <= 16x16: one wave per PU, four per workgroup
   const bool constrained = params->wpp_owf != 0 || params->mv_constraint != 0;

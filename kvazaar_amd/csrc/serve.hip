@@ -1,0 +1,328 @@
+// serve.hip -- the search service: motion searches posted concurrently by many host threads leave in shared launches.
+//
+// Reference: the encoder runs one CTU job per threadqueue worker (src/encoderstate.c:777-828; workers are pthreads,
+// threadqueue.c:263; frames in flight under --owf, encoder.c:59-119), and each worker reaches search_pu_inter
+// (search_inter.c:1451-1520) with one PU at a time and walks its reference pictures in order (:1502-1507).  This file is the
+// piece between those workers and the kernels of me_search.hip (declared in include/kvz_hip.h, "search service").
+//
+//   * No dispatcher thread.  A caller appends its request to the pending list and then either finds the launch path free --
+//     it takes EVERYTHING pending (flat combining) and launches it -- or waits for its results while another caller
+//     launches; a waiting caller that finds the path free launches what has queued up meanwhile, its own request or not.
+//     A launch call takes a few microseconds, which is exactly the window in which other workers' requests pile up:
+//     batches grow with the load, an idle service costs no wait.
+//   * A batch is copied into a ring of page-locked buffers the kernels read directly (one 176-byte unit per PU and
+//     reference picture); results come back the same way, each unit signalling its own `done` word with a system-scope
+//     release store.  There is no copy command and no stream synchronisation on the request path.
+//   * Launches rotate over a few non-blocking streams so that consecutive batches overlap on the device.
+#include "kvz_hip_internal.h"
+
+#include <sched.h>
+#include <time.h>
+
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using namespace kvzhip;
+
+namespace {
+
+constexpr int N_STREAMS = 8;          // launch streams
+constexpr int N_UPLOAD = 8;           // upload streams (put_rect)
+constexpr int N_BATCH = 64;           // ring of batch buffers
+constexpr int BATCH_CAP = 1024;       // units per batch buffer
+constexpr uint64_t WAIT_LIMIT_NS = 20ull * 1000 * 1000 * 1000;    // a request that is not answered in 20 s is a failure
+
+inline uint64_t now_ns()
+{
+  timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec;
+}
+
+struct thread_area {                  // one per calling thread, page-locked
+  serve_result res[KVZ_HIP_SERVICE_MAX_REFS];
+};
+
+struct pending_req {
+  const kvz_hip_me_request *req;      // the caller's request (alive until its results are there)
+  int thread_slot;
+};
+
+}  // namespace
+
+struct kvz_hip_me_service {
+  int device = 0;
+  int w = 0, h = 0, n_slots = 0, max_threads = 0;
+  size_t plane_bytes = 0;
+  u8 *planes = nullptr;                                 // device: n_slots planes, stride = w
+  thread_area *areas = nullptr;                         // page-locked host, device-visible
+  serve_unit *ring = nullptr;                           // page-locked host: N_BATCH x BATCH_CAP units
+  hipStream_t streams[N_STREAMS] = {};
+  hipStream_t up_streams[N_UPLOAD] = {};
+  std::mutex up_mu[N_UPLOAD];
+  hipEvent_t batch_done[N_BATCH] = {};
+  bool batch_used[N_BATCH] = {};
+  uint64_t next_batch = 0;                              // touched under launch_mu only
+  std::mutex pend_mu;
+  std::vector<pending_req> pending;
+  std::atomic<int> n_pending{0};
+  std::mutex launch_mu;
+  std::atomic<int> next_thread{0};
+  std::atomic<int> failed{0};
+  uint64_t id = 0;
+  // statistics
+  std::atomic<uint64_t> st_requests{0}, st_units{0}, st_batches{0}, st_launches{0}, st_max_batch{0}, st_rects{0}, st_rect_bytes{0}, st_wait_ns{0};
+};
+
+namespace {
+
+std::atomic<uint64_t> g_service_ids{1};
+struct thread_binding { uint64_t id; int slot; };
+thread_local thread_binding t_bind = { 0, -1 };
+
+int thread_slot(kvz_hip_me_service *svc)
+{
+  if (t_bind.id == svc->id) return t_bind.slot;
+  const int s = svc->next_thread.fetch_add(1);
+  if (s >= svc->max_threads) return -1;
+  t_bind.id = svc->id; t_bind.slot = s;
+  return s;
+}
+
+// takes everything pending and launches it; launch_mu held by the caller
+int drain_and_launch(kvz_hip_me_service *svc)
+{
+  std::vector<pending_req> grabbed;
+  {
+    std::lock_guard<std::mutex> lk(svc->pend_mu);
+    grabbed.swap(svc->pending);
+    svc->n_pending.store(0, std::memory_order_relaxed);
+  }
+  if (grabbed.empty()) return KVZ_HIP_OK;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != svc->device) {
+    if (hipSetDevice(svc->device) != hipSuccess) { set_error_msg("kvz_hip_me_service: hipSetDevice failed"); return KVZ_HIP_ERR_RUNTIME; }
+  }
+  size_t at = 0;
+  int rc = KVZ_HIP_OK;
+  while (at < grabbed.size() && rc == KVZ_HIP_OK) {
+    const int b = (int)(svc->next_batch % N_BATCH);
+    if (svc->batch_used[b]) {
+      // the buffer's previous batch must have been read: it was launched N_BATCH batches ago
+      const hipError_t e = hipEventSynchronize(svc->batch_done[b]);
+      if (e != hipSuccess) { set_error("kvz_hip_me_service: hipEventSynchronize", e); return KVZ_HIP_ERR_RUNTIME; }
+    }
+    serve_unit *buf = svc->ring + (size_t)b * BATCH_CAP;
+    // units of one size class are contiguous: class 1 from the front, class 2 after it, class 4 at the back
+    int n_cls[3] = { 0, 0, 0 };
+    size_t end = at;
+    int total = 0;
+    while (end < grabbed.size() && total + grabbed[end].req->n_refs <= BATCH_CAP) {
+      const kvz_hip_me_request *r = grabbed[end].req;
+      const int longer = r->pu[0].width > r->pu[0].height ? r->pu[0].width : r->pu[0].height;
+      n_cls[longer <= 16 ? 0 : (longer <= 32 ? 1 : 2)] += r->n_refs;
+      total += r->n_refs;
+      ++end;
+    }
+    int pos[3] = { 0, n_cls[0], n_cls[0] + n_cls[1] };
+    bool constrained = false;
+    for (size_t k = at; k < end; ++k) {
+      const kvz_hip_me_request *r = grabbed[k].req;
+      const int longer = r->pu[0].width > r->pu[0].height ? r->pu[0].width : r->pu[0].height;
+      const int c = longer <= 16 ? 0 : (longer <= 32 ? 1 : 2);
+      thread_area *area = svc->areas + grabbed[k].thread_slot;
+      constrained = constrained || r->params.wpp_owf != 0 || r->params.mv_constraint != 0;
+      for (int i = 0; i < r->n_refs; ++i) {
+        serve_unit &u = buf[pos[c]++];
+        u.pic_slot = r->pic_slot; u.ref_slot = r->ref_slot[i];
+        u.result = &area->res[i];
+        u.pu = r->pu[i];
+        // every PU of a request has the request's shape: the class was taken from pu[0]
+        u.pu.width = r->pu[0].width; u.pu.height = r->pu[0].height;
+        u.prm = r->params;
+        u.prm.cost_to_beat = nullptr; u.prm.cabac = nullptr; u.prm.mv_rdo = 0; u.prm.size_classes = 0;
+        if (u.prm.tile_w == 0 && u.prm.tile_h == 0) { u.prm.tile_x = 0; u.prm.tile_y = 0; u.prm.tile_w = svc->w; u.prm.tile_h = svc->h; }
+      }
+    }
+    hipStream_t st = svc->streams[svc->next_batch % N_STREAMS];
+    int off = 0;
+    static const int cls_id[3] = { 1, 2, 4 };
+    for (int c = 0; c < 3 && rc == KVZ_HIP_OK; ++c) {
+      if (n_cls[c] > 0) {
+        rc = serve_launch(cls_id[c], constrained, svc->planes, svc->plane_bytes, svc->n_slots, (u32)svc->w, svc->w, svc->h, buf + off, n_cls[c], st);
+        svc->st_launches.fetch_add(1, std::memory_order_relaxed);
+      }
+      off += n_cls[c];
+    }
+    if (rc == KVZ_HIP_OK) {
+      const hipError_t e = hipEventRecord(svc->batch_done[b], st);
+      if (e != hipSuccess) { set_error("kvz_hip_me_service: hipEventRecord", e); rc = KVZ_HIP_ERR_RUNTIME; }
+    }
+    svc->batch_used[b] = true;
+    ++svc->next_batch;
+    svc->st_batches.fetch_add(1, std::memory_order_relaxed);
+    svc->st_units.fetch_add((uint64_t)total, std::memory_order_relaxed);
+    uint64_t m = svc->st_max_batch.load(std::memory_order_relaxed);
+    while ((uint64_t)total > m && !svc->st_max_batch.compare_exchange_weak(m, (uint64_t)total)) {}
+    at = end;
+  }
+  if (rc != KVZ_HIP_OK) svc->failed.store(1);
+  return rc;
+}
+
+bool request_ok(const kvz_hip_me_service *svc, const kvz_hip_me_request *r)
+{
+  if (r->n_refs < 1 || r->n_refs > KVZ_HIP_SERVICE_MAX_REFS || r->pic_slot < 0 || r->pic_slot >= svc->n_slots) return false;
+  for (int i = 0; i < r->n_refs; ++i)
+    if (r->ref_slot[i] < 0 || r->ref_slot[i] >= svc->n_slots) return false;
+  const kvz_hip_me_params &p = r->params;
+  if (p.lambda_cost < 0 || p.lambda_cost > (1 << 20) || p.fme_level < 0 || p.fme_level > 4 || p.early_termination < 0 || p.early_termination > 2 ||
+      p.algorithm < 0 || p.algorithm > 3 || (p.algorithm == 3 && (p.search_range < 1 || p.search_range > 64)) || p.mv_rdo) return false;
+  if (p.mv_constraint < 0 || p.mv_constraint > 4) return false;
+  if (!(p.tile_w == 0 && p.tile_h == 0) &&
+      (p.tile_x < 0 || p.tile_y < 0 || p.tile_w <= 0 || p.tile_h <= 0 || p.tile_x + p.tile_w > svc->w || p.tile_y + p.tile_h > svc->h ||
+       (p.tile_x & 63) || (p.tile_y & 63))) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *cfg)
+{
+  if (!cfg || cfg->width < 8 || cfg->height < 8 || cfg->width > 16384 || cfg->height > 16384 || (cfg->width & 3) ||
+      cfg->max_pictures < 1 || cfg->max_pictures > 256 || cfg->max_threads < 1 || cfg->max_threads > 1024) {
+    kvzhip::invalid_arg(__func__);
+    return nullptr;
+  }
+  if (!ctx_enter() && (kvz_hip_init(-1) != KVZ_HIP_OK || !ctx_enter())) return nullptr;
+  kvz_hip_me_service *svc = new (std::nothrow) kvz_hip_me_service;
+  if (!svc) return nullptr;
+  svc->device = ctx_device();
+  svc->w = cfg->width; svc->h = cfg->height; svc->n_slots = cfg->max_pictures; svc->max_threads = cfg->max_threads;
+  svc->plane_bytes = ((size_t)cfg->width * cfg->height + 255) & ~(size_t)255;
+  svc->id = g_service_ids.fetch_add(1);
+  bool ok = hipMalloc((void **)&svc->planes, svc->plane_bytes * svc->n_slots + 64) == hipSuccess;
+  ok = ok && hipMemset(svc->planes, 0, svc->plane_bytes * svc->n_slots + 64) == hipSuccess;
+  // page-locked and device-visible: the kernels read the ring and write the result areas across PCIe
+  ok = ok && hipHostMalloc((void **)&svc->areas, sizeof(thread_area) * svc->max_threads, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&svc->ring, sizeof(serve_unit) * (size_t)N_BATCH * BATCH_CAP, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
+  if (ok) std::memset(svc->areas, 0, sizeof(thread_area) * svc->max_threads);
+  for (int i = 0; i < N_STREAMS && ok; ++i) ok = hipStreamCreateWithFlags(&svc->streams[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < N_UPLOAD && ok; ++i) ok = hipStreamCreateWithFlags(&svc->up_streams[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < N_BATCH && ok; ++i) ok = hipEventCreateWithFlags(&svc->batch_done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    set_error("kvz_hip_me_service_create", hipGetLastError());
+    kvz_hip_me_service_destroy(svc);
+    return nullptr;
+  }
+  (void)hipDeviceSynchronize();
+  return svc;
+}
+
+void kvz_hip_me_service_destroy(kvz_hip_me_service *svc)
+{
+  if (!svc) return;
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur != svc->device) (void)hipSetDevice(svc->device);
+  for (int i = 0; i < N_STREAMS; ++i) if (svc->streams[i]) { (void)hipStreamSynchronize(svc->streams[i]); (void)hipStreamDestroy(svc->streams[i]); }
+  for (int i = 0; i < N_UPLOAD; ++i) if (svc->up_streams[i]) { (void)hipStreamSynchronize(svc->up_streams[i]); (void)hipStreamDestroy(svc->up_streams[i]); }
+  for (int i = 0; i < N_BATCH; ++i) if (svc->batch_done[i]) (void)hipEventDestroy(svc->batch_done[i]);
+  if (svc->planes) (void)hipFree(svc->planes);
+  if (svc->areas) (void)hipHostFree(svc->areas);
+  if (svc->ring) (void)hipHostFree(svc->ring);
+  delete svc;
+}
+
+int kvz_hip_me_service_put_rect(kvz_hip_me_service *svc, int slot, const kvz_hip_pixel *host, uint32_t host_stride, int x, int y, int w, int h)
+{
+  if (!svc || !host || slot < 0 || slot >= svc->n_slots || x < 0 || y < 0 || w <= 0 || h <= 0 || x + w > svc->w || y + h > svc->h || host_stride < (uint32_t)w)
+    return kvzhip::invalid_arg(__func__);
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != svc->device) {
+    if (hipSetDevice(svc->device) != hipSuccess) { set_error_msg("kvz_hip_me_service_put_rect: hipSetDevice failed"); return KVZ_HIP_ERR_RUNTIME; }
+  }
+  const int ts = thread_slot(svc);
+  const int k = (ts < 0 ? 0 : ts) % N_UPLOAD;
+  u8 *dst = svc->planes + (size_t)slot * svc->plane_bytes + (size_t)y * svc->w + x;
+  hipError_t e;
+  {
+    std::lock_guard<std::mutex> lk(svc->up_mu[k]);
+    e = hipMemcpy2DAsync(dst, (size_t)svc->w, host, host_stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, svc->up_streams[k]);
+    if (e == hipSuccess) e = hipStreamSynchronize(svc->up_streams[k]);
+  }
+  if (e != hipSuccess) { set_error("kvz_hip_me_service_put_rect", e); return KVZ_HIP_ERR_RUNTIME; }
+  svc->st_rects.fetch_add(1, std::memory_order_relaxed);
+  svc->st_rect_bytes.fetch_add((uint64_t)w * h, std::memory_order_relaxed);
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request *req, kvz_hip_me_result *results)
+{
+  if (!svc || !req || !results) return kvzhip::invalid_arg(__func__);
+  if (!request_ok(svc, req)) { set_error_msg("kvz_hip_me_service_search: bad request (slots, n_refs, parameters; mv_rdo is not served)"); return KVZ_HIP_ERR_INVALID; }
+  if (svc->failed.load()) { set_error_msg("kvz_hip_me_service_search: the service has failed earlier"); return KVZ_HIP_ERR_RUNTIME; }
+  const int ts = thread_slot(svc);
+  if (ts < 0) { set_error_msg("kvz_hip_me_service_search: more calling threads than max_threads"); return KVZ_HIP_ERR_INVALID; }
+  thread_area *area = svc->areas + ts;
+  const int n = req->n_refs;
+  for (int i = 0; i < n; ++i) __atomic_store_n(&area->res[i].done, 0u, __ATOMIC_RELAXED);
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  const uint64_t t0 = now_ns();
+  {
+    std::lock_guard<std::mutex> lk(svc->pend_mu);
+    svc->pending.push_back(pending_req{ req, ts });
+    svc->n_pending.fetch_add(1, std::memory_order_relaxed);
+  }
+  svc->st_requests.fetch_add(1, std::memory_order_relaxed);
+  int spins = 0;
+  for (;;) {
+    bool all = true;
+    for (int i = 0; i < n; ++i)
+      if (__atomic_load_n(&area->res[i].done, __ATOMIC_ACQUIRE) == 0u) { all = false; break; }
+    if (all) break;
+    if (svc->n_pending.load(std::memory_order_relaxed) > 0 && svc->launch_mu.try_lock()) {
+      const int rc = drain_and_launch(svc);
+      svc->launch_mu.unlock();
+      if (rc != KVZ_HIP_OK) return rc;
+      continue;
+    }
+    if (svc->failed.load()) { set_error_msg("kvz_hip_me_service_search: a launch failed"); return KVZ_HIP_ERR_RUNTIME; }
+    if (++spins < 64) {
+      __builtin_ia32_pause();
+    } else {
+      sched_yield();
+      if ((spins & 1023) == 0 && now_ns() - t0 > WAIT_LIMIT_NS) {
+        svc->failed.store(1);
+        set_error_msg("kvz_hip_me_service_search: no answer from the device within 20 s");
+        return KVZ_HIP_ERR_RUNTIME;
+      }
+    }
+  }
+  svc->st_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+  // the sequential rule of search_pu_inter's loop (search_inter.c:1502-1507 with :1239-1252 and :1275-1290)
+  uint32_t running = req->cost_to_beat;
+  for (int i = 0; i < n; ++i) {
+    const serve_result &sr = area->res[i];
+    const kvz_hip_me_result &pick = (req->params.fme_level > 0 && sr.integer_search_cost < running) ? sr.frac : sr.integer;
+    results[i] = pick;
+    if (pick.reserved == -1) { set_error_msg("kvz_hip_me_service_search: malformed PU descriptor"); return KVZ_HIP_ERR_INVALID; }
+    if (pick.cost < running) running = pick.cost;
+  }
+  return KVZ_HIP_OK;
+}
+
+int kvz_hip_me_service_get_stats(kvz_hip_me_service *svc, kvz_hip_me_service_stats *out)
+{
+  if (!svc || !out) return kvzhip::invalid_arg(__func__);
+  out->requests = svc->st_requests.load(); out->units = svc->st_units.load(); out->batches = svc->st_batches.load();
+  out->launches = svc->st_launches.load(); out->max_batch_units = svc->st_max_batch.load(); out->rects = svc->st_rects.load();
+  out->rect_bytes = svc->st_rect_bytes.load(); out->wait_ns = svc->st_wait_ns.load();
+  return KVZ_HIP_OK;
+}
+
+}  // extern "C"

@@ -740,8 +740,12 @@ static void rec_copy_plane(kvz_pixel *dst, const kvz_picture *p, int w, int h)
   for (int r = 0; r < h; ++r) memcpy(dst + (size_t)r * w, p->y + (size_t)r * p->stride, (size_t)w);
 }
 
+/* optional: the search answered by the product's search service, from every threadqueue worker at once (ref_serve.c) */
+int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost);
+
 void __wrap_kvz_search_cu_inter(encoder_state_t * const state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
 {
+  if (svc_serve_cu_inter(state, x, y, depth, lcu, inter_cost, inter_bitcost)) return;
   if (gpu_search_serve(state, x, y, depth, lcu, inter_cost, inter_bitcost)) return;
   const encoder_control_t *ctrl = state->encoder_control;
   const int usable = g_rec.on && state->frame->ref->used_size == 1 && state->frame->slicetype == KVZ_SLICE_P &&

@@ -138,12 +138,19 @@ ME_PARAMS = np.dtype([("lambda_cost", "<i4"), ("early_termination", "<i4"), ("ma
                       ("wpp_owf", "<i4"), ("ref_delay_px", "<i4"), ("max_ref_lcu_down", "<i4"), ("max_ref_lcu_right", "<i4"),
                       ("algorithm", "<i4"), ("search_range", "<i4"), ("size_classes", "<i4"), ("mv_constraint", "<i4"),
                       ("tile_x", "<i4"), ("tile_y", "<i4"), ("tile_w", "<i4"), ("tile_h", "<i4"),
-                      ("mv_rdo", "<i4"), ("ref_idx", "<i4"), ("refs_before", "<i4"), ("reserved", "<i4"), ("cabac", "<u8"),
+                      ("mv_rdo", "<i4"), ("ref_idx", "<i4"), ("refs_before", "<i4"), ("n_cabac", "<i4"), ("cabac", "<u8"),
                       ("cost_to_beat", "<u8")])
 ME_CABAC = np.dtype([("range", "<u2"), ("ctx", "u1", (8,)), ("pad", "u1", (6,))])
 ME_RESULT = np.dtype([("mv", "<i4", (2,)), ("cost", "<u4"), ("bitcost", "<u4"), ("merged", "<i4"), ("merge_idx", "<i4"),
                       ("mv_cand", "<i4"), ("reserved", "<i4")])
 assert ME_PU.itemsize == 64 and ME_PARAMS.itemsize == 96 and ME_RESULT.itemsize == 32 and ME_CABAC.itemsize == 16
+# the search service (kvz_hip_me_request / _service_config / _service_stats)
+ME_REQUEST = np.dtype([("pic_slot", "<i4"), ("n_refs", "<i4"), ("ref_slot", "<i4", (16,)), ("cost_to_beat", "<u4"), ("reserved", "<i4"),
+                       ("params", ME_PARAMS), ("pu", ME_PU, (16,))])
+ME_SERVICE_CONFIG = np.dtype([("width", "<i4"), ("height", "<i4"), ("max_pictures", "<i4"), ("max_threads", "<i4"), ("reserved", "<i4", (4,))])
+ME_SERVICE_STATS = np.dtype([("requests", "<u8"), ("units", "<u8"), ("batches", "<u8"), ("launches", "<u8"), ("max_batch_units", "<u8"),
+                             ("rects", "<u8"), ("rect_bytes", "<u8"), ("wait_ns", "<u8")])
+assert ME_REQUEST.itemsize == 1200
 
 
 def me_params(lambda_cost=20, early_termination=1, max_steps=0xFFFFFFFF, fme_level=4, wpp_owf=0, ref_delay_px=0,

@@ -647,3 +647,26 @@ def encode_with_gpu_search(frames, w, h, opts, lib_path, strategy=None, deblock=
                   "bipred_launches"), (int(v) for v in out)))
     c["deblocked_pictures"], c["deblock_lcu_calls_skipped"] = int(dbk[0]), int(dbk[1])
     return bitstream, c
+
+
+def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8, shadow=False):
+    """ref_encode with every 2Nx2N inter search of the encoder answered by the product's search service
+    (kvz_hip_me_service_search; oracle/ref_serve.c), from all of the encoder's own worker threads at once.
+    min_size: PUs narrower than this run the reference's own search.  shadow: every served search is repeated by the
+    reference's search and compared (the reference's result is kept).
+    -> (bitstream, dict(served, passed_on, failed, shadow_mismatch, upload_rects, search_wait_ns, upload_ns, cand_ns,
+    requests, units, batches, launches, max_batch_units, rects, rect_bytes, wait_ns))"""
+    L = lib()
+    L.ref_service_begin.restype = C.c_int
+    L.ref_service_begin.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.ref_service_end.restype = None
+    L.ref_service_end.argtypes = [C.POINTER(C.c_longlong)]
+    assert L.ref_service_begin(lib_path.encode(), w, h, max_threads, min_size, 1 if shadow else 0) == 0
+    out = (C.c_longlong * 16)()
+    try:
+        bitstream, _ = encode(frames, w, h, opts)
+    finally:
+        L.ref_service_end(out)
+    keys = ("served", "passed_on", "failed", "shadow_mismatch", "upload_rects", "search_wait_ns", "upload_ns", "cand_ns",
+            "requests", "units", "batches", "launches", "max_batch_units", "rects", "rect_bytes", "wait_ns")
+    return bitstream, dict(zip(keys, (int(v) for v in out)))

@@ -123,7 +123,8 @@ def test_python_record_layouts_match_the_header(tmp_path):
     import patterns as P
     pairs = [("kvz_hip_me_pu", P.ME_PU), ("kvz_hip_me_params", P.ME_PARAMS), ("kvz_hip_me_result", P.ME_RESULT), ("kvz_hip_me_cabac", P.ME_CABAC),
              ("kvz_hip_cu_info", P.CU_INFO), ("kvz_hip_deblock_params", P.DEBLOCK_PARAMS), ("kvz_hip_inter_params", P.INTER_PARAMS),
-             ("kvz_hip_merge_cand", P.MERGE_CAND)]
+             ("kvz_hip_merge_cand", P.MERGE_CAND), ("kvz_hip_me_request", P.ME_REQUEST), ("kvz_hip_me_service_config", P.ME_SERVICE_CONFIG),
+             ("kvz_hip_me_service_stats", P.ME_SERVICE_STATS)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "kvz_hip.h"', 'int main(void) {']
     for cname, dt in pairs:
         lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

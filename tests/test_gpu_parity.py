@@ -1142,7 +1142,7 @@ def test_contexts_per_device_and_thread_binding(api):
     assert ndev >= 1
     assert L.kvz_hip_init(ndev) == -2 and b"out of range" in L.kvz_hip_last_error()
     assert L.kvz_hip_init(0) == 0 and L.kvz_hip_get_device() == 0
-    assert L.kvz_hip_abi_version() == 3
+    assert L.kvz_hip_abi_version() == 4
     errs = []
 
     def work(seed, device):

@@ -1,0 +1,183 @@
+"""GPU: the search service (include/kvz_hip.h "search service", kvazaar_amd/csrc/serve.hip).
+
+1. Requests posted from many host threads -- one PU with all its reference pictures each -- against the oracle's
+   search run picture after picture under the running cost, i.e. the loop of search_pu_inter
+   (search_inter.c:1502-1507 with :1239-1252).
+2. The compiled reference ENCODER with its own thread pool (WPP, frames in flight under --owf), every 2Nx2N inter
+   search of every worker answered by the service: the bitstream must be the untouched encoder's, byte for byte
+   (needs oracle/_ref/libkvzref.so, which travels with gpurun)."""
+import concurrent.futures
+import os
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_lib as R
+from patterns import ME_PARAMS, ME_PU, ME_REQUEST, me_frames, me_params, me_pus_in_tile, me_random_pus
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so")
+MAX_INT = 2147483647
+
+
+@pytest.fixture(scope="module")
+def api():
+    from kvazaar_amd import api as a, _lib
+    _lib.init(0)
+    return a
+
+
+def _sequential_loop(pic, refs, pus_per_ref, prm, start=MAX_INT):
+    """the oracle's search of every PU, picture after picture under the running cost -> [n_pus, n_refs] ME_RESULT records as int32"""
+    n = len(pus_per_ref[0])
+    running = np.full(n, start, dtype=np.uint32)
+    out = np.zeros((n, len(refs), 8), dtype=np.int32)
+    for r, ref in enumerate(refs):
+        res = O.search_pu_batch(pic, ref, pus_per_ref[r], prm, cost_to_beat=running)
+        out[:, r] = np.asarray(res).view(np.int32).reshape(n, 8)
+        running = np.minimum(running, np.asarray(res["cost"], dtype=np.uint32))
+    return out
+
+
+SERVICE_CASES = [
+    dict(),                                                     # hexbs, fme 4, early termination
+    dict(fme_level=2, early_termination=2, lambda_cost=37),
+    dict(algorithm=1, fme_level=0),                             # dia, no fractional stage: both outcomes coincide
+    dict(algorithm=2, early_termination=0, lambda_cost=9),      # tz
+    dict(wpp_owf=1, ref_delay_px=10, lambda_cost=25),           # the availability rule of --owf with WPP
+    dict(mv_constraint=4, tile=(64, 0, 128, 128)),
+    dict(algorithm=3, search_range=8, fme_level=1),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SERVICE_CASES)))
+def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case):
+    w, h, n_refs = 192, 128, 4
+    prm = me_params(**SERVICE_CASES[case])
+    planes = [me_frames(w, h, 300 + 7 * case + k, motion) for k, motion in enumerate(((3, -2), (-5, 4), (0, 0), (9, 7)))]
+    pic = planes[0][0]
+    refs = [p[1] for p in planes]
+    base = me_pus_in_tile(me_random_pus(w, h, 90, 4100 + case, hint=(-10, 8)), prm)
+    g = np.random.default_rng(77 + case)
+    pus_per_ref = []
+    for r in range(n_refs):
+        q = base.copy()
+        if r:                                                   # what differs per picture: AMVP pair, start vector, same_ref
+            q["mv_cand"] = g.integers(-40, 41, q["mv_cand"].shape)
+            q["extra_mv"] = g.integers(-24, 25, q["extra_mv"].shape)
+            q["merge"]["same_ref"] = g.integers(0, 2, q["merge"]["same_ref"].shape)
+        pus_per_ref.append(q)
+    want = _sequential_loop(pic, refs, pus_per_ref, prm)
+    # a second start value: something the first pictures cannot beat for many PUs
+    low = int(np.median(want[:, 0, 2].astype(np.uint32)))
+    want_low = _sequential_loop(pic, refs, pus_per_ref, prm, start=low)
+
+    svc = api.MeService(w, h, max_pictures=6, max_threads=32)
+    try:
+        svc.put_plane(0, pic)
+        for r in range(n_refs):                                 # rectangles: the way a picture under reconstruction arrives
+            svc.put_rect(1 + r, refs[r], 0, 0, w, 64)
+            svc.put_rect(1 + r, refs[r], 0, 64, 64, h - 64)
+            svc.put_rect(1 + r, refs[r], 64, 64, w - 64, h - 64)
+
+        def one(job):
+            i, start = job
+            nr = 1 + (i % n_refs) if start != MAX_INT else n_refs        # requests of 1..4 pictures
+            req = np.zeros(1, dtype=ME_REQUEST)
+            req["pic_slot"], req["n_refs"], req["cost_to_beat"] = 0, nr, start
+            req["ref_slot"][0, :n_refs] = 1 + np.arange(n_refs)
+            req["params"] = prm[0]
+            for r in range(nr):
+                req["pu"][0, r] = pus_per_ref[r][i]
+            return i, start, svc.search(req)
+
+        jobs = [(i, MAX_INT) for i in range(len(base))] + [(i, low) for i in range(len(base))]
+        with concurrent.futures.ThreadPoolExecutor(max_workers=16) as ex:
+            for i, start, got in ex.map(one, jobs):
+                ref_tab = want if start == MAX_INT else want_low
+                np.testing.assert_array_equal(got, ref_tab[i, :len(got)], err_msg="case %d PU %d start %d" % (case, i, start))
+        st = svc.stats()
+        assert st["requests"] == len(jobs) and st["units"] >= st["requests"] and st["batches"] <= st["requests"]
+        print("case %d: %d requests (%d units) in %d batches / %d launches, largest batch %d units, mean wait %.1f us"
+              % (case, st["requests"], st["units"], st["batches"], st["launches"], st["max_batch_units"], st["wait_ns"] / 1e3 / st["requests"]))
+    finally:
+        svc.close()
+
+
+def test_service_refuses_bad_requests(api):
+    from kvazaar_amd._lib import KvzHipError
+    svc = api.MeService(64, 64, max_pictures=2, max_threads=2)
+    try:
+        plane = np.zeros((64, 64), np.uint8)
+        svc.put_plane(0, plane)
+        svc.put_plane(1, plane)
+        req = np.zeros(1, dtype=ME_REQUEST)
+        req["pic_slot"], req["n_refs"], req["cost_to_beat"] = 0, 1, MAX_INT
+        req["ref_slot"][0, 0] = 1
+        req["params"] = me_params()[0]
+        req["pu"][0, 0]["width"] = req["pu"][0, 0]["height"] = 16
+        assert svc.search(req).shape == (1, 8)
+        for field, value in (("n_refs", 0), ("n_refs", 17), ("pic_slot", 2)):
+            bad = req.copy()
+            bad[field] = value
+            with pytest.raises(KvzHipError):
+                svc.search(bad)
+        bad = req.copy()
+        bad["ref_slot"][0, 0] = 5
+        with pytest.raises(KvzHipError):
+            svc.search(bad)
+        bad = req.copy()
+        bad["params"]["mv_rdo"] = 1
+        with pytest.raises(KvzHipError):
+            svc.search(bad)
+        bad = req.copy()
+        bad["pu"][0, 0]["x"] = 56                               # the PU leaves the picture: flagged by the kernel
+        with pytest.raises(KvzHipError):
+            svc.search(bad)
+        with pytest.raises(KvzHipError):
+            svc.put_rect(0, plane, 32, 32, 40, 8)
+    finally:
+        svc.close()
+
+
+ENCODE_CASES = [
+    # WPP workers and frames in flight: every worker posts its searches, reference pictures arrive as staircases
+    (320, 192, 8, "preset=medium,qp=30,threads=6,owf=2", 8),
+    (320, 192, 10, "preset=medium,qp=27,threads=8", 8),                                 # --owf auto, B pyramid, four references
+    (256, 256, 6, "preset=medium,ref=2,gop=0,qp=33,threads=4,owf=3,period=0", 8),       # P frames only, long chains of pictures in flight
+    (320, 192, 6, "preset=medium,me=tz,qp=29,threads=5,owf=1,sao=off", 8),              # deblocking delay only
+    (320, 192, 6, "preset=medium,me=full8,qp=31,threads=4,owf=2,deblock=0,sao=off", 16),  # no filter delay; small PUs stay with the reference
+    (320, 192, 5, "preset=medium,qp=32,threads=4,owf=0", 8),                            # complete reference pictures only
+    (320, 192, 5, "preset=medium,qp=32,threads=0", 8),                                  # no thread pool at all
+]
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("w,h,n,opts,min_size", ENCODE_CASES)
+def test_reference_encoder_with_worker_threads_served_by_the_service(w, h, n, opts, min_size):
+    frames = R.synthetic_sequence(w, h, n, seed=11)
+    t0 = time.perf_counter()
+    plain, _ = R.encode(frames, w, h, opts)
+    t1 = time.perf_counter()
+    served, c = R.encode_with_service(frames, w, h, opts, LIB, max_threads=32, min_size=min_size)
+    t2 = time.perf_counter()
+    print("%dx%d x %d (%s): %d searches served (%d left to the reference) in %d batches / %d launches, largest batch %d units, "
+          "%d rectangles uploaded; %.2f s untouched, %.2f s served"
+          % (w, h, n, opts, c["served"], c["passed_on"], c["batches"], c["launches"], c["max_batch_units"], c["upload_rects"], t1 - t0, t2 - t1))
+    assert c["failed"] == 0 and c["served"] > 100
+    assert served == plain, "bitstreams differ (%d vs %d bytes)" % (len(served), len(plain))
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+def test_shadow_mode_agrees_search_by_search():
+    """every served search repeated by the reference's own search on the worker that posted it, from the same encoder state"""
+    w, h, n, opts = 320, 192, 6, "preset=medium,qp=28,threads=6,owf=2"
+    frames = R.synthetic_sequence(w, h, n, seed=3)
+    plain, _ = R.encode(frames, w, h, opts)
+    served, c = R.encode_with_service(frames, w, h, opts, LIB, max_threads=32, min_size=8, shadow=True)
+    assert c["failed"] == 0 and c["served"] > 100 and c["shadow_mismatch"] == 0
+    assert served == plain
