@@ -72,10 +72,10 @@ __device__ __forceinline__ unsigned unit_order(unsigned ux, unsigned uy)
 }
 
 // is_a0_cand_coded / is_b0_cand_coded (inter.c:566-705): the neighbour's unit precedes the aligned square at the PU's
-// lower-left / upper-right corner; everything left of or above the LCU is coded
+// lower-left / upper-right corner; other LCUs are coded when they precede this one in raster order
 __device__ __forceinline__ bool corner_unit_coded(int nx, int ny, int sx, int sy)
 {
-  if ((nx >> 6) != (sx >> 6) || (ny >> 6) != (sy >> 6)) return nx < sx || ny < sy;
+  if ((nx >> 6) != (sx >> 6) || (ny >> 6) != (sy >> 6)) return (ny >> 6) < (sy >> 6) || ((ny >> 6) == (sy >> 6) && (nx >> 6) < (sx >> 6));
   return unit_order((unsigned)(nx & 63) >> 2, (unsigned)(ny & 63) >> 2) < unit_order((unsigned)(sx & 63) >> 2, (unsigned)(sy & 63) >> 2);
 }
 

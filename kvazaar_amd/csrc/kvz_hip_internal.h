@@ -58,7 +58,7 @@ struct serve_result {                     // 80 bytes
   uint32_t pad[2];
 };
 // `constrained`: some fracmv_within_tile rule is active in the batch (wpp_owf or an mv_constraint)
-int serve_launch(int cls, bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,
+int serve_launch(bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,
                  const serve_unit *units, int count, hipStream_t st);
 
 // Grid sizing for streaming kernels: enough workgroups to fill 256 CUs several

@@ -854,75 +854,48 @@ __device__ __forceinline__ bool serve_unit_ok(const serve_unit &u, int pic_w, in
   return pu_ok(u.pu, pic_w, pic_h) && u.pic_slot >= 0 && u.pic_slot < n_slots && u.ref_slot >= 0 && u.ref_slot < n_slots;
 }
 
+// One launch per batch whatever the PU sizes in it (the launch path is what the callers queue for: one command instead of one
+// per size class).  A workgroup of 512 threads takes one unit; the waves its size class does not need leave at once --
+// s_barrier counts only the waves of a workgroup that have not terminated -- so a PU up to 16x16 is searched by one wave
+// with wave-local fences, one up to 32x32 by 128 threads, a larger one by all 512: the thread counts of the batched kernels above.
 template <bool CONSTR>
-__global__ __launch_bounds__(256) void serve_small_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
-                                                          const serve_unit *__restrict__ units, int count)
-{
-  __shared__ __attribute__((aligned(16))) u8 lds[4][(frac_geom<16>::TOTAL + 15) & ~15];
-  __shared__ me_shared sh[4];
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = (int)blockIdx.x * 4 + wv;
-  if (i >= count) return;
-  const serve_unit u = units[i];
-  const int lane = threadIdx.x & 63;
-  serve_result *so = reinterpret_cast<serve_result *>(u.result);
-  if (!serve_unit_ok(u, pic_w, pic_h, n_slots) || pu_class(u.pu) != 1) { if (lane == 0) serve_flag_bad(so); return; }
-  const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
-  const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
-  kvz_hip_me_result *out = reinterpret_cast<kvz_hip_me_result *>(so);
-  if (u.pu.width == 8 && u.pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR, true>(lane, lds[wv], &sh[wv], pic, stride, ref, u.pu, u.prm, out, 0);
-  else if (u.pu.width == 16 && u.pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, CONSTR, true>(lane, lds[wv], &sh[wv], pic, stride, ref, u.pu, u.prm, out, 0);
-  else search_pu_core<16, 64, true, 0, 0, false, CONSTR, true>(lane, lds[wv], &sh[wv], pic, stride, ref, u.pu, u.prm, out, 0);
-}
-
-template <int T, bool CONSTR>
-__global__ __launch_bounds__(T) void serve_medium_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
-                                                         const serve_unit *__restrict__ units, int count)
-{
-  __shared__ __attribute__((aligned(16))) u8 lds[(frac_geom<32>::TOTAL + 15) & ~15];
-  __shared__ me_shared sh;
-  const serve_unit u = units[blockIdx.x];
-  serve_result *so = reinterpret_cast<serve_result *>(u.result);
-  if (!serve_unit_ok(u, pic_w, pic_h, n_slots) || pu_class(u.pu) != 2) { if (threadIdx.x == 0) serve_flag_bad(so); return; }
-  const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
-  const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
-  kvz_hip_me_result *out = reinterpret_cast<kvz_hip_me_result *>(so);
-  if (u.pu.width == 32 && u.pu.height == 32) search_pu_core<32, T, false, 32, 32, false, CONSTR, true>(threadIdx.x, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
-  else search_pu_core<32, T, false, 0, 0, false, CONSTR, true>(threadIdx.x, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
-}
-
-template <int T, bool CONSTR>
-__global__ __launch_bounds__(T) void serve_big_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
-                                                      const serve_unit *__restrict__ units, int count)
+__global__ __launch_bounds__(512) void serve_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
+                                                    const serve_unit *__restrict__ units, int count)
 {
   __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
   __shared__ me_shared sh;
+  if ((int)blockIdx.x >= count) return;
   const serve_unit u = units[blockIdx.x];
   serve_result *so = reinterpret_cast<serve_result *>(u.result);
-  if (!serve_unit_ok(u, pic_w, pic_h, n_slots) || pu_class(u.pu) != 4) { if (threadIdx.x == 0) serve_flag_bad(so); return; }
+  if (!serve_unit_ok(u, pic_w, pic_h, n_slots)) { if (threadIdx.x == 0) serve_flag_bad(so); return; }
+  const int cls = pu_class(u.pu);
+  const int tid = threadIdx.x;
+  if (tid >= (cls == 1 ? 64 : (cls == 2 ? 128 : 512))) return;
   const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
   const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
-  search_pu_core<64, T, false, 0, 0, false, CONSTR, true>(threadIdx.x, lds, &sh, pic, stride, ref, u.pu, u.prm, reinterpret_cast<kvz_hip_me_result *>(so), 0);
+  kvz_hip_me_result *out = reinterpret_cast<kvz_hip_me_result *>(so);
+  if (cls == 1) {
+    if (u.pu.width == 8 && u.pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+    else if (u.pu.width == 16 && u.pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, CONSTR, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+    else search_pu_core<16, 64, true, 0, 0, false, CONSTR, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+  } else if (cls == 2) {
+    if (u.pu.width == 32 && u.pu.height == 32) search_pu_core<32, 128, false, 32, 32, false, CONSTR, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+    else search_pu_core<32, 128, false, 0, 0, false, CONSTR, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+  } else {
+    search_pu_core<64, 512, false, 0, 0, false, CONSTR, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+  }
 }
 
 }  // namespace
 
-// serve.hip's launch of one size class (1: up to 16x16, 2: up to 32x32, 4: larger) of a batch; `units` is device-visible host memory
-int kvzhip::serve_launch(int cls, bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,
+// serve.hip's launch of one batch; `units` is device-visible host memory
+int kvzhip::serve_launch(bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,
                          const serve_unit *units, int count, hipStream_t st)
 {
   if (count <= 0) return KVZ_HIP_OK;
-  if (cls == 1) {
-    if (constrained) hipLaunchKernelGGL(serve_small_kernel<true>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
-    else hipLaunchKernelGGL(serve_small_kernel<false>, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
-  } else if (cls == 2) {
-    if (constrained) hipLaunchKernelGGL((serve_medium_kernel<128, true>), dim3((unsigned)count), dim3(128), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
-    else hipLaunchKernelGGL((serve_medium_kernel<128, false>), dim3((unsigned)count), dim3(128), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
-  } else {
-    if (constrained) hipLaunchKernelGGL((serve_big_kernel<512, true>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
-    else hipLaunchKernelGGL((serve_big_kernel<512, false>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
-  }
-  KVZ_CHECK_LAUNCH("search service kernels");
+  if (constrained) hipLaunchKernelGGL(serve_kernel<true>, dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  else hipLaunchKernelGGL(serve_kernel<false>, dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  KVZ_CHECK_LAUNCH("search service kernel");
   return KVZ_HIP_OK;
 }
 

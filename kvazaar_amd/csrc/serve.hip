@@ -17,6 +17,7 @@
 #include "kvz_hip_internal.h"
 
 #include <sched.h>
+#include <sys/prctl.h>
 #include <time.h>
 
 #include <atomic>
@@ -31,8 +32,9 @@ namespace {
 
 constexpr int N_STREAMS = 8;          // launch streams
 constexpr int N_UPLOAD = 8;           // upload streams (put_rect)
-constexpr int N_BATCH = 64;           // ring of batch buffers
-constexpr int BATCH_CAP = 1024;       // units per batch buffer
+constexpr int BATCH_CAP = 256;        // units per batch buffer (a larger batch leaves as several launches)
+constexpr uint64_t SPIN_NS = 40 * 1000;   // busy-polling phase of a caller's wait
+constexpr long NAP_NS = 5 * 1000;         // then naps of this length (the kernel rounds them up by the thread's timer slack)
 constexpr uint64_t WAIT_LIMIT_NS = 20ull * 1000 * 1000 * 1000;    // a request that is not answered in 20 s is a failure
 
 inline uint64_t now_ns()
@@ -59,12 +61,14 @@ struct kvz_hip_me_service {
   size_t plane_bytes = 0;
   u8 *planes = nullptr;                                 // device: n_slots planes, stride = w
   thread_area *areas = nullptr;                         // page-locked host, device-visible
-  serve_unit *ring = nullptr;                           // page-locked host: N_BATCH x BATCH_CAP units
+  serve_unit *ring = nullptr;                           // page-locked host: n_batch x BATCH_CAP units
   hipStream_t streams[N_STREAMS] = {};
   hipStream_t up_streams[N_UPLOAD] = {};
   std::mutex up_mu[N_UPLOAD];
-  hipEvent_t batch_done[N_BATCH] = {};
-  bool batch_used[N_BATCH] = {};
+  int n_batch = 0;                                      // ring of batch buffers: max_threads + 8
+  std::atomic<int> *batch_open = nullptr;               // requests of the batch in that ring buffer not answered yet
+  std::atomic<int> *slot_batch = nullptr;               // per calling thread: the ring buffer its request went out in
+  u8 *up_stage[N_UPLOAD] = {};                          // page-locked staging of put_rect, one per upload stream
   uint64_t next_batch = 0;                              // touched under launch_mu only
   std::mutex pend_mu;
   std::vector<pending_req> pending;
@@ -89,6 +93,7 @@ int thread_slot(kvz_hip_me_service *svc)
   const int s = svc->next_thread.fetch_add(1);
   if (s >= svc->max_threads) return -1;
   t_bind.id = svc->id; t_bind.slot = s;
+  prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);          // this thread's naps (see kvz_hip_me_service_search) end on time: 1 us of slack instead of 50
   return s;
 }
 
@@ -109,60 +114,41 @@ int drain_and_launch(kvz_hip_me_service *svc)
   size_t at = 0;
   int rc = KVZ_HIP_OK;
   while (at < grabbed.size() && rc == KVZ_HIP_OK) {
-    const int b = (int)(svc->next_batch % N_BATCH);
-    if (svc->batch_used[b]) {
-      // the buffer's previous batch must have been read: it was launched N_BATCH batches ago
-      const hipError_t e = hipEventSynchronize(svc->batch_done[b]);
-      if (e != hipSuccess) { set_error("kvz_hip_me_service: hipEventSynchronize", e); return KVZ_HIP_ERR_RUNTIME; }
+    // A ring buffer is free once every caller of the batch it carried has been answered (they count themselves out).  A
+    // caller has one request in flight, so at most max_threads buffers are taken and the ring has more: the next free
+    // one is used.  (Waiting for a particular buffer here could wait for the launching thread's OWN unanswered request.)
+    int b = -1;
+    for (int k = 0; k < svc->n_batch && b < 0; ++k) {
+      const int c = (int)((svc->next_batch + (uint64_t)k) % (uint64_t)svc->n_batch);
+      if (svc->batch_open[c].load(std::memory_order_acquire) == 0) b = c;
     }
+    if (b < 0) { set_error_msg("kvz_hip_me_service: no free batch buffer (more callers than max_threads?)"); rc = KVZ_HIP_ERR_RUNTIME; break; }
+    svc->next_batch = (uint64_t)b;
     serve_unit *buf = svc->ring + (size_t)b * BATCH_CAP;
-    // units of one size class are contiguous: class 1 from the front, class 2 after it, class 4 at the back
-    int n_cls[3] = { 0, 0, 0 };
     size_t end = at;
     int total = 0;
+    bool constrained = false;
     while (end < grabbed.size() && total + grabbed[end].req->n_refs <= BATCH_CAP) {
       const kvz_hip_me_request *r = grabbed[end].req;
-      const int longer = r->pu[0].width > r->pu[0].height ? r->pu[0].width : r->pu[0].height;
-      n_cls[longer <= 16 ? 0 : (longer <= 32 ? 1 : 2)] += r->n_refs;
-      total += r->n_refs;
-      ++end;
-    }
-    int pos[3] = { 0, n_cls[0], n_cls[0] + n_cls[1] };
-    bool constrained = false;
-    for (size_t k = at; k < end; ++k) {
-      const kvz_hip_me_request *r = grabbed[k].req;
-      const int longer = r->pu[0].width > r->pu[0].height ? r->pu[0].width : r->pu[0].height;
-      const int c = longer <= 16 ? 0 : (longer <= 32 ? 1 : 2);
-      thread_area *area = svc->areas + grabbed[k].thread_slot;
+      thread_area *area = svc->areas + grabbed[end].thread_slot;
       constrained = constrained || r->params.wpp_owf != 0 || r->params.mv_constraint != 0;
       for (int i = 0; i < r->n_refs; ++i) {
-        serve_unit &u = buf[pos[c]++];
+        serve_unit &u = buf[total++];
         u.pic_slot = r->pic_slot; u.ref_slot = r->ref_slot[i];
         u.result = &area->res[i];
         u.pu = r->pu[i];
-        // every PU of a request has the request's shape: the class was taken from pu[0]
-        u.pu.width = r->pu[0].width; u.pu.height = r->pu[0].height;
+        u.pu.width = r->pu[0].width; u.pu.height = r->pu[0].height;     // every picture sees the same PU
         u.prm = r->params;
         u.prm.cost_to_beat = nullptr; u.prm.cabac = nullptr; u.prm.mv_rdo = 0; u.prm.size_classes = 0;
         if (u.prm.tile_w == 0 && u.prm.tile_h == 0) { u.prm.tile_x = 0; u.prm.tile_y = 0; u.prm.tile_w = svc->w; u.prm.tile_h = svc->h; }
       }
+      svc->slot_batch[grabbed[end].thread_slot].store(b, std::memory_order_relaxed);
+      ++end;
     }
-    hipStream_t st = svc->streams[svc->next_batch % N_STREAMS];
-    int off = 0;
-    static const int cls_id[3] = { 1, 2, 4 };
-    for (int c = 0; c < 3 && rc == KVZ_HIP_OK; ++c) {
-      if (n_cls[c] > 0) {
-        rc = serve_launch(cls_id[c], constrained, svc->planes, svc->plane_bytes, svc->n_slots, (u32)svc->w, svc->w, svc->h, buf + off, n_cls[c], st);
-        svc->st_launches.fetch_add(1, std::memory_order_relaxed);
-      }
-      off += n_cls[c];
-    }
-    if (rc == KVZ_HIP_OK) {
-      const hipError_t e = hipEventRecord(svc->batch_done[b], st);
-      if (e != hipSuccess) { set_error("kvz_hip_me_service: hipEventRecord", e); rc = KVZ_HIP_ERR_RUNTIME; }
-    }
-    svc->batch_used[b] = true;
-    ++svc->next_batch;
+    svc->batch_open[b].store((int)(end - at), std::memory_order_release);
+    rc = serve_launch(constrained, svc->planes, svc->plane_bytes, svc->n_slots, (u32)svc->w, svc->w, svc->h, buf, total, svc->streams[svc->st_batches.load(std::memory_order_relaxed) % N_STREAMS]);
+    svc->st_launches.fetch_add(1, std::memory_order_relaxed);
+    svc->next_batch = (uint64_t)((b + 1) % svc->n_batch);
     svc->st_batches.fetch_add(1, std::memory_order_relaxed);
     svc->st_units.fetch_add((uint64_t)total, std::memory_order_relaxed);
     uint64_t m = svc->st_max_batch.load(std::memory_order_relaxed);
@@ -204,17 +190,23 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
   if (!svc) return nullptr;
   svc->device = ctx_device();
   svc->w = cfg->width; svc->h = cfg->height; svc->n_slots = cfg->max_pictures; svc->max_threads = cfg->max_threads;
+  svc->n_batch = cfg->max_threads + 8;
   svc->plane_bytes = ((size_t)cfg->width * cfg->height + 255) & ~(size_t)255;
   svc->id = g_service_ids.fetch_add(1);
   bool ok = hipMalloc((void **)&svc->planes, svc->plane_bytes * svc->n_slots + 64) == hipSuccess;
   ok = ok && hipMemset(svc->planes, 0, svc->plane_bytes * svc->n_slots + 64) == hipSuccess;
   // page-locked and device-visible: the kernels read the ring and write the result areas across PCIe
   ok = ok && hipHostMalloc((void **)&svc->areas, sizeof(thread_area) * svc->max_threads, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
-  ok = ok && hipHostMalloc((void **)&svc->ring, sizeof(serve_unit) * (size_t)N_BATCH * BATCH_CAP, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&svc->ring, sizeof(serve_unit) * (size_t)svc->n_batch * BATCH_CAP, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess;
   if (ok) std::memset(svc->areas, 0, sizeof(thread_area) * svc->max_threads);
   for (int i = 0; i < N_STREAMS && ok; ++i) ok = hipStreamCreateWithFlags(&svc->streams[i], hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < N_UPLOAD && ok; ++i) ok = hipStreamCreateWithFlags(&svc->up_streams[i], hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; i < N_BATCH && ok; ++i) ok = hipEventCreateWithFlags(&svc->batch_done[i], hipEventDisableTiming) == hipSuccess;
+  svc->batch_open = new (std::nothrow) std::atomic<int>[svc->n_batch];
+  ok = ok && svc->batch_open != nullptr;
+  for (int i = 0; i < svc->n_batch && ok; ++i) svc->batch_open[i].store(0);
+  svc->slot_batch = new (std::nothrow) std::atomic<int>[svc->max_threads];
+  ok = ok && svc->slot_batch != nullptr;
+  for (int i = 0; i < N_UPLOAD && ok; ++i) ok = hipHostMalloc((void **)&svc->up_stage[i], svc->plane_bytes, hipHostMallocPortable) == hipSuccess;
   if (!ok) {
     set_error("kvz_hip_me_service_create", hipGetLastError());
     kvz_hip_me_service_destroy(svc);
@@ -231,7 +223,9 @@ void kvz_hip_me_service_destroy(kvz_hip_me_service *svc)
   if (hipGetDevice(&cur) == hipSuccess && cur != svc->device) (void)hipSetDevice(svc->device);
   for (int i = 0; i < N_STREAMS; ++i) if (svc->streams[i]) { (void)hipStreamSynchronize(svc->streams[i]); (void)hipStreamDestroy(svc->streams[i]); }
   for (int i = 0; i < N_UPLOAD; ++i) if (svc->up_streams[i]) { (void)hipStreamSynchronize(svc->up_streams[i]); (void)hipStreamDestroy(svc->up_streams[i]); }
-  for (int i = 0; i < N_BATCH; ++i) if (svc->batch_done[i]) (void)hipEventDestroy(svc->batch_done[i]);
+  for (int i = 0; i < N_UPLOAD; ++i) if (svc->up_stage[i]) (void)hipHostFree(svc->up_stage[i]);
+  delete[] svc->slot_batch;
+  delete[] svc->batch_open;
   if (svc->planes) (void)hipFree(svc->planes);
   if (svc->areas) (void)hipHostFree(svc->areas);
   if (svc->ring) (void)hipHostFree(svc->ring);
@@ -252,7 +246,10 @@ int kvz_hip_me_service_put_rect(kvz_hip_me_service *svc, int slot, const kvz_hip
   hipError_t e;
   {
     std::lock_guard<std::mutex> lk(svc->up_mu[k]);
-    e = hipMemcpy2DAsync(dst, (size_t)svc->w, host, host_stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, svc->up_streams[k]);
+    // rows gathered into page-locked memory by the CPU, then ONE DMA: a 2-D copy from pageable memory is staged row by row
+    u8 *stage = svc->up_stage[k];
+    for (int r = 0; r < h; ++r) std::memcpy(stage + (size_t)r * w, host + (size_t)r * host_stride, (size_t)w);
+    e = hipMemcpy2DAsync(dst, (size_t)svc->w, stage, (size_t)w, (size_t)w, (size_t)h, hipMemcpyHostToDevice, svc->up_streams[k]);
     if (e == hipSuccess) e = hipStreamSynchronize(svc->up_streams[k]);
   }
   if (e != hipSuccess) { set_error("kvz_hip_me_service_put_rect", e); return KVZ_HIP_ERR_RUNTIME; }
@@ -292,17 +289,24 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
       continue;
     }
     if (svc->failed.load()) { set_error_msg("kvz_hip_me_service_search: a launch failed"); return KVZ_HIP_ERR_RUNTIME; }
-    if (++spins < 64) {
+    // A search takes tens of microseconds.  Spin through the first ones (a host with a core per worker loses nothing by it);
+    // a worker that is still waiting then sleeps in short naps, so that on a host with more workers than cores the core
+    // goes to a worker that has CPU work to do instead of to a poll loop.
+    if (++spins < 256) {
       __builtin_ia32_pause();
-    } else {
+    } else if (now_ns() - t0 < SPIN_NS) {
       sched_yield();
-      if ((spins & 1023) == 0 && now_ns() - t0 > WAIT_LIMIT_NS) {
+    } else {
+      timespec nap = { 0, NAP_NS };
+      nanosleep(&nap, nullptr);
+      if ((spins & 255) == 0 && now_ns() - t0 > WAIT_LIMIT_NS) {
         svc->failed.store(1);
         set_error_msg("kvz_hip_me_service_search: no answer from the device within 20 s");
         return KVZ_HIP_ERR_RUNTIME;
       }
     }
   }
+  svc->batch_open[svc->slot_batch[ts].load(std::memory_order_relaxed)].fetch_sub(1, std::memory_order_release);
   svc->st_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
   // the sequential rule of search_pu_inter's loop (search_inter.c:1502-1507 with :1239-1252 and :1275-1290)
   uint32_t running = req->cost_to_beat;

@@ -181,6 +181,27 @@ def inter_cand():
     np.savez_compressed(os.path.join(OUT, "inter_cand.npz"), **d)
 
 
+def mv_cand():
+    """the reference's file-local candidate helpers (inter.c:566-875; oracle/ref_cand_harness.c reaches them the way
+    tests/mv_cand_tests.c does) for every PU of every partition mode in a 192 x 192 picture"""
+    from patterns import valid_pu_geometries
+    geoms = valid_pu_geometries(192)
+    a0, b0, idx = R.mv_cand_helpers(geoms, 192, 192)
+    np.savez_compressed(os.path.join(OUT, "mv_cand.npz"), geoms=geoms, a0=a0.astype(np.uint8), b0=b0.astype(np.uint8), idx=idx.astype(np.int16))
+
+
+def bipred():
+    """inter_recon_bipred of the compiled reference's generic strategy (picture-generic.c:538-588) on the configuration of
+    tests/inter_recon_bipred_tests.c (16x16 at the LCU origin, all sources 14-bit, zero buffers) and seeded variants"""
+    from patterns import BIPRED_CASES, bipred_case_inputs
+    d = {}
+    for k, (seed, w, h, x, y, hi) in enumerate(BIPRED_CASES):
+        hp0, hp1, rec, tmp = bipred_case_inputs(seed)
+        out = R.bipred(hi, h, w, y, x, hp0, hp1, rec, tmp, "generic")
+        d["y%d" % k], d["u%d" % k], d["v%d" % k] = out
+    np.savez_compressed(os.path.join(OUT, "bipred.npz"), **d)
+
+
 def recorded_cand():
     """What the reference ENCODER's candidate derivation read and produced during a real encode (harness recorder with snapshots,
     oracle/ref_harness.c): for 600 of the 2Nx2N inter searches of four 192 x 128 frames the lcu->cu array as it stood, the collocated
@@ -299,7 +320,7 @@ if __name__ == "__main__":
     if not R.available():
         sys.exit("oracle/_ref/libkvzref.so missing: run `make -C oracle ref` where /root/reference exists")
     os.makedirs(OUT, exist_ok=True)
-    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, intra_ref=intra_ref, inter_cand=inter_cand, recorded_cand=recorded_cand, sao=sao, me=me, deblock=deblock, fronts=fronts)
+    groups = dict(picture=picture, dct=dct, quant=quant, ipol=ipol, intra=intra, intra_ref=intra_ref, inter_cand=inter_cand, mv_cand=mv_cand, bipred=bipred, recorded_cand=recorded_cand, sao=sao, me=me, deblock=deblock, fronts=fronts)
     for name in (sys.argv[1:] or list(groups)):          # python oracle/gen_golden.py [group ...]
         groups[name]()
     for f in sorted(os.listdir(OUT)):

@@ -1890,31 +1890,78 @@ static cand_view cand_at(const orc_cu_info *map, int stride, int x, int y)
 
 /* is_a0_cand_coded / is_b0_cand_coded (inter.c:566-705) from first principles: the neighbour's 4x4 unit precedes, in the
  * LCU's coding order, the aligned square at the PU's lower-left (A0) / upper-right (B0) corner whose side is the largest
- * power of two dividing both PU dimensions; everything left of or above the LCU is coded. */
+ * power of two dividing both PU dimensions; of the other LCUs those that precede this one in raster order are coded. */
 static int corner_unit_coded(int nx, int ny, int sx, int sy)
 {
-  if ((nx >> 6) != (sx >> 6) || (ny >> 6) != (sy >> 6)) return nx < sx || ny < sy;
+  /* another LCU: LCUs are coded in raster order (the LCU row above, or the same row further left, came first) */
+  if ((nx >> 6) != (sx >> 6) || (ny >> 6) != (sy >> 6)) return (ny >> 6) < (sy >> 6) || ((ny >> 6) == (sy >> 6) && (nx >> 6) < (sx >> 6));
   return intra_unit_order((unsigned)(nx & 63) >> 2, (unsigned)(ny & 63) >> 2) < intra_unit_order((unsigned)(sx & 63) >> 2, (unsigned)(sy & 63) >> 2);
 }
 
 typedef struct { cand_view a[2], b[3], tmp; } cand_set;    /* a0 a1 / b0 b1 b2 / the temporal one (H, else C3) */
 
-/* get_spatial_merge_candidates (inter.c:799-875) */
-static void spatial_cands(const orc_cu_info *cus, const orc_inter_params *p, int x, int y, int w, int h, cand_set *s)
+/* Where get_spatial_merge_candidates (inter.c:799-875) looks: pos[0..4] = A0 A1 B0 B1 B2 as picture coordinates, present[i] = the
+ * geometry (picture and LCU borders, coding order) lets that neighbour be used at all. */
+static void spatial_positions(int x, int y, int w, int h, int pic_w, int pic_h, int pos[5][2], int present[5])
 {
   const int side = ((w & -w) < (h & -h)) ? (w & -w) : (h & -h);
   const int xl = x & 63, yl = y & 63;
-  memset(s, 0, sizeof(*s));
+  memset(present, 0, 5 * sizeof(int));
+  pos[0][0] = x - 1; pos[0][1] = y + h;          /* A0 */
+  pos[1][0] = x - 1; pos[1][1] = y + h - 1;      /* A1 */
+  pos[2][0] = x + w; pos[2][1] = y - 1;          /* B0 */
+  pos[3][0] = x + w - 1; pos[3][1] = y - 1;      /* B1 */
+  pos[4][0] = x - 1; pos[4][1] = y - 1;          /* B2 */
+  (void)pic_w;
   if (x != 0) {
-    s->a[1] = cand_at(cus, p->cus_stride, x - 1, y + h - 1);
-    if (yl + h < 64 && y + h < p->pic_height && corner_unit_coded(x - 1, y + h, x, y + h - side))
-      s->a[0] = cand_at(cus, p->cus_stride, x - 1, y + h);
+    present[1] = 1;
+    present[0] = yl + h < 64 && y + h < pic_h && corner_unit_coded(x - 1, y + h, x, y + h - side);
   }
   if (y != 0) {
-    if (x + w < p->pic_width && (xl + w < 64 || yl == 0) && corner_unit_coded(x + w, y - 1, x + w - side, y))
-      s->b[0] = cand_at(cus, p->cus_stride, x + w, y - 1);
-    s->b[1] = cand_at(cus, p->cus_stride, x + w - 1, y - 1);
-    if (x != 0) s->b[2] = cand_at(cus, p->cus_stride, x - 1, y - 1);
+    present[2] = x + w < pic_w && (xl + w < 64 || yl == 0) && corner_unit_coded(x + w, y - 1, x + w - side, y);
+    present[3] = 1;
+    present[4] = x != 0;
+  }
+}
+
+/* get_spatial_merge_candidates (inter.c:799-875) */
+static void spatial_cands(const orc_cu_info *cus, const orc_inter_params *p, int x, int y, int w, int h, cand_set *s)
+{
+  int pos[5][2], present[5];
+  spatial_positions(x, y, w, h, p->pic_width, p->pic_height, pos, present);
+  memset(s, 0, sizeof(*s));
+  if (present[0]) s->a[0] = cand_at(cus, p->cus_stride, pos[0][0], pos[0][1]);
+  if (present[1]) s->a[1] = cand_at(cus, p->cus_stride, pos[1][0], pos[1][1]);
+  if (present[2]) s->b[0] = cand_at(cus, p->cus_stride, pos[2][0], pos[2][1]);
+  if (present[3]) s->b[1] = cand_at(cus, p->cus_stride, pos[3][0], pos[3][1]);
+  if (present[4]) s->b[2] = cand_at(cus, p->cus_stride, pos[4][0], pos[4][1]);
+}
+
+/* The reference's unit test of these helpers (tests/mv_cand_tests.c:26-260) in the oracle's terms: the coding-order
+ * tests alone (is_a0_cand_coded / is_b0_cand_coded, inter.c:566-705), and -- for an LCU whose CUs are all inter -- the
+ * entries of lcu_t.cu (cu.h:324-344: 17 per row, (0, 0) at index 18, the top-right neighbour at 289) that
+ * get_spatial_merge_candidates picks: out[0..4] = b0 b1 b2 a0 a1, -1 = none. */
+int orc_is_a0_cand_coded(int x, int y, int width, int height)
+{
+  const int side = ((width & -width) < (height & -height)) ? (width & -width) : (height & -height);
+  return corner_unit_coded(x - 1, y + height, x, y + height - side);
+}
+int orc_is_b0_cand_coded(int x, int y, int width, int height)
+{
+  const int side = ((width & -width) < (height & -height)) ? (width & -width) : (height & -height);
+  return corner_unit_coded(x + width, y - 1, x + width - side, y);
+}
+void orc_spatial_merge_candidate_indices(int x, int y, int width, int height, int pic_w, int pic_h, int *out)
+{
+  int pos[5][2], present[5];
+  spatial_positions(x, y, width, height, pic_w, pic_h, pos, present);
+  static const int order[5] = { 2, 3, 4, 0, 1 };
+  const int lx0 = x & ~63, ly0 = y & ~63;
+  for (int i = 0; i < 5; ++i) {
+    const int k = order[i];
+    if (!present[k]) { out[i] = -1; continue; }
+    const int sx = (pos[k][0] - lx0) >> 2, sy = (pos[k][1] - ly0) >> 2;      /* -1 .. 16; arithmetic shift of -1 .. -4 gives -1 */
+    out[i] = (sx == 16 && sy == -1) ? 289 : 18 + sx + sy * 17;
   }
 }
 

@@ -353,4 +353,9 @@ void orc_quantize_residual_many(const orc_quant_params *p, int cu_is_intra, int 
                                 const orc_pixel *ref_in, const orc_pixel *pred_in, orc_pixel *rec_out, orc_coeff *coeff_out,
                                 int32_t *has_coeffs, size_t count);
 
+/* the reference's own unit test of the candidate helpers (tests/mv_cand_tests.c:26-260), see kvz_oracle.c */
+int orc_is_a0_cand_coded(int x, int y, int width, int height);
+int orc_is_b0_cand_coded(int x, int y, int width, int height);
+void orc_spatial_merge_candidate_indices(int x, int y, int width, int height, int pic_w, int pic_h, int *out);
+
 #endif

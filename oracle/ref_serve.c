@@ -64,7 +64,8 @@ static struct {
   int (*get_stats)(kvz_hip_me_service *, kvz_hip_me_service_stats *);
   int (*init)(int);
   const char *(*last_error)(void);
-  int w, h, min_size, shadow;
+  int w, h, min_size, shadow, probe;
+  long long probe_ns[4], probe_n[4];    /* probe mode: the reference's own search timed per CU size 64, 32, 16, 8 */
   pthread_mutex_t table_mu;
   svc_slot_t slots[SVC_SLOTS];
   uint64_t clock;
@@ -79,7 +80,8 @@ static long long svc_now_ns(void)
   return (long long)t.tv_sec * 1000000000ll + t.tv_nsec;
 }
 
-/* flags: bit 0 = shadow mode (every served search is repeated by the reference's own search and compared; the
+/* flags: bit 1 = probe mode (nothing is served: the reference's own searches are timed per CU size);
+ * bit 0 = shadow mode (every served search is repeated by the reference's own search and compared; the
  * reference's result is kept), min_size = smallest PU width that is served (smaller ones run the reference's search) */
 int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int min_size, int flags)
 {
@@ -102,20 +104,22 @@ int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int m
   cfg.width = w; cfg.height = h; cfg.max_pictures = SVC_SLOTS; cfg.max_threads = max_threads + 8;
   g_svc.svc = g_svc.create(&cfg);
   if (!g_svc.svc) { fprintf(stderr, "kvz_hip_me_service_create: %s\n", g_svc.last_error()); return -1; }
-  g_svc.w = w; g_svc.h = h; g_svc.min_size = min_size; g_svc.shadow = flags & 1;
+  g_svc.w = w; g_svc.h = h; g_svc.min_size = min_size; g_svc.shadow = flags & 1; g_svc.probe = (flags >> 1) & 1;
   pthread_mutex_init(&g_svc.table_mu, NULL);
   for (int i = 0; i < SVC_SLOTS; ++i) pthread_mutex_init(&g_svc.slots[i].mu, NULL);
   __atomic_store_n(&g_svc.on, 1, __ATOMIC_RELEASE);
   return 0;
 }
 
-/* out[0..15]: served, passed on, failed, shadow mismatches, upload rects, search wait ns, upload ns, candidate ns,
+/* out[16..19] / out[20..23]: probe mode's summed nanoseconds / number of searches for CU sizes 64, 32, 16, 8.
+ * out[0..15]: served, passed on, failed, shadow mismatches, upload rects, search wait ns, upload ns, candidate ns,
  * then the service's own statistics: requests, units, batches, launches, max_batch_units, rects, rect_bytes, wait_ns */
 void ref_service_end(long long *out)
 {
   __atomic_store_n(&g_svc.on, 0, __ATOMIC_RELEASE);
   if (out) {
-    memset(out, 0, 16 * sizeof(out[0]));
+    memset(out, 0, 24 * sizeof(out[0]));
+    for (int i = 0; i < 4; ++i) { out[16 + i] = g_svc.probe_ns[i]; out[20 + i] = g_svc.probe_n[i]; }
     out[0] = g_svc.served; out[1] = g_svc.passed_on; out[2] = g_svc.failed; out[3] = g_svc.shadow_mismatch; out[4] = g_svc.upload_rects;
     out[5] = g_svc.search_ns; out[6] = g_svc.upload_ns; out[7] = g_svc.cand_ns;
     kvz_hip_me_service_stats st;
@@ -235,6 +239,13 @@ int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *l
 {
   if (!__atomic_load_n(&g_svc.on, __ATOMIC_ACQUIRE)) return 0;
   const int width = LCU_WIDTH >> depth;
+  if (g_svc.probe) {
+    const long long p0 = svc_now_ns();
+    __real_kvz_search_cu_inter(state, x, y, depth, lcu, inter_cost, inter_bitcost);
+    __atomic_add_fetch(&g_svc.probe_ns[depth & 3], svc_now_ns() - p0, __ATOMIC_RELAXED);
+    __atomic_add_fetch(&g_svc.probe_n[depth & 3], 1, __ATOMIC_RELAXED);
+    return 1;
+  }
   if (!svc_can_serve(state, width)) { __atomic_add_fetch(&g_svc.passed_on, 1, __ATOMIC_RELAXED); return 0; }
   const encoder_control_t *ctrl = state->encoder_control;
   const encoder_state_config_frame_t *fr = state->frame;

@@ -576,3 +576,20 @@ def inter_candidates(params, cus, col_cus, ref_cus, pus):
     L.orc_inter_candidates(cus.ctypes.data, col_cus.ctypes.data, None if ref_cus is None else ref_cus.ctypes.data,
                            np.ascontiguousarray(params).ctypes.data, pus.ctypes.data, len(pus), out.ctypes.data)
     return pus, out
+
+
+def mv_cand_helpers(geoms, pic_w, pic_h):
+    """orc_is_a0_cand_coded / orc_is_b0_cand_coded / orc_spatial_merge_candidate_indices for PUs (x, y, w, h)
+    -> (a0 [n], b0 [n], indices [n, 5] = b0 b1 b2 a0 a1 in lcu_t.cu)"""
+    L = lib()
+    geoms = np.asarray(geoms, dtype=np.int32).reshape(-1, 4)
+    a0 = np.zeros(len(geoms), np.int32)
+    b0 = np.zeros(len(geoms), np.int32)
+    idx = np.zeros((len(geoms), 5), np.int32)
+    out = (C.c_int * 5)()
+    for i, (x, y, w, h) in enumerate(geoms.tolist()):
+        a0[i] = L.orc_is_a0_cand_coded(x, y, w, h)
+        b0[i] = L.orc_is_b0_cand_coded(x, y, w, h)
+        L.orc_spatial_merge_candidate_indices(x, y, w, h, pic_w, pic_h, out)
+        idx[i] = list(out)
+    return a0, b0, idx

@@ -583,3 +583,135 @@ def cost_to_beat_case(integer_costs, seed):
     out = np.where(pick == 0, c * 4 + 1000, np.where(pick == 1, c + g.integers(1, 40, len(c)), np.where(pick == 2, c, np.where(
         pick == 3, np.maximum(c - g.integers(1, 400, len(c)), 0), np.where(pick == 4, 0, 0x7fffffff)))))
     return np.clip(out, 0, 0xffffffff).astype(np.uint32)
+
+
+# ---- known answers of the reference's candidate helpers: tests/mv_cand_tests.c ----
+# test_get_spatial_merge_cand (:26-49): an LCU of inter CUs, PU (x, y, w, h) in a picture (pic_w, pic_h) ->
+# indices into lcu_t.cu of b0, b1, b2, a0, a1
+MV_CAND_KAT_SPATIAL = ((96, 64, 32, 24, 1920, 1080), (289, 16, 8, 127, 110))
+# test_is_a0_cand_coded (:51-133): (x, y, width, height) -> expected
+MV_CAND_KAT_A0 = (
+    ((32, 64, 16, 16), True), ((32, 64, 32, 16), True), ((32, 64, 32, 8), True), ((32, 64, 32, 24), True),
+    ((16, 0, 16, 16), False),
+    ((48, 16, 16, 16), False), ((48, 0, 16, 32), False), ((40, 0, 24, 32), False), ((56, 0, 8, 32), False),
+    ((32, 16, 16, 16), False), ((32, 8, 32, 24), False), ((32, 24, 32, 8), False),
+    ((32, 0, 16, 32), False), ((32, 0, 8, 32), False), ((32, 0, 24, 32), False),
+    ((32, 8, 8, 8), True), ((32, 4, 16, 12), True), ((32, 12, 16, 4), True),
+    ((32, 0, 8, 16), True), ((32, 0, 4, 16), True), ((32, 0, 12, 16), True),
+)
+# test_is_b0_cand_coded (:135-213)
+MV_CAND_KAT_B0 = (
+    ((32, 64, 16, 16), True), ((32, 64, 16, 32), True), ((32, 64, 24, 32), True), ((32, 64, 8, 32), True),
+    ((32, 16, 16, 16), True),
+    ((48, 16, 16, 16), False), ((32, 16, 32, 16), False), ((32, 8, 32, 24), False), ((32, 24, 32, 8), False),
+    ((48, 32, 16, 16), False), ((32, 32, 32, 8), False), ((32, 32, 32, 24), False), ((56, 32, 8, 32), False), ((40, 32, 24, 32), False),
+    ((16, 0, 16, 16), True), ((0, 0, 32, 8), True), ((0, 0, 32, 24), True), ((8, 0, 24, 32), True), ((24, 0, 8, 32), True),
+)
+
+
+def valid_pu_geometries(pic=192):
+    """every PU (x, y, w, h) of every partition mode (2Nx2N, 2NxN, Nx2N, NxN, the four AMP modes from 16x16 up) of every CU
+    of 8x8 .. 64x64 in a pic x pic picture"""
+    out = []
+    for n in (8, 16, 32, 64):
+        q = n // 4
+        parts = [(0, 0, n, n), (0, 0, n, n // 2), (0, n // 2, n, n // 2), (0, 0, n // 2, n), (n // 2, 0, n // 2, n)]
+        parts += [(dx, dy, n // 2, n // 2) for dy in (0, n // 2) for dx in (0, n // 2)]
+        if n >= 16:
+            parts += [(0, 0, n, q), (0, q, n, n - q), (0, 0, n, n - q), (0, n - q, n, q),
+                      (0, 0, q, n), (q, 0, n - q, n), (0, 0, n - q, n), (n - q, 0, q, n)]
+        for cy in range(0, pic, n):
+            for cx in range(0, pic, n):
+                out += [(cx + dx, cy + dy, w, h) for (dx, dy, w, h) in parts]
+    return np.array(out, dtype=np.int32)
+
+
+def mv_cand_unique_map_case(pic=192):
+    """-> (params, cus, pus): a pic x pic P picture whose 4x4 units are all inter with a vector that names the unit (x / 4, y / 4),
+    no temporal candidates, and every PU of valid_pu_geometries(pic): which neighbours a derivation used can be read off the
+    vectors of its merge list"""
+    p = inter_params(pic, pic, tmvp=0)
+    n = pic // 4
+    cus = np.zeros((n, int(p["cus_stride"][0])), dtype=CU_INFO)
+    cus["type"], cus["mv_dir"] = 2, 1
+    ys, xs = np.mgrid[0:n, 0:cus.shape[1]]
+    cus["mv"][:, :, 0, 0], cus["mv"][:, :, 0, 1] = xs, ys
+    geoms = valid_pu_geometries(pic)
+    pus = np.zeros(len(geoms), dtype=ME_PU)
+    pus["x"], pus["y"], pus["width"], pus["height"] = geoms[:, 0], geoms[:, 1], geoms[:, 2], geoms[:, 3]
+    return p, cus, pus
+
+
+def check_unique_map_merge_lists(d, pus, merge):
+    """merge: MERGE_CAND records [n, 5]; d: mv_cand.npz"""
+    merge = np.ascontiguousarray(merge).view(MERGE_CAND).reshape(len(pus), 5)
+    for i in range(0, len(pus), 7):
+        x, y, w, h = (int(pus[i][k]) for k in ("x", "y", "width", "height"))
+        b0i, b1i, b2i, a0i, a1i = (int(v) for v in d["idx"][i])
+        place = dict(a1=(x - 1, y + h - 1), b1=(x + w - 1, y - 1), b0=(x + w, y - 1), a0=(x - 1, y + h), b2=(x - 1, y - 1))
+        have = dict(a1=a1i >= 0, b1=b1i >= 0, b0=b0i >= 0, a0=a0i >= 0, b2=b2i >= 0)
+        want = []
+        for k in ("a1", "b1", "b0", "a0", "b2"):
+            if have[k] and not (k == "b2" and len(want) == 4):
+                v = (place[k][0] // 4, place[k][1] // 4)
+                if v not in want:                              # duplicates are pruned; with unique vectors only a repeated unit repeats
+                    want.append(v)
+        got = [tuple(int(c) for c in merge[i, k]["mv"][0]) for k in range(min(len(want), 5))]
+        assert got == want[:5], "PU %s: merge list %s, places %s" % ((x, y, w, h), got, want)
+
+
+# ---- tests/inter_recon_bipred_tests.c:32-121: the blend of two 16x16 predictions at (0, 0) of an LCU, both vectors (3, 3)
+# (fractional in luma and chroma: all four sources are 14-bit samples), against the test's own plain restatement
+# (s0 + s1 + offset) >> shift through kvz_fast_clip_32bit_to_pixel ----
+BIPRED_TEST_GEOMETRY = dict(width=16, height=16, xpos=0, ypos=0, mv=((3, 3), (3, 3)))
+# the test's case first (zero-initialised buffers, as its static arrays are), then seeded ones: (seed, w, h, x, y, (hi luma 0, 1, chroma 0, 1))
+BIPRED_CASES = ((None, 16, 16, 0, 0, (1, 1, 1, 1)), (1, 16, 16, 0, 0, (1, 1, 1, 1)), (2, 16, 16, 0, 0, (0, 1, 0, 1)), (3, 16, 16, 0, 0, (1, 0, 1, 0)),
+                (4, 16, 16, 0, 0, (0, 0, 0, 0)), (5, 8, 8, 24, 40, (1, 1, 1, 1)), (6, 64, 64, 0, 0, (1, 0, 0, 1)), (7, 32, 16, 96, 72, (0, 1, 1, 0)))
+
+
+def bipred_case_inputs(seed):
+    """-> (hp0, hp1, rec, tmp): three planes each (4096, 1024, 1024 samples), 14-bit int16 samples / pixels.  seed None: all zero,
+    what the reference's test runs on; else values over the whole range a 14-bit interpolation produces, clipping both ways"""
+    if seed is None:
+        z16 = [np.zeros(n, np.int16) for n in (4096, 1024, 1024)]
+        z8 = [np.zeros(n, np.uint8) for n in (4096, 1024, 1024)]
+        return z16, [a.copy() for a in z16], z8, [a.copy() for a in z8]
+    g = np.random.default_rng(8800 + seed)
+    hp0 = [g.integers(-3000, 20000, n).astype(np.int16) for n in (4096, 1024, 1024)]
+    hp1 = [g.integers(-3000, 20000, n).astype(np.int16) for n in (4096, 1024, 1024)]
+    rec = [g.integers(0, 256, n, dtype=np.uint8) for n in (4096, 1024, 1024)]
+    tmp = [g.integers(0, 256, n, dtype=np.uint8) for n in (4096, 1024, 1024)]
+    return hp0, hp1, rec, tmp
+
+
+def bipred_expected(hi, w, h, x, y, hp0, hp1, rec, tmp):
+    """the test file's restatement (inter_recon_bipred_tests.c:74-121) in numpy: source 0 = hi-prec buffer 0 or the temporary
+    LCU's pixels << 6, source 1 = hi-prec buffer 1 or the pixels already in rec << 6; (s0 + s1 + 64) >> 7, clipped to 0..255"""
+    out = [a.copy() for a in rec]
+    for plane, (stride, sh) in enumerate(((64, 0), (32, 1), (32, 1))):
+        hi0, hi1 = (hi[0], hi[1]) if plane == 0 else (hi[2], hi[3])
+        for ty in range(h >> sh):
+            yy = ((y >> sh) + ty) & (stride - 1)
+            for tx in range(w >> sh):
+                xx = ((x >> sh) + tx) & (stride - 1)
+                i = yy * stride + xx
+                s0 = int(hp0[plane][i]) if hi0 else int(np.int16(int(tmp[plane][i]) << 6))
+                s1 = int(hp1[plane][i]) if hi1 else int(np.int16(int(out[plane][i]) << 6))
+                out[plane][i] = min(255, max(0, (s0 + s1 + 64) >> 7))
+    return out
+
+
+def bipred_case_blocks(k):
+    """BIPRED_CASES[k] as contiguous blocks per plane for the plane-wise blend entries: -> list of (w, h, hi0, s0, hi1, s1, (rows, cols))
+    for Y, U, V; s = int16 samples when hi, else pixels; (rows, cols) = where the block lies in the LCU plane"""
+    seed, w, h, x, y, hi = BIPRED_CASES[k]
+    hp0, hp1, rec, tmp = bipred_case_inputs(seed)
+    out = []
+    for plane, (stride, sh) in enumerate(((64, 0), (32, 1), (32, 1))):
+        hi0, hi1 = (hi[0], hi[1]) if plane == 0 else (hi[2], hi[3])
+        bw, bh, bx, by = w >> sh, h >> sh, (x >> sh) & (stride - 1), (y >> sh) & (stride - 1)
+        rows, cols = slice(by, by + bh), slice(bx, bx + bw)
+        s0 = (hp0[plane] if hi0 else tmp[plane]).reshape(stride, stride)[rows, cols]
+        s1 = (hp1[plane] if hi1 else rec[plane]).reshape(stride, stride)[rows, cols]
+        out.append((bw, bh, hi0, np.ascontiguousarray(s0), hi1, np.ascontiguousarray(s1), (rows, cols)))
+    return out

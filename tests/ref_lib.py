@@ -333,7 +333,9 @@ def synthetic_sequence(w, h, n, seed=5):
     big = np.clip((big - big.mean()) * 6 + 128, 0, 255)
     frames = np.zeros((n, h * 3 // 2, w), dtype=np.uint8)
     for i in range(n):
-        oy, ox = 3 * i, 5 * i
+        k = i % 24
+        k = k if k <= 12 else 24 - k          # the pan turns round after 12 frames (the texture has a 64-pixel margin)
+        oy, ox = 3 * k, 5 * k
         y = big[oy:oy + 2 * h:2, ox:ox + 2 * w:2] + g.normal(0, 1.5, (h, w))
         frames[i, :h] = np.clip(y, 0, 255).astype(np.uint8)
         c = big[oy:oy + 2 * h:4, ox:ox + 2 * w:4]
@@ -649,7 +651,7 @@ def encode_with_gpu_search(frames, w, h, opts, lib_path, strategy=None, deblock=
     return bitstream, c
 
 
-def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8, shadow=False):
+def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8, shadow=False, probe=False):
     """ref_encode with every 2Nx2N inter search of the encoder answered by the product's search service
     (kvz_hip_me_service_search; oracle/ref_serve.c), from all of the encoder's own worker threads at once.
     min_size: PUs narrower than this run the reference's own search.  shadow: every served search is repeated by the
@@ -661,12 +663,33 @@ def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8
     L.ref_service_begin.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ref_service_end.restype = None
     L.ref_service_end.argtypes = [C.POINTER(C.c_longlong)]
-    assert L.ref_service_begin(lib_path.encode(), w, h, max_threads, min_size, 1 if shadow else 0) == 0
-    out = (C.c_longlong * 16)()
+    assert L.ref_service_begin(lib_path.encode(), w, h, max_threads, min_size, (1 if shadow else 0) | (2 if probe else 0)) == 0
+    out = (C.c_longlong * 24)()
     try:
         bitstream, _ = encode(frames, w, h, opts)
     finally:
         L.ref_service_end(out)
     keys = ("served", "passed_on", "failed", "shadow_mismatch", "upload_rects", "search_wait_ns", "upload_ns", "cand_ns",
             "requests", "units", "batches", "launches", "max_batch_units", "rects", "rect_bytes", "wait_ns")
-    return bitstream, dict(zip(keys, (int(v) for v in out)))
+    c = dict(zip(keys, (int(v) for v in out)))
+    if probe:       # nothing served: the reference's own kvz_search_cu_inter timed per CU size
+        c["probe_us_per_search"] = {64 >> i: round(out[16 + i] / 1e3 / max(1, out[20 + i]), 2) for i in range(4)}
+        c["probe_searches"] = {64 >> i: int(out[20 + i]) for i in range(4)}
+    return bitstream, c
+
+
+def mv_cand_helpers(geoms, pic_w, pic_h):
+    """the reference's file-local is_a0_cand_coded / is_b0_cand_coded / get_spatial_merge_candidates (inter.c:566-875, reached the way
+    tests/mv_cand_tests.c does: oracle/ref_cand_harness.c) for PUs (x, y, w, h) -> (a0 [n], b0 [n], indices [n, 5] = b0 b1 b2 a0 a1 in lcu_t.cu)"""
+    L = lib()
+    geoms = np.asarray(geoms, dtype=np.int32).reshape(-1, 4)
+    a0 = np.zeros(len(geoms), np.int32)
+    b0 = np.zeros(len(geoms), np.int32)
+    idx = np.zeros((len(geoms), 5), np.int32)
+    out = (C.c_int * 5)()
+    for i, (x, y, w, h) in enumerate(geoms.tolist()):
+        a0[i] = L.ref_is_a0_cand_coded(x, y, w, h)
+        b0[i] = L.ref_is_b0_cand_coded(x, y, w, h)
+        L.ref_spatial_merge_candidate_indices(x, y, w, h, pic_w, pic_h, out)
+        idx[i] = list(out)
+    return a0, b0, idx

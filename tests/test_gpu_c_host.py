@@ -29,3 +29,17 @@ def test_c_host_runs():
         exe = g.build_c_host()
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert r.returncode == 0 and "c_host_smoke ok" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads,per_thread", [(4, 1500), (16, 1500), (48, 700)])
+def test_service_stress_from_c_threads(threads, per_thread):
+    """tests/c_host/service_stress.c: pthread workers post searches concurrently; every answer must equal the one the same request
+    got single-threaded (any interleaving, batching, ring wrap-around; more workers than the box has cores for the last case)"""
+    exe = os.path.join(ROOT, "tests", "c_host", "service_stress")
+    if not os.access(exe, os.X_OK):
+        import __graft_entry__ as g
+        g.build_c_host()
+    r = subprocess.run([exe, str(threads), str(per_thread)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    print(r.stdout)
+    assert r.returncode == 0 and "service_stress ok" in r.stdout, r.stdout

@@ -108,6 +108,30 @@ def test_golden_inter_candidates(api):
         np.testing.assert_array_equal(got_merge.ravel(), d[name + "_out_merge"].view(np.uint8).ravel(), err_msg=name)
 
 
+def test_candidate_places_of_the_reference_unit_test(api):
+    """tests/mv_cand_tests.c through the device derivation: every PU of every partition mode in a picture whose units carry a vector
+    naming them; the merge lists must start with the units at the places the reference's get_spatial_merge_candidates /
+    is_a0_cand_coded / is_b0_cand_coded gave (tests/golden/mv_cand.npz)"""
+    from patterns import check_unique_map_merge_lists, mv_cand_unique_map_case
+    d = gold("mv_cand.npz")
+    p, cus, pus = mv_cand_unique_map_case(192)
+    got_pus, got_merge = api.inter_candidates_batch(p, cus, None, None, pus)
+    check_unique_map_merge_lists(d, pus, got_merge)
+
+
+def test_reference_bipred_unit_test_configuration(api):
+    """tests/inter_recon_bipred_tests.c's configuration and seeded variants through kvz_hip_bipred_blend_batch against what the compiled
+    reference's generic strategy wrote (tests/golden/bipred.npz)"""
+    from patterns import BIPRED_CASES, bipred_case_blocks
+    d = gold("bipred.npz")
+    for k in range(len(BIPRED_CASES)):
+        want = [d["y%d" % k], d["u%d" % k], d["v%d" % k]]
+        for plane, (bw, bh, hi0, s0, hi1, s1, (rows, cols)) in enumerate(bipred_case_blocks(k)):
+            stride = 64 if plane == 0 else 32
+            got = api.bipred_blend_batch(bw, bh, hi0, s0, hi1, s1)[0]
+            np.testing.assert_array_equal(got, want[plane].reshape(stride, stride)[rows, cols], err_msg="case %d plane %d" % (k, plane))
+
+
 def test_golden_recorded_candidates(api):
     """candidates the reference encoder derived during a real encode, re-derived on the device from snapshots of the state"""
     from patterns import ME_PU, recorded_cand_fixture

@@ -167,6 +167,55 @@ def test_golden_inter_candidates():
         np.testing.assert_array_equal(got_merge.view(np.uint8), d[name + "_out_merge"].view(np.uint8), err_msg=name)
 
 
+def test_reference_known_answers_of_the_candidate_helpers():
+    """tests/mv_cand_tests.c: the spatial candidates' places in lcu_t.cu (:26-49) and the truth tables of is_a0_cand_coded (:51-133)
+    and is_b0_cand_coded (:135-213); then every PU of every partition mode against what the reference's functions returned
+    (tests/golden/mv_cand.npz, oracle/gen_golden.py: mv_cand)"""
+    from patterns import MV_CAND_KAT_A0, MV_CAND_KAT_B0, MV_CAND_KAT_SPATIAL
+    (x, y, w, h, pw, ph), want = MV_CAND_KAT_SPATIAL
+    assert tuple(O.mv_cand_helpers([(x, y, w, h)], pw, ph)[2][0]) == want
+    a0 = O.mv_cand_helpers([g for g, _ in MV_CAND_KAT_A0], 1920, 1080)[0]
+    assert [bool(v) for v in a0] == [e for _, e in MV_CAND_KAT_A0]
+    b0 = O.mv_cand_helpers([g for g, _ in MV_CAND_KAT_B0], 1920, 1080)[1]
+    assert [bool(v) for v in b0] == [e for _, e in MV_CAND_KAT_B0]
+    d = gold("mv_cand.npz")
+    a0, b0, idx = O.mv_cand_helpers(d["geoms"], 192, 192)
+    np.testing.assert_array_equal(a0, d["a0"])
+    np.testing.assert_array_equal(b0, d["b0"])
+    np.testing.assert_array_equal(idx, d["idx"])
+
+
+def test_candidate_places_show_in_the_derived_merge_lists():
+    """the same places through the full derivation: in a picture whose units all carry a vector naming them, the first merge
+    candidates of every PU are the units at A1, B1, B0, A0, B2 (inter.c:1314-1446 order) that mv_cand.npz says exist"""
+    from patterns import mv_cand_unique_map_case
+    d = gold("mv_cand.npz")
+    p, cus, pus = mv_cand_unique_map_case(192)
+    out_pus, out_merge = O.inter_candidates(p, cus, None, None, pus)
+    from patterns import check_unique_map_merge_lists
+    check_unique_map_merge_lists(d, pus, np.asarray(out_merge))
+
+
+def test_reference_bipred_unit_test_configuration():
+    """tests/inter_recon_bipred_tests.c: its configuration (16x16 at the LCU origin, both vectors fractional, zero buffers) and seeded
+    variants -- the test file's own restatement of the blend (:74-121, patterns.bipred_expected), the oracle's blend and what the
+    compiled reference's generic strategy wrote (tests/golden/bipred.npz) must all agree"""
+    from patterns import BIPRED_CASES, bipred_case_blocks, bipred_case_inputs, bipred_expected
+    d = gold("bipred.npz")
+    for k, (seed, w, h, x, y, hi) in enumerate(BIPRED_CASES):
+        hp0, hp1, rec, tmp = bipred_case_inputs(seed)
+        want = [d["y%d" % k], d["u%d" % k], d["v%d" % k]]
+        for a, b in zip(bipred_expected(hi, w, h, x, y, hp0, hp1, rec, tmp), want):
+            np.testing.assert_array_equal(a, b, err_msg="case %d: the test file's formula" % k)
+        for plane, (bw, bh, hi0, s0, hi1, s1, (rows, cols)) in enumerate(bipred_case_blocks(k)):
+            stride = 64 if plane == 0 else 32
+            np.testing.assert_array_equal(O.bipred_blend_plane(bw, bh, hi0, s0, hi1, s1), want[plane].reshape(stride, stride)[rows, cols],
+                                          err_msg="case %d plane %d" % (k, plane))
+            outside = want[plane].reshape(stride, stride).copy()
+            outside[rows, cols] = rec[plane].reshape(stride, stride)[rows, cols]
+            np.testing.assert_array_equal(outside.ravel(), rec[plane], err_msg="case %d: pixels outside the block are untouched" % k)
+
+
 def test_golden_recorded_candidates():
     """candidates the reference encoder derived during a real encode, from snapshots of the state its functions read"""
     from patterns import recorded_cand_fixture

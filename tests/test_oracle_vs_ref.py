@@ -638,3 +638,16 @@ def test_candidates_on_recorded_encoder_states():
         np.testing.assert_array_equal(got[fld], want[fld], err_msg=fld)
     # the states are not trivial: spatial / temporal candidates and non-zero predictors occur
     assert (np.abs(want["mv_cand"]).sum(axis=(1, 2)) > 0).mean() > 0.3 and (np.abs(want["extra_mv"]).sum(axis=1) > 0).any()
+
+
+def test_candidate_helpers_vs_the_reference_unit_test_functions():
+    """is_a0_cand_coded / is_b0_cand_coded / get_spatial_merge_candidates themselves (file-local in inter.c, reached like
+    tests/mv_cand_tests.c reaches them) for every PU of every partition mode, and the test's own known answers"""
+    from patterns import MV_CAND_KAT_A0, MV_CAND_KAT_B0, MV_CAND_KAT_SPATIAL, valid_pu_geometries
+    geoms = valid_pu_geometries(192)
+    for a, b in zip(O.mv_cand_helpers(geoms, 192, 192), R.mv_cand_helpers(geoms, 192, 192)):
+        np.testing.assert_array_equal(a, b)
+    (x, y, w, h, pw, ph), want = MV_CAND_KAT_SPATIAL
+    assert tuple(R.mv_cand_helpers([(x, y, w, h)], pw, ph)[2][0]) == want
+    assert [bool(v) for v in R.mv_cand_helpers([g for g, _ in MV_CAND_KAT_A0], 1920, 1080)[0]] == [e for _, e in MV_CAND_KAT_A0]
+    assert [bool(v) for v in R.mv_cand_helpers([g for g, _ in MV_CAND_KAT_B0], 1920, 1080)[1]] == [e for _, e in MV_CAND_KAT_B0]

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(w, h, n, opts, threads, min_sizes, seed=5, repeat=1, shadow=False):
+def run(w, h, n, opts, threads, min_sizes, seed=5, repeat=1, shadow=False, probe=False):
     import ref_lib as R
     lib = os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so")
     frames = R.synthetic_sequence(w, h, n, seed=seed)
@@ -31,6 +31,9 @@ def run(w, h, n, opts, threads, min_sizes, seed=5, repeat=1, shadow=False):
             plain, _ = R.encode(frames, w, h, o)
             dt = time.perf_counter() - t0
             best_plain = dt if best_plain is None else min(best_plain, dt)
+        if probe:
+            _, c = R.encode_with_service(frames, w, h, o, lib, max_threads=max(64, t + 8), probe=True)
+            print(json.dumps(dict(size="%dx%d" % (w, h), opts=o, cpu_search_us=c["probe_us_per_search"], cpu_searches=c["probe_searches"])), flush=True)
         for ms in min_sizes:
             best, c, same = None, None, True
             for _ in range(repeat):
@@ -66,10 +69,11 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--shadow", action="store_true")
+    ap.add_argument("--probe", action="store_true", help="also time the reference's own inter searches per CU size (nothing served)")
     a = ap.parse_args()
     w, h = (int(v) for v in a.size.split("x"))
     rows = run(w, h, a.frames, a.opts, [int(v) for v in a.threads.split(",")], [int(v) for v in a.min_size.split(",")],
-               seed=a.seed, repeat=a.repeat, shadow=a.shadow)
+               seed=a.seed, repeat=a.repeat, shadow=a.shadow, probe=a.probe)
     ok = all(r["identical_bitstream"] and r["failed"] == 0 for r in rows)
     print(json.dumps(dict(summary="served_encode", all_identical=ok, runs=len(rows))))
     return 0 if ok else 1
