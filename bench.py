@@ -209,6 +209,14 @@ class Env:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [int(v) for v in t.tolist()]
 
+    def all_gather(self, obj):
+        """[obj of rank 0, ...] on every rank (descriptions of the shards; outside the timed regions)"""
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def events(self, n):
         return [self.L.kvz_hip_event_create() for _ in range(n)]
 
@@ -280,18 +288,26 @@ def headline_leg(env, steps, warmup, frames):
     return dt, ms, blocks
 
 
-def shard_kernel_leg(env, sh, steps, warmup, frames):
-    """the three block kernels over this rank's CTU rows of a fixed batch of 4K frames"""
+def shard_kernel_leg(env, sh, steps, warmup, frames, partition):
+    """the three block kernels over this rank's share of a fixed batch of 4K frames: a raster span of CTUs (partition "spans":
+    shares equal to within one CTU) or whole CTU rows ("rows")"""
     from kvazaar_amd import shard as S
     torch, dev = env.torch, env.dev
-    cur, ref, res = [], [], []
-    for r, h in sh.ctu_row_heights():
-        c, f = S.block_pairs_of_ctu_row(torch, dev, SEED, r, h, sh.width, frames, 8)
-        cur.append(c); ref.append(f)
-        res.append(S.residual_blocks_of_ctu_row(torch, dev, SEED, r, h, sh.width, frames, 32))
-    cur, ref, res = torch.cat(cur), torch.cat(ref), torch.cat(res)
+    if partition == "spans":
+        sp = S.SpanShard(sh.width, sh.height, env.world, env.rank)
+        cur, ref = S.block_pairs_of_ctu_span(torch, dev, SEED, sp.ctus(), frames, 8)
+        res = S.residual_blocks_of_ctu_span(torch, dev, SEED, sp.ctus(), frames, 32)
+        want8, want32, descr = sp.blocks(8) * frames, sp.blocks(32) * frames, sp.describe()
+    else:
+        cur, ref, res = [], [], []
+        for r, h in sh.ctu_row_heights():
+            c, f = S.block_pairs_of_ctu_row(torch, dev, SEED, r, h, sh.width, frames, 8)
+            cur.append(c); ref.append(f)
+            res.append(S.residual_blocks_of_ctu_row(torch, dev, SEED, r, h, sh.width, frames, 32))
+        cur, ref, res = torch.cat(cur), torch.cat(ref), torch.cat(res)
+        want8, want32, descr = sh.blocks(8) * frames, sh.blocks(32) * frames, sh.describe()
     n8, n32 = cur.shape[0], res.shape[0]
-    assert n8 == sh.blocks(8) * frames and n32 == sh.blocks(32) * frames
+    assert n8 == want8 and n32 == want32
     sad = torch.empty(n8, dtype=torch.int32, device=dev)
     satd = torch.empty(n8, dtype=torch.int32, device=dev)
     coef = torch.empty_like(res)
@@ -302,7 +318,8 @@ def shard_kernel_leg(env, sh, steps, warmup, frames):
     ms = collect_event_ms(env, evs)
     ca, cw = S.coeff_checksum(torch, coef)
     sums = env.all_sum([S.cost_checksum(sad), S.cost_checksum(satd), ca, cw, n8, n32])
-    return dt, ms, {"sad_8x8": n8, "satd_8x8": n8, "dct_32x32": n32}, sums
+    per_rank = env.all_gather([2 * n8 + n32, descr])
+    return dt, ms, {"sad_8x8": n8, "satd_8x8": n8, "dct_32x32": n32}, sums, per_rank
 
 
 def shard_search_leg(env, sh, steps, warmup, frames):
@@ -318,20 +335,38 @@ def shard_search_leg(env, sh, steps, warmup, frames):
     recs = [S.shard_plane(torch, dev, sh, SEED, f, 1, extended=False) for f in range(frames)]      # reconstruction, own rows
     ext_ref = torch.zeros((sh.ext_rows, W), dtype=torch.uint8, device=dev)
     pus_np, spans = S.shard_pus(np, sh, (8, 16, 32, 64), ME_PU)
+    # The exchange overlaps with the search: the CTU rows away from the shared edges ("interior", vectors confined to the rank's
+    # own rows) are searched while the halo rows travel on a second stream; the CTU rows next to a shared edge ("boundary",
+    # own rows + halo) wait for them on the device (kvz_hip_stream_wait_event).  PUs are regrouped so that every launch takes a
+    # contiguous run of one size class.
+    order, groups = [], []                        # groups: (name, first PU in the regrouped list, count, params)
+    for name, idx, tile in S.search_groups(np, sh, pus_np):
+        for hint, sizes in ((1, (8, 16)), (2, (32,)), (4, (64,))):
+            sel = idx[np.isin(pus_np["width"][idx], sizes)]
+            if len(sel):
+                # preset medium: hexbs, early termination on, fme_level 4; mv_constraint 4: no vector may make the search or its
+                # interpolation read beyond the group's rectangle
+                p = me_params(lambda_cost=20, early_termination=1, fme_level=4, mv_constraint=4, tile=tile)
+                p["size_classes"] = hint
+                groups.append((name, len(order), len(sel), p))
+                order += sel.tolist()
+    pus_np = pus_np[np.asarray(order, dtype=np.int64)]
     pus = torch.from_numpy(pus_np.view(np.uint8).reshape(-1, 64)).to(dev)
     results = torch.zeros((frames, len(pus_np), 8), dtype=torch.int32, device=dev)
-    # preset medium: hexbs, early termination on, fme_level 4; mv_constraint 4 on the extended buffer (= the tile):
-    # no vector may make the search or its interpolation read beyond the halo
-    groups = []                                   # (first PU, count, params) per launch: <=16x16 in one, 32x32, 64x64
-    a8, c8 = spans[8]; a16, c16 = spans[16]
-    for first, count, hint in ((a8, c8 + c16, 1), (spans[32][0], spans[32][1], 2), (spans[64][0], spans[64][1], 4)):
-        p = me_params(lambda_cost=20, early_termination=1, fme_level=4, mv_constraint=4)
-        p["size_classes"] = hint
-        groups.append((first, count, p))
     staging = {}
+    xstream = L.kvz_hip_stream_create()                                   # the exchange's stream
+    xt = torch.cuda.ExternalStream(int(xstream), device=dev)
+    ev_rows, ev_halo = L.kvz_hip_event_create(), L.kvz_hip_event_create()
     torch.cuda.synchronize()
-    evs = [[env.events(3) for _ in range(frames)] for _ in range(steps)]
+    evs = [[env.events(4) for _ in range(frames)] for _ in range(steps)]
     row_bytes = sh.rows * W
+
+    def search(f, which):
+        for name, first, count, p in groups:
+            if name == which:
+                env.check(L.kvz_hip_search_pu_batch(pics[f].data_ptr(), W, W, sh.ext_rows, ext_ref.data_ptr(), W, W, sh.ext_rows,
+                                                    pus.data_ptr() + 64 * first, count, p.ctypes.data,
+                                                    results[f].data_ptr() + 32 * first, st), "search_pu")
 
     def step(k):
         for f in range(frames):
@@ -340,27 +375,33 @@ def shard_search_leg(env, sh, steps, warmup, frames):
             prev = recs[(f - 1) % frames]
             env.check(L.kvz_hip_memcpy_d2d(ext_ref.data_ptr() + sh.top * W, prev.data_ptr(), row_bytes, st), "rec rows")
             if env.dist:
-                with torch.cuda.stream(env.tstream):
+                L.kvz_hip_event_record(ev_rows, st)
+                env.check(L.kvz_hip_stream_wait_event(xstream, ev_rows), "wait rows")
+                with torch.cuda.stream(xt):
                     S.exchange_halo_into(ext_ref, sh, env.dist, staging)
+                L.kvz_hip_event_record(ev_halo, xstream)
             if ev: L.kvz_hip_event_record(ev[1], st)
-            for first, count, p in groups:
-                if count:
-                    env.check(L.kvz_hip_search_pu_batch(pics[f].data_ptr(), W, W, sh.ext_rows, ext_ref.data_ptr(), W, W, sh.ext_rows,
-                                                        pus.data_ptr() + 64 * first, count, p.ctypes.data,
-                                                        results[f].data_ptr() + 32 * first, st), "search_pu")
+            search(f, "interior")
             if ev: L.kvz_hip_event_record(ev[2], st)
+            if env.dist:                                                  # also keeps the next frame's copy into ext_ref behind this frame's sends
+                env.check(L.kvz_hip_stream_wait_event(st, ev_halo), "wait halo")
+            search(f, "boundary")
+            if ev: L.kvz_hip_event_record(ev[3], st)
 
     dt = env.timed(step, steps, warmup)
-    ex_ms, se_ms = [], []
+    ex_ms, se_ms, bd_ms = [], [], []
     for k in range(steps):
         for f in range(frames):
             ex_ms.append(env.elapsed(evs[k][f][0], evs[k][f][1]))
             se_ms.append(env.elapsed(evs[k][f][1], evs[k][f][2]))
+            bd_ms.append(env.elapsed(evs[k][f][2], evs[k][f][3]))
     r = results.cpu().numpy().view(ME_RESULT).reshape(frames, -1)
     found = int((r["cost"] != 0xFFFFFFFF).sum())
     sums = env.all_sum([len(pus_np), found, int(r["mv"].astype(np.int64).sum()), int(r["cost"].astype(np.int64).sum()),
                         int((np.abs(r["mv"][..., 0] - S.NOMINAL_MV[0]) + np.abs(r["mv"][..., 1] - S.NOMINAL_MV[1]) <= 2).sum())])
-    return dt, ex_ms, se_ms, sums
+    n_boundary = sum(c for (name, _, c, _) in groups if name == "boundary")
+    L.kvz_hip_stream_sync(xstream); L.kvz_hip_stream_destroy(xstream)
+    return dt, ex_ms, se_ms, bd_ms, sums, n_boundary
 
 
 SHARD_LEG_LIMIT_S = 300
@@ -376,6 +417,8 @@ def main():
     ap.add_argument("--search-frames", type=int, default=8, help="4K frames per step of the sharded search sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-leg", action="store_true")
+    ap.add_argument("--partition", choices=("spans", "rows"), default="spans",
+                    help="shard_4k block-kernel leg: raster spans of CTUs (equal to within one CTU) or whole CTU rows")
     args = ap.parse_args()
     env = Env(args)
     torch, world, rank = env.torch, env.world, env.rank
@@ -427,7 +470,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     # The shard leg exchanges halo rows between ranks; should a collective ever hang, the headline line is still printed: a
-    # watchdog emits it (with the failure noted) and ends the process.
+    # watchdog emits it (with the failure noted) and ends the process with a non-zero exit code.
     watchdog = None
     if not args.no_shard_leg and world > 1:
         import threading
@@ -436,7 +479,7 @@ def main():
             sys.stderr.write("rank %d: shard_4k leg exceeded %d s, giving up on it\n" % (rank, SHARD_LEG_LIMIT_S))
             if rank == 0:
                 emit({"error": "timed out after %d s" % SHARD_LEG_LIMIT_S, "note": "the shard_4k leg hung; `value` (headline leg) is unaffected"})
-            os._exit(0)
+            os._exit(3)                 # a hung exchange is a failed run: the line above is for the record, the exit code says so
         watchdog = threading.Timer(SHARD_LEG_LIMIT_S, give_up)
         watchdog.daemon = True
         watchdog.start()
@@ -448,15 +491,11 @@ def main():
         F4, FS = args.frames_4k, args.search_frames
         shard_err = None
         try:
-            kdt, kms, kblocks, ksums = shard_kernel_leg(env, sh, args.steps, args.warmup, F4)
+            kdt, kms, kblocks, ksums, kper_rank = shard_kernel_leg(env, sh, args.steps, args.warmup, F4, args.partition)
             torch.cuda.empty_cache()
             s_steps, s_warm = max(1, args.steps // 10), max(1, args.warmup // 10)        # a search step is FS frames, ~8 ms at N = 1
-            sdt, ex_ms, se_ms, ssums = shard_search_leg(env, sh, s_steps, s_warm, FS)
-            descr = [None] * world
-            if env.dist:
-                env.dist.all_gather_object(descr, sh.describe())
-            else:
-                descr = [sh.describe()]
+            sdt, ex_ms, se_ms, bd_ms, ssums, n_boundary = shard_search_leg(env, sh, s_steps, s_warm, FS)
+            descr = env.all_gather([sh.describe(), sh.rows, n_boundary])
         except Exception as e:              # noqa: BLE001 -- the headline line must still be printed; the failure is reported in it
             import traceback
             shard_err = "%s: %s" % (type(e).__name__, e)
@@ -469,13 +508,18 @@ def main():
             kern = kernel_stats(kms, kblocks)
             n_pus = ssums[0]
             shard_out = {
-                "metric": "Mblocks/s (SAD8/SATD8/DCT32) over ONE fixed batch of 4K frames cut by CTU rows across the ranks",
+                "metric": "Mblocks/s (SAD8/SATD8/DCT32) over ONE fixed batch of 4K frames cut across the ranks (%s)"
+                          % ("raster spans of CTUs, equal to within one CTU" if args.partition == "spans" else "whole CTU rows"),
                 "value": round((2 * tot8 + tot32) * args.steps / kdt / 1e6, 1), "unit": "Mblocks/s", "scaling": "strong",
                 "n_gpus": world, "steps": args.steps, "ms_per_step": round(kdt / args.steps * 1e3, 5),
                 "workload": "3840x2160 x %d frames, fixed for every N: %d 8x8 pairs (sad_8x8 + satd_8x8) and %d 32x32 residual blocks "
-                            "(dct_32x32) in total; rank r owns its CTU rows (kvazaar_amd/shard.py row_range over 34 rows) of every frame; "
-                            "no data-path collective" % (F4, tot8, tot32),
-                "rows_per_rank": descr,
+                            "(dct_32x32) in total; rank r owns its %s of every frame; no data-path collective"
+                            % (F4, tot8, tot32, "raster span of the 2040 CTUs (kvazaar_amd/shard.py SpanShard)" if args.partition == "spans"
+                               else "CTU rows (kvazaar_amd/shard.py row_range over 34 rows)"),
+                "partition": args.partition,
+                "share_per_rank": [d for (_, d) in kper_rank],
+                # what the partition itself allows: all blocks / the largest rank's blocks (whole CTU rows over 8 ranks: 34 / 5 = 6.8)
+                "ideal_speedup": round(S.ideal_speedup([b for (b, _) in kper_rank]), 3),
                 "rank0_kernels": kern,
                 "checksums_over_all_ranks": {"sum_sad": ksums[0], "sum_satd": ksums[1], "sum_abs_coeff": ksums[2], "sum_weighted_coeff": ksums[3],
                                              "note": "partition-independent: equal for every n_gpus"},
@@ -484,14 +528,18 @@ def main():
                     "value": round(n_pus * FS * s_steps / sdt / 1e6, 3), "unit": "M PUs/s", "scaling": "strong",
                     "frames_per_s": round(FS * s_steps / sdt, 1), "ms_per_frame": round(sdt / (FS * s_steps) * 1e3, 4),
                     "steps": s_steps, "frames_per_step": FS, "PUs_per_frame": n_pus,
-                    "rank0_ms_per_frame": {"rec_rows_copy_plus_halo_exchange": round(sum(ex_ms) / len(ex_ms), 4),
-                                           "exchange_median": round(sorted(ex_ms)[len(ex_ms) // 2], 4),
-                                           "search_launches": round(sum(se_ms) / len(se_ms), 4)},
+                    "rows_per_rank": [d for (d, _, _) in descr],
+                    "ideal_speedup": round(S.ideal_speedup([r for (_, r, _) in descr]), 3),
+                    "rank0_ms_per_frame": {"rec_rows_copy_and_exchange_enqueue": round(sum(ex_ms) / len(ex_ms), 4),
+                                           "interior_search_while_the_halo_travels": round(sum(se_ms) / len(se_ms), 4),
+                                           "wait_for_halo_plus_boundary_search": round(sum(bd_ms) / len(bd_ms), 4)},
+                    "boundary_PUs_per_rank": [b for (_, _, b) in descr],
                     "exchange": {"backend": env.backend if world > 1 else None, "halo_rows": S.HALO_ROWS,
                                  "bytes_per_boundary_per_frame_each_way": S.HALO_ROWS * W4K,
-                                 "what": "luma rows of the previous frame's reconstruction, isend/irecv between ring neighbours, "
-                                         "enqueued on the kernel stream inside the timed region"},
-                    "mv_constraint": "4 (frame and tile margin) with the tile = the rank's rows + halo: no read beyond the halo",
+                                 "what": "luma rows of the previous frame's reconstruction, isend/irecv between ring neighbours on a second "
+                                         "stream inside the timed region; the CTU rows away from the shared edges are searched meanwhile, the "
+                                         "two CTU rows next to an edge after the halo has landed (kvz_hip_stream_wait_event)"},
+                    "mv_constraint": "4 (frame and tile margin): interior CTU rows confined to the rank's own rows, boundary CTU rows to rows + halo",
                     "results": {"searched": ssums[0] * FS, "found": ssums[1], "within_half_pel_of_true_motion": ssums[4],
                                 "sum_mv": ssums[2], "sum_cost": ssums[3],
                                 "note": "depends on the partition (the halo bounds the vectors), like tiles in the reference"},

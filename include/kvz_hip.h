@@ -382,7 +382,8 @@ typedef struct {
   int32_t mv_constraint;         /* cfg.mv_constraint (enum kvz_mv_constraint, kvazaar.h:113-119): 0 none, 1 frame, 2 tile, 3 frame and tile,
                                     4 frame and tile with the interpolation margin -- the five branches of fracmv_within_tile
                                     (search_inter.c:142-171; the reference treats 1..3 alike) */
-  int32_t tile_x, tile_y;        /* state->tile->offset_x / offset_y: top-left of the tile (multiples of 64) in the picture */
+  int32_t tile_x, tile_y;        /* state->tile->offset_x / offset_y: top-left of the tile in the picture (multiples of 64 in the reference;
+                                    required here only with wpp_owf, whose rule counts LCUs from the tile origin) */
   int32_t tile_w, tile_h;        /* state->tile->frame->width / height; 0 x 0 = the whole picture is one tile.  PU coordinates stay
                                     picture coordinates; the entry derives the tile-relative info->origin the reference tests.
                                     A CTU-row shard of a frame is a tile of full width: with mv_constraint 3 or 4 its

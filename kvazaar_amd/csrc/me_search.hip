@@ -936,8 +936,8 @@ static int search_pu_launch(const kvz_hip_pixel *pic, uint32_t pic_stride, int p
   kvz_hip_me_params prm_v = *params;
   if (prm_v.tile_w == 0 && prm_v.tile_h == 0) { prm_v.tile_x = 0; prm_v.tile_y = 0; prm_v.tile_w = pic_w; prm_v.tile_h = pic_h; }
   if (prm_v.mv_constraint < 0 || prm_v.mv_constraint > 4 || prm_v.tile_x < 0 || prm_v.tile_y < 0 || prm_v.tile_w <= 0 || prm_v.tile_h <= 0 ||
-      prm_v.tile_x + prm_v.tile_w > pic_w || prm_v.tile_y + prm_v.tile_h > pic_h || (prm_v.tile_x & 63) || (prm_v.tile_y & 63)) {
-    set_error_msg("kvz_hip_search_pu_batch: mv_constraint must be 0..4 and the tile (origin a multiple of 64) must lie inside the picture");
+      prm_v.tile_x + prm_v.tile_w > pic_w || prm_v.tile_y + prm_v.tile_h > pic_h || (prm_v.wpp_owf && ((prm_v.tile_x & 63) || (prm_v.tile_y & 63)))) {
+    set_error_msg("kvz_hip_search_pu_batch: mv_constraint must be 0..4 and the tile must lie inside the picture (origin a multiple of 64 when wpp_owf is set: its rule counts LCUs from there)");
     return KVZ_HIP_ERR_INVALID;
   }
   params = &prm_v;

@@ -170,7 +170,7 @@ bool request_ok(const kvz_hip_me_service *svc, const kvz_hip_me_request *r)
   if (p.mv_constraint < 0 || p.mv_constraint > 4) return false;
   if (!(p.tile_w == 0 && p.tile_h == 0) &&
       (p.tile_x < 0 || p.tile_y < 0 || p.tile_w <= 0 || p.tile_h <= 0 || p.tile_x + p.tile_w > svc->w || p.tile_y + p.tile_h > svc->h ||
-       (p.tile_x & 63) || (p.tile_y & 63))) return false;
+       (p.wpp_owf && ((p.tile_x & 63) || (p.tile_y & 63))))) return false;
   return true;
 }
 

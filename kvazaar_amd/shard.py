@@ -45,6 +45,47 @@ def blocks_in_rows(frame_width, y_lo, y_hi, n):
     return max(0, last - first) * (frame_width // n)
 
 
+def span_range(n_units, world, rank):
+    """contiguous [lo, hi) of `n_units` units in raster order owned by `rank`; sizes differ by at most one"""
+    return row_range(n_units, world, rank)
+
+
+def ideal_speedup(sizes):
+    """the best speed-up a partition into shards of these sizes can reach over one rank: total / largest"""
+    sizes = list(sizes)
+    return float(sum(sizes)) / float(max(sizes)) if sizes and max(sizes) > 0 else 0.0
+
+
+class SpanShard:
+    """One rank's share of a frame for the BLOCK kernels: a contiguous raster span of CTUs [ctu_lo, ctu_hi).  Blocks are
+    independent, so a shard need not be a rectangle: spans balance to within one CTU (4K over 8 ranks: 2040 CTUs -> 255
+    each, ideal speed-up 8.0, where whole CTU rows give 5,5,4,... of 34 and at best 6.8).  The reference's analogue is a
+    slice of consecutive LCUs (slices end at arbitrary LCU addresses, encoder.c:513-560 `slice_addresses_in_ts`); its tiles
+    split in both directions (encoder.c:430-510).  A span longer than one CTU row still has only its two raster neighbours
+    as neighbours, so the exchange pattern of a row shard (rank r <-> r +- 1) carries over."""
+
+    def __init__(self, width, height, world, rank, ctu=CTU):
+        self.width, self.height, self.world, self.rank, self.ctu = width, height, world, rank, ctu
+        self.cols, self.rows_ctu = (width + ctu - 1) // ctu, (height + ctu - 1) // ctu
+        self.n_ctus = self.cols * self.rows_ctu
+        self.ctu_lo, self.ctu_hi = span_range(self.n_ctus, world, rank)
+
+    def ctus(self):
+        """[(ctu index, width, height of the CTU inside the frame)] of this shard, raster order"""
+        out = []
+        for i in range(self.ctu_lo, self.ctu_hi):
+            cy, cx = divmod(i, self.cols)
+            out.append((i, min(self.ctu, self.width - cx * self.ctu), min(self.ctu, self.height - cy * self.ctu)))
+        return out
+
+    def blocks(self, n):
+        """full n x n blocks of one frame that lie in this shard"""
+        return sum((w // n) * (h // n) for (_, w, h) in self.ctus())
+
+    def describe(self):
+        return {"ctus": [self.ctu_lo, self.ctu_hi], "of": self.n_ctus}
+
+
 def max_over_ranks(dt, dist=None, device=None):
     """bench contract: the reported time is the MAX over ranks"""
     if dist is None or not dist.is_initialized():
@@ -69,8 +110,13 @@ class RowShard:
         self.ext_hi = min(height, self.y_hi + margin) if rank < world - 1 else self.y_hi
         self.top = self.y_lo - self.ext_lo
         self.ext_rows = self.ext_hi - self.ext_lo
-        if world > 1 and self.rows < margin:
-            raise ValueError("a shard of %d rows is thinner than the halo margin %d: use fewer ranks" % (self.rows, margin))
+        # every rank evaluates every rank's share, so that all of them raise together (one rank raising alone would leave the
+        # others waiting in the exchange until its timeout)
+        if world > 1:
+            n_rows = ctu_rows(height, ctu)
+            thinnest = min(min(row_range(n_rows, world, r)[1] * ctu, height) - row_range(n_rows, world, r)[0] * ctu for r in range(world))
+            if thinnest < margin:
+                raise ValueError("a shard of %d rows is thinner than the halo margin %d: use fewer ranks" % (thinnest, margin))
 
     def blocks(self, n):
         """full n x n blocks of one frame that lie in this shard"""
@@ -115,6 +161,35 @@ def residual_blocks_of_ctu_row(torch, device, seed, ctu_row, row_height, width, 
     count = frames * (row_height // n) * (width // n)
     g = _gen(torch, device, seed * 1000003 + ctu_row * 2 + 1)
     return torch.randint(-255, 256, (count, n * n), dtype=torch.int16, device=device, generator=g)
+
+
+def block_pairs_of_ctu_span(torch, device, seed, ctus, frames, n=8):
+    """(cur, ref): the n x n block pairs of the CTUs `ctus` = [(index, w, h)] of `frames` frames, generated PER CTU from a seed
+    that names the CTU, so that the union over any partition is the same data (each CTU keeps its own random stream)."""
+    cur, ref = [], []
+    for (i, w, h) in ctus:
+        count = frames * (h // n) * (w // n)
+        g = _gen(torch, device, seed * 1000003 + 500009 + i * 2)
+        c = torch.randint(0, 256, (count, n * n), dtype=torch.uint8, device=device, generator=g)
+        noise = torch.randint(-8, 9, (count, n * n), dtype=torch.int16, device=device, generator=g)
+        cur.append(c)
+        ref.append((c.to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8))
+    if not cur:
+        z = torch.zeros((0, n * n), dtype=torch.uint8, device=device)
+        return z, z.clone()
+    return torch.cat(cur), torch.cat(ref)
+
+
+def residual_blocks_of_ctu_span(torch, device, seed, ctus, frames, n=32):
+    """int16 [blocks, n*n] residual blocks in [-255, 255] of the CTUs `ctus`, one stream per CTU (see block_pairs_of_ctu_span)"""
+    res = []
+    for (i, w, h) in ctus:
+        count = frames * (h // n) * (w // n)
+        g = _gen(torch, device, seed * 1000003 + 500009 + i * 2 + 1)
+        res.append(torch.randint(-255, 256, (count, n * n), dtype=torch.int16, device=device, generator=g))
+    if not res:
+        return torch.zeros((0, n * n), dtype=torch.int16, device=device)
+    return torch.cat(res)
 
 
 NOMINAL_MV = (12, 4)      # quarter-pel: the synthetic sequence moves 3 px / 1 px per frame (plane_rows_of_ctu_row)
@@ -253,6 +328,31 @@ def shard_pus(np, shard, sizes=(8, 16, 32, 64), me_pu_dtype=None):
         spans[n] = (sum(len(r) for r in recs), len(a))
         recs.append(a)
     return np.concatenate(recs), spans
+
+
+BOUNDARY_CTU_ROWS = 2      # HALO_ROWS = 80 > 64: the two CTU rows next to a shared edge are the ones whose search may read halo rows
+
+
+def search_groups(np, shard, pus, boundary_ctu_rows=BOUNDARY_CTU_ROWS):
+    """Splits a shard's PUs (shard_pus: extended-buffer coordinates) for an exchange that overlaps with the search:
+    -> [(name, index array, tile)] with tile = (x, y, w, h) in EXTENDED-buffer coordinates.
+      "interior": PUs of CTU rows at least `boundary_ctu_rows` away from every edge the shard shares with a neighbour; their
+                  vectors are confined to the shard's OWN rows (kvz_hip_me_params.tile_*, mv_constraint 4), so this group
+                  can be searched while the halo rows are still in flight;
+      "boundary": the PUs of the CTU rows next to a shared edge, searched under own rows + halo once the exchange has landed.
+    A rank without neighbours (world 1) has only interior PUs.  An unsharded search of the same PUs under the same
+    rectangles (moved to frame coordinates by ext_lo) gives the same results: tests/test_shard_gloo.py."""
+    ctu = shard.ctu
+    row = (pus["y"] + shard.ext_lo) // ctu
+    near_top = (row < shard.ctu_lo + boundary_ctu_rows) if shard.rank > 0 else np.zeros(len(pus), bool)
+    near_bot = (row >= shard.ctu_hi - boundary_ctu_rows) if shard.rank < shard.world - 1 else np.zeros(len(pus), bool)
+    boundary = near_top | near_bot
+    own = (0, shard.top, shard.width, shard.rows)
+    ext = (0, 0, shard.width, shard.ext_rows)
+    out = [("interior", np.nonzero(~boundary)[0], own)]
+    if boundary.any():
+        out.append(("boundary", np.nonzero(boundary)[0], ext))
+    return out
 
 
 def cost_checksum(costs):

@@ -125,14 +125,11 @@ def _shard_leg_worker(rank, world, port, q):
     dev = torch.device("cpu")
     W, H, margin, frames, seed = 192, 64 * 5 + 40, 48, 2, 77        # 6 CTU rows, the last one ragged (40 px)
     sh = shard.RowShard(W, H, world, rank, margin)
-    # -- block kernels: this rank's blocks only; checksums summed over ranks
-    cur, ref, res = [], [], []
-    for r, h in sh.ctu_row_heights():
-        c, f = shard.block_pairs_of_ctu_row(torch, dev, seed, r, h, W, frames, 8)
-        cur.append(c); ref.append(f)
-        res.append(shard.residual_blocks_of_ctu_row(torch, dev, seed, r, h, W, frames, 32))
-    cur, ref, res = torch.cat(cur), torch.cat(ref), torch.cat(res)
-    assert cur.shape[0] == sh.blocks(8) * frames and res.shape[0] == sh.blocks(32) * frames
+    # -- block kernels: this rank's blocks only (a raster span of CTUs, bench.py's default partition); checksums summed over ranks
+    sp = shard.SpanShard(W, H, world, rank)
+    cur, ref = shard.block_pairs_of_ctu_span(torch, dev, seed, sp.ctus(), frames, 8)
+    res = shard.residual_blocks_of_ctu_span(torch, dev, seed, sp.ctus(), frames, 32)
+    assert cur.shape[0] == sp.blocks(8) * frames and res.shape[0] == sp.blocks(32) * frames
     sad = torch.from_numpy(O.cost_nxn_many("sad", 8, cur.numpy(), ref.numpy(), threads=1).astype(np.int64))
     satd = torch.from_numpy(O.cost_nxn_many("satd", 8, cur.numpy(), ref.numpy(), threads=1).astype(np.int64))
     coef = torch.from_numpy(O.transform_many("dct", 32, res.numpy(), threads=1))
@@ -142,34 +139,46 @@ def _shard_leg_worker(rank, world, port, q):
     # -- search: frame by frame, rec rows of the previous frame -> extended buffer -> exchange -> search inside rows + halo
     pus, spans = shard.shard_pus(np, sh, (8, 16, 32, 64), ME_PU)
     pus = pus[::7]                                                  # the oracle takes ~1 ms per PU
-    prm = me_params(lambda_cost=20, mv_constraint=4)                # tile 0 x 0: the extended buffer is the tile
+    groups = shard.search_groups(np, sh, pus, boundary_ctu_rows=1)   # margin 48 < 64: one CTU row next to a shared edge reads halo rows
     ext_ref = torch.zeros((sh.ext_rows, W), dtype=torch.uint8)
     results = []
     for f in range(1, frames + 1):
         own = shard.shard_plane(torch, dev, sh, seed, f - 1, 1, extended=False)
         ext_ref[sh.top:sh.top + sh.rows] = own
+        pic = shard.shard_plane(torch, dev, sh, seed, f, 0)
+        res_f = {}
+        # the interior CTU rows BEFORE the halo rows are there (they are zero at this point): confined to the rank's own rows
+        name, idx, tile = groups[0]
+        assert name == "interior"
+        halo_poisoned = ext_ref.clone()
+        if rank > 0:
+            halo_poisoned[:sh.top] = 255 - halo_poisoned[:sh.top]
+        res_f[name] = O.search_pu_batch(pic.numpy(), halo_poisoned.numpy(), pus[idx], me_params(lambda_cost=20, mv_constraint=4, tile=tile))
         shard.exchange_halo_into(ext_ref, sh, dist)
         whole = shard.full_plane(torch, dev, W, H, seed, f - 1, 1)
         assert torch.equal(ext_ref, whole[sh.ext_lo:sh.ext_hi]), "halo rows differ from the neighbour's rows"
-        pic = shard.shard_plane(torch, dev, sh, seed, f, 0)
-        results.append(O.search_pu_batch(pic.numpy(), ext_ref.numpy(), pus, prm))
+        for name, idx, tile in groups[1:]:
+            res_f[name] = O.search_pu_batch(pic.numpy(), ext_ref.numpy(), pus[idx], me_params(lambda_cost=20, mv_constraint=4, tile=tile))
+        results.append(res_f)
     gathered = [None] * world
-    dist.all_gather_object(gathered, (sh.describe(), sh.tile_in_frame(), sh.ext_lo, pus, results))
+    dist.all_gather_object(gathered, (sh.describe(), [(n, i, t) for (n, i, t) in groups], sh.ext_lo, pus, results))
     if rank == 0:
         ok = True
-        # unsharded: the same PUs on the whole frame, under the tile rectangle of their shard
-        for (_, tile, ext_lo, p, res_sh) in gathered:
+        # unsharded: the same PUs on the whole frame, under the rectangle of their group moved to frame coordinates
+        for (_, grp, ext_lo, p, res_sh) in gathered:
             pf = p.copy()
             pf["y"] += ext_lo                                       # extended-buffer -> frame coordinates
-            prm_full = me_params(lambda_cost=20, mv_constraint=4, tile=tile)
-            for f in range(1, frames + 1):
-                pic = shard.full_plane(torch, dev, W, H, seed, f, 0).numpy()
-                ref_full = shard.full_plane(torch, dev, W, H, seed, f - 1, 1).numpy()
-                want = O.search_pu_batch(pic, ref_full, pf, prm_full)
-                ok = ok and bool((want.view(np.int32) == res_sh[f - 1].view(np.int32)).all())
-        found = sum(int((r["cost"] != 0xFFFFFFFF).sum()) for g_ in gathered for r in g_[4])
-        total = sum(len(r) for g_ in gathered for r in g_[4])
-        q.put((ok, sums.tolist(), [g_[0] for g_ in gathered], found, total))
+            for (name, idx, tile) in grp:
+                prm_full = me_params(lambda_cost=20, mv_constraint=4, tile=(tile[0], tile[1] + ext_lo, tile[2], tile[3]))
+                for f in range(1, frames + 1):
+                    pic = shard.full_plane(torch, dev, W, H, seed, f, 0).numpy()
+                    ref_full = shard.full_plane(torch, dev, W, H, seed, f - 1, 1).numpy()
+                    want = O.search_pu_batch(pic, ref_full, pf[idx], prm_full)
+                    ok = ok and bool((want.view(np.int32) == res_sh[f - 1][name].view(np.int32)).all())
+        found = sum(int((r["cost"] != 0xFFFFFFFF).sum()) for g_ in gathered for rf in g_[4] for r in rf.values())
+        total = sum(len(r) for g_ in gathered for rf in g_[4] for r in rf.values())
+        n_boundary = [sum(len(i) for (n, i, t) in g_[1] if n == "boundary") for g_ in gathered]
+        q.put((ok, sums.tolist(), [g_[0] for g_ in gathered], found, total, n_boundary))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -188,8 +197,10 @@ def _run_shard_leg(world):
 
 def test_shard_leg_sharded_equals_unsharded_and_checksums_do_not_depend_on_world():
     single = _run_shard_leg(1)
+    assert single[5] == [0]                       # a rank without neighbours has no boundary PUs
     for world in (2, 3):
-        ok, sums, descr, found, total = _run_shard_leg(world)
+        ok, sums, descr, found, total, n_boundary = _run_shard_leg(world)
+        assert all(b > 0 for b in n_boundary)
         assert ok, "a shard's search differs from the unsharded search under its tile rectangle (world %d)" % world
         assert sums == single[1], "kernel checksums depend on the partition (world %d)" % world
         assert descr[0]["pixel_rows"][0] == 0 and descr[-1]["pixel_rows"][1] == 64 * 5 + 40
@@ -212,3 +223,23 @@ def test_row_shard_geometry_4k():
     assert shard.HALO_ROWS * 3840 == 307200            # bytes per boundary per frame each way (luma)
     with pytest.raises(ValueError):
         shard.RowShard(3840, 2160, 34, 3, margin=80)   # one CTU row per rank is thinner than the halo
+
+
+def test_span_shards_balance_to_one_ctu_and_cover_the_frame():
+    """the block-kernel partition of bench.py's shard_4k leg: raster spans of CTUs; 4K over 8 ranks = 255 CTUs each (whole CTU rows: 5,5,4,...)"""
+    for (w, h) in ((3840, 2160), (1920, 1080), (200, 136)):
+        for world in (1, 2, 3, 4, 8):
+            shards = [shard.SpanShard(w, h, world, r) for r in range(world)]
+            sizes = [s.ctu_hi - s.ctu_lo for s in shards]
+            assert sum(sizes) == shards[0].n_ctus and max(sizes) - min(sizes) <= 1
+            assert [s.ctu_lo for s in shards[1:]] == [s.ctu_hi for s in shards[:-1]]
+            for n in (8, 32):
+                assert sum(s.blocks(n) for s in shards) == (w // n) * (h // 64) * (64 // n) + (w // n) * ((h % 64) // n)
+    sh8 = [shard.SpanShard(3840, 2160, 8, r) for r in range(8)]
+    assert [s.ctu_hi - s.ctu_lo for s in sh8] == [255] * 8
+    assert shard.ideal_speedup([s.blocks(8) for s in sh8]) > 7.9
+    assert abs(shard.ideal_speedup([shard.RowShard(3840, 2160, 8, r).blocks(8) for r in range(8)]) - 6.75) < 1e-9
+    # generated per CTU: the union over any partition is the same data
+    a = torch.cat([shard.block_pairs_of_ctu_span(torch, "cpu", 3, shard.SpanShard(200, 136, 3, r).ctus(), 2, 8)[0] for r in range(3)])
+    b = shard.block_pairs_of_ctu_span(torch, "cpu", 3, shard.SpanShard(200, 136, 1, 0).ctus(), 2, 8)[0]
+    assert torch.equal(a, b)
