@@ -91,7 +91,10 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * descriptor for frame-level pair batches of up to 4096 descriptors), "wg_chunk_min_wgs" (the workgroup-per-descriptor
  * kernels of the sampling / fractional search entries take up to 64 descriptors per workgroup once the list would give
  * more workgroups than this; 0: always one), "pair_satd_threads" (128 / 256 / 512 threads per workgroup of the
- * descriptor SATD kernel).
+ * descriptor SATD kernel), "qr8_tile_kernel" (0: 8x8 TUs of the fused quantize_residual on the register kernel instead of sixteen to a
+ * matrix-core tile), "qr_tile_pipe" (0: the tile kernels' wait on vector memory left to the compiler instead of placed before the
+ * iteration's first store), "pipe" / "dct_pipe" (1: the same hand placement in the 4x4 / 8x8 register kernels / the 32x32
+ * transform, where it measured slower).
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
  * knobs at kvz_hip_init() for A/B runs of an unmodified host. */
 KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);

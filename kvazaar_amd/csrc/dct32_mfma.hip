@@ -37,7 +37,9 @@ using namespace kvzhip;
 // diag(M16, M16) (dct32_mfma_core.h): the same instruction stream, every lane and accumulator register live -- the round-1
 // two-blocks-per-tile 16x16 kernel left half of K dead (5.7 TB/s forward) and its inverse lost to the VALU butterflies (5.2).
 // `count` is in blocks; a tile's chunks are permuted between memory order and tile order on the way through LDS.
-template <int N, bool INVERSE, bool DST = false>
+// PIPE: the iteration's wait on vector memory placed by hand before its stores (wait_vmem_all, kvz_hip_internal.h) -- for grids
+// whose waves take several tiles each; with one tile per wave there is no loop to pipeline.
+template <int N, bool INVERSE, bool DST = false, bool PIPE = false>
 __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restrict__ in, i16 *__restrict__ out, size_t count)
 {
   constexpr int LOG2N = N == 32 ? 5 : N == 16 ? 4 : 2;
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
   u32x4v cur[2], nx1[2], nx2[2];
   if (t < ntiles) load(t, cur);
   if (t + nwaves < ntiles) load(t + nwaves, nx1);
+  if (PIPE) wait_vmem_all();
   for (; t < ntiles; t += nwaves) {
     const size_t tn = t + 2 * nwaves;
     if (tn < ntiles) load(tn, nx2);                    // keep two of the wave's next tiles in flight
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256, 4) void dct32_mfma_kernel(const i16 *__restric
     int o[16];
     if (!INVERSE) fwd32_core<LOG2N>(hi, lo, t_nat, t_kap, rowsum, o);
     else inv32_core(hi, lo, t_id, t_col, colsum, s_c2[h], o);
+    if (PIPE) wait_vmem_all();
     if (N == 32) rows_to_chunks_store(tile, lane, r, h, o, out + t * 1024);
     else {
 #pragma unroll
@@ -146,7 +150,10 @@ int launch_dct32_mfma(bool inverse, const i16 *in, i16 *out, size_t count, hipSt
   // bounds the grid for lists beyond 4 M blocks.
   const size_t cap = (size_t)num_cus() * (size_t)(inverse ? tuning("idct32_wgs_per_cu", 96) : tuning("dct32_wgs_per_cu", 4096));
   if (wgs > cap) wgs = cap;
-  if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<32, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
+  if (tuning("dct_pipe", 0)) {
+    if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<32, true, false, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
+    else hipLaunchKernelGGL((dct32_mfma_kernel<32, false, false, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
+  } else if (inverse) hipLaunchKernelGGL((dct32_mfma_kernel<32, true>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   else hipLaunchKernelGGL((dct32_mfma_kernel<32, false>), dim3((unsigned)wgs), dim3(256), 0, st, in, out, count);
   KVZ_CHECK_LAUNCH("dct32_mfma_kernel");
   return KVZ_HIP_OK;

@@ -120,6 +120,20 @@ __device__ __forceinline__ void st_stream_u4(void *p, uint4 v)
   __builtin_nontemporal_store(w, (kvz_u32x4 *)p);
 }
 
+// Every outstanding vector-memory operation of the wave has completed; nothing is scheduled across it.
+// Why the streaming kernels place this by hand: gfx950 counts vector loads AND stores in one counter (vmcnt), and loads and
+// stores complete out of order with each other -- once a store is in flight, "wait for that earlier load" can only be
+// expressed as vmcnt(0), which also waits for the stores and for any younger prefetch.  Left to the compiler, a
+// load-compute-store loop with a prefetch waits at its top for the stores it has just issued (or even for the prefetch it
+// has just issued).  The kernels put the iteration's one vmcnt(0) right BEFORE its first store instead: what is
+// outstanding there is the prefetch, issued a stretch of arithmetic earlier, and the previous iteration's stores.
+__device__ __forceinline__ void wait_vmem_all()
+{
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0); expcnt and lgkmcnt left alone (gfx9 encoding)
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // kvz_fast_clip_16bit_to_pixel (picture-generic.c:30-48): int16 argument,

@@ -423,7 +423,9 @@ __global__ __launch_bounds__(256) void quantize_residual_kernel(const u8 *__rest
 // accesses and a wave's are fully coalesced, so there is no LDS and no barrier.  (The LDS kernel below needed
 // nine barriers per 64 TUs and reached 2.2 TB/s.)
 // ---------------------------------------------------------------------------
-template <int TRK>     // 0 DCT, 2 DST (intra luma), 4 transform skip
+// FLAT: flat scaling (no per-coefficient table), compiled without the table loads -- with them in the loop every branch that
+// may have issued one ends in a wait on vector memory, which would also wait for the prefetch.
+template <int TRK, bool PIPE = true, bool FLAT = false>     // TRK: 0 DCT, 2 DST (intra luma), 4 transform skip
 __global__ __launch_bounds__(256) void quantize_residual4_lane_kernel(const u8 *__restrict__ ref_in, const u8 *pred_in, u8 *rec_out,
                                                                       i16 *__restrict__ coeff_out, i32 *__restrict__ has_coeffs,
                                                                       size_t count, quant_consts k,
@@ -431,9 +433,22 @@ __global__ __launch_bounds__(256) void quantize_residual4_lane_kernel(const u8 *
 {
   constexpr int TS_SHIFT = 15 - 8 - 2;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-    const uint4 rv = ld_stream_u4(ref_in + i * 16);
-    const uint4 pv = *(const uint4 *)(pred_in + i * 16);
+  // Software pipeline (wait_vmem_all, kvz_hip_internal.h): the next TU's 32 bytes are requested before this one is worked on, and
+  // the iteration's one wait on vector memory sits just before its stores -- the plain loop waited at its top for the loads
+  // it had just issued AND for the stores of the TU before.  PIPE false: that plain loop, for A/B runs ("pipe" 0).
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4 rv = make_uint4(0, 0, 0, 0), pv = rv, rn = rv, pn = rv;
+  constexpr bool PF = PIPE && FLAT;                       // the prefetch only where nothing else in the loop loads
+  if (PF && i < count) { rv = ld_stream_u4(ref_in + i * 16); pv = *(const uint4 *)(pred_in + i * 16); }
+  if (PF) wait_vmem_all();
+  for (; i < count; i += stride) {
+    if (PF) {
+      const size_t in = i + stride;
+      if (in < count) { rn = ld_stream_u4(ref_in + in * 16); pn = *(const uint4 *)(pred_in + in * 16); }
+    } else {
+      rv = ld_stream_u4(ref_in + i * 16);
+      pv = *(const uint4 *)(pred_in + i * 16);
+    }
     const u32 rr[4] = { rv.x, rv.y, rv.z, rv.w }, pq[4] = { pv.x, pv.y, pv.z, pv.w };
     int res[4][4], c[4][4];
 #pragma unroll
@@ -468,7 +483,7 @@ __global__ __launch_bounds__(256) void quantize_residual4_lane_kernel(const u8 *
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         const int n = y * 4 + x;
-        q[y][x] = quant_one(c[y][x], k.qtable ? k.qtable[n] : k.flat_qc, k);
+        q[y][x] = quant_one(c[y][x], (!FLAT && k.qtable) ? k.qtable[n] : k.flat_qc, k);
         any |= q[y][x];
         sab += (u32)(q[y][x] < 0 ? -q[y][x] : q[y][x]);
       }
@@ -479,7 +494,9 @@ __global__ __launch_bounds__(256) void quantize_residual4_lane_kernel(const u8 *
 #pragma unroll
       for (int y = 0; y < 4; ++y)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) d[y][x] = (int)(i16)dequant_one(q[y][x], y * 4 + x, k);
+        for (int x = 0; x < 4; ++x)
+          d[y][x] = FLAT ? (int)(i16)clip16((int)((unsigned)__mul24(q[y][x], k.dq_scale) + (unsigned)k.dq_add) >> k.dq_shift)
+                         : (int)(i16)dequant_one(q[y][x], y * 4 + x, k);
       if (TRK == 4) {
 #pragma unroll
         for (int y = 0; y < 4; ++y)
@@ -521,6 +538,7 @@ __global__ __launch_bounds__(256) void quantize_residual4_lane_kernel(const u8 *
         out[y] = wv;
       }
     }
+    if (PF) { wait_vmem_all(); rv = rn; pv = pn; }          // rr / pq hold this TU's pixels: the registers can take the next one's
     *(uint4 *)(rec_out + i * 16) = make_uint4(out[0], out[1], out[2], out[3]);
     uint4 c0, c1;
     c0.x = (u32)(q[0][0] & 0xffff) | ((u32)q[0][1] << 16); c0.y = (u32)(q[0][2] & 0xffff) | ((u32)q[0][3] << 16);
@@ -638,14 +656,24 @@ static int quantize_residual_impl(const kvz_hip_quant_params *p, int cu_is_intra
   if ((width == 32 || width == 16) && !use_trskip && !k.signhide && tuning("qr_tile_kernel", 1))
     return launch_quantize_residual_tile(width, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
                                          k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, ssd_out, abs_sum_out, st);
+  // 8x8: sixteen TUs per matrix-core tile (quant_tile_mfma.hip); the cost variant and "qr8_tile_kernel" = 0 use the register kernel
+  if (width == 8 && !use_trskip && !k.signhide && !ssd_out && tuning("qr_tile_kernel", 1) && tuning("qr8_tile_kernel", 1))
+    return launch_quantize_residual_tile(8, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc, k.qtable,
+                                         k.dq_mode, k.dq_shift, k.dq_add, k.dq_scale, k.dqtable, nullptr, nullptr, st);
   if (width == 8 && !use_trskip && !k.signhide && !k.qtable && k.dq_mode == 0 && tuning("qr8_reg_kernel", 1))
     return launch_quantize_residual8_reg(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k.q_bits, k.add, k.flat_qc,
                                          k.dq_shift, k.dq_add, k.dq_scale, ssd_out, abs_sum_out, st);
   if (width == 4 && !k.signhide && tuning("qr4_lane_kernel", 1)) {
     const unsigned grid = stream_grid(count, 256, (unsigned)tuning("qr4_wgs_per_cu", 96)       /* measured: 16: 4.8 TB/s, 64: 5.4, 128: 5.4 */);
-    if (use_trskip) hipLaunchKernelGGL((quantize_residual4_lane_kernel<4>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
-    else if (dst) hipLaunchKernelGGL((quantize_residual4_lane_kernel<2>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
-    else hipLaunchKernelGGL((quantize_residual4_lane_kernel<0>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out);
+    const bool flat = !k.qtable && k.dq_mode == 0;
+    // measured A/B on one box (0.5 GiB operands): with the in-wave prefetch 5.00-5.05 TB/s, without 5.15-5.21: at 8 waves per SIMD the
+    // hardware's wave interleaving already hides the latency and the prefetch costs a wave of occupancy (72 against 60 VGPRs)
+    const bool pipe = tuning("pipe", 0) != 0;
+#define KVZ_QR4(T) do { if (flat && pipe) hipLaunchKernelGGL((quantize_residual4_lane_kernel<T, true, true>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out); \
+                        else if (flat) hipLaunchKernelGGL((quantize_residual4_lane_kernel<T, false, true>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out); \
+                        else hipLaunchKernelGGL((quantize_residual4_lane_kernel<T, false, false>), dim3(grid), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out); } while (0)
+    if (use_trskip) KVZ_QR4(4); else if (dst) KVZ_QR4(2); else KVZ_QR4(0);
+#undef KVZ_QR4
     KVZ_CHECK_LAUNCH("quantize_residual4_lane_kernel");
     return KVZ_HIP_OK;
   }

@@ -125,7 +125,7 @@ __device__ __forceinline__ void inv8(const u32 (&y)[4], int (&x)[8], int add, in
 
 struct q8_consts { int q_bits, add, flat_qc, dq_shift, dq_add, dq_scale; };
 
-template <bool COST>
+template <bool COST, bool PIPE = false>
 __global__ __launch_bounds__(256) void quantize_residual8_reg_kernel(const u8 *__restrict__ ref_in, const u8 *pred_in, u8 *rec_out,
                                                                      i16 *__restrict__ coeff_out, i32 *__restrict__ has_coeffs,
                                                                      size_t count, q8_consts k,
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void quantize_residual8_reg_kernel(const u8 *_
   u32x2v rv, pv, rn, pn;
   bool live = false, live_n = false;
   if (g < ngroups) load(g, rv, pv, live);
+  if (PIPE) wait_vmem_all();
   for (; g < ngroups; g += nwaves) {
     const size_t gn = g + nwaves;
     if (gn < ngroups) load(gn, rn, pn, live_n);        // prefetch the wave's next group (never one being written)
@@ -195,6 +196,12 @@ __global__ __launch_bounds__(256) void quantize_residual8_reg_kernel(const u8 *_
     }
     u32 qr[4] = { q[0], q[1], q[2], q[3] };
     transpose8(qr, tile, wr, rd);                        // lane j: row j of the quantized block
+    // the iteration's one wait on vector memory, just before its first store (wait_vmem_all, kvz_hip_internal.h): the prefetch
+    // is half an iteration old, the previous iteration's stores a whole one.  (The compiler's own placement was vmcnt(0) at the
+    // loop top, i.e. on the stores the iteration before had issued last.)
+    if (PIPE) wait_vmem_all();
+    const u32x2v rv_next = rn, pv_next = pn;
+    const bool live_next = live_n;
     if (live) {
       const u32x4r qrow = { qr[0], qr[1], qr[2], qr[3] };
       __builtin_nontemporal_store(qrow, (u32x4r *)(coeff_out + tu * 64) + j);
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256) void quantize_residual8_reg_kernel(const u8 *_
       *((u32x2v *)(rec_out + tu * 64) + j) = out;
       if (j == 0) has_coeffs[tu] = has ? 1 : 0;
     }
-    rv = rn; pv = pn; live = live_n;
+    rv = rv_next; pv = pv_next; live = live_next;
   }
 }
 
@@ -264,7 +271,13 @@ int launch_quantize_residual8_reg(const u8 *ref_in, const u8 *pred_in, u8 *rec_o
   size_t wgs = (ngroups + 3) / 4;                       // 4 waves per workgroup, one group of 8 TUs per wave step
   const size_t cap = (size_t)num_cus() * (size_t)tuning("qr8_wgs_per_cu", 32);   // measured (0.5 GiB operands): 32: 4.95, 64: 4.84, 128: 4.79, 192: 4.67 TB/s
   if (wgs > cap) wgs = cap;
-  if (ssd_out)
+  // "pipe" 1: the iteration's wait on vector memory placed by hand before its first store (wait_vmem_all).  Measured A/B on one
+  // box: 4.59 TB/s with it, 4.73 without -- at this kernel's 8 waves per SIMD the wave interleaving hides the latency by itself;
+  // the matrix-core tile kernels (4 waves per SIMD) gain 10-15 % from the same placement.
+  if (!ssd_out && tuning("pipe", 0))
+    hipLaunchKernelGGL((quantize_residual8_reg_kernel<false, true>), dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out,
+                       has_coeffs, count, k, ssd_out, abs_sum_out);
+  else if (ssd_out)
     hipLaunchKernelGGL(quantize_residual8_reg_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out,
                        has_coeffs, count, k, ssd_out, abs_sum_out);
   else

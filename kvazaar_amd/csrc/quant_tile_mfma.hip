@@ -1,5 +1,7 @@
-// quant_tile_mfma.hip -- fused kvz_quantize_residual for 32x32 and 16x16 TUs on the matrix cores: one 32x32 pixel
-// "tile" per wave step = one 32x32 TU, or FOUR 16x16 TUs arranged 2 x 2, with the same instruction stream.
+// quant_tile_mfma.hip -- fused kvz_quantize_residual for 32x32, 16x16 and 8x8 TUs on the matrix cores: one 32x32 pixel
+// "tile" per wave step = one 32x32 TU, FOUR 16x16 TUs arranged 2 x 2, or SIXTEEN 8x8 TUs arranged 4 x 4, with the same
+// instruction stream (8x8: ~25 vector instructions per TU where the register kernel of quant8_reg.hip spends 35 and is
+// bound by their issue).
 //
 // Reference: src/strategies/generic/quant-generic.c:180-273 (rdoq off, no transform skip, sign hiding off -- the other
 // variants stay on quantize_residual_kernel in quant.hip) around the transform pairs of dct-generic.c:368-597
@@ -39,7 +41,7 @@ typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 template <int N>
 __host__ __device__ constexpr int mx(int a, int b)
 {
-  return N == 32 ? dct_coef(32, a, b) : (((a >> 4) == (b >> 4)) ? dct_coef(16, a & 15, b & 15) : 0);
+  return N == 32 ? dct_coef(32, a, b) : ((a / N == b / N) ? dct_coef(N, a % N, b % N) : 0);
 }
 __host__ __device__ constexpr int kap(int h, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
@@ -53,7 +55,7 @@ struct tile_table {
   int c[4][64][16];
   constexpr tile_table() : t_kap(), t_col(), c()
   {
-    constexpr int LOG2N = N == 32 ? 5 : 4;
+    constexpr int LOG2N = N == 32 ? 5 : (N == 16 ? 4 : 3);
     int rowsum[32] = {}, colsum[32] = {};
     for (int a = 0; a < 32; ++a)
       for (int b = 0; b < 32; ++b) { rowsum[a] += mx<N>(a, b); colsum[b] += mx<N>(a, b); }
@@ -79,9 +81,11 @@ struct tile_table {
 };
 static __constant__ tile_table<32> c_tile32 = tile_table<32>();
 static __constant__ tile_table<16> c_tile16 = tile_table<16>();
+static __constant__ tile_table<8> c_tile8 = tile_table<8>();
 template <int N> __device__ __forceinline__ const tile_table<N> &tile_tab();
 template <> __device__ __forceinline__ const tile_table<32> &tile_tab<32>() { return c_tile32; }
 template <> __device__ __forceinline__ const tile_table<16> &tile_tab<16>() { return c_tile16; }
+template <> __device__ __forceinline__ const tile_table<8> &tile_tab<8>() { return c_tile8; }
 
 struct qt_consts {
   int q_bits, add, flat_qc;
@@ -130,14 +134,15 @@ __device__ __forceinline__ void planes_sat(const int (&t)[16], op16 &hi, op16 &l
   planes_from_rows(d, hi, lo);
 }
 
-template <int N, bool COST>
+template <int N, bool COST, bool PIPE = true>
 __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8 *__restrict__ ref_in, const u8 *pred_in, u8 *rec_out,
                                                                      i16 *__restrict__ coeff_out, i32 *__restrict__ has_coeffs,
                                                                      size_t count, qt_consts k,
                                                                      u32 *__restrict__ ssd_out, u32 *__restrict__ abs_sum_out)
 {
-  constexpr int LOG2N = N == 32 ? 5 : 4;
-  constexpr int TUS = N == 32 ? 1 : 4;                 // TUs per tile
+  constexpr int LOG2N = N == 32 ? 5 : (N == 16 ? 4 : 3);
+  constexpr int TUS = (32 / N) * (32 / N);             // TUs per tile
+  static_assert(!(N == 8 && COST), "the 8x8 cost variant stays on quant8_reg.hip");
   constexpr size_t TU_PX = (size_t)N * N;
   const tile_table<N> &tb = tile_tab<N>();
   __shared__ __attribute__((aligned(16))) u8 s_tile[4][2048];
@@ -162,20 +167,38 @@ __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8
   const int bias_pos = k.add, bias_neg = (int)((1u << k.q_bits) - 1u) - k.add;
 
   // this lane's 16-byte chunk of the tile's pixels: row r, columns 16h .. 16h+15.  16x16: TU (r >> 4) + 2h of the four, row r & 15
-  const int my_tu = N == 32 ? 0 : (r >> 4) + 2 * h;
-  const size_t px_off = N == 32 ? (size_t)(2 * r + h) * 16 : (size_t)my_tu * 256 + (size_t)(r & 15) * 16;
-  auto load = [&](size_t t, u32x4v &rv, u32x4v &pv, bool &live) {
+  // 8x8: the 16 pixels are row r & 7 of the two TUs (r >> 3) * 4 + 2h and + 1 of the tile's sixteen: two 8-byte accesses
+  // (`live` bit 0 / bit 1 = the first / second of them exists)
+  const int my_tu = N == 32 ? 0 : (N == 16 ? (r >> 4) + 2 * h : (r >> 3) * 4 + 2 * h);
+  const size_t px_off = N == 32 ? (size_t)(2 * r + h) * 16 : (N == 16 ? (size_t)my_tu * 256 + (size_t)(r & 15) * 16 : (size_t)my_tu * 64 + (size_t)(r & 7) * 8);
+  auto load = [&](size_t t, u32x4v &rv, u32x4v &pv, int &live) {
     const size_t tu = t * TUS + (size_t)my_tu;
-    live = tu < count;
+    if (N == 8) {
+      live = (tu < count ? 1 : 0) | (tu + 1 < count ? 2 : 0);
+      const size_t last = (count - 1) * TU_PX + (size_t)(r & 7) * 8;          // a missing TU mirrors the last one
+      const size_t a = (live & 1) ? t * TUS * TU_PX + px_off : last, b = (live & 2) ? t * TUS * TU_PX + px_off + 64 : last;
+      const u32x2v ra = __builtin_nontemporal_load((const u32x2v *)(ref_in + a)), rb = __builtin_nontemporal_load((const u32x2v *)(ref_in + b));
+      const u32x2v pa = *(const u32x2v *)(pred_in + a), pb = *(const u32x2v *)(pred_in + b);
+      rv = u32x4v{ ra.x, ra.y, rb.x, rb.y };
+      pv = u32x4v{ pa.x, pa.y, pb.x, pb.y };
+      return;
+    }
+    live = tu < count ? 3 : 0;
     const size_t base = live ? t * TUS * TU_PX + px_off : (count - 1) * TU_PX + (px_off & 255);   // a missing TU mirrors the last one
     rv = __builtin_nontemporal_load((const u32x4v *)(ref_in + base));
     pv = *(const u32x4v *)(pred_in + base);
   };
 
+  // Software pipeline (wait_vmem_all, kvz_hip_internal.h).  Left to the compiler, this loop waited for its OWN prefetch right
+  // after issuing it (s_waitcnt vmcnt(0) at the loop top: the rotation of the prefetch registers was scheduled there) and
+  // every iteration paid a full memory latency -- the 43 % of wave-cycles parked on memory of
+  // profiles/r02_z_qr_pmc_after.txt.  The one vmcnt(0) of an iteration now sits just before the iteration's first store:
+  // the prefetch was issued half an iteration of arithmetic earlier, the previous iteration's stores a whole one.
   size_t t = wave;
   u32x4v rv, pv, rn, pn;
-  bool live = false, live_n = false;
+  int live = 0, live_n = 0;
   if (t < ntiles) load(t, rv, pv, live);
+  if (PIPE) wait_vmem_all();
   for (; t < ntiles; t += nwaves) {
     const size_t tn = t + nwaves;
     if (tn < ntiles) load(tn, rn, pn, live_n);          // prefetch the wave's next tile (never one being written)
@@ -215,7 +238,7 @@ __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int x = kap(h, g);
-        const int n = N == 32 ? x * 32 + r : (x & 15) * 16 + (r & 15);
+        const int n = N == 32 ? x * 32 + r : (x & (N - 1)) * N + (r & (N - 1));
         const int c = (int)(short)v[g], a = c < 0 ? -c : c;
         const int qc = k.qtable ? k.qtable[n] : k.flat_qc;
         const int level = (int)(((long long)a * qc + k.add) >> k.q_bits);
@@ -226,11 +249,38 @@ __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8
     int any_top = 0, any_bot = 0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) { any_top |= lv[g]; any_bot |= lv[8 + g]; }
+    // the iteration's one wait on vector memory (see above), then the prefetched registers become the next tile's
+    if (PIPE) wait_vmem_all();          // PIPE false (tuning "qr_tile_pipe" 0): the compiler's own placement, for A/B runs
+    const u32x4v rv_next = rn, pv_next = pn;
+    const int live_next = live_n;
     bool has_row0, has_row1;                              // of this lane's PIXEL row half: column halves 0 and 1
+    u32 has_q = 0;                                        // 8x8: bit q = the TU of this lane's pixel row block and column block q has coefficients
     unsigned long long any_tile;
     if (N == 32) {
       any_tile = __ballot((any_top | any_bot) != 0);
       has_row0 = has_row1 = any_tile != 0ull;
+    } else if (N == 8) {
+      // coefficient layout: TU (row block, column block) = (register quartet g >> 2, lane r >> 3); one ballot per quartet
+      unsigned long long bq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = __ballot((lv[4 * q] | lv[4 * q + 1] | lv[4 * q + 2] | lv[4 * q + 3]) != 0);
+      any_tile = bq[0] | bq[1] | bq[2] | bq[3];
+      has_row0 = has_row1 = false;
+      // the lanes of column block c: r >> 3 == c in both halves
+      const unsigned long long m0 = 0x000000ff000000ffull;
+      {
+        // pixel layout: this lane's row block r >> 3, column blocks q = 0..3 (its four output dwords)
+        const int rb = r >> 3;
+        const unsigned long long mine = rb == 0 ? bq[0] : rb == 1 ? bq[1] : rb == 2 ? bq[2] : bq[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) has_q |= ((mine & (m0 << (8 * q))) != 0ull ? 1u : 0u) << q;
+      }
+      if (lane < 16) {
+        const size_t tu = t * 16 + (size_t)lane;
+        const int q = lane >> 2, cb = lane & 3;
+        const unsigned long long b = q == 0 ? bq[0] : q == 1 ? bq[1] : q == 2 ? bq[2] : bq[3];
+        if (tu < count) has_coeffs[tu] = (b & (m0 << (8 * cb))) != 0ull ? 1 : 0;
+      }
     } else {
       const unsigned long long lo_lanes = 0x0000ffff0000ffffull;
       const unsigned long long bt = __ballot(any_top != 0), bb = __ballot(any_bot != 0);
@@ -253,7 +303,17 @@ __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8
       *(i16 *)(tile + slot_of(4 * x + (r >> 3)) * 16 + (r & 7) * 2) = (i16)lv[g];
     }
     wave_lds_fence();
-    {
+    if (N == 8) {
+      // lane l: row l & 7 of TU (l >> 3) of the tile's first eight, and of the TU eight further: consecutive lanes store
+      // consecutive 16-byte rows (2 x 1 KiB per wave, fully coalesced)
+      const int tin = lane >> 3, row = lane & 7, x0 = (tin >> 2) * 8 + row, c = tin & 3;
+      const u32x4v a = *(const u32x4v *)(tile + slot_of(4 * x0 + c) * 16);
+      const u32x4v b = *(const u32x4v *)(tile + slot_of(4 * (x0 + 16) + c) * 16);
+      wave_lds_fence();
+      const size_t tu_a = t * 16 + (size_t)tin, tu_b = tu_a + 8;
+      if (tu_a < count) __builtin_nontemporal_store(a, (u32x4v *)(coeff_out + tu_a * 64) + row);
+      if (tu_b < count) __builtin_nontemporal_store(b, (u32x4v *)(coeff_out + tu_b * 64) + row);
+    } else {
       const u32x4v a = *(const u32x4v *)(tile + slot_of(lane) * 16);
       const u32x4v b = *(const u32x4v *)(tile + slot_of(64 + lane) * 16);
       wave_lds_fence();
@@ -281,7 +341,7 @@ __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
           const int x = kap(h, g);
-          const int n = N == 32 ? x * 32 + r : (x & 15) * 16 + (r & 15);
+          const int n = N == 32 ? x * 32 + r : (x & (N - 1)) * N + (r & (N - 1));
           if (k.dq_mode == 0) dv[g] = (__mul24(lv[g], k.dq_scale) + k.dq_add) >> k.dq_shift;
           else if (k.dq_mode == 1) dv[g] = (lv[g] * k.dqtable[n] + k.dq_add) >> k.dq_shift;
           else dv[g] = (int)((u32)clip16(lv[g] * k.dqtable[n]) << k.dq_shift);
@@ -309,7 +369,7 @@ __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const bool has = q < 2 ? has_row0 : has_row1;
+        const bool has = N == 8 ? ((has_q >> q) & 1u) != 0u : (q < 2 ? has_row0 : has_row1);
         if (has) out[q] = __builtin_amdgcn_perm(o16[2 * q + 1], o16[2 * q], 0x06040200u);
       }
     }
@@ -348,12 +408,16 @@ __global__ __launch_bounds__(256, 4) void quantize_residual_tile_kernel(const u8
       }
     }
     kappa_unswap(out);
-    if (live) {
+    if (N == 8) {
+      const size_t base = t * TUS * TU_PX + px_off;
+      if (live & 1) *(u32x2v *)(rec_out + base) = u32x2v{ out[0], out[1] };
+      if (live & 2) *(u32x2v *)(rec_out + base + 64) = u32x2v{ out[2], out[3] };
+    } else if (live) {
       const u32x4v ov = { out[0], out[1], out[2], out[3] };
       const size_t base = t * TUS * TU_PX + px_off;
       *(u32x4v *)(rec_out + base) = ov;
     }
-    rv = rn; pv = pn; live = live_n;
+    rv = rv_next; pv = pv_next; live = live_next;
   }
 }
 
@@ -361,12 +425,19 @@ template <int N>
 int launch_tile(const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, i32 *has_coeffs, size_t count, const qt_consts &k,
                 u32 *ssd_out, u32 *abs_sum_out, hipStream_t st)
 {
-  const size_t ntiles = N == 32 ? count : (count + 3) / 4;
+  constexpr size_t TUS = (size_t)(32 / N) * (32 / N);
+  const size_t ntiles = (count + TUS - 1) / TUS;
   size_t wgs = (ntiles + 3) / 4;
   // workgroups per CU, measured at 0.5 GiB operands: 32x32 -- 8: 5.47, 16: 5.12, 32: 4.88, 64: 4.49 TB/s; 16x16 -- 8: 5.32, 16: 5.13, 32: 4.90, 64: 4.47
-  const size_t cap = (size_t)num_cus() * (size_t)tuning(N == 32 ? "qr32_wgs_per_cu" : "qr16_wgs_per_cu", 8);
+  const size_t cap = (size_t)num_cus() * (size_t)tuning(N == 32 ? "qr32_wgs_per_cu" : (N == 16 ? "qr16_wgs_per_cu" : "qr8_wgs_per_cu"), 8);
   if (wgs > cap) wgs = cap;
-  if (ssd_out)
+  if constexpr (N == 8) {
+    hipLaunchKernelGGL((quantize_residual_tile_kernel<8, false>), dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out,
+                       has_coeffs, count, k, ssd_out, abs_sum_out);
+  } else if (!ssd_out && !tuning("qr_tile_pipe", 1)) {
+    hipLaunchKernelGGL((quantize_residual_tile_kernel<N, false, false>), dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out,
+                       has_coeffs, count, k, ssd_out, abs_sum_out);
+  } else if (ssd_out)
     hipLaunchKernelGGL((quantize_residual_tile_kernel<N, true>), dim3((unsigned)wgs), dim3(256), 0, st, ref_in, pred_in, rec_out, coeff_out,
                        has_coeffs, count, k, ssd_out, abs_sum_out);
   else
@@ -386,6 +457,7 @@ int launch_quantize_residual_tile(int n, const u8 *ref_in, const u8 *pred_in, u8
 {
   const qt_consts k = { q_bits, add, flat_qc, qtable, dq_mode, dq_shift, dq_add, dq_scale, dqtable };
   if (n == 32) return launch_tile<32>(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out, st);
+  if (n == 8) return launch_tile<8>(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, nullptr, nullptr, st);
   return launch_tile<16>(ref_in, pred_in, rec_out, coeff_out, has_coeffs, count, k, ssd_out, abs_sum_out, st);
 }
 }  // namespace kvzhip

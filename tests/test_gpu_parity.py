@@ -339,11 +339,15 @@ def test_quantize_residual_fast_and_lds_kernels(api, n):
                     for i in range(count):
                         assert got[3][i] == O.pixels_calc_ssd(ref_in[i], 0, want[0][i], 0, n, n, n)
                         assert got[4][i] == O.coeff_abs_sum(want[1][i])
-                    plain = api.quantize_residual_batch(ref_in, pred, n, qp, color, 0, 0)
-                    for a, b in zip(plain[:3], want):
-                        np.testing.assert_array_equal(a, b)
+                    # the plain entry: 8x8 TUs ride sixteen to a matrix-core tile by default ("qr8_tile_kernel" 0: the register kernel)
+                    for tile8 in ((1, 0) if n == 8 else (1,)):
+                        _lib.check(L.kvz_hip_set_tuning(b"qr8_tile_kernel", tile8), "tuning")
+                        plain = api.quantize_residual_batch(ref_in, pred, n, qp, color, 0, 0)
+                        for a, b, nm in zip(plain[:3], want, ("rec", "coeff", "has")):
+                            np.testing.assert_array_equal(a, b, err_msg="plain %s n=%d count=%d qp=%d fast=%d tile8=%d" % (nm, n, count, qp, use, tile8))
     finally:
         L.kvz_hip_set_tuning(key, -1)
+        L.kvz_hip_set_tuning(b"qr8_tile_kernel", -1)
 
 
 def test_quantize_residual_4_both_kernels(api):
