@@ -404,6 +404,121 @@ def shard_search_leg(env, sh, steps, warmup, frames):
     return dt, ex_ms, se_ms, bd_ms, sums, n_boundary
 
 
+def reference_workload_leg(env, budget_s=0.4):
+    """The reference's OWN benchmark workload (tests/speed_tests.c) next to the random batches of the headline: the radial-gradient
+    chunk set for sad_8x8 / satd_8x8 / dct_32x32 (:63-92, :116-153, :252-300) and the reg_sad loop on the 4K frame `inter_a` with the
+    sparse +-6 vector grid at 8x8, 16x16, 32x32, 64x64, 64x63 and 1x1 (:94-103, :198-236, :400-403) -- the shape the encoder's motion
+    search really issues.  GPU: the batched entries on the same data resident in HBM (HIP events); CPU: the reference's best
+    registered strategy for each function (oracle/_ref) on one thread and on all the box's threads."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import patterns as P
+    torch, dev, L, st = env.torch, env.dev, env.L, env.stream
+    try:
+        cores = min(16, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        import ref_lib as R
+        have_ref = R.available()
+    except Exception:                                  # noqa: BLE001
+        have_ref = False
+    RL = R.lib() if have_ref else None
+
+    def gpu_rate(fn, calls, iters=10):
+        e0, e1 = L.kvz_hip_event_create(), L.kvz_hip_event_create()
+        for _ in range(2):
+            fn()
+        L.kvz_hip_event_record(e0, st)
+        for _ in range(iters):
+            fn()
+        L.kvz_hip_event_record(e1, st)
+        ms = env.elapsed(e0, e1)
+        L.kvz_hip_event_destroy(e0); L.kvz_hip_event_destroy(e1)
+        return calls * iters / (ms * 1e-3)
+
+    def cpu_threads(fn):
+        one = fn(0)
+        out = [0.0] * cores
+
+        def work(i):
+            out[i] = fn(i)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+        [t.start() for t in ts]; [t.join() for t in ts]
+        return one, sum(out)
+
+    def best_name(type_, order=("avx2", "sse41", "sse2", "generic")):
+        for n in order:
+            if R.has_strategy(type_, n):
+                return n
+        return None
+
+    rows = {}
+    bufs = P.speed_test_bufs()
+    u8p, i16p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16)
+    # -- contiguous block kernels on the gradient set, replicated to > 256 MiB per operand so that the GPU streams from HBM
+    for kind, n in (("sad", 8), ("satd", 8)):
+        b1, b2 = P.speed_test_intra_pairs(bufs, n)
+        rep = max(1, (300 << 20) // b1.nbytes)
+        d1, d2 = torch.from_numpy(b1).to(dev).repeat(rep, 1), torch.from_numpy(b2).to(dev).repeat(rep, 1)
+        cost = torch.empty(d1.shape[0], dtype=torch.int32, device=dev)
+        f = L.kvz_hip_sad_nxn_batch if kind == "sad" else L.kvz_hip_satd_nxn_batch
+        g = gpu_rate(lambda: env.check(f(n, d1.data_ptr(), d2.data_ptr(), d1.shape[0], cost.data_ptr(), st), kind), d1.shape[0])
+        env.sync()
+        row = {"gpu_Mcalls_s": round(g / 1e6, 1), "calls_per_launch": int(d1.shape[0]), "pattern": "radial gradients, first chunk of 36 against the other 35"}
+        if have_ref:
+            t = ("%s_%dx%d" % (kind, n, n)).encode()
+            name = best_name(t.decode())
+            a1, a2 = R._aligned(b1.ravel()), R._aligned(b2.ravel())
+            one, all_ = cpu_threads(lambda i: RL.ref_bench_cost_nxn(t, name.encode(), n, a1.ctypes.data_as(u8p), a2.ctypes.data_as(u8p), b1.shape[0], budget_s, None))
+            row.update({"cpu_strategy": name, "cpu_Mcalls_s_1_thread": round(one / 1e6, 2), "cpu_Mcalls_s_%d_threads" % cores: round(all_ / 1e6, 1),
+                        "gpu_over_cpu_all_threads": round(g / all_, 1)})
+        rows["%s_%dx%d" % (kind, n, n)] = row
+        del d1, d2, cost
+    res = P.speed_test_dct_residuals(bufs, 32)
+    rep = max(1, (300 << 20) // res.nbytes)
+    dr = torch.from_numpy(res).to(dev).repeat(rep, 1)
+    dc = torch.empty_like(dr)
+    g = gpu_rate(lambda: env.check(L.kvz_hip_transform_batch(0, 32, dr.data_ptr(), dc.data_ptr(), dr.shape[0], st), "dct"), dr.shape[0])
+    env.sync()
+    row = {"gpu_Mcalls_s": round(g / 1e6, 2), "calls_per_launch": int(dr.shape[0]), "pattern": "residuals of the gradient chunks (first chunk - chunk)"}
+    if have_ref:
+        name = best_name("dct_32x32")
+        x = R._aligned(res.ravel())
+        ys = [R._aligned(np.zeros(res.size, np.int16)) for _ in range(cores)]
+        one, all_ = cpu_threads(lambda i: RL.ref_bench_transform(b"dct_32x32", name.encode(), 32, x.ctypes.data_as(i16p), ys[i].ctypes.data_as(i16p),
+                                                               res.shape[0], budget_s))
+        row.update({"cpu_strategy": name, "cpu_Mcalls_s_1_thread": round(one / 1e6, 3), "cpu_Mcalls_s_%d_threads" % cores: round(all_ / 1e6, 2),
+                    "gpu_over_cpu_all_threads": round(g / all_, 1)})
+    rows["dct_32x32"] = row
+    del dr, dc
+    # -- reg_sad on the 4K frame: descriptors of the reference's loop, 64 sweeps over the 58 x 31 inner LCUs per launch
+    frame = P.speed_test_inter_frame(W4K, H4K)
+    dframe = torch.from_numpy(frame).to(dev)
+    if have_ref:
+        RL.ref_bench_speed_inter_sad.restype = C.c_double
+        RL.ref_bench_speed_inter_sad.argtypes = [C.c_char_p, C.c_void_p] + [C.c_int] * 4 + [C.c_double, C.POINTER(C.c_ulonglong)]
+    for (bw, bh) in ((8, 8), (16, 16), (32, 32), (64, 64), (64, 63), (1, 1)):
+        sweeps = 64 if bw * bh <= 1024 else 8
+        pairs = P.speed_test_inter_pairs(bw, bh, 58 * 31 * sweeps, W4K, H4K)
+        dp = torch.from_numpy(pairs).to(dev)
+        cost = torch.empty(pairs.shape[0], dtype=torch.int32, device=dev)
+        g = gpu_rate(lambda: env.check(L.kvz_hip_reg_sad_batch(dframe.data_ptr(), W4K, dframe.data_ptr(), W4K, dp.data_ptr(), pairs.shape[0], cost.data_ptr(), st),
+                                       "reg_sad"), pairs.shape[0], iters=5)
+        env.sync()
+        row = {"gpu_Mcalls_s": round(g / 1e6, 1), "calls_per_launch": int(pairs.shape[0]), "gpu_checksum": int(cost.long().sum().item()),
+               "pattern": "4K frame inter_a, first CU of every inner LCU x the 25 vectors {-6,-3,0,3,6}^2"}
+        if have_ref:
+            name = best_name("reg_sad", ("x86_asm_avx", "avx2", "sse41", "generic"))
+            one, all_ = cpu_threads(lambda i: RL.ref_bench_speed_inter_sad(name.encode(), frame.ctypes.data, W4K, H4K, bw, bh, budget_s, None))
+            row.update({"cpu_strategy": name, "cpu_Mcalls_s_1_thread": round(one / 1e6, 2), "cpu_Mcalls_s_%d_threads" % cores: round(all_ / 1e6, 1),
+                        "gpu_over_cpu_all_threads": round(g / all_, 1)})
+        rows["reg_sad_%dx%d" % (bw, bh)] = row
+        del dp, cost
+    return {"what": "the reference's own benchmark workload (tests/speed_tests.c): GPU batched entries vs the reference's best registered CPU strategy "
+                    "on the same data; M calls/s like the reference's speed tests report", "cpu_threads": cores, "rows": rows}
+
+
 SHARD_LEG_LIMIT_S = 300
 
 
@@ -417,6 +532,7 @@ def main():
     ap.add_argument("--search-frames", type=int, default=8, help="4K frames per step of the sharded search sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-leg", action="store_true")
+    ap.add_argument("--no-reference-workload", action="store_true", help="skip the leg that runs the reference's own benchmark patterns (tests/speed_tests.c)")
     ap.add_argument("--partition", choices=("spans", "rows"), default="spans",
                     help="shard_4k block-kernel leg: raster spans of CTUs (equal to within one CTU) or whole CTU rows")
     args = ap.parse_args()
@@ -426,6 +542,13 @@ def main():
 
     dt, ms, blocks = headline_leg(env, args.steps, args.warmup, F)
     torch.cuda.empty_cache()
+    ref_workload = None
+    if world == 1 and not args.no_reference_workload:
+        try:
+            ref_workload = reference_workload_leg(env)
+        except Exception as e:                          # noqa: BLE001 -- an extra leg must not cost the headline line
+            ref_workload = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
 
     def emit(shard_out):
         """rank 0: the one JSON line (the headline numbers are final before the shard leg starts)"""
@@ -467,6 +590,8 @@ def main():
             out["shard_4k"] = shard_out
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+        if ref_workload is not None:
+            out["reference_workload"] = ref_workload
         print(json.dumps(out), flush=True)
 
     # The shard leg exchanges halo rows between ranks; should a collective ever hang, the headline line is still printed: a

@@ -117,6 +117,22 @@ KVZ_HIP_API int kvz_hip_memcpy_d2d(void *dst, const void *src, size_t bytes, kvz
  * the `margin` rows at its top / bottom edge into the halo rows of the shard above / below: with stride == width
  * those rows are one contiguous range, i.e. one call per direction per plane. */
 KVZ_HIP_API int kvz_hip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, kvz_hip_stream s);
+/* The calling thread's current device must be src_device or dst_device; peer access towards the other one is enabled on first
+ * use (an error if the devices cannot reach each other); a stream that belongs to another device is refused.
+ *
+ * One shard's whole exchange step in one call: the C form of kvazaar_amd/shard.py exchange_halo_into for a host whose shards
+ * live on several devices of ONE process.  A shard's plane is an EXTENDED buffer: `rows` own rows starting at row `top`, the
+ * neighbour's rows (the halo, `margin` of them) above and below.  The calling thread's shard PUSHES the first `margin` of its own
+ * rows into the halo below the own rows of `up`, and its last `margin` own rows into the halo above the own rows of `down`
+ * (either may be NULL: the frame's edge).  Asynchronous on stream s of self->device; the receiving shard orders its search
+ * behind it with kvz_hip_event_record on that stream + kvz_hip_stream_wait_event on its own. */
+typedef struct {
+  void *ext;                    /* the shard's extended plane on `device`: (top + rows + halo below) rows of `stride` bytes */
+  int32_t device;
+  int32_t top, rows;            /* where the own rows start, and how many there are */
+} kvz_hip_shard_plane;
+KVZ_HIP_API int kvz_hip_halo_exchange(const kvz_hip_shard_plane *self, const kvz_hip_shard_plane *up, const kvz_hip_shard_plane *down,
+                                      uint32_t stride, int margin, kvz_hip_stream s);
 KVZ_HIP_API kvz_hip_stream kvz_hip_stream_create(void);
 KVZ_HIP_API void kvz_hip_stream_destroy(kvz_hip_stream s);
 KVZ_HIP_API int kvz_hip_stream_sync(kvz_hip_stream s);

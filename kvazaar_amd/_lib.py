@@ -59,6 +59,7 @@ SIGNATURES = {
     "kvz_hip_memset": (_I, [_P, _I, _SZ, _P]),
     "kvz_hip_memcpy_d2d": (_I, [_P, _P, _SZ, _P]),
     "kvz_hip_memcpy_peer": (_I, [_P, _I, _P, _I, _SZ, _P]),
+    "kvz_hip_halo_exchange": (_I, [_P, _P, _P, _U, _I, _P]),
     "kvz_hip_stream_create": (_P, []),
     "kvz_hip_stream_destroy": (None, [_P]),
     "kvz_hip_stream_sync": (_I, [_P]),

@@ -256,14 +256,81 @@ int kvz_hip_memcpy_d2d(void *dst, const void *src, size_t bytes, kvz_hip_stream 
 }
 // Rows of a reconstructed plane from one device's shard into a neighbour's halo, inside one process:
 // an asynchronous peer copy over xGMI on a stream of the calling thread's current device.
+static std::atomic<bool> g_peer_on[KVZ_MAX_DEVICES][KVZ_MAX_DEVICES];      // [from][to]: peer access enabled
+
+// the calling thread's current device `cur` may read / write memory of device `other` (once per ordered pair)
+static int enable_peer(int cur, int other)
+{
+  if (cur == other || g_peer_on[cur][other].load(std::memory_order_acquire)) return KVZ_HIP_OK;
+  int can = 0;
+  hipError_t e = hipDeviceCanAccessPeer(&can, cur, other);
+  if (e != hipSuccess || !can) {
+    std::snprintf(g_err, sizeof(g_err), "kvz_hip_memcpy_peer: device %d cannot access device %d", cur, other);
+    return KVZ_HIP_ERR_RUNTIME;
+  }
+  e = hipDeviceEnablePeerAccess(other, 0);
+  if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { set_error("hipDeviceEnablePeerAccess", e); return KVZ_HIP_ERR_RUNTIME; }
+  (void)hipGetLastError();              // "already enabled" is not a failure
+  g_peer_on[cur][other].store(true, std::memory_order_release);
+  return KVZ_HIP_OK;
+}
+
+// a stream handed in by the caller must be a stream of the calling thread's current device
+static int stream_on_current_device(kvz_hip_stream s, const char *entry)
+{
+  if (!s) return KVZ_HIP_OK;
+  hipDevice_t dev = -1;
+  if (hipStreamGetDevice((hipStream_t)s, &dev) != hipSuccess) { (void)hipGetLastError(); return KVZ_HIP_OK; }   // cannot tell: the copy itself will
+  if ((int)dev != ctx_device()) {
+    std::snprintf(g_err, sizeof(g_err), "%s: the stream belongs to device %d, the calling thread works on device %d", entry, (int)dev, ctx_device());
+    return KVZ_HIP_ERR_INVALID;
+  }
+  return KVZ_HIP_OK;
+}
+
 int kvz_hip_memcpy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, kvz_hip_stream s)
 {
   KVZ_CHECK_CTX();
   if (!dst || !src || dst_device < 0 || src_device < 0 || dst_device >= KVZ_MAX_DEVICES || src_device >= KVZ_MAX_DEVICES ||
       !g_ctx[dst_device].ready.load(std::memory_order_acquire) || !g_ctx[src_device].ready.load(std::memory_order_acquire))
     return kvzhip::invalid_arg(__func__);
+  const int cur = ctx_device();
+  if (cur != dst_device && cur != src_device) {
+    set_error_msg("kvz_hip_memcpy_peer: the calling thread's current device must be the source or the destination");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  int rc = stream_on_current_device(s, "kvz_hip_memcpy_peer");
+  if (rc != KVZ_HIP_OK) return rc;
   if (bytes == 0) return KVZ_HIP_OK;
+  if ((rc = enable_peer(cur, cur == dst_device ? src_device : dst_device)) != KVZ_HIP_OK) return rc;
   HIP_TRY(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, ctx_stream(s)), "hipMemcpyPeerAsync");
+  return KVZ_HIP_OK;
+}
+
+// The halo exchange of kvazaar_amd/shard.py (exchange_halo_into) for a host that drives its shards from ONE process: the
+// calling thread's shard pushes the `margin` rows at the top / bottom edge of its own rows into the halo rows of the shard
+// above / below.  See include/kvz_hip.h.
+int kvz_hip_halo_exchange(const kvz_hip_shard_plane *self, const kvz_hip_shard_plane *up, const kvz_hip_shard_plane *down,
+                          uint32_t stride, int margin, kvz_hip_stream s)
+{
+  KVZ_CHECK_CTX();
+  if (!self || !self->ext || margin < 0 || stride == 0 || self->top < 0 || self->rows < margin || self->device != ctx_device()) {
+    set_error_msg("kvz_hip_halo_exchange: the calling thread must work on self->device, and a shard cannot be thinner than the margin");
+    return KVZ_HIP_ERR_INVALID;
+  }
+  if ((up && (!up->ext || up->top < 0 || up->rows < 0)) || (down && (!down->ext || down->top < margin))) return kvzhip::invalid_arg(__func__);
+  if (margin == 0) return KVZ_HIP_OK;
+  const size_t bytes = (size_t)margin * stride;
+  const u8 *own = (const u8 *)self->ext + (size_t)self->top * stride;
+  if (up) {                  // my first rows -> the halo below the upper shard's own rows
+    const int rc = kvz_hip_memcpy_peer((u8 *)up->ext + (size_t)(up->top + up->rows) * stride, up->device, own, self->device, bytes, s);
+    if (rc != KVZ_HIP_OK) return rc;
+  }
+  if (down) {                // my last rows -> the halo above the lower shard's own rows
+    const int rc = kvz_hip_memcpy_peer((u8 *)down->ext + (size_t)(down->top - margin) * stride, down->device,
+                                       own + (size_t)(self->rows - margin) * stride, self->device, bytes, s);
+    if (rc != KVZ_HIP_OK) return rc;
+  }
   return KVZ_HIP_OK;
 }
 kvz_hip_stream kvz_hip_stream_create(void)

@@ -373,6 +373,11 @@ __global__ __launch_bounds__(64) void inter_candidates_multi_kernel(const kvz_hi
             p.pic_width > 0 && p.pic_height > 0 && p.tile_x >= 0 && p.tile_y >= 0 && p.in_width >= p.tile_x + p.pic_width &&
             p.in_height >= p.tile_y + p.pic_height && p.cus_stride * 4 >= p.pic_width && p.col_stride * 4 >= p.in_width &&
             p.ref_idx >= 0 && p.ref_idx < 16 && !(p.num_refs > 0 && p.tmvp_enable && pc.col_cus == nullptr);
+  // list entries 0..15, like the one-picture entry's host check (a bad entry flags the picture's PUs; it is never masked into range)
+  if (ok) {
+    for (int l = 0; l < 2; ++l)
+      for (int e = 0; e < 16; ++e) if (e < p.ref_LX_size[l] && p.ref_LX[l][e] > 15) ok = false;
+  }
   int reflist = -1, lx = 0;
   if (ok) find_list(p, reflist, lx);
   derive_pu(pc.cus, pc.col_cus, pc.ref_cus, p, ok, reflist, lx, pus, i, s_mc[threadIdx.x], merge_out);

@@ -368,6 +368,30 @@ double ref_bench_reg_sad(const char *name, const kvz_pixel *a, const kvz_pixel *
   return (double)done / (t1 - t0);
 }
 
+/* The reg_sad loop of the reference's own benchmark (tests/speed_tests.c:198-236, test_inter_speed): "a sparse full search on
+ * the first CU of every LCU" of a 4K frame -- iteration i takes LCU (1 + i % (W/64 - 2), 1 + (i / (H/64 - 2)) % (H/64 - 2)) and
+ * the 5 x 5 vectors {-6, -3, 0, 3, 6}^2, both blocks in the SAME frame -- run for budget_s seconds.  Returns calls per second. */
+double ref_bench_speed_inter_sad(const char *name, const kvz_pixel *frame, int W, int H, int bw, int bh, double budget_s, unsigned long long *checksum)
+{
+  reg_sad_func *f = (reg_sad_func *)ref_strategy("reg_sad", name);
+  if (!f) return -1.0;
+  const int dx = W / 64 - 2, dy = H / 64 - 2;
+  size_t done = 0; unsigned long long acc = 0;
+  double t0 = now_s(), t1;
+  uint64_t i = 0;
+  do {
+    for (int rep = 0; rep < 256; ++rep, ++i) {
+      const int lx = 1 + (int)(i % (uint64_t)dx), ly = 1 + (int)((i / (uint64_t)dy) % (uint64_t)dy);
+      const kvz_pixel *buf1 = frame + (size_t)ly * 64 * W + (size_t)lx * 64;
+      for (int my = -6; my <= 6; my += 3)
+        for (int mx = -6; mx <= 6; mx += 3) { acc += f(buf1, buf1 + my * W + mx, bw, bh, W, W); ++done; }
+    }
+    t1 = now_s();
+  } while (t1 - t0 < budget_s);
+  if (checksum) *checksum = acc;
+  return (double)done / (t1 - t0);
+}
+
 /* ------------------------------------------------------------------------
  * Integration check of the drop-in boundary: load libkvzhip.so and let it
  * register its "hip" strategies into THIS process's reference registry through

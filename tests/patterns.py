@@ -715,3 +715,60 @@ def bipred_case_blocks(k):
         s1 = (hp1[plane] if hi1 else rec[plane]).reshape(stride, stride)[rows, cols]
         out.append((bw, bh, hi0, np.ascontiguousarray(s0), hi1, np.ascontiguousarray(s1), (rows, cols)))
     return out
+
+
+# ---- the reference's own benchmark workload: tests/speed_tests.c ----
+SPEED_NUM_TESTS, SPEED_NUM_CHUNKS = 113, 36          # speed_tests.c:33-34
+
+
+def speed_test_bufs():
+    """setup_tests (speed_tests.c:77-92): bufs[test][chunk] = 64x64 radial gradient init_gradient(64 - x, y, 64, 255 / 64, .) (:63-74) with
+    x = (test + chunk) % 64, y = (test + chunk) / 64 -> uint8 [113, 36 * 4096]"""
+    yy, xx = np.mgrid[0:64, 0:64]
+    out = np.zeros((SPEED_NUM_TESTS, SPEED_NUM_CHUNKS, 4096), dtype=np.uint8)
+    slope = 255 // 64
+    for test in range(SPEED_NUM_TESTS):
+        for chunk in range(SPEED_NUM_CHUNKS):
+            x, y = (test + chunk) % 64, (test + chunk) // 64
+            val = (slope * np.sqrt(((64 - x) - xx) ** 2 + (y - yy) ** 2) + 0.5).astype(np.int64)
+            out[test, chunk] = np.clip(val, 0, 255).astype(np.uint8).ravel()
+    return out.reshape(SPEED_NUM_TESTS, SPEED_NUM_CHUNKS * 4096)
+
+
+def speed_test_intra_pairs(bufs, n):
+    """test_intra_speed (speed_tests.c:116-153) for one pass over all 113 tests: the first chunk of every group of 36 n x n chunks against
+    the 35 others -> (blk1, blk2) uint8 [113 * (4096 / n^2) * 35, n * n]"""
+    size = n * n
+    groups = bufs.reshape(SPEED_NUM_TESTS, 4096 // size, SPEED_NUM_CHUNKS, size)
+    b1 = np.repeat(groups[:, :, :1, :], SPEED_NUM_CHUNKS - 1, axis=2)
+    b2 = groups[:, :, 1:, :]
+    return np.ascontiguousarray(b1.reshape(-1, size)), np.ascontiguousarray(b2.reshape(-1, size))
+
+
+def speed_test_dct_residuals(bufs, n):
+    """dct_speed (speed_tests.c:252-300): residual = first chunk - chunk, all 36 chunks of every group -> int16 [113 * (4096 / n^2) * 36, n * n]"""
+    size = n * n
+    groups = bufs.reshape(SPEED_NUM_TESTS, 4096 // size, SPEED_NUM_CHUNKS, size).astype(np.int16)
+    return np.ascontiguousarray((groups[:, :, :1, :] - groups).reshape(-1, size))
+
+
+def speed_test_inter_frame(w=3840, h=2160):
+    """setup_tests (speed_tests.c:94-103): inter_a, the 4K luma plane the reg_sad benchmark runs on (unsigned 32-bit i * i)"""
+    i = np.arange(w * h, dtype=np.uint64)
+    sq = (i * i) & np.uint64(0xffffffff)
+    pattern1 = (((sq >> np.uint64(10)) % np.uint64(255)) >> np.uint64(2)).astype(np.uint8)
+    gradient = (((i >> np.uint64(12)) + i) & np.uint64(255)).astype(np.uint8)
+    return ((pattern1.astype(np.int32) + gradient.astype(np.int32)) % 255).astype(np.uint8).reshape(h, w)
+
+
+def speed_test_inter_pairs(bw, bh, iterations, w=3840, h=2160):
+    """test_inter_speed (speed_tests.c:198-236): iteration i takes LCU (1 + i % (w/64 - 2), 1 + (i / (h/64 - 2)) % (h/64 - 2)) and the 25
+    vectors {-6, -3, 0, 3, 6}^2, both blocks in the same frame -> kvz_hip_block_pair rows (x1, y1, x2, y2, bw, bh) int32 [25 * iterations, 6]"""
+    dx, dy = w // 64 - 2, h // 64 - 2
+    i = np.arange(iterations, dtype=np.int64)
+    lx, ly = 1 + i % dx, 1 + (i // dy) % dy
+    mv = np.array([(mx, my) for my in range(-6, 7, 3) for mx in range(-6, 7, 3)], dtype=np.int64)
+    x1 = np.repeat(lx * 64, 25); y1 = np.repeat(ly * 64, 25)
+    x2 = x1 + np.tile(mv[:, 0], iterations); y2 = y1 + np.tile(mv[:, 1], iterations)
+    out = np.stack([x1, y1, x2, y2, np.full_like(x1, bw), np.full_like(x1, bh)], axis=1)
+    return np.ascontiguousarray(out.astype(np.int32))

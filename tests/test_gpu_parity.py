@@ -1162,6 +1162,54 @@ def test_contexts_per_device_and_thread_binding(api):
     assert not errs, errs
 
 
+def test_halo_exchange_through_the_c_abi(api):
+    """kvz_hip_halo_exchange / kvz_hip_memcpy_peer: three row shards of one plane held by one process, each pushing its edge rows
+    into its neighbours' halos -- on different devices when the box has several (device i % count, peer access enabled on first
+    use), on one device otherwise; afterwards every extended buffer equals the matching rows of the whole plane.  A stream of
+    another device and a calling thread on a third device are refused."""
+    import ctypes as C
+    from kvazaar_amd import _lib, shard as S
+    L = _lib.load()
+    ndev = L.kvz_hip_device_count()
+    W, H, margin, world = 256, 64 * 7 + 24, 40, 3
+    plane = rng(77).integers(0, 256, (H, W), dtype=np.uint8)
+
+    class ShardPlane(C.Structure):
+        _fields_ = [("ext", C.c_void_p), ("device", C.c_int32), ("top", C.c_int32), ("rows", C.c_int32)]
+    shards, bufs, recs = [], [], []
+    for r in range(world):
+        sh = S.RowShard(W, H, world, r, margin)
+        dev = r % ndev
+        assert L.kvz_hip_set_device(dev) == 0
+        ext = np.zeros((sh.ext_rows, W), np.uint8)
+        ext[sh.top:sh.top + sh.rows] = plane[sh.y_lo:sh.y_hi]
+        b = api.DeviceBuffer.from_numpy(ext)
+        shards.append(sh); bufs.append(b); recs.append(ShardPlane(b.ptr, dev, sh.top, sh.rows))
+    for r in range(world):
+        assert L.kvz_hip_set_device(recs[r].device) == 0
+        up = C.byref(recs[r - 1]) if r > 0 else None
+        down = C.byref(recs[r + 1]) if r < world - 1 else None
+        _lib.check(L.kvz_hip_halo_exchange(C.byref(recs[r]), up, down, W, margin, None), "halo_exchange")
+        _lib.check(L.kvz_hip_stream_sync(None), "sync")
+    for r in range(world):
+        assert L.kvz_hip_set_device(recs[r].device) == 0
+        got = bufs[r].to_numpy(np.uint8, (shards[r].ext_rows, W))
+        np.testing.assert_array_equal(got, plane[shards[r].ext_lo:shards[r].ext_hi], err_msg="shard %d" % r)
+    # refusals: the calling thread must work on self->device; a shard thinner than the margin
+    assert L.kvz_hip_set_device(recs[0].device) == 0
+    thin = ShardPlane(bufs[0].ptr, recs[0].device, 0, margin - 1)
+    assert L.kvz_hip_halo_exchange(C.byref(thin), None, C.byref(recs[1]), W, margin, None) == -2
+    if ndev >= 2:
+        assert L.kvz_hip_set_device(1) == 0
+        assert L.kvz_hip_halo_exchange(C.byref(recs[0]), None, C.byref(recs[1]), W, margin, None) == -2      # recs[0] lives on device 0
+        st1 = L.kvz_hip_stream_create()                                                                       # a stream of device 1 ...
+        assert L.kvz_hip_set_device(0) == 0
+        assert L.kvz_hip_memcpy_peer(bufs[1].ptr, 1, bufs[0].ptr, 0, 16, st1) == -2                           # ... handed in on device 0
+        assert b"stream belongs to device" in L.kvz_hip_last_error()
+        L.kvz_hip_stream_destroy(st1)
+    assert L.kvz_hip_set_device(0) == 0
+
+
 @pytest.mark.parametrize("n", [4, 8, 16, 32])
 def test_transform_skip_kinds(api, n):
     """KVZ_HIP_TRSKIP / KVZ_HIP_ITRSKIP = kvz_transformskip / kvz_itransformskip (transform.c:150-180): a shift by
@@ -1344,3 +1392,12 @@ def test_inter_candidates_of_several_pictures_in_one_launch(api):
     assert got2["num_merge_cand"][0] == -1 and (got2["num_merge_cand"][owner == 1] == -1).all()
     keep = (owner != 1) & (np.arange(len(owner)) != 0)
     np.testing.assert_array_equal(got2[keep], want_pus[keep])
+    # a list entry beyond 15 in one picture (what the one-picture entry refuses on the host): that picture's PUs are flagged, the
+    # entry is not masked into range, the other pictures are derived as before
+    bad_list = [(p.copy(), cus, col, refm) for (p, cus, col, refm) in pictures]
+    bad_list[2][0]["ref_LX"][0, 0, 0] = 16
+    got3 = api.inter_candidates_multi_batch(bad_list, allpus)[0].view(ME_PU_DT).ravel()
+    assert (got3["num_merge_cand"][owner == 2] == -1).all()
+    np.testing.assert_array_equal(got3[owner != 2], want_pus[owner != 2])
+    with pytest.raises(Exception):
+        api.inter_candidates_batch(bad_list[2][0], cases[2][1], cases[2][2], cases[2][3], cases[2][4][:4])
