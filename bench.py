@@ -519,6 +519,53 @@ def reference_workload_leg(env, budget_s=0.4):
                     "on the same data; M calls/s like the reference's speed tests report", "cpu_threads": cores, "rows": rows}
 
 
+def encoder_leg(frames=16, threads=16, timeout_s=280):
+    """BASELINE's second half, "encoder fps 1080p medium": the compiled reference encoder (oracle/_ref, Kvazaar built from
+    /root/reference by oracle/Makefile) at 1920x1080, preset medium, its own thread pool and --owf auto, timed untouched and with
+    its 2Nx2N inter searches answered by the product's search service (kvz_hip_me_service_*) from all its worker threads; the
+    bitstreams must be identical.  Runs tools/served_encode.py in a child process (the encoder is a host application of the
+    library, not part of it); returns None when oracle/_ref is not there."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libkvzref.so")):
+        return None
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "served_encode.py"), "--size", "1920x1080", "--frames", str(frames), "--threads", str(threads),
+           "--min-size", "8,32,64", "--probe"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "tools/served_encode.py did not finish in %d s" % timeout_s}
+    rows, probe, summary = [], None, None
+    for line in r.stdout.splitlines():
+        try:
+            d = json.loads(line)
+        except ValueError:
+            continue
+        if "cpu_search_us" in d:
+            probe = d
+        elif "summary" in d:
+            summary = d
+        elif "fps_served" in d:
+            rows.append(d)
+    if not rows or summary is None:
+        return {"error": "tools/served_encode.py failed (rc %d)" % r.returncode}
+    out = {
+        "what": "reference encoder (oracle/_ref) 1920x1080 preset medium qp 32, %d synthetic frames, threads=%d, owf auto: frames/s untouched (avx2 "
+                "strategies) and with its 2Nx2N inter searches of at least `min_pu_served` pixels answered by kvz_hip_me_service_search from all "
+                "worker threads (all reference pictures of a PU in parallel, concurrent requests in shared launches)" % (frames, threads),
+        "fps_untouched_same_threads": rows[0]["fps_untouched"],
+        "all_bitstreams_identical": bool(summary.get("all_identical")),
+        "served": [{k: row[k] for k in ("min_pu_served", "fps_served", "searches_served", "searches_left_to_cpu", "launches", "mean_requests_per_batch",
+                                        "mean_units_per_launch", "max_batch_units", "mean_wait_us", "upload_MB", "failed")} for row in rows],
+        # what a served search has to beat: the reference's own kvz_search_cu_inter per CU size on this host (all reference pictures of the PU)
+        "cpu_search_us_per_cu": probe["cpu_search_us"] if probe else None,
+        "cpu_searches_per_cu_size": probe["cpu_searches"] if probe else None,
+        "note": "a served search costs its caller mean_wait_us; the CPU does the same search in cpu_search_us_per_cu -- at preset medium (hexbs, early "
+                "termination) that is 4-60 us, below a launch + kernel + PCIe round trip for every size but 64x64, so the served encode trails the "
+                "untouched one; DESIGN.md section 6 has the account",
+    }
+    return out
+
+
 SHARD_LEG_LIMIT_S = 300
 
 
@@ -532,6 +579,7 @@ def main():
     ap.add_argument("--search-frames", type=int, default=8, help="4K frames per step of the sharded search sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-leg", action="store_true")
+    ap.add_argument("--no-encoder-leg", action="store_true", help="skip the served-encode leg (reference encoder + search service)")
     ap.add_argument("--no-reference-workload", action="store_true", help="skip the leg that runs the reference's own benchmark patterns (tests/speed_tests.c)")
     ap.add_argument("--partition", choices=("spans", "rows"), default="spans",
                     help="shard_4k block-kernel leg: raster spans of CTUs (equal to within one CTU) or whole CTU rows")
@@ -549,6 +597,12 @@ def main():
         except Exception as e:                          # noqa: BLE001 -- an extra leg must not cost the headline line
             ref_workload = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+    encoder = None
+    if world == 1 and not args.no_encoder_leg:
+        try:
+            encoder = encoder_leg()
+        except Exception as e:                          # noqa: BLE001
+            encoder = {"error": "%s: %s" % (type(e).__name__, e)}
 
     def emit(shard_out):
         """rank 0: the one JSON line (the headline numbers are final before the shard leg starts)"""
@@ -592,6 +646,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         if ref_workload is not None:
             out["reference_workload"] = ref_workload
+        if encoder is not None:
+            out["encoder"] = encoder
         print(json.dumps(out), flush=True)
 
     # The shard leg exchanges halo rows between ranks; should a collective ever hang, the headline line is still printed: a

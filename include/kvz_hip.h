@@ -496,6 +496,8 @@ typedef struct {
   uint64_t max_batch_units;
   uint64_t rects, rect_bytes;   /* kvz_hip_me_service_put_rect calls and the bytes they moved */
   uint64_t wait_ns;             /* summed over callers: time between posting a request and seeing its results */
+  uint64_t tables, table_bytes; /* kvz_hip_me_service_sad_tables: (CTU, picture) tables filled and the bytes the kernels wrote to host memory */
+  uint64_t table_ns;            /* summed over callers: time spent in kvz_hip_me_service_sad_tables */
 } kvz_hip_me_service_stats;
 KVZ_HIP_API kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *cfg);
 KVZ_HIP_API void kvz_hip_me_service_destroy(kvz_hip_me_service *svc);
@@ -506,6 +508,21 @@ KVZ_HIP_API int kvz_hip_me_service_put_rect(kvz_hip_me_service *svc, int slot, c
 /* Blocks until the request's results[0 .. n_refs - 1] are there. */
 KVZ_HIP_API int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request *req, kvz_hip_me_result *results);
 KVZ_HIP_API int kvz_hip_me_service_get_stats(kvz_hip_me_service *svc, kvz_hip_me_service_stats *out);
+/* The device plane of a slot, for a host that wants to run another batched entry on the resident pictures. */
+KVZ_HIP_API const kvz_hip_pixel *kvz_hip_me_service_plane(kvz_hip_me_service *svc, int slot);
+/* The candidate-INDEPENDENT half of the integer search, for hosts that keep the search itself: every value check_mv_cost
+ * (search_inter.c:195-232) can ask kvz_image_calc_sad (image.c:455-486) for while it searches the square PUs of one CTU
+ * within +-range full pixels of their own position -- no neighbour decision enters, so the host can ask for it when it
+ * starts the CTU.  One kvz_hip_ctu_sad_grid_batch launch per picture (a workgroup per window row: the CTU's source block and
+ * that row's reference pixels staged in LDS once, larger PUs as sums of the 8x8 SADs), written by the kernels straight into
+ * page-locked host memory owned by the service.  Returns the calling thread's table, valid until its next call:
+ *   table[((i * side + (dy + range)) * side + (dx + range)) * KVZ_HIP_CTU_PUS + k],  side = 2 * range + 1,
+ * i = index in ref_slots, k = the PU as in kvz_hip_ctu_sad_grid_batch (0: 64x64; 1..4: 32x32; 5..20: 16x16; 21..84: 8x8, raster
+ * order inside the CTU); 0xFFFFFFFF = the PU is not inside the picture.  Reference blocks that leave the picture are edge
+ * replicated like image_interpolated_sad (image.c:320-444).  range 1..32; ctu_x, ctu_y multiples of 64.  NULL on failure.
+ * Bytes per call: n_refs * side^2 * 340 (range 16: 370 KB per picture). */
+KVZ_HIP_API const uint32_t *kvz_hip_me_service_sad_tables(kvz_hip_me_service *svc, int pic_slot, int n_refs, const int32_t *ref_slots,
+                                                          int ctu_x, int ctu_y, int range);
 
 /* ---- candidate derivation next to the search: what a host derives between two dependency fronts ---- */
 /* One record per 4x4 SCU, row-major: the fields of cu_info_t (cu.h:117-153) the candidate derivation and the

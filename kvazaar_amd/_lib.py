@@ -101,6 +101,8 @@ SIGNATURES = {
     "kvz_hip_me_service_put_rect": (_I, [_P, _I, _P, _U, _I, _I, _I, _I]),
     "kvz_hip_me_service_search": (_I, [_P, _P, _P]),
     "kvz_hip_me_service_get_stats": (_I, [_P, _P]),
+    "kvz_hip_me_service_plane": (_P, [_P, _I]),
+    "kvz_hip_me_service_sad_tables": (_P, [_P, _I, _I, _P, _I, _I, _I]),
     "kvz_hip_bipred_cost_batch": (_I, [_P, _U, _I, _I, _P, _U, _P, _U, _I, _I, _P, _SZ, _P, _P]),
     "kvz_hip_inter_candidates_batch": (_I, [_P, _P, _P, _P, _P, _SZ, _P, _P]),
     "kvz_hip_inter_candidates_multi_batch": (_I, [_P, _I, _P, _SZ, _P, _P]),

@@ -542,9 +542,21 @@ class MeService:
         return out[:n]
 
     def stats(self):
-        s = np.zeros(8, dtype=np.uint64)
+        s = np.zeros(11, dtype=np.uint64)
         check(self.lib.kvz_hip_me_service_get_stats(self.ptr, s.ctypes.data), "me_service_get_stats")
-        return dict(zip(("requests", "units", "batches", "launches", "max_batch_units", "rects", "rect_bytes", "wait_ns"), (int(v) for v in s)))
+        return dict(zip(("requests", "units", "batches", "launches", "max_batch_units", "rects", "rect_bytes", "wait_ns", "tables", "table_bytes", "table_ns"),
+                        (int(v) for v in s)))
+
+    def sad_tables(self, pic_slot, ref_slots, ctu_x, ctu_y, rng):
+        """kvz_hip_me_service_sad_tables -> uint32 [n_refs, 2 rng + 1 (dy), 2 rng + 1 (dx), 85] (a copy of the thread's table)"""
+        import ctypes as C
+        refs = np.ascontiguousarray(ref_slots, dtype=np.int32)
+        p = self.lib.kvz_hip_me_service_sad_tables(self.ptr, pic_slot, len(refs), refs.ctypes.data, ctu_x, ctu_y, rng)
+        if not p:
+            raise KvzHipError("kvz_hip_me_service_sad_tables failed: %s" % self.lib.kvz_hip_last_error().decode())
+        side = 2 * rng + 1
+        n = len(refs) * side * side * 85
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n,)).reshape(len(refs), side, side, 85).copy()
 
     def close(self):
         if self.ptr:

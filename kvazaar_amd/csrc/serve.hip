@@ -44,8 +44,17 @@ inline uint64_t now_ns()
   return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec;
 }
 
+constexpr int MAX_TABLE_RANGE = 32;   // kvz_hip_me_service_sad_tables: +-range, (2 * range + 1)^2 candidates per CTU and picture
 struct thread_area {                  // one per calling thread, page-locked
   serve_result res[KVZ_HIP_SERVICE_MAX_REFS];
+  // SAD tables: one descriptor per row of the window and picture (the row's candidates are its mv_offsets), the offsets of a row
+  kvz_hip_ctu_search ctus[KVZ_HIP_SERVICE_MAX_REFS][2 * MAX_TABLE_RANGE + 1];
+  int16_t offs[2 * MAX_TABLE_RANGE + 1][2];
+};
+struct thread_tables {                // per calling thread, host side: the page-locked table buffer (grown on demand) and its stream
+  uint32_t *buf = nullptr;
+  size_t bytes = 0;
+  hipStream_t stream = nullptr;
 };
 
 struct pending_req {
@@ -69,6 +78,8 @@ struct kvz_hip_me_service {
   std::atomic<int> *batch_open = nullptr;               // requests of the batch in that ring buffer not answered yet
   std::atomic<int> *slot_batch = nullptr;               // per calling thread: the ring buffer its request went out in
   u8 *up_stage[N_UPLOAD] = {};                          // page-locked staging of put_rect, one per upload stream
+  thread_tables *tables = nullptr;                      // [max_threads], each touched by its own thread only
+  std::atomic<uint64_t> st_tables{0}, st_table_bytes{0}, st_table_ns{0};
   uint64_t next_batch = 0;                              // touched under launch_mu only
   std::mutex pend_mu;
   std::vector<pending_req> pending;
@@ -204,6 +215,8 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
   svc->batch_open = new (std::nothrow) std::atomic<int>[svc->n_batch];
   ok = ok && svc->batch_open != nullptr;
   for (int i = 0; i < svc->n_batch && ok; ++i) svc->batch_open[i].store(0);
+  svc->tables = new (std::nothrow) thread_tables[svc->max_threads];
+  ok = ok && svc->tables != nullptr;
   svc->slot_batch = new (std::nothrow) std::atomic<int>[svc->max_threads];
   ok = ok && svc->slot_batch != nullptr;
   for (int i = 0; i < N_UPLOAD && ok; ++i) ok = hipHostMalloc((void **)&svc->up_stage[i], svc->plane_bytes, hipHostMallocPortable) == hipSuccess;
@@ -224,6 +237,12 @@ void kvz_hip_me_service_destroy(kvz_hip_me_service *svc)
   for (int i = 0; i < N_STREAMS; ++i) if (svc->streams[i]) { (void)hipStreamSynchronize(svc->streams[i]); (void)hipStreamDestroy(svc->streams[i]); }
   for (int i = 0; i < N_UPLOAD; ++i) if (svc->up_streams[i]) { (void)hipStreamSynchronize(svc->up_streams[i]); (void)hipStreamDestroy(svc->up_streams[i]); }
   for (int i = 0; i < N_UPLOAD; ++i) if (svc->up_stage[i]) (void)hipHostFree(svc->up_stage[i]);
+  if (svc->tables)
+    for (int i = 0; i < svc->max_threads; ++i) {
+      if (svc->tables[i].stream) { (void)hipStreamSynchronize(svc->tables[i].stream); (void)hipStreamDestroy(svc->tables[i].stream); }
+      if (svc->tables[i].buf) (void)hipHostFree(svc->tables[i].buf);
+    }
+  delete[] svc->tables;
   delete[] svc->slot_batch;
   delete[] svc->batch_open;
   if (svc->planes) (void)hipFree(svc->planes);
@@ -320,12 +339,67 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
   return KVZ_HIP_OK;
 }
 
+// The candidate-independent half of the integer search (include/kvz_hip.h): every SAD check_mv_cost could ask
+// kvz_image_calc_sad for inside +-range of a CTU, for every square PU of the CTU and every listed reference picture.
+const uint32_t *kvz_hip_me_service_sad_tables(kvz_hip_me_service *svc, int pic_slot, int n_refs, const int32_t *ref_slots,
+                                              int ctu_x, int ctu_y, int range)
+{
+  if (!svc || !ref_slots || n_refs < 1 || n_refs > KVZ_HIP_SERVICE_MAX_REFS || pic_slot < 0 || pic_slot >= svc->n_slots || range < 1 ||
+      range > MAX_TABLE_RANGE || ctu_x < 0 || ctu_y < 0 || ctu_x >= svc->w || ctu_y >= svc->h || (ctu_x & 63) || (ctu_y & 63)) {
+    kvzhip::invalid_arg(__func__);
+    return nullptr;
+  }
+  for (int i = 0; i < n_refs; ++i)
+    if (ref_slots[i] < 0 || ref_slots[i] >= svc->n_slots) { kvzhip::invalid_arg(__func__); return nullptr; }
+  const int ts = thread_slot(svc);
+  if (ts < 0) { set_error_msg("kvz_hip_me_service_sad_tables: more calling threads than max_threads"); return nullptr; }
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != svc->device) {
+    if (hipSetDevice(svc->device) != hipSuccess) { set_error_msg("kvz_hip_me_service_sad_tables: hipSetDevice failed"); return nullptr; }
+  }
+  const uint64_t t0 = now_ns();
+  thread_tables &tt = svc->tables[ts];
+  const int side = 2 * range + 1;
+  const size_t per_ref = (size_t)side * side * KVZ_HIP_CTU_PUS, need = per_ref * (size_t)n_refs * sizeof(uint32_t);
+  if (!tt.stream && hipStreamCreateWithFlags(&tt.stream, hipStreamNonBlocking) != hipSuccess) { set_error("kvz_hip_me_service_sad_tables: hipStreamCreate", hipGetLastError()); return nullptr; }
+  if (tt.bytes < need) {
+    if (tt.buf) (void)hipHostFree(tt.buf);
+    tt.buf = nullptr; tt.bytes = 0;
+    if (hipHostMalloc((void **)&tt.buf, need, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { set_error("kvz_hip_me_service_sad_tables: hipHostMalloc", hipGetLastError()); return nullptr; }
+    tt.bytes = need;
+  }
+  thread_area *area = svc->areas + ts;
+  for (int k = 0; k < side; ++k) { area->offs[k][0] = (int16_t)(k - range); area->offs[k][1] = 0; }
+  for (int i = 0; i < n_refs; ++i) {
+    for (int k = 0; k < side; ++k) { kvz_hip_ctu_search &c = area->ctus[i][k]; c.x = ctu_x; c.y = ctu_y; c.mvx = 0; c.mvy = k - range; }
+    // one workgroup per row of the window: `side` rows of `side` candidates each, all 85 PU sums per candidate, written
+    // straight into the caller's page-locked table
+    const int rc = kvz_hip_ctu_sad_grid_batch(svc->planes + (size_t)pic_slot * svc->plane_bytes, (uint32_t)svc->w, svc->w, svc->h,
+                                              svc->planes + (size_t)ref_slots[i] * svc->plane_bytes, (uint32_t)svc->w, svc->w, svc->h,
+                                              area->ctus[i], (size_t)side, &area->offs[0][0], side, tt.buf + per_ref * (size_t)i, (kvz_hip_stream)tt.stream);
+    if (rc != KVZ_HIP_OK) return nullptr;
+  }
+  const hipError_t e = hipStreamSynchronize(tt.stream);
+  if (e != hipSuccess) { set_error("kvz_hip_me_service_sad_tables: hipStreamSynchronize", e); return nullptr; }
+  svc->st_tables.fetch_add((uint64_t)n_refs, std::memory_order_relaxed);
+  svc->st_table_bytes.fetch_add((uint64_t)need, std::memory_order_relaxed);
+  svc->st_table_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
+  return tt.buf;
+}
+
+const kvz_hip_pixel *kvz_hip_me_service_plane(kvz_hip_me_service *svc, int slot)
+{
+  if (!svc || slot < 0 || slot >= svc->n_slots) { kvzhip::invalid_arg(__func__); return nullptr; }
+  return svc->planes + (size_t)slot * svc->plane_bytes;
+}
+
 int kvz_hip_me_service_get_stats(kvz_hip_me_service *svc, kvz_hip_me_service_stats *out)
 {
   if (!svc || !out) return kvzhip::invalid_arg(__func__);
   out->requests = svc->st_requests.load(); out->units = svc->st_units.load(); out->batches = svc->st_batches.load();
   out->launches = svc->st_launches.load(); out->max_batch_units = svc->st_max_batch.load(); out->rects = svc->st_rects.load();
   out->rect_bytes = svc->st_rect_bytes.load(); out->wait_ns = svc->st_wait_ns.load();
+  out->tables = svc->st_tables.load(); out->table_bytes = svc->st_table_bytes.load(); out->table_ns = svc->st_table_ns.load();
   return KVZ_HIP_OK;
 }
 

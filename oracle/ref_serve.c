@@ -65,6 +65,9 @@ static struct {
   int (*init)(int);
   const char *(*last_error)(void);
   int w, h, min_size, shadow, probe;
+  int table_range;                      /* > 0: SAD-table mode (the search stays with the reference, kvz_image_calc_sad is answered from tables) */
+  const uint32_t *(*sad_tables)(kvz_hip_me_service *, int, int, const int32_t *, int, int, int);
+  long long tab_hits, tab_range_misses, tab_other, tab_ns;
   long long probe_ns[4], probe_n[4];    /* probe mode: the reference's own search timed per CU size 64, 32, 16, 8 */
   pthread_mutex_t table_mu;
   svc_slot_t slots[SVC_SLOTS];
@@ -80,7 +83,10 @@ static long long svc_now_ns(void)
   return (long long)t.tv_sec * 1000000000ll + t.tv_nsec;
 }
 
-/* flags: bit 1 = probe mode (nothing is served: the reference's own searches are timed per CU size);
+/* flags: bits 8..15 = SAD-table mode with that range (1..32): nothing of the search is served, but at the start of each CTU the
+ * worker fetches kvz_hip_me_service_sad_tables for every reference picture and the reference's own kvz_image_calc_sad calls
+ * (check_mv_cost, search_inter.c:200) are answered from them; a call the table does not hold runs the reference's function;
+ * bit 1 = probe mode (nothing is served: the reference's own searches are timed per CU size);
  * bit 0 = shadow mode (every served search is repeated by the reference's own search and compared; the
  * reference's result is kept), min_size = smallest PU width that is served (smaller ones run the reference's search) */
 int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int min_size, int flags)
@@ -94,9 +100,10 @@ int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int m
   *(void **)&g_svc.put_rect = dlsym(l, "kvz_hip_me_service_put_rect");
   *(void **)&g_svc.search = dlsym(l, "kvz_hip_me_service_search");
   *(void **)&g_svc.get_stats = dlsym(l, "kvz_hip_me_service_get_stats");
+  *(void **)&g_svc.sad_tables = dlsym(l, "kvz_hip_me_service_sad_tables");
   *(void **)&g_svc.init = dlsym(l, "kvz_hip_init");
   *(void **)&g_svc.last_error = dlsym(l, "kvz_hip_last_error");
-  if (!g_svc.create || !g_svc.destroy || !g_svc.put_rect || !g_svc.search || !g_svc.get_stats || !g_svc.init || !g_svc.last_error) return -1;
+  if (!g_svc.create || !g_svc.destroy || !g_svc.put_rect || !g_svc.search || !g_svc.get_stats || !g_svc.init || !g_svc.last_error || !g_svc.sad_tables) return -1;
   if (g_svc.init(-1) != KVZ_HIP_OK) { fprintf(stderr, "kvz_hip_init: %s\n", g_svc.last_error()); return -1; }
   if ((h + 63) / 64 + 1 > SVC_MAX_BANDS) return -1;
   kvz_hip_me_service_config cfg;
@@ -105,21 +112,28 @@ int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int m
   g_svc.svc = g_svc.create(&cfg);
   if (!g_svc.svc) { fprintf(stderr, "kvz_hip_me_service_create: %s\n", g_svc.last_error()); return -1; }
   g_svc.w = w; g_svc.h = h; g_svc.min_size = min_size; g_svc.shadow = flags & 1; g_svc.probe = (flags >> 1) & 1;
+  g_svc.table_range = (flags >> 8) & 0xff;
   pthread_mutex_init(&g_svc.table_mu, NULL);
   for (int i = 0; i < SVC_SLOTS; ++i) pthread_mutex_init(&g_svc.slots[i].mu, NULL);
   __atomic_store_n(&g_svc.on, 1, __ATOMIC_RELEASE);
   return 0;
 }
 
-/* out[16..19] / out[20..23]: probe mode's summed nanoseconds / number of searches for CU sizes 64, 32, 16, 8.
+/* out[24..30]: SAD-table mode: lookups answered, lookups outside the range, other calls, ns in the wrapper's misses (unused),
+ * tables fetched, their bytes, ns spent fetching them.  out[16..19] / out[20..23]: probe mode's summed nanoseconds / number of searches for CU sizes 64, 32, 16, 8.
  * out[0..15]: served, passed on, failed, shadow mismatches, upload rects, search wait ns, upload ns, candidate ns,
  * then the service's own statistics: requests, units, batches, launches, max_batch_units, rects, rect_bytes, wait_ns */
 void ref_service_end(long long *out)
 {
   __atomic_store_n(&g_svc.on, 0, __ATOMIC_RELEASE);
   if (out) {
-    memset(out, 0, 24 * sizeof(out[0]));
+    memset(out, 0, 32 * sizeof(out[0]));
     for (int i = 0; i < 4; ++i) { out[16 + i] = g_svc.probe_ns[i]; out[20 + i] = g_svc.probe_n[i]; }
+    out[24] = g_svc.tab_hits; out[25] = g_svc.tab_range_misses; out[26] = g_svc.tab_other; out[27] = g_svc.tab_ns;
+    if (g_svc.svc) {
+      kvz_hip_me_service_stats st2;
+      if (g_svc.get_stats(g_svc.svc, &st2) == KVZ_HIP_OK) { out[28] = (long long)st2.tables; out[29] = (long long)st2.table_bytes; out[30] = (long long)st2.table_ns; }
+    }
     out[0] = g_svc.served; out[1] = g_svc.passed_on; out[2] = g_svc.failed; out[3] = g_svc.shadow_mismatch; out[4] = g_svc.upload_rects;
     out[5] = g_svc.search_ns; out[6] = g_svc.upload_ns; out[7] = g_svc.cand_ns;
     kvz_hip_me_service_stats st;
@@ -231,8 +245,57 @@ static int svc_in_flight(const encoder_state_t *state, int32_t poc)
   return 0;
 }
 
+/* SAD-table mode: the calling worker's tables for the CTU it is searching */
+static __thread struct {
+  const uint32_t *tab;
+  const kvz_picture *pic, *refs[KVZ_HIP_SERVICE_MAX_REFS];
+  int n_refs, ctu_x, ctu_y, range, valid;
+  long long hits, range_misses, other;
+} t_tab;
+
+unsigned __real_kvz_image_calc_sad(const kvz_picture *pic, const kvz_picture *ref, int pic_x, int pic_y, int ref_x, int ref_y, int block_width, int block_height);
+
+/* kvz_image_calc_sad (image.c:455-486; -Wl,--wrap): the one call site is check_mv_cost (search_inter.c:200) */
+unsigned __wrap_kvz_image_calc_sad(const kvz_picture *pic, const kvz_picture *ref, int pic_x, int pic_y, int ref_x, int ref_y, int block_width, int block_height)
+{
+  if (t_tab.valid && pic == t_tab.pic && block_width == block_height && (pic_x & ~63) == t_tab.ctu_x && (pic_y & ~63) == t_tab.ctu_y) {
+    const int n = block_width, bx = pic_x & 63, by = pic_y & 63;
+    int k = -1;
+    if (!((bx | by) & (n - 1))) {
+      if (n == 8) k = 21 + (by >> 3) * 8 + (bx >> 3);
+      else if (n == 16) k = 5 + (by >> 4) * 4 + (bx >> 4);
+      else if (n == 32) k = 1 + (by >> 5) * 2 + (bx >> 5);
+      else if (n == 64) k = 0;
+    }
+    if (k >= 0) {
+      const int R = t_tab.range, side = 2 * R + 1, dx = ref_x - pic_x, dy = ref_y - pic_y;
+      if (dx >= -R && dx <= R && dy >= -R && dy <= R) {
+        for (int i = 0; i < t_tab.n_refs; ++i)
+          if (t_tab.refs[i] == ref) {
+            const uint32_t v = t_tab.tab[(((size_t)i * side + (size_t)(dy + R)) * side + (size_t)(dx + R)) * KVZ_HIP_CTU_PUS + k];
+            if (v != 0xffffffffu) { ++t_tab.hits; return v; }
+            break;
+          }
+      } else {
+        ++t_tab.range_misses;
+        return __real_kvz_image_calc_sad(pic, ref, pic_x, pic_y, ref_x, ref_y, block_width, block_height);
+      }
+    }
+  }
+  ++t_tab.other;
+  return __real_kvz_image_calc_sad(pic, ref, pic_x, pic_y, ref_x, ref_y, block_width, block_height);
+}
+
+static void svc_flush_table_counters(void)
+{
+  __atomic_add_fetch(&g_svc.tab_hits, t_tab.hits, __ATOMIC_RELAXED);
+  __atomic_add_fetch(&g_svc.tab_range_misses, t_tab.range_misses, __ATOMIC_RELAXED);
+  __atomic_add_fetch(&g_svc.tab_other, t_tab.other, __ATOMIC_RELAXED);
+  t_tab.hits = t_tab.range_misses = t_tab.other = 0;
+}
+
 /* the last CTU this worker uploaded a staircase for */
-static __thread struct { int32_t poc, lx, ly; int valid; } t_last_ctu;
+static __thread struct { int32_t poc, lx, ly; int valid; int32_t pic_slot, ref_slot[KVZ_HIP_SERVICE_MAX_REFS]; } t_last_ctu;
 
 /* kvz_search_cu_inter's 2Nx2N PU through the service.  Returns 1 when served. */
 int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu, double *inter_cost, uint32_t *inter_bitcost)
@@ -246,7 +309,7 @@ int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *l
     __atomic_add_fetch(&g_svc.probe_n[depth & 3], 1, __ATOMIC_RELAXED);
     return 1;
   }
-  if (!svc_can_serve(state, width)) { __atomic_add_fetch(&g_svc.passed_on, 1, __ATOMIC_RELAXED); return 0; }
+  if (!svc_can_serve(state, g_svc.table_range > 0 ? 64 : width)) { t_tab.valid = 0; __atomic_add_fetch(&g_svc.passed_on, 1, __ATOMIC_RELAXED); return 0; }
   const encoder_control_t *ctrl = state->encoder_control;
   const encoder_state_config_frame_t *fr = state->frame;
   const int nref = (int)fr->ref->used_size;
@@ -257,25 +320,49 @@ int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *l
   kvz_hip_me_request req;
   memset(&req, 0, sizeof(req));
   const kvz_picture *src = state->tile->frame->source;
-  int idx;
-  svc_slot_t *s = svc_slot_of(src, fr->poc, 0, &idx);
-  bad |= svc_upload_whole(s, idx, src);
-  req.pic_slot = idx;
   req.n_refs = nref;
   const int wpp_owf = ctrl->cfg.owf && ctrl->cfg.wpp;
   const int delay = ctrl->cfg.sao_type ? SAO_DELAY_PX : (ctrl->cfg.deblock_enable ? DEBLOCK_DELAY_PX : 0);
   const int lx = x / LCU_WIDTH, ly = y / LCU_WIDTH;
   const int new_ctu = !t_last_ctu.valid || t_last_ctu.poc != fr->poc || t_last_ctu.lx != lx || t_last_ctu.ly != ly;
-  for (int i = 0; i < nref && !bad; ++i) {
-    const kvz_picture *ref = fr->ref->images[i];
-    s = svc_slot_of(ref, fr->ref->pocs[i], 1, &idx);
-    req.ref_slot[i] = idx;
-    if (__atomic_load_n(&s->complete, __ATOMIC_ACQUIRE)) continue;
-    if (!wpp_owf || !svc_in_flight(state, fr->ref->pocs[i])) bad |= svc_upload_whole(s, idx, ref);
-    else if (new_ctu) bad |= svc_upload_staircase(s, idx, ref, lx, ly, delay, ctrl->max_inter_ref_lcu.down, ctrl->max_inter_ref_lcu.right);
+  if (new_ctu) {
+    /* once per CTU and worker: where the pictures live on the device, and whatever of them has become final since (the slots are
+     * remembered for the CTU's other searches: the table lookups take a lock) */
+    int idx;
+    svc_slot_t *s = svc_slot_of(src, fr->poc, 0, &idx);
+    bad |= svc_upload_whole(s, idx, src);
+    t_last_ctu.pic_slot = idx;
+    for (int i = 0; i < nref && !bad; ++i) {
+      const kvz_picture *ref = fr->ref->images[i];
+      s = svc_slot_of(ref, fr->ref->pocs[i], 1, &idx);
+      t_last_ctu.ref_slot[i] = idx;
+      if (__atomic_load_n(&s->complete, __ATOMIC_ACQUIRE)) continue;
+      if (!wpp_owf || !svc_in_flight(state, fr->ref->pocs[i])) bad |= svc_upload_whole(s, idx, ref);
+      else bad |= svc_upload_staircase(s, idx, ref, lx, ly, delay, ctrl->max_inter_ref_lcu.down, ctrl->max_inter_ref_lcu.right);
+    }
+    t_last_ctu.poc = fr->poc; t_last_ctu.lx = lx; t_last_ctu.ly = ly; t_last_ctu.valid = !bad;
   }
-  t_last_ctu.poc = fr->poc; t_last_ctu.lx = lx; t_last_ctu.ly = ly; t_last_ctu.valid = 1;
+  req.pic_slot = t_last_ctu.pic_slot;
+  for (int i = 0; i < nref; ++i) req.ref_slot[i] = t_last_ctu.ref_slot[i];
   long long t1 = svc_now_ns();
+  if (g_svc.table_range > 0) {
+    /* SAD-table mode: the search stays with the reference; a new CTU gets its tables (every reference picture, +-range) first */
+    if (new_ctu || !t_tab.valid) {
+      svc_flush_table_counters();
+      t_tab.valid = 0;
+      if (!bad) {
+        const uint32_t *tab = g_svc.sad_tables(g_svc.svc, req.pic_slot, nref, req.ref_slot, lx * LCU_WIDTH, ly * LCU_WIDTH, g_svc.table_range);
+        if (tab) {
+          t_tab.tab = tab; t_tab.pic = src; t_tab.n_refs = nref; t_tab.ctu_x = lx * LCU_WIDTH; t_tab.ctu_y = ly * LCU_WIDTH; t_tab.range = g_svc.table_range;
+          for (int i = 0; i < nref; ++i) t_tab.refs[i] = fr->ref->images[i];
+          t_tab.valid = 1;
+        } else if (__atomic_fetch_add(&g_svc.failed, 1, __ATOMIC_RELAXED) == 0) fprintf(stderr, "sad_tables: %s\n", g_svc.last_error());
+      }
+      __atomic_add_fetch(&g_svc.upload_ns, t1 - t0, __ATOMIC_RELAXED);
+    }
+    __atomic_add_fetch(&g_svc.passed_on, 1, __ATOMIC_RELAXED);
+    return 0;
+  }
 
   /* ---- the request: search_pu_inter :1492-1500, then per picture search_pu_inter_ref :1143-1206 ---- */
   cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));

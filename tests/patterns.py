@@ -149,7 +149,7 @@ ME_REQUEST = np.dtype([("pic_slot", "<i4"), ("n_refs", "<i4"), ("ref_slot", "<i4
                        ("params", ME_PARAMS), ("pu", ME_PU, (16,))])
 ME_SERVICE_CONFIG = np.dtype([("width", "<i4"), ("height", "<i4"), ("max_pictures", "<i4"), ("max_threads", "<i4"), ("reserved", "<i4", (4,))])
 ME_SERVICE_STATS = np.dtype([("requests", "<u8"), ("units", "<u8"), ("batches", "<u8"), ("launches", "<u8"), ("max_batch_units", "<u8"),
-                             ("rects", "<u8"), ("rect_bytes", "<u8"), ("wait_ns", "<u8")])
+                             ("rects", "<u8"), ("rect_bytes", "<u8"), ("wait_ns", "<u8"), ("tables", "<u8"), ("table_bytes", "<u8"), ("table_ns", "<u8")])
 assert ME_REQUEST.itemsize == 1200
 
 

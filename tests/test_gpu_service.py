@@ -181,3 +181,53 @@ def test_shadow_mode_agrees_search_by_search():
     served, c = R.encode_with_service(frames, w, h, opts, LIB, max_threads=32, min_size=8, shadow=True)
     assert c["failed"] == 0 and c["served"] > 100 and c["shadow_mismatch"] == 0
     assert served == plain
+
+
+def test_sad_tables_equal_image_calc_sad(api):
+    """kvz_hip_me_service_sad_tables against the oracle's kvz_image_calc_sad for every PU of a CTU, every vector of the window and two
+    pictures, at an inner CTU, at the picture's corner CTUs (edge replication) and at a ragged last row (PUs outside the picture: 0xFFFFFFFF)"""
+    w, h, rng_ = 200, 152, 5                                    # 4 x 3 CTUs, the last column 8 and the last row 24 pixels
+    planes = [me_frames(w, h, 900 + k, motion)[1] for k, motion in enumerate(((0, 0), (2, -1), (-3, 2)))]
+    svc = api.MeService(w, h, max_pictures=4, max_threads=4)
+    try:
+        for k, p in enumerate(planes):
+            svc.put_plane(k, p)
+        for (cx, cy) in ((64, 64), (0, 0), (192, 128), (128, 128), (192, 0)):
+            tab = svc.sad_tables(0, [1, 2], cx, cy, rng_)
+            assert tab.shape == (2, 2 * rng_ + 1, 2 * rng_ + 1, 85)
+            for i, ref in enumerate((planes[1], planes[2])):
+                for k, (n, bx, by) in enumerate([(64, 0, 0)] + [(32, x, y) for y in (0, 32) for x in (0, 32)] +
+                                                [(16, x, y) for y in range(0, 64, 16) for x in range(0, 64, 16)] +
+                                                [(8, x, y) for y in range(0, 64, 8) for x in range(0, 64, 8)]):
+                    px, py = cx + bx, cy + by
+                    inside = px + n <= w and py + n <= h
+                    for dy in (-rng_, -1, 0, 2, rng_):
+                        for dx in (-rng_, 0, 1, rng_):
+                            got = int(tab[i, dy + rng_, dx + rng_, k])
+                            want = O.image_calc("sad", planes[0], ref, px, py, px + dx, py + dy, n, n) if inside else 0xFFFFFFFF
+                            assert got == want, ((cx, cy), i, n, bx, by, dx, dy, got, want)
+        st = svc.stats()
+        assert st["tables"] == 10 and st["table_bytes"] == 5 * 2 * (2 * rng_ + 1) ** 2 * 85 * 4
+    finally:
+        svc.close()
+
+
+TABLE_ENCODES = [
+    (320, 192, 6, "preset=medium,qp=30,threads=6,owf=2", 16),                            # hexbs: most vectors inside +-16
+    (320, 192, 5, "preset=medium,me=full8,qp=31,threads=4,owf=1", 8),                    # exhaustive +-8: the first window is the table
+    (256, 256, 5, "preset=medium,me=tz,ref=2,gop=0,qp=33,threads=3,owf=0,period=0", 12),
+]
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("w,h,n,opts,table_range", TABLE_ENCODES)
+def test_reference_encoder_with_its_sads_answered_from_tables(w, h, n, opts, table_range):
+    """the reference's own searches, their kvz_image_calc_sad calls answered from kvz_hip_me_service_sad_tables fetched once per CTU
+    by the worker that starts it: same SADs, hence same decisions and the same bitstream"""
+    frames = R.synthetic_sequence(w, h, n, seed=21)
+    plain, _ = R.encode(frames, w, h, opts)
+    served, c = R.encode_with_service(frames, w, h, opts, LIB, max_threads=32, table_range=table_range)
+    print("%dx%d x %d (%s), +-%d: %d SADs from tables, %d outside the range, %d other calls; %d tables (%.1f MB) in %.1f ms of worker time"
+          % (w, h, n, opts, table_range, c["table_hits"], c["table_range_misses"], c["table_other_calls"], c["tables"], c["table_bytes"] / 1e6, c["table_ns"] / 1e6))
+    assert c["failed"] == 0 and c["table_hits"] > 1000 and c["served"] == 0
+    assert served == plain, "bitstreams differ (%d vs %d bytes)" % (len(served), len(plain))

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(w, h, n, opts, threads, min_sizes, seed=5, repeat=1, shadow=False, probe=False):
+def run(w, h, n, opts, threads, min_sizes, seed=5, repeat=1, shadow=False, probe=False, table_ranges=()):
     import ref_lib as R
     lib = os.path.join(ROOT, "kvazaar_amd", "libkvzhip.so")
     frames = R.synthetic_sequence(w, h, n, seed=seed)
@@ -34,6 +34,20 @@ def run(w, h, n, opts, threads, min_sizes, seed=5, repeat=1, shadow=False, probe
         if probe:
             _, c = R.encode_with_service(frames, w, h, o, lib, max_threads=max(64, t + 8), probe=True)
             print(json.dumps(dict(size="%dx%d" % (w, h), opts=o, cpu_search_us=c["probe_us_per_search"], cpu_searches=c["probe_searches"])), flush=True)
+        for tr in table_ranges:
+            t0 = time.perf_counter()
+            served, c = R.encode_with_service(frames, w, h, o, lib, max_threads=max(64, t + 8), table_range=tr)
+            dt = time.perf_counter() - t0
+            looked = c["table_hits"] + c["table_range_misses"]
+            row = dict(size="%dx%d" % (w, h), frames=n, opts=o, threads=t, mode="sad_tables", table_range=tr, fps_untouched=round(n / best_plain, 3),
+                       fps_with_tables=round(n / dt, 3), identical_bitstream=bool(served == plain), failed=c["failed"],
+                       sad_calls_answered_from_tables=c["table_hits"], sad_calls_outside_the_range=c["table_range_misses"], other_sad_calls=c["table_other_calls"],
+                       hit_rate=round(c["table_hits"] / max(1, looked + c["table_other_calls"]), 4), tables=c["tables"],
+                       table_MB=round(c["table_bytes"] / 1e6, 1), table_KB_per_ctu_and_picture=round(c["table_bytes"] / 1e3 / max(1, c["tables"]), 1),
+                       mean_us_per_ctu_fetch=round(c["table_ns"] / 1e3 / max(1, c["tables"]) * (c["tables"] / max(1, c["tables"])), 1),
+                       worker_ms_fetching_tables=round(c["table_ns"] / 1e6, 1), upload_MB=round(c["rect_bytes"] / 1e6, 1))
+            print(json.dumps(row), flush=True)
+            rows.append(row)
         for ms in min_sizes:
             best, c, same = None, None, True
             for _ in range(repeat):
@@ -69,11 +83,13 @@ def main():
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--shadow", action="store_true")
+    ap.add_argument("--tables", default="", help="comma-separated ranges: SAD-table mode runs (kvz_hip_me_service_sad_tables answering kvz_image_calc_sad)")
     ap.add_argument("--probe", action="store_true", help="also time the reference's own inter searches per CU size (nothing served)")
     a = ap.parse_args()
     w, h = (int(v) for v in a.size.split("x"))
-    rows = run(w, h, a.frames, a.opts, [int(v) for v in a.threads.split(",")], [int(v) for v in a.min_size.split(",")],
-               seed=a.seed, repeat=a.repeat, shadow=a.shadow, probe=a.probe)
+    rows = run(w, h, a.frames, a.opts, [int(v) for v in a.threads.split(",")], [int(v) for v in a.min_size.split(",") if v],
+               seed=a.seed, repeat=a.repeat, shadow=a.shadow, probe=a.probe,
+               table_ranges=[int(v) for v in a.tables.split(",") if v])
     ok = all(r["identical_bitstream"] and r["failed"] == 0 for r in rows)
     print(json.dumps(dict(summary="served_encode", all_identical=ok, runs=len(rows))))
     return 0 if ok else 1
