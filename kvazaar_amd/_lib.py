@@ -133,6 +133,13 @@ def load(path=None):
     if _LIB is not None:
         return _LIB
     path = path or LIB_PATH
+    # One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64; if this library is loaded first it brings in the
+    # system's copy and a later `import torch` in the same process fails to see the device ("no ROCm-capable device").  A Python
+    # host that has torch gets it loaded first, so that both share the runtime torch ships (a C host is not concerned).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise KvzHipError("%s not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                           "kvazaar_amd has no CPU fallback" % path)

@@ -189,6 +189,73 @@ __device__ __forceinline__ void sample_core(int tid, u8 *s_win, i16 *s_hor, cons
   }
 }
 
+// 8x8 luma blocks owned by one wave -- the commonest motion-compensation block, and the worst fit of the 2 x 4-sample work items
+// above: its 15 x 8 horizontal samples are 16 items and its 64 outputs 8 items, so a quarter and an eighth of the wave worked
+// (246 vector instructions per block, instruction-issue bound: profiles/r02_z_frame_kernels_pmc.txt).  Here every lane works in
+// both passes: horizontal = (window row l >> 2, two neighbouring columns 2 (l & 3), + 1), the byte windows cut from three aligned
+// dwords with a per-lane v_alignbyte shift; vertical = one output sample per lane (x = l & 7, y = l >> 3) as five v_dot2_i32_i16
+// down its transposed column, the coefficient pairs picked per lane by the parity of y.  Same arithmetic, same results.
+template <bool OUT14>
+__device__ __forceinline__ void sample8x8_luma_wave(int lane, u8 *s_win, u32 *s_hor, const refplane_t &ref, const kvz_hip_ipol_block &b,
+                                                    size_t o, void *__restrict__ dst)
+{
+  typedef sample_geom<8, 16> G;
+  constexpr int WS = 16 + 8;
+  const signed char *hf = c_luma_filter[b.mv_frac_x & 3], *vf = c_luma_filter[b.mv_frac_y & 3];
+  {
+    // the 15 x 15 window: rows of 4 dwords when the dword-rounded window lies inside the frame, else bytes with edge replication
+    const int x0 = b.x - 3, y0 = b.y - 3;
+    if (x0 >= 0 && y0 >= 0 && x0 + 16 <= ref.w && y0 + 15 <= ref.h) {
+      if (lane < 60) {
+        const int y = lane >> 2, q = lane & 3;
+        u32 v;
+        __builtin_memcpy(&v, ref.p + (size_t)(y0 + y) * ref.stride + x0 + 4 * q, 4);
+        *(u32 *)(s_win + y * WS + 4 * q) = v;
+      }
+    } else {
+      for (int i = lane; i < 15 * 15; i += 64) {
+        const int y = i / 15, x = i - y * 15;
+        s_win[y * WS + x] = ref_px(ref, x0 + x, y0 + y);
+      }
+    }
+  }
+  wave_lds_fence();
+  u32 h0 = 0, h1 = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { h0 |= (u32)(u8)hf[t] << (8 * t); h1 |= (u32)(u8)hf[4 + t] << (8 * t); }
+  {
+    const int row = lane >> 2, c = 2 * (lane & 3);           // window row 0..15 (15: past the window), columns c, c + 1
+    if (row < 15) {
+      const u32 *q = (const u32 *)(s_win + row * WS + (c & ~3));
+      const u32 d0 = q[0] ^ 0x80808080u, d1 = q[1] ^ 0x80808080u, d2 = q[2] ^ 0x80808080u, k = (u32)c & 3u;
+      const u32 lo0 = __builtin_amdgcn_alignbyte(d1, d0, k), hi0 = __builtin_amdgcn_alignbyte(d2, d1, k);
+      const u32 lo1 = __builtin_amdgcn_alignbyte(d1, d0, k + 1), hi1 = __builtin_amdgcn_alignbyte(d2, d1, k + 1);
+      const int s0 = __builtin_amdgcn_sdot4((int)h0, (int)lo0, __builtin_amdgcn_sdot4((int)h1, (int)hi0, 8192, false), false);
+      const int s1 = __builtin_amdgcn_sdot4((int)h0, (int)lo1, __builtin_amdgcn_sdot4((int)h1, (int)hi1, 8192, false), false);
+      // transposed plane: column x at dword x * HP, rows (2t, 2t + 1) in dword t
+      unsigned short *col0 = (unsigned short *)(s_hor + c * G::HP) + row, *col1 = (unsigned short *)(s_hor + (c + 1) * G::HP) + row;
+      *col0 = (unsigned short)s0;
+      *col1 = (unsigned short)s1;
+    }
+  }
+  wave_lds_fence();
+  {
+    const int x = lane & 7, y = lane >> 3, odd = y & 1;
+    const u32 *col = s_hor + x * G::HP + (y >> 1);
+    int acc = 0;
+#pragma unroll
+    for (int t = 0; t <= 4; ++t) {
+      // even y: taps (2t, 2t + 1) on row pair t; odd y: the window starts half a pair later, taps (2t - 1, 2t)
+      const u32 ce = t < 4 ? frac_pack16(vf[2 * t], vf[2 * t + 1]) : 0u;
+      const u32 co = frac_pack16(t > 0 ? vf[2 * t - 1] : 0, t < 4 ? vf[2 * t] : 0);
+      acc = __builtin_amdgcn_sdot2(as_v2s(col[t]), as_v2s(odd ? co : ce), acc, false);
+    }
+    acc >>= 6;
+    if (OUT14) ((i16 *)dst)[o + (size_t)lane] = (i16)acc;
+    else ((u8 *)dst)[o + (size_t)lane] = fast_clip32((acc + 32) >> 6);
+  }
+}
+
 // The workgroup-per-descriptor kernels share their descriptor list with the wave-per-descriptor kernels of the smaller
 // size classes, and on a frame of small blocks they own nothing: a launch of `count` workgroups that each fetch one
 // descriptor and leave took 23 us of the 83 us of 129 600 8x8 samples.  So a workgroup owns `chunk` (<= 64) consecutive
@@ -251,7 +318,7 @@ __global__ __launch_bounds__(256) void sample_big_kernel(refplane_t ref, const k
 // blocks up to 16x16: one wave per block, four blocks per workgroup, wave-private LDS, no barrier
 template <int TAPS, bool OUT14>
 __global__ __launch_bounds__(256) void sample_small_kernel(refplane_t ref, const kvz_hip_ipol_block *__restrict__ blocks, size_t count,
-                                                           const unsigned long long *__restrict__ out_offsets, void *__restrict__ dst)
+                                                           const unsigned long long *__restrict__ out_offsets, void *__restrict__ dst, int kvz_sample8_wave)
 {
   __shared__ __attribute__((aligned(16))) u8 s_win[4][sample_geom<TAPS, 16>::WIN_BYTES];
   __shared__ __attribute__((aligned(16))) i16 s_hor[4][2 * sample_geom<TAPS, 16>::HOR_DWORDS];
@@ -260,6 +327,10 @@ __global__ __launch_bounds__(256) void sample_small_kernel(refplane_t ref, const
   if (i >= count) return;
   const kvz_hip_ipol_block b = blocks[i];
   if (b.width < 1 || b.height < 1 || b.width > 16 || b.height > 16) return;
+  if (TAPS == 8 && b.width == 8 && b.height == 8 && kvz_sample8_wave) {
+    sample8x8_luma_wave<OUT14>(threadIdx.x & 63, s_win[wv], (u32 *)s_hor[wv], ref, b, (size_t)out_offsets[i], dst);
+    return;
+  }
   sample_core<TAPS, OUT14, 16, 64, true>(threadIdx.x & 63, s_win[wv], s_hor[wv], ref, b, (size_t)out_offsets[i], dst);
 }
 
@@ -552,10 +623,11 @@ static int sample_launch(bool luma, const kvz_hip_pixel *ref, uint32_t ref_strid
   hipStream_t st = ctx_stream(s);
   const unsigned long long *oo = (const unsigned long long *)out_offsets;
   const unsigned chunk = wg_chunk(count);
+  const int s8w = kvzhip::tuning("sample8_wave", 1);          // 0: 8x8 luma blocks on the general 2 x 4-sample path (A/B)
   const unsigned gs = (unsigned)((count + 3) / 4), gb = (unsigned)((count + chunk - 1) / chunk);
 #define KVZ_SAMPLE(TAPS, O14)                                                                                        \
   do {                                                                                                               \
-    hipLaunchKernelGGL((sample_small_kernel<TAPS, O14>), dim3(gs), dim3(256), 0, st, r, blocks, count, oo, dst);     \
+    hipLaunchKernelGGL((sample_small_kernel<TAPS, O14>), dim3(gs), dim3(256), 0, st, r, blocks, count, oo, dst, s8w); \
     hipLaunchKernelGGL((sample_big_kernel<TAPS, O14>), dim3(gb), dim3(256), 0, st, r, blocks, count, chunk, oo, dst); \
   } while (0)
   if (luma) { if (out_14bit) KVZ_SAMPLE(8, true); else KVZ_SAMPLE(8, false); }

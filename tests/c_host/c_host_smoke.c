@@ -205,6 +205,35 @@ int main(void)
     CHECK(kvz_hip_set_device(da) == KVZ_HIP_OK, "set_device"); kvz_hip_free(src);
     CHECK(kvz_hip_set_device(home) == KVZ_HIP_OK, "set_device");
   }
+  /* the same exchange as one call per shard (kvz_hip_halo_exchange): two row shards with a halo of MARGIN rows towards each other */
+  {
+    const int da = 0, db = ndev > 1 ? 1 : 0;
+    enum { MARGIN = 16, ROWS = 64, W = 256 };
+    const size_t ext = (size_t)(ROWS + MARGIN) * W;        /* A: own rows then the halo below; B: the halo above then own rows */
+    unsigned char *h = malloc(ext), *back = malloc(ext);
+    CHECK(kvz_hip_set_device(da) == KVZ_HIP_OK, "set_device");
+    unsigned char *a = kvz_hip_malloc(ext);
+    for (size_t i = 0; i < ext; ++i) h[i] = i < (size_t)ROWS * W ? (unsigned char)(1 + i % 101) : 0;
+    CHECK(a && kvz_hip_memcpy_h2d(a, h, ext, NULL) == KVZ_HIP_OK && kvz_hip_stream_sync(NULL) == KVZ_HIP_OK, "shard A");
+    CHECK(kvz_hip_set_device(db) == KVZ_HIP_OK, "set_device");
+    unsigned char *b = kvz_hip_malloc(ext);
+    for (size_t i = 0; i < ext; ++i) h[i] = i >= (size_t)MARGIN * W ? (unsigned char)(7 + i % 89) : 0;
+    CHECK(b && kvz_hip_memcpy_h2d(b, h, ext, NULL) == KVZ_HIP_OK && kvz_hip_stream_sync(NULL) == KVZ_HIP_OK, "shard B");
+    const kvz_hip_shard_plane pa = { a, da, 0, ROWS }, pb = { b, db, MARGIN, ROWS };
+    CHECK(kvz_hip_set_device(da) == KVZ_HIP_OK && kvz_hip_halo_exchange(&pa, NULL, &pb, W, MARGIN, NULL) == KVZ_HIP_OK &&
+          kvz_hip_stream_sync(NULL) == KVZ_HIP_OK, "A pushes its last rows: %s", kvz_hip_last_error());
+    CHECK(kvz_hip_set_device(db) == KVZ_HIP_OK && kvz_hip_halo_exchange(&pb, &pa, NULL, W, MARGIN, NULL) == KVZ_HIP_OK &&
+          kvz_hip_stream_sync(NULL) == KVZ_HIP_OK, "B pushes its first rows: %s", kvz_hip_last_error());
+    CHECK(kvz_hip_memcpy_d2h(back, b, ext, NULL) == KVZ_HIP_OK, "d2h");
+    for (size_t i = 0; i < (size_t)MARGIN * W; ++i) CHECK(back[i] == (unsigned char)(1 + ((size_t)(ROWS - MARGIN) * W + i) % 101), "B's halo byte %zu", i);
+    CHECK(kvz_hip_set_device(da) == KVZ_HIP_OK && kvz_hip_memcpy_d2h(back, a, ext, NULL) == KVZ_HIP_OK, "d2h");
+    for (size_t i = 0; i < (size_t)MARGIN * W; ++i) CHECK(back[(size_t)ROWS * W + i] == (unsigned char)(7 + ((size_t)MARGIN * W + i) % 89), "A's halo byte %zu", i);
+    CHECK(kvz_hip_halo_exchange(&pb, &pa, NULL, W, MARGIN, NULL) == KVZ_HIP_ERR_INVALID || da == db, "a shard of another device is refused");
+    kvz_hip_free(a);
+    CHECK(kvz_hip_set_device(db) == KVZ_HIP_OK, "set_device"); kvz_hip_free(b);
+    CHECK(kvz_hip_set_device(home) == KVZ_HIP_OK, "set_device");
+    free(h); free(back);
+  }
 
   kvz_hip_free(d_a); kvz_hip_free(d_b); kvz_hip_free(d_cost); kvz_hip_free(d_res); kvz_hip_free(d_coef);
   kvz_hip_stream_destroy(st);

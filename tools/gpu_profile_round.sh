@@ -1,9 +1,10 @@
 #!/bin/bash
 # End-of-work profile set of one build, written under gpurun_out/TAG_* (copy what is to be judged into profiles/):
-#   0. bench.py as the driver runs it (no profiler): TAG_bench.json
-#   1. bench.py --no-shard-leg under rocprofv3 --kernel-trace --stats: TAG_bench_profiled.json + TAG_kernel_stats.csv (the headline
-#      leg alone, so that a kernel's average in the CSV is the average of the launches the bench line's roofline describes;
-#      with the shard_4k leg the same kernels also run on the four times larger 4K batch: TAG_kernel_stats_all_legs.csv)
+#   0. bench.py with the driver's exact command, `python3 bench.py --gpus 1 --steps 20 --warmup 5` (no profiler): TAG_bench.json
+#   1. the same command with the legs that launch the same kernels on other batches switched off (--no-shard-leg
+#      --no-reference-workload --no-encoder-leg) under rocprofv3 --kernel-trace --stats: TAG_bench_profiled.json + TAG_kernel_stats.csv,
+#      so that a kernel's average in the CSV is the average of the launches the bench line's roofline describes; with every leg on:
+#      TAG_kernel_stats_all_legs.csv; the kernel trace of the headline leg (start / end of every launch): TAG_kernel_trace.csv
 #   2. bench.py headline leg under --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -> TAG_pmc_traffic.json
 #   3. the fused quantize_residual kernels under the SQ / TCC counter groups -> TAG_qr_pmc.txt
 #   4. the frame-level sampling / SATD kernels under the same groups -> TAG_frame_kernels_pmc.txt
@@ -17,14 +18,16 @@ COMMIT=${2:-unknown}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O/${TAG}_prof
-python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_prof/bench.log
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats -o p --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-shard-leg > $O/${TAG}_bench_profiled.json 2> $O/${TAG}_prof/stats.log
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_prof/bench.log
+ONLY="--no-shard-leg --no-reference-workload --no-encoder-leg"
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats -o p --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 $ONLY > $O/${TAG}_bench_profiled.json 2> $O/${TAG}_prof/stats.log
 cp $O/${TAG}_prof/stats/p_kernel_stats.csv $O/${TAG}_kernel_stats.csv
+python3 tools/trace_launches.py $O/${TAG}_prof/stats/p_kernel_trace.csv > $O/${TAG}_kernel_trace_summary.txt 2>&1 || true
 rm -rf $O/${TAG}_prof/stats
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats2 -o p --output-format csv -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_profiled_all_legs.json 2> $O/${TAG}_prof/stats2.log
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats2 -o p --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-encoder-leg > $O/${TAG}_bench_profiled_all_legs.json 2> $O/${TAG}_prof/stats2.log
 cp $O/${TAG}_prof/stats2/p_kernel_stats.csv $O/${TAG}_kernel_stats_all_legs.csv
 rm -rf $O/${TAG}_prof/stats2
-B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-shard-leg"
+B="python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $ONLY"
 rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_prof/fetch -o p --output-format csv -- $B > $O/${TAG}_prof/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_prof/write -o p --output-format csv -- $B > $O/${TAG}_prof/write.log 2>&1
 for p in fetch write; do python3 tools/pmc_filter.py $O/${TAG}_prof/$p sad_nxn_kernel,satd8_kernel,dct32_mfma_kernel; done
@@ -51,4 +54,10 @@ if [ "${3:-}" = "all" ]; then
   rm -rf $O/${TAG}_prof/fr /tmp/kvz_case0.bin
   python3 -m pytest tests/test_gpu_dropin.py -m gpu -q -s -k "served or deblocked_by_one" 2>&1 | grep -E "frames: |frames, untouched|passed|failed" > $O/${TAG}_gpu_served_encode.txt
 fi
+#   7. the search service: C pthread hosts hammering it, and the reference encoder with its own thread pool served by it /
+#      with its SADs answered from tables, each next to the untouched encoder at the same thread count
+(for t in 1 4 16 48; do tests/c_host/service_stress $t 1500; done) > $O/${TAG}_service_stress.txt 2>&1 || true
+python3 tools/served_encode.py --size 1920x1080 --frames 16 --threads 16 --min-size 8,16,32,64 --tables 8,16 --probe > $O/${TAG}_served_encode_1080p_medium.jsonl 2> $O/${TAG}_prof/served1.err || true
+python3 tools/served_encode.py --size 1920x1080 --frames 6 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 64 --tables 16 --probe > $O/${TAG}_served_encode_1080p_full16.jsonl 2> $O/${TAG}_prof/served2.err || true
+python3 tools/served_encode.py --size 3840x2160 --frames 8 --threads 16 --min-size 32,64 --tables 16 --probe > $O/${TAG}_served_encode_4k_medium.jsonl 2> $O/${TAG}_prof/served3.err || true
 echo "profile set $TAG done"
