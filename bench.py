@@ -548,6 +548,23 @@ def encoder_leg(frames=16, threads=16, timeout_s=280):
             rows.append(d)
     if not rows or summary is None:
         return {"error": "tools/served_encode.py failed (rc %d)" % r.returncode}
+    # the same host where the SAD path is the bulk of its work: --me full16 (exhaustive +-16 around the zero vector, the start vector
+    # and the merge candidates, search_inter.c:886-962), its kvz_image_calc_sad calls answered from kvz_hip_me_service_sad_tables
+    full = None
+    try:
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "served_encode.py"), "--size", "1920x1080", "--frames", "4", "--threads", str(threads),
+                             "--opts", "preset=medium,qp=32,me=full16", "--min-size", "", "--tables", "16"],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+        for line in r2.stdout.splitlines():
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if d.get("mode") == "sad_tables":
+                full = {k: d[k] for k in ("opts", "table_range", "fps_untouched", "fps_with_tables", "identical_bitstream", "hit_rate",
+                                          "sad_calls_answered_from_tables", "sad_calls_outside_the_range", "table_KB_per_ctu_and_picture", "table_MB")}
+    except subprocess.TimeoutExpired:
+        full = {"error": "timed out"}
     out = {
         "what": "reference encoder (oracle/_ref) 1920x1080 preset medium qp 32, %d synthetic frames, threads=%d, owf auto: frames/s untouched (avx2 "
                 "strategies) and with its 2Nx2N inter searches of at least `min_pu_served` pixels answered by kvz_hip_me_service_search from all "
@@ -557,6 +574,7 @@ def encoder_leg(frames=16, threads=16, timeout_s=280):
         "served": [{k: row[k] for k in ("min_pu_served", "fps_served", "searches_served", "searches_left_to_cpu", "launches", "mean_requests_per_batch",
                                         "mean_units_per_launch", "max_batch_units", "mean_wait_us", "upload_MB", "failed")} for row in rows],
         # what a served search has to beat: the reference's own kvz_search_cu_inter per CU size on this host (all reference pictures of the PU)
+        "full_search_with_sad_tables": full,
         "cpu_search_us_per_cu": probe["cpu_search_us"] if probe else None,
         "cpu_searches_per_cu_size": probe["cpu_searches"] if probe else None,
         "note": "a served search costs its caller mean_wait_us; the CPU does the same search in cpu_search_us_per_cu -- at preset medium (hexbs, early "
