@@ -45,6 +45,9 @@ W4K, H4K = 3840, 2160
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); copy-shaped kernels measure 6.3-6.75 TB/s on this pool
 BYTES = {"sad_8x8": 132, "satd_8x8": 132, "dct_32x32": 4096}   # SURVEY 8(d) algorithmic bytes per block
 NAMES = ("sad_8x8", "satd_8x8", "dct_32x32")
+# the order of the three launches inside a step (A/B knob for measurements of launch-to-launch effects; the work is the same)
+STEP_ORDER = tuple(os.environ.get("KVZ_BENCH_STEP_ORDER", "sad_8x8,satd_8x8,dct_32x32").split(","))
+assert sorted(STEP_ORDER) == sorted(NAMES)
 SEED = 12345
 
 
@@ -242,22 +245,25 @@ def kernel_stats(ms_lists, blocks):
 
 def three_kernel_step(env, cur, ref, res, sad, satd, coef, n8, n32):
     L, st = env.L, env.stream
+    launches = {
+        "sad_8x8": lambda: env.check(L.kvz_hip_sad_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, sad.data_ptr(), st), "sad_8x8"),
+        "satd_8x8": lambda: env.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd.data_ptr(), st), "satd_8x8"),
+        "dct_32x32": lambda: env.check(L.kvz_hip_transform_batch(0, 32, res.data_ptr(), coef.data_ptr(), n32, st), "dct_32x32"),
+    }
+    order = [launches[n] for n in STEP_ORDER]
 
     def step(ev):
         if ev: L.kvz_hip_event_record(ev[0], st)
-        env.check(L.kvz_hip_sad_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, sad.data_ptr(), st), "sad_8x8")
-        if ev: L.kvz_hip_event_record(ev[1], st)
-        env.check(L.kvz_hip_satd_nxn_batch(8, cur.data_ptr(), ref.data_ptr(), n8, satd.data_ptr(), st), "satd_8x8")
-        if ev: L.kvz_hip_event_record(ev[2], st)
-        env.check(L.kvz_hip_transform_batch(0, 32, res.data_ptr(), coef.data_ptr(), n32, st), "dct_32x32")
-        if ev: L.kvz_hip_event_record(ev[3], st)
+        for i, launch in enumerate(order):
+            launch()
+            if ev: L.kvz_hip_event_record(ev[i + 1], st)
     return step
 
 
 def collect_event_ms(env, evs):
     ms = {n: [] for n in NAMES}
     for ev in evs:
-        for i, name in enumerate(NAMES):
+        for i, name in enumerate(STEP_ORDER):
             ms[name].append(env.elapsed(ev[i], ev[i + 1]))
     return ms
 
