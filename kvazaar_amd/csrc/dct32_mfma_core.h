@@ -1,5 +1,5 @@
 // dct32_mfma_core.h -- building blocks of the 32x32 integer DCT on the CDNA4 matrix
-// cores, shared by dct32_mfma.hip (standalone transforms) and quant32_mfma.hip (fused
+// cores, shared by dct32_mfma.hip (standalone transforms) and quant_tile_mfma.hip (fused
 // quantize_residual).  See dct32_mfma.hip for the method.
 #pragma once
 

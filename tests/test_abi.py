@@ -147,3 +147,28 @@ def test_python_record_layouts_match_the_header(tmp_path):
                 continue
             assert int(got["%s.%s" % (cname, field)]) == dt.fields[field][1], "%s.%s" % (cname, field)
     assert (int(got["kvz_hip_intra_ref"]), int(got["kvz_hip_intra_pos"]), int(got["kvz_hip_block_pair"]), int(got["kvz_hip_bipred_cand"])) == (130, 8, 24, 24)
+
+
+def _init_with_env_device(value):
+    """kvz_hip_init(-1) in a child process whose $KVZ_HIP_DEVICE is `value` -> (exit code, rc, error text)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from kvazaar_amd import _lib; L = _lib.load(); rc = L.kvz_hip_init(-1); "
+            "print(rc, (L.kvz_hip_last_error() or b'').decode())" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KVZ_HIP_DEVICE=value), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    out = r.stdout.strip().split(" ", 1)
+    return r.returncode, int(out[0]) if out and out[0].lstrip("-").isdigit() else None, out[1] if len(out) > 1 else ""
+
+
+def test_negative_env_device_is_refused_not_indexed():
+    """$KVZ_HIP_DEVICE=-1 used to reach the context table with index -1: now an error code, never a crash.  Without a
+    GPU the device count fails first (KVZ_HIP_ERR_NO_DEVICE); the GPU variant below sees KVZ_HIP_ERR_INVALID."""
+    code, rc, _ = _init_with_env_device("-1")
+    assert code == 0 and rc in (-1, -2)
+
+
+@pytest.mark.gpu
+def test_negative_env_device_is_refused_on_a_gpu_box():
+    code, rc, text = _init_with_env_device("-1")
+    assert code == 0 and rc == -2 and "out of range" in text
