@@ -68,7 +68,9 @@ static struct {
   int table_range;                      /* > 0: SAD-table mode (the search stays with the reference, kvz_image_calc_sad is answered from tables) */
   const uint32_t *(*sad_tables)(kvz_hip_me_service *, int, int, const int32_t *, int, int, int);
   long long tab_hits, tab_range_misses, tab_other, tab_ns;
-  long long probe_ns[4], probe_n[4];    /* probe mode: the reference's own search timed per CU size 64, 32, 16, 8 */
+  long long probe_ns[4], probe_n[4];
+  long long spec_n[4], spec_hit[4];     /* speculation probe */
+  int spec_probe;    /* probe mode: the reference's own search timed per CU size 64, 32, 16, 8 */
   pthread_mutex_t table_mu;
   svc_slot_t slots[SVC_SLOTS];
   uint64_t clock;
@@ -92,6 +94,11 @@ static long long svc_now_ns(void)
 int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int min_size, int flags)
 {
   memset(&g_svc, 0, sizeof(g_svc));
+  if (flags & 16) {           /* host only: the timing and speculation probes, no device library, nothing served */
+    g_svc.w = w; g_svc.h = h; g_svc.min_size = min_size; g_svc.probe = 1; g_svc.spec_probe = (flags >> 3) & 1;
+    __atomic_store_n(&g_svc.on, 1, __ATOMIC_RELEASE);
+    return 0;
+  }
   void *l = dlopen(lib_path, RTLD_NOW | RTLD_GLOBAL);
   if (!l) { fprintf(stderr, "dlopen %s: %s\n", lib_path, dlerror()); return -1; }
   g_svc.lib = l;
@@ -113,6 +120,7 @@ int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int m
   if (!g_svc.svc) { fprintf(stderr, "kvz_hip_me_service_create: %s\n", g_svc.last_error()); return -1; }
   g_svc.w = w; g_svc.h = h; g_svc.min_size = min_size; g_svc.shadow = flags & 1; g_svc.probe = (flags >> 1) & 1;
   g_svc.table_range = (flags >> 8) & 0xff;
+  g_svc.spec_probe = (flags >> 3) & 1;
   pthread_mutex_init(&g_svc.table_mu, NULL);
   for (int i = 0; i < SVC_SLOTS; ++i) pthread_mutex_init(&g_svc.slots[i].mu, NULL);
   __atomic_store_n(&g_svc.on, 1, __ATOMIC_RELEASE);
@@ -122,13 +130,15 @@ int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int m
 /* out[24..30]: SAD-table mode: lookups answered, lookups outside the range, other calls, ns in the wrapper's misses (unused),
  * tables fetched, their bytes, ns spent fetching them.  out[16..19] / out[20..23]: probe mode's summed nanoseconds / number of searches for CU sizes 64, 32, 16, 8.
  * out[0..15]: served, passed on, failed, shadow mismatches, upload rects, search wait ns, upload ns, candidate ns,
- * then the service's own statistics: requests, units, batches, launches, max_batch_units, rects, rect_bytes, wait_ns */
+ * then the service's own statistics: requests, units, batches, launches, max_batch_units, rects, rect_bytes, wait_ns
+ * (with the speculation probe and no service: out[8..11] searches compared, out[12..15] searches whose CTU-start candidates were the real ones). */
 void ref_service_end(long long *out)
 {
   __atomic_store_n(&g_svc.on, 0, __ATOMIC_RELEASE);
   if (out) {
     memset(out, 0, 32 * sizeof(out[0]));
     for (int i = 0; i < 4; ++i) { out[16 + i] = g_svc.probe_ns[i]; out[20 + i] = g_svc.probe_n[i]; }
+    if (g_svc.spec_probe) for (int i = 0; i < 4; ++i) { out[8 + i] = g_svc.spec_n[i]; out[12 + i] = g_svc.spec_hit[i]; }   /* probe-only runs: in place of the service's statistics */
     out[24] = g_svc.tab_hits; out[25] = g_svc.tab_range_misses; out[26] = g_svc.tab_other; out[27] = g_svc.tab_ns;
     if (g_svc.svc) {
       kvz_hip_me_service_stats st2;
@@ -232,6 +242,84 @@ static int svc_can_serve(const encoder_state_t *state, int width)
   return 1;
 }
 
+/* What search_pu_inter (:1492-1500) and search_pu_inter_ref (:1143-1206) derive for a 2Nx2N PU before the searches, for every reference
+ * picture, with the encoder's own functions on the given lcu: the merge list as calc_mvd_cost sees it, the AMVP pair and the start
+ * vector of each picture.  Returns non-zero when a picture is in neither list. */
+static int svc_derive_pus(encoder_state_t *state, int x, int y, int width, lcu_t *lcu, kvz_hip_me_pu *pus, int8_t *ref_list_of, int8_t *lx_idx_of)
+{
+  const encoder_state_config_frame_t *fr = state->frame;
+  const int nref = (int)fr->ref->used_size;
+  cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
+  inter_merge_cand_t merge[MRG_MAX_NUM_CANDS];
+  const int n_merge = kvz_inter_get_merge_cand(state, x, y, width, width, true, true, merge, lcu);
+  CU_SET_MV_CAND(cur_cu, 0, 0);
+  CU_SET_MV_CAND(cur_cu, 1, 0);
+  const int8_t lx_max = MAX(fr->ref_LX_size[0], fr->ref_LX_size[1]);
+  for (int ref_idx = 0; ref_idx < nref; ++ref_idx) {
+    int8_t ref_list = -1, LX_idx;
+    for (LX_idx = 0; LX_idx < lx_max; LX_idx++) {
+      if (LX_idx < fr->ref_LX_size[0] && fr->ref_LX[0][LX_idx] == ref_idx) { ref_list = 0; break; }
+      if (LX_idx < fr->ref_LX_size[1] && fr->ref_LX[1][LX_idx] == ref_idx) { ref_list = 1; break; }
+    }
+    if (ref_list < 0) return 1;
+    ref_list_of[ref_idx] = ref_list; lx_idx_of[ref_idx] = LX_idx;
+    kvz_hip_me_pu *pu = &pus[ref_idx];
+    memset(pu, 0, sizeof(*pu));
+    pu->x = x; pu->y = y; pu->width = width; pu->height = width;
+    pu->num_merge_cand = (int16_t)n_merge;
+    for (int i = 0; i < n_merge; ++i) {
+      const int dir = merge[i].dir;
+      pu->merge[i].usable = dir != 3;
+      if (dir != 3) {
+        pu->merge[i].mv[0] = merge[i].mv[dir - 1][0]; pu->merge[i].mv[1] = merge[i].mv[dir - 1][1];
+        pu->merge[i].same_ref = fr->ref_LX[dir - 1][merge[i].ref[dir - 1]] == ref_idx;
+      }
+    }
+    /* :1170-1187: the AMVP pair of this picture; cur_cu->inter.mv_ref is borrowed for the call and put back */
+    const int8_t temp = cur_cu->inter.mv_ref[ref_list];
+    cur_cu->inter.mv_ref[ref_list] = LX_idx;
+    kvz_inter_get_mv_cand(state, x, y, width, width, pu->mv_cand, cur_cu, lcu, ref_list);
+    cur_cu->inter.mv_ref[ref_list] = temp;
+    /* :1190-1206 */
+    const cu_info_t *ref_cu = kvz_cu_array_at_const(fr->ref->cu_arrays[ref_idx], state->tile->offset_x + x + (width >> 1),
+                                                    state->tile->offset_y + y + (width >> 1));
+    if (ref_cu->type == CU_INTER) {
+      const int l = (ref_cu->inter.mv_dir & 1) ? 0 : 1;
+      pu->extra_mv[0] = ref_cu->inter.mv[l][0]; pu->extra_mv[1] = ref_cu->inter.mv[l][1];
+    }
+  }
+  return 0;
+}
+
+/* Speculation probe (flags bit 3; nothing is served or changed): how often would the candidates of a search have been known when its CTU
+ * STARTED?  At the first search of a CTU the worker keeps a copy of the lcu (inside the CTU nothing is decided yet); at every search the
+ * candidates are derived twice -- on the real lcu and on that copy -- and compared.  Equal = a search issued at CTU start would have been
+ * the right one.  Counted per CU size. */
+static __thread lcu_t t_spec_lcu;
+static __thread struct { int32_t poc, lx, ly; int valid; } t_spec_ctu;
+static void svc_spec_probe(encoder_state_t *state, int x, int y, int depth, lcu_t *lcu)
+{
+  const encoder_state_config_frame_t *fr = state->frame;
+  const int nref = (int)fr->ref->used_size;
+  if (fr->slicetype == KVZ_SLICE_I || nref < 1 || nref > KVZ_HIP_SERVICE_MAX_REFS) return;
+  const int width = LCU_WIDTH >> depth, lx = x / LCU_WIDTH, ly = y / LCU_WIDTH;
+  if (!t_spec_ctu.valid || t_spec_ctu.poc != fr->poc || t_spec_ctu.lx != lx || t_spec_ctu.ly != ly) {
+    if (depth != 0) { t_spec_ctu.valid = 0; return; }     /* a CTU whose first search is not the 64x64 one (picture edge): not speculated */
+    memcpy(&t_spec_lcu, lcu, sizeof(lcu_t));
+    t_spec_ctu.poc = fr->poc; t_spec_ctu.lx = lx; t_spec_ctu.ly = ly; t_spec_ctu.valid = 1;
+  }
+  kvz_hip_me_pu real[KVZ_HIP_SERVICE_MAX_REFS], spec[KVZ_HIP_SERVICE_MAX_REFS];
+  int8_t a[KVZ_HIP_SERVICE_MAX_REFS], b[KVZ_HIP_SERVICE_MAX_REFS];
+  cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
+  const cu_info_t saved = *cur_cu;
+  const int bad = svc_derive_pus(state, x, y, width, lcu, real, a, b);
+  *cur_cu = saved;
+  if (bad || svc_derive_pus(state, x, y, width, &t_spec_lcu, spec, a, b)) return;
+  const int same = !memcmp(real, spec, sizeof(real[0]) * (size_t)nref);
+  __atomic_add_fetch(&g_svc.spec_n[depth & 3], 1, __ATOMIC_RELAXED);
+  if (same) __atomic_add_fetch(&g_svc.spec_hit[depth & 3], 1, __ATOMIC_RELAXED);
+}
+
 /* Is the picture with this POC possibly still being reconstructed?  The frames in flight are the ones the other encoder
  * states hold (kvazaar.c:115-125: a ring of owf + 1 states, each linked to the state of the frame coded before it). */
 static int svc_in_flight(const encoder_state_t *state, int32_t poc)
@@ -304,6 +392,7 @@ int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *l
   const int width = LCU_WIDTH >> depth;
   if (g_svc.probe) {
     const long long p0 = svc_now_ns();
+    if (g_svc.spec_probe) svc_spec_probe(state, x, y, depth, lcu);
     __real_kvz_search_cu_inter(state, x, y, depth, lcu, inter_cost, inter_bitcost);
     __atomic_add_fetch(&g_svc.probe_ns[depth & 3], svc_now_ns() - p0, __ATOMIC_RELAXED);
     __atomic_add_fetch(&g_svc.probe_n[depth & 3], 1, __ATOMIC_RELAXED);
@@ -367,44 +456,8 @@ int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *l
   /* ---- the request: search_pu_inter :1492-1500, then per picture search_pu_inter_ref :1143-1206 ---- */
   cu_info_t *cur_cu = LCU_GET_CU_AT_PX(lcu, SUB_SCU(x), SUB_SCU(y));
   const cu_info_t saved = *cur_cu;
-  inter_merge_cand_t merge[MRG_MAX_NUM_CANDS];
-  const int n_merge = kvz_inter_get_merge_cand(state, x, y, width, width, true, true, merge, lcu);
-  CU_SET_MV_CAND(cur_cu, 0, 0);
-  CU_SET_MV_CAND(cur_cu, 1, 0);
-  const int8_t lx_max = MAX(fr->ref_LX_size[0], fr->ref_LX_size[1]);
   int8_t ref_list_of[KVZ_HIP_SERVICE_MAX_REFS], lx_idx_of[KVZ_HIP_SERVICE_MAX_REFS];
-  for (int ref_idx = 0; ref_idx < nref && !bad; ++ref_idx) {
-    int8_t ref_list = -1, LX_idx;
-    for (LX_idx = 0; LX_idx < lx_max; LX_idx++) {
-      if (LX_idx < fr->ref_LX_size[0] && fr->ref_LX[0][LX_idx] == ref_idx) { ref_list = 0; break; }
-      if (LX_idx < fr->ref_LX_size[1] && fr->ref_LX[1][LX_idx] == ref_idx) { ref_list = 1; break; }
-    }
-    if (ref_list < 0) { bad = 1; break; }
-    ref_list_of[ref_idx] = ref_list; lx_idx_of[ref_idx] = LX_idx;
-    kvz_hip_me_pu *pu = &req.pu[ref_idx];
-    pu->x = x; pu->y = y; pu->width = width; pu->height = width;
-    pu->num_merge_cand = (int16_t)n_merge;
-    for (int i = 0; i < n_merge; ++i) {
-      const int dir = merge[i].dir;
-      pu->merge[i].usable = dir != 3;
-      if (dir != 3) {
-        pu->merge[i].mv[0] = merge[i].mv[dir - 1][0]; pu->merge[i].mv[1] = merge[i].mv[dir - 1][1];
-        pu->merge[i].same_ref = fr->ref_LX[dir - 1][merge[i].ref[dir - 1]] == ref_idx;
-      }
-    }
-    /* :1170-1187: the AMVP pair of this picture; cur_cu->inter.mv_ref is borrowed for the call and put back */
-    const int8_t temp = cur_cu->inter.mv_ref[ref_list];
-    cur_cu->inter.mv_ref[ref_list] = LX_idx;
-    kvz_inter_get_mv_cand(state, x, y, width, width, pu->mv_cand, cur_cu, lcu, ref_list);
-    cur_cu->inter.mv_ref[ref_list] = temp;
-    /* :1190-1206 */
-    const cu_info_t *ref_cu = kvz_cu_array_at_const(fr->ref->cu_arrays[ref_idx], state->tile->offset_x + x + (width >> 1),
-                                                    state->tile->offset_y + y + (width >> 1));
-    if (ref_cu->type == CU_INTER) {
-      const int l = (ref_cu->inter.mv_dir & 1) ? 0 : 1;
-      pu->extra_mv[0] = ref_cu->inter.mv[l][0]; pu->extra_mv[1] = ref_cu->inter.mv[l][1];
-    }
-  }
+  bad |= svc_derive_pus(state, x, y, width, lcu, req.pu, ref_list_of, lx_idx_of);
   kvz_hip_me_params *p = &req.params;
   p->lambda_cost = (int32_t)(state->lambda_sqrt + 0.5);
   p->early_termination = ctrl->cfg.me_early_termination;
