@@ -94,7 +94,9 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * descriptor SATD kernel), "qr8_tile_kernel" (0: 8x8 TUs of the fused quantize_residual on the register kernel instead of sixteen to a
  * matrix-core tile), "qr_tile_pipe" (0: the tile kernels' wait on vector memory left to the compiler instead of placed before the
  * iteration's first store), "pipe" / "dct_pipe" (1: the same hand placement in the 4x4 / 8x8 register kernels / the 32x32
- * transform, where it measured slower).
+ * transform, where it measured slower), "full_qsad" (0: the search service's exhaustive search prices positions with v_sad_u8 on
+ * byte-aligned operands instead of four alignments per v_qsad_pk_u16_u8), "sample8_wave" (0: 8x8 luma blocks of the sampling entry
+ * on the general path).
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
  * knobs at kvz_hip_init() for A/B runs of an unmodified host. */
 KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);

@@ -279,6 +279,172 @@ __constant__ signed char c_et_hex[7][2] = { { 0, -1 }, { -1, 0 }, { 0, 1 }, { 1,
 constexpr int ME_GROUP = 64;                          // candidates evaluated per round (the patterns use at most 8)
 struct me_shared { u32 sad[ME_GROUP]; int cx[ME_GROUP], cy[ME_GROUP]; };
 
+constexpr int FULL_OUT = 32;                          // me_shared slot where full_search_wg leaves (x, y, cost, bits)
+constexpr int FULL_MAX_WINDOWS = 7;                   // zero vector, extra_mv, five merge candidates
+
+// search_mv_full (search_inter.c:886-962) for the search service: ALL threads of the workgroup on the positions of one PU
+// and one reference picture, whatever the PU's size -- the latency form of the exhaustive search (the one-wave-per-PU form
+// in search_pu_core is the throughput form: 64 positions per round).
+//   * the (w + 2R) x (h + 2R) reference pixels of as many windows as fit are staged in LDS at once (edge replicated,
+//     image.c:320-444), the current block beside them;
+//   * a work item is FOUR neighbouring positions of one window row: v_qsad_pk_u16_u8 prices the four alignments of a
+//     reference dword pair against one dword of the block in one instruction (16-bit packed sums, emptied into 32-bit
+//     ones before 64 of them can overflow: 64 x 4 x 255 < 2^16); QSAD = false keeps v_alignbyte + v_sad_u8;
+//   * the reference walks the windows in order and replaces its best on a strictly smaller cost, so the winner is the
+//     smallest (cost, visiting order) pair: every thread keeps its own 64-bit minimum and one reduction ends the search.
+// A position inside an earlier window is skipped as :936-952 does; one that fails fracmv_within_tile costs 2^32 - 1 and
+// never wins.  Result (all threads must call; ends with the values in sh, NOT yet visible: the caller synchronises).
+template <bool CONSTR, bool QSAD, int T>
+__device__ __forceinline__ void full_search_wg(int tid, u8 *lds, int lds_bytes, me_shared *sh, const u8 *__restrict__ pic, u32 pic_stride,
+                                               const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm)
+{
+  const me_cost_model_t<false, CONSTR> mvc(pu, prm);
+  const int w = pu.width, h = pu.height, R = prm.search_range, side = 2 * R + 1, groups = (side + 3) >> 2;
+  const int wq = w >> 2;                               // every PU width is a multiple of 4
+  // ---- the windows, in the reference's order: sh->cx / cy = centre, sh->sad = index of the merge candidate (or -1) ----
+  int n_win = 1;
+  auto add_window = [&](int cx, int cy, int merge_index) {
+    if (tid == 0) { sh->cx[n_win] = cx; sh->cy[n_win] = cy; sh->sad[n_win] = (u32)merge_index; }
+    ++n_win;
+  };
+  if (tid == 0) { sh->cx[0] = 0; sh->cy[0] = 0; sh->sad[0] = ~0u; }
+  {
+    const int ex = pu.extra_mv[0] >> 2, ey = pu.extra_mv[1] >> 2;
+    // (an extra window on the zero vector repeats window 0 and can improve nothing: costs must be strictly smaller)
+    if (!mvc.in_merge(ex, ey) && (ex != 0 || ey != 0)) add_window(ex, ey, -1);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (!(mvc.usable >> i & 1u)) continue;
+      const int cx0 = mvc.mx[i] >> 2, cy0 = mvc.my[i] >> 2;        // plain shift here (:917-920)
+      if (cx0 == 0 && cy0 == 0) continue;
+      add_window(cx0, cy0, i);
+    }
+  }
+  // ---- the current block, stride w ----
+  u8 *const s_cur = lds;
+  for (int i = tid; i < wq * h; i += T) {
+    const int y = i / wq, x = (i - y * wq) * 4;
+    u32 v;
+    __builtin_memcpy(&v, pic + (size_t)(pu.y + y) * pic_stride + pu.x + x, 4);
+    *(u32 *)(s_cur + y * w + x) = v;
+  }
+  const int cur_bytes = (w * h + 15) & ~15;
+  u8 *const s_win = lds + cur_bytes;
+  const int wstride = (w + 2 * R + 8 + 3) & ~3, wrows = h + 2 * R, win_bytes = wstride * wrows, wsq = wstride >> 2;
+  int per_chunk = (lds_bytes - cur_bytes) / win_bytes;  // >= 1 for every legal PU and range (64x64, R = 64: 39 168 bytes)
+  if (per_chunk > FULL_MAX_WINDOWS) per_chunk = FULL_MAX_WINDOWS;
+  const int flush_rows = wq >= 64 ? 1 : 64 / wq;        // rows of 16-bit sums that cannot overflow
+  const int items_per_win = side * groups;
+  unsigned long long best = ~0ull;
+  __syncthreads();                                      // the window list
+  for (int k0 = 0; k0 < n_win; k0 += per_chunk) {
+    const int nk = n_win - k0 < per_chunk ? n_win - k0 : per_chunk;
+    if (k0) __syncthreads();                            // the previous chunk has been read
+    for (int k = 0; k < nk; ++k) {
+      const int x0 = pu.x + sh->cx[k0 + k] - R, y0 = pu.y + sh->cy[k0 + k] - R;
+      u8 *const dst = s_win + k * win_bytes;
+      for (int i = tid; i < wsq * wrows; i += T) {
+        const int y = i / wsq, q = (i - y * wsq) * 4;
+        u32 v;
+        if (x0 + q >= 0 && x0 + q + 4 <= ref.w && y0 + y >= 0 && y0 + y < ref.h) {
+          __builtin_memcpy(&v, ref.p + (size_t)(y0 + y) * ref.stride + x0 + q, 4);
+        } else {
+          v = (u32)ref_px(ref, x0 + q, y0 + y) | ((u32)ref_px(ref, x0 + q + 1, y0 + y) << 8) |
+              ((u32)ref_px(ref, x0 + q + 2, y0 + y) << 16) | ((u32)ref_px(ref, x0 + q + 3, y0 + y) << 24);
+        }
+        *(u32 *)(dst + y * wstride + q) = v;
+      }
+    }
+    __syncthreads();
+    for (int it = tid; it < nk * items_per_win; it += T) {
+      const int k = it / items_per_win, rem = it - k * items_per_win, r = rem / groups, g = rem - r * groups;
+      const u32 *q = (const u32 *)(s_win + k * win_bytes + r * wstride) + g;
+      const u32 *c = (const u32 *)s_cur;
+      u32 tot[4] = { 0, 0, 0, 0 };
+      for (int yb = 0; yb < h; yb += flush_rows) {
+        const int ye = yb + flush_rows < h ? yb + flush_rows : h;
+        if (QSAD) {
+          unsigned long long acc = 0;
+          for (int y = yb; y < ye; ++y) {
+            u32 lo = q[0];
+            for (int xq = 0; xq < wq; ++xq) {
+              const u32 hi = q[xq + 1];
+              acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, c[xq], acc);
+              lo = hi;
+            }
+            q += wsq; c += wq;
+          }
+          tot[0] += (u32)acc & 0xffffu; tot[1] += (u32)(acc >> 16) & 0xffffu;
+          tot[2] += (u32)(acc >> 32) & 0xffffu; tot[3] += (u32)(acc >> 48);
+        } else {
+          for (int y = yb; y < ye; ++y) {
+            u32 lo = q[0];
+            for (int xq = 0; xq < wq; ++xq) {
+              const u32 hi = q[xq + 1], cv = c[xq];
+              tot[0] = __builtin_amdgcn_sad_u8(cv, lo, tot[0]);
+              tot[1] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(hi, lo, 1u), tot[1]);
+              tot[2] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(hi, lo, 2u), tot[2]);
+              tot[3] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(hi, lo, 3u), tot[3]);
+              lo = hi;
+            }
+            q += wsq; c += wq;
+          }
+        }
+      }
+      const int kk = k0 + k, cx = sh->cx[kk], cy = sh->cy[kk], mine = (int)sh->sad[kk];
+      const int y = cy + r - R;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int col = 4 * g + p, x = cx + col - R;
+        if (col >= side) continue;
+        bool skip = false;
+        if (mine >= 0) {                                   // a merge candidate's window: :936-952
+          if (!mvc.within(x * 4, y * 4)) skip = true;
+          if (x >= -R && x <= R && y >= -R && y <= R) skip = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j >= mine || !(mvc.usable >> j & 1u)) continue;
+            const int xx = mvc.mx[j] >> 2, yy = mvc.my[j] >> 2;
+            if (x >= xx - R && x <= xx + R && y >= yy - R && y <= yy + R) skip = true;
+          }
+        }
+        if (skip || !mvc.within(x * 4, y * 4)) continue;
+        u32 bits;
+        const u32 cost = tot[p] + mvc.cost(x, y, 2, bits);                  // < 2^32: lambda_cost is bounded by the entry
+        const unsigned long long key = ((unsigned long long)cost << 32) | (u32)(kk * side * side + r * side + col);
+        best = key < best ? key : best;
+      }
+    }
+  }
+  // ---- the smallest (cost, order) of the workgroup ----
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const u32 lo = (u32)__shfl_xor((int)(u32)best, off, 64), hi = (u32)__shfl_xor((int)(u32)(best >> 32), off, 64);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    best = o < best ? o : best;
+  }
+  __syncthreads();                                      // every reader of the window list is done; sh->sad is reused
+  if ((tid & 63) == 0) { sh->sad[48 + 2 * (tid >> 6)] = (u32)best; sh->sad[49 + 2 * (tid >> 6)] = (u32)(best >> 32); }
+  __syncthreads();
+  best = ~0ull;
+#pragma unroll
+  for (int v = 0; v < T / 64; ++v) {
+    const unsigned long long o = ((unsigned long long)sh->sad[49 + 2 * v] << 32) | sh->sad[48 + 2 * v];
+    best = o < best ? o : best;
+  }
+  if (tid == 0) {
+    int bx = 0, by = 0;
+    u32 bcost = 0xffffffffu, bbits = 0;
+    if ((u32)(best >> 32) != 0xffffffffu) {
+      const int seq = (int)(u32)best, kk = seq / (side * side), rem = seq - kk * side * side, r = rem / side, col = rem - r * side;
+      bx = sh->cx[kk] + col - R; by = sh->cy[kk] + r - R;
+      bcost = (u32)(best >> 32);
+      mvc.cost(bx, by, 2, bbits);
+    }
+    sh->cx[FULL_OUT] = bx; sh->cy[FULL_OUT] = by; sh->sad[FULL_OUT] = bcost; sh->sad[FULL_OUT + 1] = bbits;
+  }
+}
+
 // One PU.  T threads (a wave with wave-private LDS, or the whole workgroup) share the work; every thread
 // carries the same search state, so all decisions are uniform across them.
 // BOTH (the search service, serve.hip): the fractional stage always runs and `out` is a serve_result that also receives the
@@ -433,7 +599,12 @@ __device__ __forceinline__ void search_pu_core(int tid, u8 *lds, me_shared *sh, 
   auto set_cand = [&](int k, int x, int y) { if (tid == 0) { sh->cx[k] = x; sh->cy[k] = y; } };
 
   bool done = false;
-  if (prm.algorithm == 3) {
+  if (BOTH && prm.algorithm == 3) {
+    // the search service: the whole workgroup has already walked the windows (full_search_wg, below); its outcome waits in sh
+    best_x = sh->cx[FULL_OUT]; best_y = sh->cy[FULL_OUT];
+    best_cost = sh->sad[FULL_OUT]; best_bits = sh->sad[FULL_OUT + 1];
+    done = true;
+  } else if (prm.algorithm == 3) {
     // ---- search_mv_full (:886-962): the windows around the zero vector, extra_mv and the merge candidates, in the
     // reference's visiting order, ME_GROUP positions per round ----
     const int R = prm.search_range;
@@ -858,7 +1029,7 @@ __device__ __forceinline__ bool serve_unit_ok(const serve_unit &u, int pic_w, in
 // per size class).  A workgroup of 512 threads takes one unit; the waves its size class does not need leave at once --
 // s_barrier counts only the waves of a workgroup that have not terminated -- so a PU up to 16x16 is searched by one wave
 // with wave-local fences, one up to 32x32 by 128 threads, a larger one by all 512: the thread counts of the batched kernels above.
-template <bool CONSTR>
+template <bool CONSTR, bool QSAD>
 __global__ __launch_bounds__(512) void serve_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
                                                     const serve_unit *__restrict__ units, int count)
 {
@@ -870,9 +1041,13 @@ __global__ __launch_bounds__(512) void serve_kernel(const u8 *__restrict__ plane
   if (!serve_unit_ok(u, pic_w, pic_h, n_slots)) { if (threadIdx.x == 0) serve_flag_bad(so); return; }
   const int cls = pu_class(u.pu);
   const int tid = threadIdx.x;
-  if (tid >= (cls == 1 ? 64 : (cls == 2 ? 128 : 512))) return;
   const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
   const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
+  if (u.prm.algorithm == 3) {                            // the exhaustive search: every wave on the positions, then the class's waves go on
+    full_search_wg<CONSTR, QSAD, 512>(tid, lds, (int)sizeof(lds), &sh, pic, stride, ref, u.pu, u.prm);
+    __syncthreads();
+  }
+  if (tid >= (cls == 1 ? 64 : (cls == 2 ? 128 : 512))) return;
   kvz_hip_me_result *out = reinterpret_cast<kvz_hip_me_result *>(so);
   if (cls == 1) {
     if (u.pu.width == 8 && u.pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, CONSTR, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
@@ -893,8 +1068,11 @@ int kvzhip::serve_launch(bool constrained, const u8 *planes, size_t plane_bytes,
                          const serve_unit *units, int count, hipStream_t st)
 {
   if (count <= 0) return KVZ_HIP_OK;
-  if (constrained) hipLaunchKernelGGL(serve_kernel<true>, dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
-  else hipLaunchKernelGGL(serve_kernel<false>, dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  const bool qsad = kvzhip::tuning("full_qsad", 1) != 0;
+  if (constrained && qsad) hipLaunchKernelGGL((serve_kernel<true, true>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  else if (constrained) hipLaunchKernelGGL((serve_kernel<true, false>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  else if (qsad) hipLaunchKernelGGL((serve_kernel<false, true>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
+  else hipLaunchKernelGGL((serve_kernel<false, false>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, units, count);
   KVZ_CHECK_LAUNCH("search service kernel");
   return KVZ_HIP_OK;
 }

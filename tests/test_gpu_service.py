@@ -51,13 +51,22 @@ SERVICE_CASES = [
     dict(wpp_owf=1, ref_delay_px=10, lambda_cost=25),           # the availability rule of --owf with WPP
     dict(mv_constraint=4, tile=(64, 0, 128, 128)),
     dict(algorithm=3, search_range=8, fme_level=1),
+    # the exhaustive search on the whole workgroup (full_search_wg): overlapping windows, several staging chunks, the tile and
+    # availability rules inside the windows, the largest range (one window of a 64x64 PU fills the staging area)
+    dict(algorithm=3, search_range=16, fme_level=4, lambda_cost=30),
+    dict(algorithm=3, search_range=33, fme_level=0, wpp_owf=1, ref_delay_px=10, lambda_cost=14),
+    dict(algorithm=3, search_range=20, fme_level=2, mv_constraint=4, tile=(64, 0, 128, 128)),
+    dict(algorithm=3, search_range=64, fme_level=1, lambda_cost=51),
+    dict(algorithm=3, search_range=16, fme_level=3, lambda_cost=22, tune=(b"full_qsad", 0)),
 ]
 
 
 @pytest.mark.parametrize("case", range(len(SERVICE_CASES)))
 def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case):
     w, h, n_refs = 192, 128, 4
-    prm = me_params(**SERVICE_CASES[case])
+    spec = dict(SERVICE_CASES[case])
+    tune = spec.pop("tune", None)
+    prm = me_params(**spec)
     planes = [me_frames(w, h, 300 + 7 * case + k, motion) for k, motion in enumerate(((3, -2), (-5, 4), (0, 0), (9, 7)))]
     pic = planes[0][0]
     refs = [p[1] for p in planes]
@@ -76,8 +85,11 @@ def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case)
     low = int(np.median(want[:, 0, 2].astype(np.uint32)))
     want_low = _sequential_loop(pic, refs, pus_per_ref, prm, start=low)
 
+    from kvazaar_amd import _lib
     svc = api.MeService(w, h, max_pictures=6, max_threads=32)
     try:
+        if tune:
+            _lib.check(_lib.load().kvz_hip_set_tuning(tune[0], tune[1]), "tuning")
         svc.put_plane(0, pic)
         for r in range(n_refs):                                 # rectangles: the way a picture under reconstruction arrives
             svc.put_rect(1 + r, refs[r], 0, 0, w, 64)
@@ -105,6 +117,8 @@ def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case)
         print("case %d: %d requests (%d units) in %d batches / %d launches, largest batch %d units, mean wait %.1f us"
               % (case, st["requests"], st["units"], st["batches"], st["launches"], st["max_batch_units"], st["wait_ns"] / 1e3 / st["requests"]))
     finally:
+        if tune:
+            _lib.load().kvz_hip_set_tuning(tune[0], -1)
         svc.close()
 
 
