@@ -57,6 +57,36 @@ struct serve_result {                     // 80 bytes
   uint32_t done;                          // written last
   uint32_t pad[2];
 };
+// Resident workers (the service's other way to the device; serve.hip explains the protocol): units travel through a ring of slots in
+// page-locked host memory, workgroups that stay on the device take them by ticket.
+constexpr int SERVE_MAX_WORKERS = 256;
+struct serve_slot {                       // 192 bytes
+  serve_unit u;
+  uint32_t seq;                           // ticket + 1 once the unit is written (host), 0 once a worker has copied it (device)
+  uint32_t pad[3];
+};
+struct serve_ring_ctl {                   // page-locked host memory
+  unsigned long long tail;                // units published so far (host writes, workers read across PCIe)
+  uint32_t quit;                          // host: every worker leaves when it next finds no work
+  uint32_t failed;                        // a worker gave up waiting for a slot to be written
+  uint32_t pad[12];
+  uint32_t alive[SERVE_MAX_WORKERS];      // worker w: 0 = gone (or going and no longer counted), else launched / running
+};
+struct serve_ring_dev {                   // device memory
+  unsigned long long head;                // next ticket to take
+  unsigned long long tail;                // the workers' copy of ctl->tail
+  unsigned long long reserved0;
+  unsigned long long last_claim;          // wall clock of the last ticket taken by anybody: the workers leave together when the service falls idle
+  unsigned long long pad[4];
+  // what the workers measured (10 ns ticks, summed over units): ticket -> unit copied, ticket -> results written; units served
+  unsigned long long fetch_ticks, busy_ticks, units_served, backlog, idle_ticks, pad2[3];   // backlog: units published and not taken, summed at every ticket
+};
+struct serve_worker_ids { unsigned char id[SERVE_MAX_WORKERS]; };
+// starts `count` workers (512 threads each) named ids.id[0 .. count); they leave after linger_ticks without work, or at the first
+// idle moment after life_ticks (wall-clock ticks of 10 ns), or when ctl->quit is set
+int serve_workers_launch(const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h, serve_slot *ring, u32 ring_mask,
+                         serve_ring_ctl *ctl, serve_ring_dev *dev, const serve_worker_ids &ids, int count,
+                         unsigned long long linger_ticks, unsigned long long life_ticks, unsigned long long poll_period_ticks, hipStream_t st);
 // `constrained`: some fracmv_within_tile rule is active in the batch (wpp_owf or an mv_constraint)
 int serve_launch(bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,
                  const serve_unit *units, int count, hipStream_t st);

@@ -1061,7 +1061,198 @@ __global__ __launch_bounds__(512) void serve_kernel(const u8 *__restrict__ plane
   }
 }
 
+// ---- resident workers ----
+// A workgroup that stays on the device and takes units from the ring by ticket (protocol: serve.hip).  Every wait in here ends on a
+// wall-clock limit, so the grid always drains: no work for linger_ticks, the first idle moment after life_ticks, ctl->quit, or -- a
+// slot that is not written within a second of its ticket being published (never observed; the host publishes after writing) -- failure.
+__device__ __forceinline__ unsigned long long sys_load64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ u32 sys_load32(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void sys_store32(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+constexpr unsigned long long SERVE_NO_TICKET = ~0ull;
+constexpr unsigned long long SERVE_POLL_TICKS = 50;          // ctl->tail is read across PCIe at most every 0.5 us, by one worker at a time
+constexpr unsigned long long SERVE_SLOT_LIMIT_TICKS = 100000000ull;     // 1 s
+
+// thread 0 of a worker: the next ticket, or SERVE_NO_TICKET when it is time to leave (alive[me] is 0 by then).
+// ctl->tail lives in host memory; a worker reads it across PCIe every poll_period ticks (the period is the workers' number x 0.5 us
+// and their phases are spread, so SOMEBODY reads it every 0.5 us) and mirrors it in device memory, where everybody looks.
+__device__ __forceinline__ unsigned long long serve_take_ticket(serve_ring_ctl *ctl, serve_ring_dev *dev, u32 me, unsigned long long born,
+                                                                unsigned long long linger_ticks, unsigned long long life_ticks,
+                                                                unsigned long long poll_period, unsigned long long &next_poll, bool &retired)
+{
+  const unsigned long long idle0 = wall_clock64();
+  bool quit = false;
+  for (;;) {
+    unsigned long long now = wall_clock64();
+    // Device memory is cached in the L2 of the XCD that reads it, and the eight L2s are only made coherent at kernel boundaries: a
+    // plain (even agent-scope) load in this loop may return the same stale line for as long as the kernel runs -- measured: with
+    // loads only, a handful of the workers ever saw a unit.  Read-modify-write atomics are performed at the memory, so the tail is
+    // read with the atomicMax that also publishes what the host said; a stale head only costs a compare-and-swap that fails and
+    // returns the fresh one.
+    if (!retired && now - born > life_ticks) {             // end of life: said at once, busy or not (see the leaving protocol below)
+      sys_store32(&ctl->alive[me], 0u);
+      __threadfence_system();
+      retired = true;
+    }
+    unsigned long long from_host = 0;
+    if (retired) {
+      from_host = sys_load64(&ctl->tail);                  // behind the store of alive[me] = 0 on the way to the host: see below
+    } else if (now >= next_poll) {
+      from_host = sys_load64(&ctl->tail);
+      quit = sys_load32(&ctl->quit) != 0u;
+      next_poll = now + poll_period;
+    }
+    unsigned long long tail = atomicMax(&dev->tail, from_host);
+    if (from_host > tail) tail = from_host;
+    const unsigned long long head = __hip_atomic_load(&dev->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a compare-and-swap that loses returns the head it lost to: the next try needs no reload (many idle workers see the same unit)
+    for (unsigned long long h = head; h < tail;) {
+      const unsigned long long seen = atomicCAS(&dev->head, h, h + 1);
+      if (seen == h) {
+        now = wall_clock64();
+        atomicMax(&dev->last_claim, now);
+        atomicAdd(&dev->backlog, tail - h - 1); atomicAdd(&dev->idle_ticks, now - idle0);
+        return h;
+      }
+      h = seen;
+    }
+    if (retired) return SERVE_NO_TICKET;
+    // Idle means nobody has taken a ticket for linger_ticks, not "not me": the workers of a launch leave together (a kernel ends when
+    // its last workgroup does, and the next launch on its stream waits for that), and so they do at the end of their life.
+    bool idle = false;
+    if (now - idle0 > linger_ticks) {
+      const unsigned long long last_claim = atomicMax(&dev->last_claim, 0ull);
+      idle = now < last_claim || now - last_claim > linger_ticks;
+    }
+    if (idle || quit) {
+      // Leaving.  The host publishes a unit FIRST and looks at alive[] AFTERWARDS; this side says "gone" first and looks for work
+      // afterwards, with a read that cannot overtake the store on its way to host memory.  So either the host sees the 0 and starts
+      // a worker, or the read above sees the unit -- and then it is taken here (being uncounted while still working is harmless).
+      sys_store32(&ctl->alive[me], 0u);
+      __threadfence_system();
+      retired = true;
+      continue;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+template <bool QSAD>
+__global__ __launch_bounds__(512) void serve_worker_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
+                                                           serve_slot *ring, u32 ring_mask, serve_ring_ctl *ctl, serve_ring_dev *dev, serve_worker_ids ids,
+                                                           unsigned long long linger_ticks, unsigned long long life_ticks, unsigned long long poll_period)
+{
+  __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
+  __shared__ me_shared sh;
+  __shared__ u32 s_unit[sizeof(serve_unit) / 4];
+  __shared__ unsigned long long s_ticket;
+  const int tid = threadIdx.x;
+  const u32 me = ids.id[blockIdx.x];
+  const unsigned long long born = wall_clock64();
+  __shared__ u32 s_fail;
+  __shared__ unsigned long long s_claimed;
+  bool retired = false;                                     // thread 0's: alive[me] is 0, the host no longer counts this worker
+  unsigned long long next_poll = born + (unsigned long long)me * SERVE_POLL_TICKS;      // thread 0's
+  int served_retired = 0;
+  for (;;) {
+    if (tid == 0) {
+      // A worker that has said it is gone (end of life, or idle) looks once more and serves what it finds, twice at most, then goes
+      // without looking: the callers that wait keep starting the workers that are missing (serve.hip), and this one is not among
+      // the counted.  Its kernel must END -- the next launch on the same hardware queue starts only then (measured: a few workers
+      // that never found an idle moment kept a whole new crowd waiting behind them).
+      unsigned long long t = SERVE_NO_TICKET;
+      if (!(retired && served_retired >= 2)) {
+        t = serve_take_ticket(ctl, dev, me, born, linger_ticks, life_ticks, poll_period, next_poll, retired);
+        if (t != SERVE_NO_TICKET && retired) ++served_retired;
+      }
+      s_ticket = t;
+      s_fail = 0u;
+      s_claimed = wall_clock64();
+    }
+    __syncthreads();
+    const unsigned long long ticket = s_ticket;
+    if (ticket == SERVE_NO_TICKET) return;
+    serve_slot *slot = ring + (ticket & ring_mask);
+    // the slot was written before its ticket was published: unit and sequence word come in one pass; the retry is a guard
+    if (tid < 64) {
+      const unsigned long long t0 = wall_clock64();
+      constexpr int UNIT_DWORDS = (int)(sizeof(serve_unit) / 4);
+      for (;;) {
+        u32 v = 0;
+        if (tid <= UNIT_DWORDS) v = sys_load32(reinterpret_cast<const u32 *>(slot) + tid);      // dword UNIT_DWORDS is slot->seq
+        const u32 seq = (u32)__shfl((int)v, UNIT_DWORDS, 64);
+        if (seq == (u32)(ticket + 1)) {
+          if (tid < UNIT_DWORDS) s_unit[tid] = v;
+          break;
+        }
+        if (wall_clock64() - t0 > SERVE_SLOT_LIMIT_TICKS) {
+          if (tid == 0) { sys_store32(&ctl->failed, 1u); sys_store32(&ctl->alive[me], 0u); __threadfence_system(); s_fail = 1u; }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      // What the previous units' pictures left in this CU's vector cache may be older than an upload that was finished before this
+      // unit was posted: one wave drops it (what a kernel boundary would have done) before the others are let through the barrier.
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_fail) return;
+    unsigned long long t_fetched = 0;
+    if (tid == 0) {
+      sys_store32(&slot->seq, 0u);                           // the host may write the slot again
+      t_fetched = wall_clock64();
+    }
+    serve_unit u;
+    {
+      u32 *d = reinterpret_cast<u32 *>(&u);
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(serve_unit) / 4); ++i) d[i] = (u32)__builtin_amdgcn_readfirstlane((int)s_unit[i]);   // uniform: keep it in SGPRs
+    }
+    serve_result *so = reinterpret_cast<serve_result *>(u.result);
+    if (tid == 0) { const unsigned long long c = s_claimed; so->pad[0] = (u32)c; so->pad[1] = (u32)(c >> 32); }   // when the ticket was taken (statistics)
+    if (!serve_unit_ok(u, pic_w, pic_h, n_slots)) {
+      if (tid == 0) serve_flag_bad(so);
+    } else {
+      const int cls = pu_class(u.pu);
+      const u8 *pic = planes + (size_t)u.pic_slot * plane_bytes;
+      const refplane_t ref = { planes + (size_t)u.ref_slot * plane_bytes, stride, pic_w, pic_h };
+      kvz_hip_me_result *out = reinterpret_cast<kvz_hip_me_result *>(so);
+      if (u.prm.algorithm == 3) {
+        full_search_wg<true, QSAD, 512>(tid, lds, (int)sizeof(lds), &sh, pic, stride, ref, u.pu, u.prm);
+        __syncthreads();
+      }
+      if (cls == 1) {                                        // one wave, wave-local fences; the others wait at the barrier below
+        if (tid < 64) {
+          if (u.pu.width == 8 && u.pu.height == 8) search_pu_core<16, 64, true, 8, 8, false, true, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+          else if (u.pu.width == 16 && u.pu.height == 16) search_pu_core<16, 64, true, 16, 16, false, true, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+          else search_pu_core<16, 64, true, 0, 0, false, true, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+        }
+      } else {
+        search_pu_core<64, 512, false, 0, 0, false, true, true>(tid, lds, &sh, pic, stride, ref, u.pu, u.prm, out, 0);
+      }
+    }
+    __syncthreads();                                         // lds, sh and s_unit are free again
+    if (tid == 0) {
+      const unsigned long long t_claimed = s_claimed, now = wall_clock64();
+      atomicAdd(&dev->fetch_ticks, t_fetched - t_claimed); atomicAdd(&dev->busy_ticks, now - t_claimed); atomicAdd(&dev->units_served, 1ull);
+    }
+  }
+}
+
 }  // namespace
+
+int kvzhip::serve_workers_launch(const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h, serve_slot *ring, u32 ring_mask,
+                                 serve_ring_ctl *ctl, serve_ring_dev *dev, const serve_worker_ids &ids, int count,
+                                 unsigned long long linger_ticks, unsigned long long life_ticks, unsigned long long poll_period, hipStream_t st)
+{
+  if (count <= 0) return KVZ_HIP_OK;
+  if (kvzhip::tuning("full_qsad", 1))
+    hipLaunchKernelGGL((serve_worker_kernel<true>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, ring, ring_mask, ctl, dev, ids, linger_ticks, life_ticks, poll_period);
+  else
+    hipLaunchKernelGGL((serve_worker_kernel<false>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, ring, ring_mask, ctl, dev, ids, linger_ticks, life_ticks, poll_period);
+  KVZ_CHECK_LAUNCH("search service workers");
+  return KVZ_HIP_OK;
+}
 
 // serve.hip's launch of one batch; `units` is device-visible host memory
 int kvzhip::serve_launch(bool constrained, const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h,

@@ -13,7 +13,21 @@
 //   * A batch is copied into a ring of page-locked buffers the kernels read directly (one 176-byte unit per PU and
 //     reference picture); results come back the same way, each unit signalling its own `done` word with a system-scope
 //     release store.  There is no copy command and no stream synchronisation on the request path.
-//   * Launches rotate over a few non-blocking streams so that consecutive batches overlap on the device.
+//   * Launches rotate over a few non-blocking streams so that consecutive batches overlap on the device; at most `service_inflight`
+//     batches are in the air (the runtime has four hardware queues: more launches than that wait behind each other one by one,
+//     fewer and larger ones do not).
+//
+// Resident workers (tuning "service_workers" > 0): the same requests without a launch on their way.  Workgroups of
+// me_search.hip's serve_worker_kernel stay on the device and take units by ticket from a ring of slots in page-locked memory:
+//   host, under ring_mu:  wait until slot.seq == 0, write the unit, slot.seq = ticket + 1, ... ctl->tail += n      (publish)
+//   worker:               ticket = head++ while head < tail (device atomics; ctl->tail is read across PCIe by one worker at a
+//                         time and mirrored in device memory), copy the unit, slot.seq = 0, search, write the results and `done`.
+//   Workers leave when they have found no work for `service_linger_us`, or at the first idle moment after `service_life_ms`, or when
+//   the service is destroyed.  Who makes sure somebody is there: a worker says "gone" (ctl->alive[w] = 0) BEFORE its last look at
+//   ctl->tail, and the look is a PCIe read that cannot overtake that store; a caller publishes BEFORE it looks at alive[] (and keeps
+//   looking while it waits) and starts the workers that are missing.  So a published unit is seen either by a worker's last look or
+//   by a caller that finds the worker gone.  alive[w] has one writer at a time: the host sets it when it launches worker w, which it
+//   only does when it reads 0; the worker clears it once.
 #include "kvz_hip_internal.h"
 
 #include <sched.h>
@@ -21,6 +35,8 @@
 #include <time.h>
 
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -32,6 +48,8 @@ namespace {
 
 constexpr int N_STREAMS = 32;         // launch streams at most (tuning "service_streams", default 8)
 constexpr int N_UPLOAD = 8;           // upload streams (put_rect)
+constexpr int N_WSTREAMS = 4;         // streams the worker generations rotate over (their own priority level, hence their own hardware queues)
+constexpr unsigned WRING_SLOTS = 4096;    // a power of two, more than any number of units in flight (max_threads x 16 is checked)
 constexpr int BATCH_CAP = 256;        // units per batch buffer (a larger batch leaves as several launches)
 constexpr uint64_t SPIN_NS = 40 * 1000;   // busy-polling phase of a caller's wait
 constexpr long NAP_NS = 5 * 1000;         // then naps of this length (the kernel rounds them up by the thread's timer slack)
@@ -84,6 +102,19 @@ struct kvz_hip_me_service {
   thread_tables *tables = nullptr;                      // [max_threads], each touched by its own thread only
   std::atomic<uint64_t> st_tables{0}, st_table_bytes{0}, st_table_ns{0};
   uint64_t next_batch = 0;                              // touched under launch_mu only
+  // resident workers
+  int n_workers = 0;                                    // 0: a launch per batch
+  serve_slot *wring = nullptr;                          // page-locked: WRING_SLOTS slots
+  serve_ring_ctl *ctl = nullptr;                        // page-locked
+  serve_ring_dev *wdev = nullptr;                       // device
+  std::mutex ring_mu;
+  unsigned long long wtail = 0;                         // under ring_mu
+  std::atomic<int> units_in_air{0};
+  bool debug = false;                                   // KVZ_HIP_SERVICE_DEBUG: a line of worker statistics on stderr when the service is destroyed
+  std::atomic<long long> dbg_sum_pick{0}, dbg_n_pick{0}, dbg_alive_sum{0}, dbg_alive_n{0}, dbg_hist[16] = {};
+  hipStream_t wstreams[N_WSTREAMS] = {};
+  int wnext = 0;                                        // under launch_mu
+  unsigned long long linger_ticks = 0, life_ticks = 0;
   std::mutex pend_mu;
   std::vector<pending_req> pending;
   std::atomic<int> n_pending{0};
@@ -174,6 +205,75 @@ int drain_and_launch(kvz_hip_me_service *svc)
   return rc;
 }
 
+// starts the workers that are missing; cheap when none is (alive[] is 16 flags to the cache line and only changes when a worker comes or goes)
+int ensure_workers(kvz_hip_me_service *svc)
+{
+  serve_ring_ctl *ctl = svc->ctl;
+  int alive = 0;
+  for (int w = 0; w < svc->n_workers; ++w) alive += __atomic_load_n(&ctl->alive[w], __ATOMIC_RELAXED) != 0u;
+  // Workers come and go as a crowd: those of one launch were born together and leave together (end of life, or the service idle), and
+  // a launch is one kernel that ends with its last worker -- the next kernel on its stream waits for that, so launches must be few and
+  // whole.  More than half there: enough.  Otherwise everybody who is missing is started as one launch, on the stream the previous
+  // launch did not use.
+  if (svc->debug) { svc->dbg_alive_sum.fetch_add(alive, std::memory_order_relaxed); svc->dbg_alive_n.fetch_add(1, std::memory_order_relaxed); }
+  if (alive > svc->n_workers / 2) return KVZ_HIP_OK;
+  if (!svc->launch_mu.try_lock()) return KVZ_HIP_OK;    // somebody else is starting them
+  serve_worker_ids ids;
+  int n = 0;
+  for (int w = 0; w < svc->n_workers; ++w)
+    if (__atomic_load_n(&ctl->alive[w], __ATOMIC_ACQUIRE) == 0u) { ids.id[n++] = (unsigned char)w; __atomic_store_n(&ctl->alive[w], 2u, __ATOMIC_RELAXED); }
+  if (n < svc->n_workers / 2) {                          // they came back meanwhile (another caller's launch)
+    for (int i = 0; i < n; ++i) __atomic_store_n(&ctl->alive[ids.id[i]], 0u, __ATOMIC_RELAXED);
+    n = 0;
+  }
+  int rc = KVZ_HIP_OK;
+  if (n > 0) {
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != svc->device) (void)hipSetDevice(svc->device);
+    rc = serve_workers_launch(svc->planes, svc->plane_bytes, svc->n_slots, (u32)svc->w, svc->w, svc->h, svc->wring, WRING_SLOTS - 1, ctl, svc->wdev,
+                              ids, n, svc->linger_ticks, svc->life_ticks, 50ull * (unsigned long long)svc->n_workers, svc->wstreams[svc->wnext++ % N_WSTREAMS]);
+    svc->st_launches.fetch_add(1, std::memory_order_relaxed);
+    if (rc != KVZ_HIP_OK) {
+      for (int i = 0; i < n; ++i) __atomic_store_n(&ctl->alive[ids.id[i]], 0u, __ATOMIC_RELAXED);
+      svc->failed.store(1);
+    }
+  }
+  svc->launch_mu.unlock();
+  return rc;
+}
+
+// writes the units of a request into the ring and publishes them
+int post_to_ring(kvz_hip_me_service *svc, const kvz_hip_me_request *r, thread_area *area)
+{
+  std::lock_guard<std::mutex> lk(svc->ring_mu);
+  const unsigned long long t0 = svc->wtail;
+  for (int i = 0; i < r->n_refs; ++i) {
+    serve_slot *slot = svc->wring + ((t0 + (unsigned)i) & (WRING_SLOTS - 1));
+    // free unless the ring has gone round while a worker was still copying the unit of 4096 tickets ago
+    for (uint64_t t = 0; __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != 0u;) {
+      __builtin_ia32_pause();
+      if (t == 0) t = now_ns();
+      else if (now_ns() - t > WAIT_LIMIT_NS) { svc->failed.store(1); set_error_msg("kvz_hip_me_service_search: the ring does not drain"); return KVZ_HIP_ERR_RUNTIME; }
+    }
+    serve_unit &u = slot->u;
+    u.pic_slot = r->pic_slot; u.ref_slot = r->ref_slot[i];
+    u.result = &area->res[i];
+    u.pu = r->pu[i];
+    u.pu.width = r->pu[0].width; u.pu.height = r->pu[0].height;     // every picture sees the same PU
+    u.prm = r->params;
+    u.prm.cost_to_beat = nullptr; u.prm.cabac = nullptr; u.prm.mv_rdo = 0; u.prm.size_classes = 0;
+    if (u.prm.tile_w == 0 && u.prm.tile_h == 0) { u.prm.tile_x = 0; u.prm.tile_y = 0; u.prm.tile_w = svc->w; u.prm.tile_h = svc->h; }
+    __atomic_store_n(&slot->seq, (uint32_t)(t0 + (unsigned)i + 1), __ATOMIC_RELEASE);
+  }
+  svc->wtail = t0 + (unsigned)r->n_refs;
+  svc->units_in_air.fetch_add(r->n_refs, std::memory_order_relaxed);
+  __atomic_store_n(&svc->ctl->tail, svc->wtail, __ATOMIC_RELEASE);
+  svc->st_batches.fetch_add(1, std::memory_order_relaxed);
+  svc->st_units.fetch_add((uint64_t)r->n_refs, std::memory_order_relaxed);
+  return KVZ_HIP_OK;
+}
+
 bool request_ok(const kvz_hip_me_service *svc, const kvz_hip_me_request *r)
 {
   if (r->n_refs < 1 || r->n_refs > KVZ_HIP_SERVICE_MAX_REFS || r->pic_slot < 0 || r->pic_slot >= svc->n_slots) return false;
@@ -220,6 +320,27 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
   if (svc->n_streams > N_STREAMS) svc->n_streams = N_STREAMS;
   for (int i = 0; i < svc->n_streams && ok; ++i) ok = hipStreamCreateWithFlags(&svc->streams[i], hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; i < N_UPLOAD && ok; ++i) ok = hipStreamCreateWithFlags(&svc->up_streams[i], hipStreamNonBlocking) == hipSuccess;
+  // Resident workers are the default way to the device (measured against a launch per batch on the same box, 1080p, 16 encoder
+  // threads: exhaustive +-16 search 4.3 -> 6.8 frames/s, preset medium 5.8 -> 6.3, 16 closed-loop C threads 211k -> 317k requests/s);
+  // "service_workers" 0 selects the launches, and so does a service with more calling threads than the ring is sized for.
+  svc->n_workers = kvzhip::tuning("service_workers", 64);
+  svc->debug = getenv("KVZ_HIP_SERVICE_DEBUG") != nullptr;
+  if (svc->n_workers > SERVE_MAX_WORKERS) svc->n_workers = SERVE_MAX_WORKERS;
+  if ((unsigned)svc->max_threads * KVZ_HIP_SERVICE_MAX_REFS > WRING_SLOTS / 2) svc->n_workers = 0;
+  if (svc->n_workers > 0 && ok) {
+    // the wall clock counts 10 ns.  Idle workers cost a few atomics per microsecond; a relaunch costs the first request after a
+    // pause ~15 us, so they stay through pauses of a couple of milliseconds (an encoder that serves only its largest PUs posts that rarely)
+    svc->linger_ticks = 100ull * (unsigned long long)kvzhip::tuning("service_linger_us", 2000);
+    svc->life_ticks = 100000ull * (unsigned long long)kvzhip::tuning("service_life_ms", 20);
+    ok = ok && hipHostMalloc((void **)&svc->wring, sizeof(serve_slot) * WRING_SLOTS, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&svc->ctl, sizeof(serve_ring_ctl), hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess;
+    ok = ok && hipMalloc((void **)&svc->wdev, sizeof(serve_ring_dev)) == hipSuccess;
+    ok = ok && hipMemset(svc->wdev, 0, sizeof(serve_ring_dev)) == hipSuccess;
+    if (ok) { std::memset(svc->wring, 0, sizeof(serve_slot) * WRING_SLOTS); std::memset(svc->ctl, 0, sizeof(serve_ring_ctl)); }
+    int least = 0, greatest = 0;
+    ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+    for (int i = 0; i < N_WSTREAMS && ok; ++i) ok = hipStreamCreateWithPriority(&svc->wstreams[i], hipStreamNonBlocking, greatest) == hipSuccess;
+  }
   svc->batch_open = new (std::nothrow) std::atomic<int>[svc->n_batch];
   ok = ok && svc->batch_open != nullptr;
   for (int i = 0; i < svc->n_batch && ok; ++i) svc->batch_open[i].store(0);
@@ -242,6 +363,26 @@ void kvz_hip_me_service_destroy(kvz_hip_me_service *svc)
   if (!svc) return;
   int cur = -1;
   if (hipGetDevice(&cur) == hipSuccess && cur != svc->device) (void)hipSetDevice(svc->device);
+  if (svc->ctl) {                                       // the workers leave at their next idle moment
+    __atomic_store_n(&svc->ctl->quit, 1u, __ATOMIC_SEQ_CST);
+    for (int i = 0; i < N_WSTREAMS; ++i) if (svc->wstreams[i]) { (void)hipStreamSynchronize(svc->wstreams[i]); (void)hipStreamDestroy(svc->wstreams[i]); }
+    if (svc->debug && svc->wdev) {
+      if (svc->dbg_n_pick.load()) {
+        fprintf(stderr, "kvz_hip service workers: pick-up delay histogram (bins of 1 us x 2^b):");
+        for (int b = 0; b < 16; ++b) fprintf(stderr, " %lld", svc->dbg_hist[b].load());
+        fprintf(stderr, "\n");
+      }
+      if (svc->dbg_n_pick.load())
+        fprintf(stderr, "kvz_hip service workers: post -> last ticket of the request taken, above the smallest seen: %.2f us (mean of %lld requests), request wait %.2f us\n",
+                svc->dbg_sum_pick.load() / (double)svc->dbg_n_pick.load() / 1e3, svc->dbg_n_pick.load(),
+                svc->st_wait_ns.load() / 1e3 / (double)svc->st_requests.load());
+      serve_ring_dev d;
+      if (hipMemcpy(&d, svc->wdev, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess && d.units_served)
+        fprintf(stderr, "kvz_hip service workers: %llu units, ticket -> unit copied %.2f us, ticket -> results written %.2f us, idle before a ticket %.2f us, units waiting behind a taken ticket %.2f (means), %llu worker launches, workers alive when a request was posted %.1f\n",
+                d.units_served, d.fetch_ticks / 100.0 / d.units_served, d.busy_ticks / 100.0 / d.units_served, d.idle_ticks / 100.0 / d.units_served,
+                (double)d.backlog / d.units_served, (unsigned long long)svc->st_launches.load(), svc->dbg_alive_sum.load() / (double)(svc->dbg_alive_n.load() ? svc->dbg_alive_n.load() : 1));
+    }
+  }
   for (int i = 0; i < N_STREAMS; ++i) if (svc->streams[i]) { (void)hipStreamSynchronize(svc->streams[i]); (void)hipStreamDestroy(svc->streams[i]); }
   for (int i = 0; i < N_UPLOAD; ++i) if (svc->up_streams[i]) { (void)hipStreamSynchronize(svc->up_streams[i]); (void)hipStreamDestroy(svc->up_streams[i]); }
   for (int i = 0; i < N_UPLOAD; ++i) if (svc->up_stage[i]) (void)hipHostFree(svc->up_stage[i]);
@@ -256,6 +397,9 @@ void kvz_hip_me_service_destroy(kvz_hip_me_service *svc)
   if (svc->planes) (void)hipFree(svc->planes);
   if (svc->areas) (void)hipHostFree(svc->areas);
   if (svc->ring) (void)hipHostFree(svc->ring);
+  if (svc->wring) (void)hipHostFree(svc->wring);
+  if (svc->ctl) (void)hipHostFree(svc->ctl);
+  if (svc->wdev) (void)hipFree(svc->wdev);
   delete svc;
 }
 
@@ -297,7 +441,12 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
   for (int i = 0; i < n; ++i) __atomic_store_n(&area->res[i].done, 0u, __ATOMIC_RELAXED);
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
   const uint64_t t0 = now_ns();
-  {
+  const bool workers = svc->n_workers > 0;
+  if (workers) {
+    const int rc = post_to_ring(svc, req, area);
+    if (rc != KVZ_HIP_OK) return rc;
+    std::atomic_thread_fence(std::memory_order_seq_cst);      // published; now look who is there
+  } else {
     std::lock_guard<std::mutex> lk(svc->pend_mu);
     svc->pending.push_back(pending_req{ req, ts });
     svc->n_pending.fetch_add(1, std::memory_order_relaxed);
@@ -309,6 +458,13 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
     for (int i = 0; i < n; ++i)
       if (__atomic_load_n(&area->res[i].done, __ATOMIC_ACQUIRE) == 0u) { all = false; break; }
     if (all) break;
+    if (workers) {
+      if ((spins & 31) == 0 || spins >= 256) {
+        const int rc = ensure_workers(svc);
+        if (rc != KVZ_HIP_OK) return rc;
+        if (__atomic_load_n(&svc->ctl->failed, __ATOMIC_RELAXED)) svc->failed.store(1);
+      }
+    } else
     // With a cap on the batches in the air a request that finds them all taken waits for one to come back and then shares its
     // launch with everything that arrived meanwhile: the device runs only as many kernels side by side as the runtime has hardware
     // queues (four unless GPU_MAX_HW_QUEUES says otherwise), more launches than that queue up behind each other one request at a time.
@@ -337,7 +493,34 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
       }
     }
   }
-  if (svc->batch_open[svc->slot_batch[ts].load(std::memory_order_relaxed)].fetch_sub(1, std::memory_order_release) == 1)
+  if (workers) {
+    svc->units_in_air.fetch_sub(n, std::memory_order_relaxed);
+    if (svc->debug) {
+      // post -> ticket taken, on two clocks: the smallest difference seen stands for "no delay" (it is a PCIe read or two)
+      unsigned long long last = 0;
+      for (int i = 0; i < n; ++i) { const unsigned long long c = ((unsigned long long)area->res[i].pad[1] << 32) | area->res[i].pad[0]; if (c > last) last = c; }
+      const long long d = (long long)(last * 10ull) - (long long)t0;
+      // per calling thread, over windows of 128 requests (the two clocks drift apart by microseconds per second)
+      static thread_local long long w_min = (long long)1 << 62, w_d[128];
+      static thread_local int w_n = 0;
+      if (d < w_min) w_min = d;
+      w_d[w_n] = d;
+      if (++w_n == 128) {
+        long long sum = 0;
+        for (int i = 0; i < 128; ++i) {
+          const long long e = w_d[i] - w_min;
+          sum += e;
+          int b = 0;
+          while (b < 15 && (e >> (10 + b)) > 0) ++b;      // bin 0: < 1.02 us, bin b: < 1.02 us * 2^b
+          svc->dbg_hist[b].fetch_add(1, std::memory_order_relaxed);
+        }
+        svc->dbg_sum_pick.fetch_add(sum, std::memory_order_relaxed);
+        svc->dbg_n_pick.fetch_add(128, std::memory_order_relaxed);
+        w_min = (long long)1 << 62; w_n = 0;
+      }
+    }
+  }
+  if (!workers && svc->batch_open[svc->slot_batch[ts].load(std::memory_order_relaxed)].fetch_sub(1, std::memory_order_release) == 1)
     svc->inflight.fetch_sub(1, std::memory_order_relaxed);          // the last caller of its batch
   svc->st_wait_ns.fetch_add(now_ns() - t0, std::memory_order_relaxed);
   // the sequential rule of search_pu_inter's loop (search_inter.c:1502-1507 with :1239-1252 and :1275-1290)

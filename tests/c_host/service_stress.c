@@ -1,7 +1,9 @@
 /* service_stress.c -- a plain C99 pthread host of the search service (include/kvz_hip.h "search service"), shaped like
  * the reference's thread pool (threadqueue.c:263: N workers, each posting one search at a time and blocking on it).
  *
- *   service_stress THREADS REQUESTS_PER_THREAD [WIDTH HEIGHT N_REFS]
+ *   service_stress THREADS REQUESTS_PER_THREAD [WIDTH HEIGHT N_REFS [THINK_US [FULL_RANGE]]]
+ *   (THINK_US: each worker computes for that long between two requests, like an encoder worker does; FULL_RANGE > 0: the
+ *   exhaustive search of that range instead of hexbs)
  *
  * 1. a table of PUs (8x8 .. 64x64, random candidates) is searched ONCE through the service by one thread: the expected answers;
  * 2. THREADS workers then post the same PUs concurrently, in different orders, and every answer must equal the table's
@@ -32,6 +34,7 @@ static kvz_hip_me_service *g_svc;
 static kvz_hip_me_request g_req[N_PUS];
 static kvz_hip_me_result g_want[N_PUS][KVZ_HIP_SERVICE_MAX_REFS];
 static int g_per_thread;
+static double g_think_s;
 
 typedef struct { int id, failed; long done; char msg[200]; } worker_arg;
 
@@ -53,6 +56,7 @@ static void *worker(void *p)
       return NULL;
     }
     ++a->done;
+    if (g_think_s > 0) { const double t = now_s(); while (now_s() - t < g_think_s) {} }
   }
   return NULL;
 }
@@ -62,6 +66,8 @@ int main(int argc, char **argv)
   const int threads = argc > 1 ? atoi(argv[1]) : 16;
   g_per_thread = argc > 2 ? atoi(argv[2]) : 2000;
   const int w = argc > 3 ? atoi(argv[3]) : 640, h = argc > 4 ? atoi(argv[4]) : 384, n_refs = argc > 5 ? atoi(argv[5]) : 4;
+  g_think_s = argc > 6 ? 1e-6 * atof(argv[6]) : 0.0;
+  const int full_range = argc > 7 ? atoi(argv[7]) : 0;
   if (threads < 1 || threads > 512 || n_refs < 1 || n_refs > KVZ_HIP_SERVICE_MAX_REFS || w < 128 || h < 128 || (w & 7) || (h & 7)) return 2;
   if (kvz_hip_init(-1) != KVZ_HIP_OK) { fprintf(stderr, "kvz_hip_init: %s\n", kvz_hip_last_error()); return 1; }
   kvz_hip_me_service_config cfg;
@@ -93,6 +99,7 @@ int main(int argc, char **argv)
     r->params.lambda_cost = 10 + (int)(lcg(&s) % 40); r->params.early_termination = 1; r->params.max_steps = 0xffffffffu;
     r->params.fme_level = 4; r->params.max_ref_lcu_down = 1; r->params.max_ref_lcu_right = 1;
     if (i % 5 == 0) { r->params.wpp_owf = 1; r->params.ref_delay_px = 10; }
+    if (full_range > 0) { r->params.algorithm = 3; r->params.search_range = full_range; }
     const int x = (int)(lcg(&s) % (uint32_t)((w - size) / 8 + 1)) * 8, y = (int)(lcg(&s) % (uint32_t)((h - size) / 8 + 1)) * 8;
     for (int k = 0; k < r->n_refs; ++k) {
       kvz_hip_me_pu *pu = &r->pu[k];

@@ -32,14 +32,22 @@ def test_c_host_runs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("threads,per_thread", [(4, 1500), (16, 1500), (48, 700)])
-def test_service_stress_from_c_threads(threads, per_thread):
+@pytest.mark.parametrize("threads,per_thread,extra,tune", [
+    (4, 1500, (), ""), (16, 1500, (), ""), (48, 700, (), ""),
+    (16, 1500, (), "service_workers=0"),                                  # a launch per batch instead of the resident workers
+    (16, 3000, ("640", "384", "4", "40"), "service_linger_us=30,service_life_ms=1"),    # workers come and go all the time
+    (16, 600, ("640", "384", "4", "0", "16"), ""),                        # the exhaustive search on the whole workgroup
+])
+def test_service_stress_from_c_threads(threads, per_thread, extra, tune):
     """tests/c_host/service_stress.c: pthread workers post searches concurrently; every answer must equal the one the same request
-    got single-threaded (any interleaving, batching, ring wrap-around; more workers than the box has cores for the last case)"""
+    got single-threaded (any interleaving, batching, ring wrap-around; more workers than the box has cores for the 48-thread case)"""
     exe = os.path.join(ROOT, "tests", "c_host", "service_stress")
     if not os.access(exe, os.X_OK):
         import __graft_entry__ as g
         g.build_c_host()
-    r = subprocess.run([exe, str(threads), str(per_thread)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    env = dict(os.environ)
+    if tune:
+        env["KVZ_HIP_TUNE"] = tune
+    r = subprocess.run([exe, str(threads), str(per_thread)] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240, env=env)
     print(r.stdout)
     assert r.returncode == 0 and "service_stress ok" in r.stdout, r.stdout

@@ -61,11 +61,17 @@ SERVICE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("workers", [0, 40], ids=["launches", "resident_workers"])
 @pytest.mark.parametrize("case", range(len(SERVICE_CASES)))
-def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case):
+def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case, workers):
+    """workers > 0: the same requests through the ring and the resident workgroups (tuning "service_workers", read when the service is
+    created) instead of a launch per batch; short linger and life so that workers come and go while the test runs"""
     w, h, n_refs = 192, 128, 4
     spec = dict(SERVICE_CASES[case])
     tune = spec.pop("tune", None)
+    from kvazaar_amd import _lib as _l
+    for key, value in ((b"service_workers", workers), (b"service_linger_us", 60 if case % 2 else 2000), (b"service_life_ms", 1 if case % 3 == 0 else 20)):
+        _l.check(_l.load().kvz_hip_set_tuning(key, value), "tuning")             # workers = 0: a launch per batch
     prm = me_params(**spec)
     planes = [me_frames(w, h, 300 + 7 * case + k, motion) for k, motion in enumerate(((3, -2), (-5, 4), (0, 0), (9, 7)))]
     pic = planes[0][0]
@@ -114,11 +120,13 @@ def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case)
                 np.testing.assert_array_equal(got, ref_tab[i, :len(got)], err_msg="case %d PU %d start %d" % (case, i, start))
         st = svc.stats()
         assert st["requests"] == len(jobs) and st["units"] >= st["requests"] and st["batches"] <= st["requests"]
-        print("case %d: %d requests (%d units) in %d batches / %d launches, largest batch %d units, mean wait %.1f us"
-              % (case, st["requests"], st["units"], st["batches"], st["launches"], st["max_batch_units"], st["wait_ns"] / 1e3 / st["requests"]))
+        print("case %d (%s): %d requests (%d units) in %d batches / %d launches, largest batch %d units, mean wait %.1f us"
+              % (case, "workers" if workers else "launches", st["requests"], st["units"], st["batches"], st["launches"], st["max_batch_units"], st["wait_ns"] / 1e3 / st["requests"]))
     finally:
         if tune:
             _lib.load().kvz_hip_set_tuning(tune[0], -1)
+        for key in (b"service_workers", b"service_linger_us", b"service_life_ms"):
+            _lib.load().kvz_hip_set_tuning(key, -1)
         svc.close()
 
 
