@@ -555,12 +555,13 @@ def encoder_leg(frames=16, threads=16, timeout_s=280):
     if not rows or summary is None:
         return {"error": "tools/served_encode.py failed (rc %d)" % r.returncode}
     # the same host where the SAD path is the bulk of its work: --me full16 (exhaustive +-16 around the zero vector, the start vector
-    # and the merge candidates, search_inter.c:886-962), its kvz_image_calc_sad calls answered from kvz_hip_me_service_sad_tables
-    full = None
+    # and the merge candidates, search_inter.c:886-962): every search served (the service's workgroup-wide exhaustive search), and --
+    # the candidate-independent half alone -- its kvz_image_calc_sad calls answered from kvz_hip_me_service_sad_tables
+    full, full_served = None, None
     try:
-        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "served_encode.py"), "--size", "1920x1080", "--frames", "4", "--threads", str(threads),
-                             "--opts", "preset=medium,qp=32,me=full16", "--min-size", "", "--tables", "16"],
-                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=120)
+        r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "served_encode.py"), "--size", "1920x1080", "--frames", "6", "--threads", str(threads),
+                             "--opts", "preset=medium,qp=32,me=full16", "--min-size", "8", "--tables", "16"],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=150)
         for line in r2.stdout.splitlines():
             try:
                 d = json.loads(line)
@@ -569,23 +570,29 @@ def encoder_leg(frames=16, threads=16, timeout_s=280):
             if d.get("mode") == "sad_tables":
                 full = {k: d[k] for k in ("opts", "table_range", "fps_untouched", "fps_with_tables", "identical_bitstream", "hit_rate",
                                           "sad_calls_answered_from_tables", "sad_calls_outside_the_range", "table_KB_per_ctu_and_picture", "table_MB")}
+            elif "fps_served" in d:
+                full_served = {k: d[k] for k in ("opts", "frames", "min_pu_served", "fps_untouched", "fps_served", "identical_bitstream", "searches_served",
+                                                 "searches_left_to_cpu", "mean_wait_us", "failed")}
+                full_served["speedup"] = round(d["fps_served"] / d["fps_untouched"], 3) if d["fps_untouched"] else None
     except subprocess.TimeoutExpired:
         full = {"error": "timed out"}
     out = {
         "what": "reference encoder (oracle/_ref) 1920x1080 preset medium qp 32, %d synthetic frames, threads=%d, owf auto: frames/s untouched (avx2 "
                 "strategies) and with its 2Nx2N inter searches of at least `min_pu_served` pixels answered by kvz_hip_me_service_search from all "
-                "worker threads (all reference pictures of a PU in parallel, concurrent requests in shared launches)" % (frames, threads),
+                "worker threads (all reference pictures of a PU in parallel; resident workgroups take the units from a ring, no launch per request)" % (frames, threads),
         "fps_untouched_same_threads": rows[0]["fps_untouched"],
         "all_bitstreams_identical": bool(summary.get("all_identical")),
         "served": [{k: row[k] for k in ("min_pu_served", "fps_served", "searches_served", "searches_left_to_cpu", "launches", "mean_requests_per_batch",
                                         "mean_units_per_launch", "max_batch_units", "mean_wait_us", "upload_MB", "failed")} for row in rows],
         # what a served search has to beat: the reference's own kvz_search_cu_inter per CU size on this host (all reference pictures of the PU)
+        "full_search_served": full_served,
         "full_search_with_sad_tables": full,
         "cpu_search_us_per_cu": probe["cpu_search_us"] if probe else None,
         "cpu_searches_per_cu_size": probe["cpu_searches"] if probe else None,
         "note": "a served search costs its caller mean_wait_us; the CPU does the same search in cpu_search_us_per_cu -- at preset medium (hexbs, early "
-                "termination) that is 4-60 us, below a launch + kernel + PCIe round trip for every size but 64x64, so the served encode trails the "
-                "untouched one; DESIGN.md section 6 has the account",
+                "termination) that is 4-60 us, below the device's search + PCIe round trip for every size but 64x64, so the served encode trails the "
+                "untouched one there; with the exhaustive search (full_search_served) the CPU needs 117-790 us per search and the served encode "
+                "wins; DESIGN.md section 6 has the account",
     }
     return out
 

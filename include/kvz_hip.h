@@ -96,7 +96,10 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * iteration's first store), "pipe" / "dct_pipe" (1: the same hand placement in the 4x4 / 8x8 register kernels / the 32x32
  * transform, where it measured slower), "full_qsad" (0: the search service's exhaustive search prices positions with v_sad_u8 on
  * byte-aligned operands instead of four alignments per v_qsad_pk_u16_u8), "sample8_wave" (0: 8x8 luma blocks of the sampling entry
- * on the general path).
+ * on the general path), "service_workers" (resident workgroups of the search service, 0: a launch per batch), "service_linger_us" /
+ * "service_life_ms" (how long they stay without work / at most), "service_inflight" / "service_streams" (batches in the air and
+ * launch streams of the launch-per-batch way); the service reads its knobs when it is created.  KVZ_HIP_SERVICE_DEBUG in the
+ * environment: a few lines of the workers' own timing on stderr when a service is destroyed.
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
  * knobs at kvz_hip_init() for A/B runs of an unmodified host. */
 KVZ_HIP_API int kvz_hip_set_tuning(const char *key, int value);
@@ -454,7 +457,7 @@ KVZ_HIP_API int kvz_hip_search_pu_multi_batch(const kvz_hip_pixel *const *pics, 
                                               const kvz_hip_me_pu *pus, size_t count, const kvz_hip_me_params *params,
                                               kvz_hip_me_result *results, kvz_hip_stream s);
 
-/* ---- search service: the searches of MANY host threads in shared launches ---- */
+/* ---- search service: the searches of MANY host threads, without a launch per search ---- */
 /* The reference runs one CTU job per threadqueue worker (encoderstate.c:777-828: WPP rows, frames in flight under
  * --owf, tiles), and every worker reaches search_pu_inter (search_inter.c:1451-1520) with ONE PU at a time.  A launch per
  * PU and per reference picture leaves the chip idle and pays the launch price every time; the service is the piece
@@ -462,10 +465,12 @@ KVZ_HIP_API int kvz_hip_search_pu_multi_batch(const kvz_hip_pixel *const *pics, 
  *   - the luma planes the searches read (source pictures, reconstructed pictures) stay resident on the device in
  *     numbered slots, written rectangle by rectangle as the host produces them;
  *   - kvz_hip_me_service_search() is called concurrently by the workers, each with one PU and ALL the reference pictures
- *     of search_pu_inter's loop (:1502-1507).  Requests that are pending at the same time leave in one launch (one per
- *     size class): whichever caller finds the launch path free takes everything that is queued -- its own request and
- *     those of the callers that arrived while the previous launch was being issued -- so batches grow with the load and
- *     an idle service adds no wait;
+ *     of search_pu_inter's loop (:1502-1507).  By default the (PU, picture) units go into a ring in page-locked memory and are
+ *     taken by workgroups that stay on the device ("resident workers": started when a request finds none, gone when the
+ *     service has been idle for a couple of milliseconds; tuning "service_workers" = their number, default 64, 0 = off).
+ *     Without them -- and always with more than 128 calling threads -- requests that are pending at the same time leave in
+ *     one launch: whichever caller finds the launch path free takes everything that is queued, so batches grow with the load;
+ *     at most "service_inflight" (4) such batches are in the air;
  *   - the reference pictures of a PU are searched IN PARALLEL.  The loop of :1502-1507 is sequential only through
  *     *inter_cost: a picture whose integer search does not get below it skips search_frac and is re-scored with SATD
  *     (:1239-1252).  Every (PU, picture) unit therefore computes both outcomes -- the search with its fractional stage,
@@ -494,8 +499,8 @@ typedef struct {
 } kvz_hip_me_request;
 typedef struct {
   uint64_t requests, units;     /* searches asked for; (PU, picture) units searched */
-  uint64_t batches, launches;   /* times the queue was drained; kernel launches (up to three size classes per batch) */
-  uint64_t max_batch_units;
+  uint64_t batches, launches;   /* a launch per batch: times the queue was drained = kernel launches; resident workers: requests posted to the ring, times workers were started */
+  uint64_t max_batch_units;     /* (0 with resident workers) */
   uint64_t rects, rect_bytes;   /* kvz_hip_me_service_put_rect calls and the bytes they moved */
   uint64_t wait_ns;             /* summed over callers: time between posting a request and seeing its results */
   uint64_t tables, table_bytes; /* kvz_hip_me_service_sad_tables: (CTU, picture) tables filled and the bytes the kernels wrote to host memory */
