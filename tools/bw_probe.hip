@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 ntload(const uint4* p) { u32x4 v = __builtin_nontemporal_load((const u32x4*)p); return make_uint4(v.x, v.y, v.z, v.w); }
@@ -77,6 +78,38 @@ __global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ a, 
   }
 }
 
+// the fused quantize_residual traffic: two byte planes in (reference, prediction), one byte plane (reconstruction) and one
+// int16 plane (coefficients) out -- 2 bytes read, 3 written per pixel, nothing computed
+template <int U, bool NTS>
+__global__ __launch_bounds__(256) void qr_mix_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ rec,
+                                                     uint4* __restrict__ coef, size_t n16)
+{
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lane = threadIdx.x & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  for (size_t base = wave * 64 * U; base < n16; base += nwaves * 64 * U) {
+    uint4 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + u * 64 + lane;
+      if (i < n16) { x[u] = ntload(a + i); y[u] = ntload(b + i); } else { x[u] = make_uint4(0, 0, 0, 0); y[u] = x[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + u * 64 + lane;
+      if (i < n16) {
+        const uint4 r = make_uint4(x[u].x ^ y[u].x, x[u].y ^ y[u].y, x[u].z ^ y[u].z, x[u].w ^ y[u].w);
+        const uint4 c0 = make_uint4(x[u].x + y[u].y, x[u].y, y[u].z, x[u].w), c1 = make_uint4(y[u].x, x[u].z + y[u].w, y[u].y, x[u].x);
+        if (NTS) {
+          u32x4 w = { r.x, r.y, r.z, r.w }, w0 = { c0.x, c0.y, c0.z, c0.w }, w1 = { c1.x, c1.y, c1.z, c1.w };
+          __builtin_nontemporal_store(w, (u32x4*)(rec + i));
+          __builtin_nontemporal_store(w0, (u32x4*)(coef + 2 * i)); __builtin_nontemporal_store(w1, (u32x4*)(coef + 2 * i + 1));
+        } else { rec[i] = r; coef[2 * i] = c0; coef[2 * i + 1] = c1; }
+      }
+    }
+  }
+}
+
 template <typename F>
 float timeit(F f, int iters = 20)
 {
@@ -89,8 +122,22 @@ float timeit(F f, int iters = 20)
   return ms / iters;
 }
 
-int main()
+int main(int argc, char** argv)
 {
+  if (argc > 1 && !strcmp(argv[1], "qrmix")) {
+    // 256 MiB per byte plane (what one launch of the fused kernels moves in bench_all: 268 MB read, 457 MB written incl. flags)
+    const size_t bytes = (size_t)256 << 20, n16 = bytes / 16;
+    uint4 *a, *b, *rec, *coef;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&rec, bytes)); CK(hipMalloc(&coef, 2 * bytes));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
+    int grids[] = { 256 * 4, 256 * 8, 256 * 16, 256 * 32, 256 * 128 };
+    printf("%-34s %8s %10s\n", "variant (2 B read + 3 B written per pixel)", "grid", "GB/s");
+#define RUN_MIX(U, NTS) for (int g : grids) { \
+    float ms = timeit([&] { hipLaunchKernelGGL((qr_mix_kernel<U, NTS>), dim3(g), dim3(256), 0, 0, a, b, rec, coef, n16); }); \
+    printf("qr mix U=%d nts=%d                   %8d %10.1f\n", U, (int)NTS, g, 5.0 * bytes / ms / 1e6); }
+    RUN_MIX(1, false) RUN_MIX(2, false) RUN_MIX(4, false) RUN_MIX(1, true) RUN_MIX(2, true) RUN_MIX(4, true)
+    return 0;
+  }
   const size_t bytes = (size_t)512 << 20;   // 512 MiB per array (> 256 MiB Infinity Cache)
   const size_t n16 = bytes / 16;
   uint4 *a, *b, *o; unsigned* out;
