@@ -15,6 +15,7 @@
 // reference pixels come from L2/HBM with the clamp addressing of image_interpolated_sad
 // (image.c:320-444).  The fractional stage is frac_core.h with the MV cost model plugged in.
 #include "kvz_hip_internal.h"
+#include <type_traits>
 #include "frac_core.h"
 
 using namespace kvzhip;
@@ -299,7 +300,7 @@ __device__ __forceinline__ void full_search_wg(int tid, u8 *lds, int lds_bytes, 
                                                const refplane_t &ref, const kvz_hip_me_pu &pu, const kvz_hip_me_params &prm)
 {
   const me_cost_model_t<false, CONSTR> mvc(pu, prm);
-  const int w = pu.width, h = pu.height, R = prm.search_range, side = 2 * R + 1, groups = (side + 3) >> 2;
+  const int w = pu.width, h = pu.height, R = prm.search_range, side = 2 * R + 1;
   const int wq = w >> 2;                               // every PU width is a multiple of 4
   // ---- the windows, in the reference's order: sh->cx / cy = centre, sh->sad = index of the merge candidate (or -1) ----
   int n_win = 1;
@@ -320,23 +321,113 @@ __device__ __forceinline__ void full_search_wg(int tid, u8 *lds, int lds_bytes, 
       add_window(cx0, cy0, i);
     }
   }
-  // ---- the current block, stride w ----
-  u8 *const s_cur = lds;
-  for (int i = tid; i < wq * h; i += T) {
-    const int y = i / wq, x = (i - y * wq) * 4;
-    u32 v;
-    __builtin_memcpy(&v, pic + (size_t)(pu.y + y) * pic_stride + pu.x + x, 4);
-    *(u32 *)(s_cur + y * w + x) = v;
-  }
-  const int cur_bytes = (w * h + 15) & ~15;
-  u8 *const s_win = lds + cur_bytes;
-  const int wstride = (w + 2 * R + 8 + 3) & ~3, wrows = h + 2 * R, win_bytes = wstride * wrows, wsq = wstride >> 2;
-  int per_chunk = (lds_bytes - cur_bytes) / win_bytes;  // >= 1 for every legal PU and range (64x64, R = 64: 39 168 bytes)
+  // ---- the current block never enters LDS: its address is the same in every lane, so it is read with scalar loads (constant address
+  // space: s_load_dwordx2..x16 per row) and feeds the SAD instructions as SGPR operands.  The scalar cache may hold what a previous
+  // unit of a resident worker read from a slot that has been overwritten since: dropped here.
+  __builtin_amdgcn_s_dcache_inv();
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  const cu32 *const cur_c = (const cu32 *)(unsigned long long)(pic + (size_t)pu.y * pic_stride + pu.x);     // 4-byte aligned: x and the stride are multiples of 4
+  const int cstride = (int)(pic_stride >> 2);
+  u8 *const s_win = lds;
+  // an item is NQ quads of neighbouring positions of one window row: 4 positions when the windows give the 512 threads one round of
+  // items or less, 8 otherwise (one more reference dword per row serves four more positions: half the LDS traffic per position)
+  const int groups4 = (side + 3) >> 2, groups8 = (side + 7) >> 3;
+  // (blocks up to 16 pixels wide are bound by the pricing of the positions, not by LDS: there 8 positions per item only pay when they
+  // save rounds outright -- an item of two quads costs about 1.6 items of one)
+  const int rounds4 = (n_win * side * groups4 + T - 1) / T, rounds8 = (n_win * side * groups8 + T - 1) / T;
+  const bool wide = wq >= 8 ? rounds4 > 1 : 16 * rounds8 < 10 * rounds4;
+  const int groups = wide ? groups8 : groups4;
+  const int wstride = (w + 8 * groups8 + 4 + 3) & ~3, wrows = h + 2 * R, win_bytes = wstride * wrows, wsq = wstride >> 2;
+  int per_chunk = lds_bytes / win_bytes;                // >= 1 for every legal PU and range (64x64, R = 64: 204 x 192 bytes)
   if (per_chunk > FULL_MAX_WINDOWS) per_chunk = FULL_MAX_WINDOWS;
-  const int flush_rows = wq >= 64 ? 1 : 64 / wq;        // rows of 16-bit sums that cannot overflow
   const int items_per_win = side * groups;
   unsigned long long best = ~0ull;
   __syncthreads();                                      // the window list
+
+  // prices the positions of one quad of an item and keeps the thread's smallest (cost, visiting order)
+  auto price_quad = [&](int kk, int r, int col0, const u32 (&tot)[4]) {
+    const int cx = sh->cx[kk], cy = sh->cy[kk], mine = (int)sh->sad[kk];
+    const int y = cy + r - R;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int col = col0 + p, x = cx + col - R;
+      if (col >= side) continue;
+      bool skip = false;
+      if (mine >= 0) {                                   // a merge candidate's window: :936-952
+        if (x >= -R && x <= R && y >= -R && y <= R) skip = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j >= mine || !(mvc.usable >> j & 1u)) continue;
+          const int xx = mvc.mx[j] >> 2, yy = mvc.my[j] >> 2;
+          if (x >= xx - R && x <= xx + R && y >= yy - R && y <= yy + R) skip = true;
+        }
+      }
+      if (skip || !mvc.within(x * 4, y * 4)) continue;
+      u32 bits;
+      const u32 cost = tot[p] + mvc.cost(x, y, 2, bits);                  // < 2^32: lambda_cost is bounded by the entry
+      const unsigned long long key = ((unsigned long long)cost << 32) | (u32)(kk * side * side + r * side + col);
+      best = key < best ? key : best;
+    }
+  };
+  // the SADs of an item: WQ = dwords per block row (0: any width, one scalar load per dword), NQ = quads
+  auto run_items = [&](auto wq_tag, auto nq_tag, int k0, int nk) {
+    constexpr int WQ = decltype(wq_tag)::value, NQ = decltype(nq_tag)::value;
+    const int nwq = WQ ? WQ : wq;
+    const int flush_rows = nwq >= 64 ? 1 : 64 / nwq;    // rows of 16-bit sums that cannot overflow: 64 x 4 x 255 < 2^16
+    for (int it = tid; it < nk * items_per_win; it += T) {
+      const int k = it / items_per_win, rem = it - k * items_per_win, r = rem / groups, g = rem - r * groups;
+      const u32 *q = (const u32 *)(s_win + k * win_bytes + r * wstride) + NQ * g;
+      const cu32 *c = cur_c;
+      u32 tot[NQ][4] = {};
+      for (int yb = 0; yb < h; yb += flush_rows) {
+        const int ye = yb + flush_rows < h ? yb + flush_rows : h;
+        unsigned long long acc[NQ] = {};
+        for (int y = yb; y < ye; ++y) {
+          u32 d[NQ + 1];
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) d[i] = q[i];
+#pragma unroll 16
+          for (int xq = 0; xq < nwq; ++xq) {
+            d[NQ] = q[xq + NQ];
+            const u32 cv = c[xq];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+              if (QSAD) {
+                acc[i] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d[i + 1] << 32) | d[i], cv, acc[i]);
+              } else {
+                tot[i][0] = __builtin_amdgcn_sad_u8(cv, d[i], tot[i][0]);
+                tot[i][1] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(d[i + 1], d[i], 1u), tot[i][1]);
+                tot[i][2] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2u), tot[i][2]);
+                tot[i][3] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(d[i + 1], d[i], 3u), tot[i][3]);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) d[i] = d[i + 1];
+          }
+          q += wsq; c += cstride;
+        }
+        if (QSAD) {
+#pragma unroll
+          for (int i = 0; i < NQ; ++i) {
+            tot[i][0] += (u32)acc[i] & 0xffffu; tot[i][1] += (u32)(acc[i] >> 16) & 0xffffu;
+            tot[i][2] += (u32)(acc[i] >> 32) & 0xffffu; tot[i][3] += (u32)(acc[i] >> 48);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) price_quad(k0 + k, r, 4 * (NQ * g + i), tot[i]);
+    }
+  };
+  auto run_width = [&](auto nq_tag, int k0, int nk) {
+    switch (wq) {
+      case 2: run_items(std::integral_constant<int, 2>(), nq_tag, k0, nk); break;
+      case 4: run_items(std::integral_constant<int, 4>(), nq_tag, k0, nk); break;
+      case 8: run_items(std::integral_constant<int, 8>(), nq_tag, k0, nk); break;
+      case 16: run_items(std::integral_constant<int, 16>(), nq_tag, k0, nk); break;
+      default: run_items(std::integral_constant<int, 0>(), nq_tag, k0, nk); break;
+    }
+  };
+
   for (int k0 = 0; k0 < n_win; k0 += per_chunk) {
     const int nk = n_win - k0 < per_chunk ? n_win - k0 : per_chunk;
     if (k0) __syncthreads();                            // the previous chunk has been read
@@ -356,65 +447,8 @@ __device__ __forceinline__ void full_search_wg(int tid, u8 *lds, int lds_bytes, 
       }
     }
     __syncthreads();
-    for (int it = tid; it < nk * items_per_win; it += T) {
-      const int k = it / items_per_win, rem = it - k * items_per_win, r = rem / groups, g = rem - r * groups;
-      const u32 *q = (const u32 *)(s_win + k * win_bytes + r * wstride) + g;
-      const u32 *c = (const u32 *)s_cur;
-      u32 tot[4] = { 0, 0, 0, 0 };
-      for (int yb = 0; yb < h; yb += flush_rows) {
-        const int ye = yb + flush_rows < h ? yb + flush_rows : h;
-        if (QSAD) {
-          unsigned long long acc = 0;
-          for (int y = yb; y < ye; ++y) {
-            u32 lo = q[0];
-            for (int xq = 0; xq < wq; ++xq) {
-              const u32 hi = q[xq + 1];
-              acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, c[xq], acc);
-              lo = hi;
-            }
-            q += wsq; c += wq;
-          }
-          tot[0] += (u32)acc & 0xffffu; tot[1] += (u32)(acc >> 16) & 0xffffu;
-          tot[2] += (u32)(acc >> 32) & 0xffffu; tot[3] += (u32)(acc >> 48);
-        } else {
-          for (int y = yb; y < ye; ++y) {
-            u32 lo = q[0];
-            for (int xq = 0; xq < wq; ++xq) {
-              const u32 hi = q[xq + 1], cv = c[xq];
-              tot[0] = __builtin_amdgcn_sad_u8(cv, lo, tot[0]);
-              tot[1] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(hi, lo, 1u), tot[1]);
-              tot[2] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(hi, lo, 2u), tot[2]);
-              tot[3] = __builtin_amdgcn_sad_u8(cv, __builtin_amdgcn_alignbyte(hi, lo, 3u), tot[3]);
-              lo = hi;
-            }
-            q += wsq; c += wq;
-          }
-        }
-      }
-      const int kk = k0 + k, cx = sh->cx[kk], cy = sh->cy[kk], mine = (int)sh->sad[kk];
-      const int y = cy + r - R;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int col = 4 * g + p, x = cx + col - R;
-        if (col >= side) continue;
-        bool skip = false;
-        if (mine >= 0) {                                   // a merge candidate's window: :936-952
-          if (!mvc.within(x * 4, y * 4)) skip = true;
-          if (x >= -R && x <= R && y >= -R && y <= R) skip = true;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j >= mine || !(mvc.usable >> j & 1u)) continue;
-            const int xx = mvc.mx[j] >> 2, yy = mvc.my[j] >> 2;
-            if (x >= xx - R && x <= xx + R && y >= yy - R && y <= yy + R) skip = true;
-          }
-        }
-        if (skip || !mvc.within(x * 4, y * 4)) continue;
-        u32 bits;
-        const u32 cost = tot[p] + mvc.cost(x, y, 2, bits);                  // < 2^32: lambda_cost is bounded by the entry
-        const unsigned long long key = ((unsigned long long)cost << 32) | (u32)(kk * side * side + r * side + col);
-        best = key < best ? key : best;
-      }
-    }
+    if (wide) run_width(std::integral_constant<int, 2>(), k0, nk);
+    else run_width(std::integral_constant<int, 1>(), k0, nk);
   }
   // ---- the smallest (cost, order) of the workgroup ----
 #pragma unroll

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--algos", default="hexbs,full8,full16,full32,full64")
     ap.add_argument("--sizes", default="8,16,32,64")
     ap.add_argument("--tune", default="")
+    ap.add_argument("--plain", action="store_true", help="PUs without merge candidates and start vector: the exhaustive search has one window")
     a = ap.parse_args()
     from kvazaar_amd import api, _lib
     from patterns import ME_REQUEST, me_frames, me_params, me_random_pus
@@ -47,6 +48,9 @@ def main():
                 prm = me_params(algorithm={"hexbs": 0, "dia": 1, "tz": 2}[algo], fme_level=4, lambda_cost=30)
             for size in [int(s) for s in a.sizes.split(",")]:
                 pus = me_random_pus(w, h, a.n, 31 + size, hint=(-10, 8), sizes=((size, size),))
+                if a.plain:
+                    pus["num_merge_cand"] = 0
+                    pus["extra_mv"] = 0
                 req = np.zeros(1, dtype=ME_REQUEST)
                 req["pic_slot"], req["n_refs"], req["cost_to_beat"] = 0, a.refs, 2147483647
                 req["ref_slot"][0, :a.refs] = 1 + np.arange(a.refs)
@@ -59,7 +63,7 @@ def main():
                     svc.search(req)
                     times.append(time.perf_counter_ns() - t0)
                 t = np.asarray(times[a.n // 10:], dtype=np.float64) / 1e3          # the first tenth warms up
-                print(json.dumps(dict(algorithm=algo, pu=size, refs=a.refs, tune=a.tune, mean_us=round(float(t.mean()), 1),
+                print(json.dumps(dict(algorithm=algo, pu=size, refs=a.refs, tune=a.tune, plain=bool(a.plain), mean_us=round(float(t.mean()), 1),
                                       median_us=round(float(np.median(t)), 1), p95_us=round(float(np.percentile(t, 95)), 1))), flush=True)
     finally:
         svc.close()
