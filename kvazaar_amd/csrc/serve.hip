@@ -51,7 +51,10 @@ constexpr int N_UPLOAD = 8;           // upload streams (put_rect)
 constexpr int N_WSTREAMS = 4;         // streams the worker generations rotate over (their own priority level, hence their own hardware queues)
 constexpr unsigned WRING_SLOTS = 4096;    // a power of two, more than any number of units in flight (max_threads x 16 is checked)
 constexpr int BATCH_CAP = 256;        // units per batch buffer (a larger batch leaves as several launches)
-constexpr uint64_t SPIN_NS = 40 * 1000;   // busy-polling phase of a caller's wait
+// busy-polling phase of a caller's wait (tuning "service_spin_us"): a search takes 25-45 us, so a caller that has a core to itself polls
+// through it (1080p --me full16, 16 threads on 16 cores: 6.6 -> 7.5 frames/s against 40 us); with more callers than cores the core
+// is needed by somebody else (48 threads: 7.6 frames/s with 40 us, 6.9 with 100)
+constexpr uint64_t SPIN_NS = 100 * 1000, SPIN_CROWDED_NS = 40 * 1000;
 constexpr long NAP_NS = 5 * 1000;         // then naps of this length (the kernel rounds them up by the thread's timer slack)
 constexpr uint64_t WAIT_LIMIT_NS = 20ull * 1000 * 1000 * 1000;    // a request that is not answered in 20 s is a failure
 
@@ -104,12 +107,14 @@ struct kvz_hip_me_service {
   uint64_t next_batch = 0;                              // touched under launch_mu only
   // resident workers
   int n_workers = 0;                                    // 0: a launch per batch
+  uint64_t spin_ns = SPIN_NS;
+  bool spin_tuned = false;
+  int host_cpus = 1;                                    // CPUs this process may run on
   serve_slot *wring = nullptr;                          // page-locked: WRING_SLOTS slots
   serve_ring_ctl *ctl = nullptr;                        // page-locked
   serve_ring_dev *wdev = nullptr;                       // device
   std::mutex ring_mu;
   unsigned long long wtail = 0;                         // under ring_mu
-  std::atomic<int> units_in_air{0};
   bool debug = false;                                   // KVZ_HIP_SERVICE_DEBUG: a line of worker statistics on stderr when the service is destroyed
   std::atomic<long long> dbg_sum_pick{0}, dbg_n_pick{0}, dbg_alive_sum{0}, dbg_alive_n{0}, dbg_hist[16] = {};
   hipStream_t wstreams[N_WSTREAMS] = {};
@@ -267,7 +272,6 @@ int post_to_ring(kvz_hip_me_service *svc, const kvz_hip_me_request *r, thread_ar
     __atomic_store_n(&slot->seq, (uint32_t)(t0 + (unsigned)i + 1), __ATOMIC_RELEASE);
   }
   svc->wtail = t0 + (unsigned)r->n_refs;
-  svc->units_in_air.fetch_add(r->n_refs, std::memory_order_relaxed);
   __atomic_store_n(&svc->ctl->tail, svc->wtail, __ATOMIC_RELEASE);
   svc->st_batches.fetch_add(1, std::memory_order_relaxed);
   svc->st_units.fetch_add((uint64_t)r->n_refs, std::memory_order_relaxed);
@@ -325,6 +329,25 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
   // "service_workers" 0 selects the launches, and so does a service with more calling threads than the ring is sized for.
   svc->n_workers = kvzhip::tuning("service_workers", 64);
   svc->debug = getenv("KVZ_HIP_SERVICE_DEBUG") != nullptr;
+  svc->spin_tuned = kvzhip::tuning("service_spin_us", -1) >= 0;
+  svc->spin_ns = 1000ull * (uint64_t)kvzhip::tuning("service_spin_us", (int)(SPIN_NS / 1000));
+  {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    svc->host_cpus = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 1;
+    // a container's share of the machine (cgroup v2 "cpu.max", v1 quota / period) when it is smaller than the affinity mask
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = "";
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+      fclose(g);
+      if (FILE *p = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(p, "%lld", &period) != 1) period = 0; fclose(p); }
+    }
+    if (quota > 0 && period > 0 && (quota + period - 1) / period < svc->host_cpus) svc->host_cpus = (int)((quota + period - 1) / period);
+  }
   if (svc->n_workers > SERVE_MAX_WORKERS) svc->n_workers = SERVE_MAX_WORKERS;
   if ((unsigned)svc->max_threads * KVZ_HIP_SERVICE_MAX_REFS > WRING_SLOTS / 2) svc->n_workers = 0;
   if (svc->n_workers > 0 && ok) {
@@ -481,7 +504,7 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
     // goes to a worker that has CPU work to do instead of to a poll loop.
     if (++spins < 256) {
       __builtin_ia32_pause();
-    } else if (now_ns() - t0 < SPIN_NS) {
+    } else if (now_ns() - t0 < (svc->spin_tuned || svc->next_thread.load(std::memory_order_relaxed) <= svc->host_cpus ? svc->spin_ns : SPIN_CROWDED_NS)) {
       sched_yield();
     } else {
       timespec nap = { 0, NAP_NS };
@@ -494,7 +517,6 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
     }
   }
   if (workers) {
-    svc->units_in_air.fetch_sub(n, std::memory_order_relaxed);
     if (svc->debug) {
       // post -> ticket taken, on two clocks: the smallest difference seen stands for "no delay" (it is a PCIe read or two)
       unsigned long long last = 0;
