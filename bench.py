@@ -328,6 +328,11 @@ def shard_kernel_leg(env, sh, steps, warmup, frames, partition):
     return dt, ms, {"sad_8x8": n8, "satd_8x8": n8, "dct_32x32": n32}, sums, per_rank
 
 
+def _dbg(msg):
+    if os.environ.get("KVZ_BENCH_DEBUG"):
+        sys.stderr.write("[rank %s] %s\n" % (os.environ.get("RANK", "0"), msg)); sys.stderr.flush()
+
+
 def shard_search_leg(env, sh, steps, warmup, frames):
     """frame after frame: reconstruction rows of frame f-1 -> extended reference buffer -> halo exchange -> motion search of
     every PU of the rank's rows of frame f"""
@@ -357,6 +362,7 @@ def shard_search_leg(env, sh, steps, warmup, frames):
                 groups.append((name, len(order), len(sel), p))
                 order += sel.tolist()
     pus_np = pus_np[np.asarray(order, dtype=np.int64)]
+    _dbg("search leg: %d PUs, groups %s" % (len(pus_np), [(g[0], g[1], g[2]) for g in groups]))
     pus = torch.from_numpy(pus_np.view(np.uint8).reshape(-1, 64)).to(dev)
     results = torch.zeros((frames, len(pus_np), 8), dtype=torch.int32, device=dev)
     staging = {}
@@ -383,8 +389,10 @@ def shard_search_leg(env, sh, steps, warmup, frames):
             if env.dist:
                 L.kvz_hip_event_record(ev_rows, st)
                 env.check(L.kvz_hip_stream_wait_event(xstream, ev_rows), "wait rows")
+                _dbg("frame %d: exchange" % f)
                 with torch.cuda.stream(xt):
                     S.exchange_halo_into(ext_ref, sh, env.dist, staging)
+                _dbg("frame %d: exchanged" % f)
                 L.kvz_hip_event_record(ev_halo, xstream)
             if ev: L.kvz_hip_event_record(ev[1], st)
             search(f, "interior")
@@ -394,7 +402,9 @@ def shard_search_leg(env, sh, steps, warmup, frames):
             search(f, "boundary")
             if ev: L.kvz_hip_event_record(ev[3], st)
 
+    _dbg("search leg: first step")
     dt = env.timed(step, steps, warmup)
+    _dbg("search leg: timed done")
     ex_ms, se_ms, bd_ms = [], [], []
     for k in range(steps):
         for f in range(frames):
@@ -406,7 +416,9 @@ def shard_search_leg(env, sh, steps, warmup, frames):
     sums = env.all_sum([len(pus_np), found, int(r["mv"].astype(np.int64).sum()), int(r["cost"].astype(np.int64).sum()),
                         int((np.abs(r["mv"][..., 0] - S.NOMINAL_MV[0]) + np.abs(r["mv"][..., 1] - S.NOMINAL_MV[1]) <= 2).sum())])
     n_boundary = sum(c for (name, _, c, _) in groups if name == "boundary")
-    L.kvz_hip_stream_sync(xstream); L.kvz_hip_stream_destroy(xstream)
+    # the exchange's stream stays alive until the process ends: torch keeps events (pinned-memory bookkeeping, collectives' work
+    # objects) that were recorded on it, and destroying it under them crashed the multi-rank run on exit from this function
+    L.kvz_hip_stream_sync(xstream)
     return dt, ex_ms, se_ms, bd_ms, sums, n_boundary
 
 
