@@ -11,7 +11,7 @@
 #   5. every entry of the ABI: TAG_bench_all_kernels.txt
 #   6. (third argument `all`) front replay, frame pipeline, served encodes: TAG_front_replay.json, TAG_front_replay_kernel_stats.csv,
 #      TAG_frame_pipeline.txt, TAG_gpu_served_encode.txt
-# The program always follows `--` directly (no env / bash -c hop).  usage: tools/gpu_profile_round.sh TAG COMMIT [all]
+# The program always follows `--` directly (no env / bash -c hop).  usage: tools/gpu_profile_round.sh TAG COMMIT [all | headline]
 set -e
 TAG=${1:-r02}
 COMMIT=${2:-unknown}
@@ -32,6 +32,7 @@ rocprofv3 --pmc FETCH_SIZE -d $O/${TAG}_prof/fetch -o p --output-format csv -- $
 rocprofv3 --pmc WRITE_SIZE -d $O/${TAG}_prof/write -o p --output-format csv -- $B > $O/${TAG}_prof/write.log 2>&1
 for p in fetch write; do python3 tools/pmc_filter.py $O/${TAG}_prof/$p sad_nxn_kernel,satd8_kernel,dct32_mfma_kernel; done
 python3 tools/pmc_traffic.py $O/${TAG}_prof/fetch $O/${TAG}_prof/write $O/${TAG}_pmc_traffic.json $COMMIT > /dev/null
+if [ "${3:-}" = "headline" ]; then echo "profile set $TAG done (headline part)"; exit 0; fi    # steps 0-2 only: after a change that leaves the other kernels alone
 tools/gpu_pmc_qr.sh ${TAG}
 # frame-level kernels: sampling and descriptor SATD
 F="python3 tools/bench_all.py --only sample_luma,image_satd --rounds 1"
