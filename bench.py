@@ -49,6 +49,7 @@ NAMES = ("sad_8x8", "satd_8x8", "dct_32x32")
 STEP_ORDER = tuple(os.environ.get("KVZ_BENCH_STEP_ORDER", "sad_8x8,satd_8x8,dct_32x32").split(","))
 assert sorted(STEP_ORDER) == sorted(NAMES)
 SEED = 12345
+SETTLE_S = float(os.environ.get("KVZ_BENCH_SETTLE_S", "0.03"))     # untimed launches before the warm-up steps (Env.timed)
 
 
 def kernel_sources_digest():
@@ -190,6 +191,17 @@ class Env:
 
     def timed(self, step, steps, warmup):
         """the contract's bracket: W untimed steps, then K steps between barrier + device sync on both sides, MAX over ranks"""
+        # Before the contract's warm-up: ~30 ms of the same launches, untimed.  A burst that starts on an idle device runs 5-10 % slower
+        # between its 3rd and 7th millisecond (clock / power management settling: profiles/r03_launch_sequence.txt lists every launch of
+        # such a run in order) -- with K = 20 steps of 0.37 ms the timed region would sit exactly there, and `value` is a steady-state rate.
+        if SETTLE_S > 0:
+            t0 = time.perf_counter()
+            for _ in range(4):
+                step(None)
+            self.sync()
+            per = max((time.perf_counter() - t0) / 4, 1e-5)
+            for _ in range(min(2000, int(SETTLE_S / per))):
+                step(None)
         for _ in range(warmup):
             step(None)
         self.sync(); self.barrier(); self.sync()
@@ -677,7 +689,10 @@ def main():
             "config": {"workload": "1080p CTU grid x %d frames per launch per GPU: sad_8x8 + satd_8x8 on %d 8x8 block pairs, "
                                    "dct_32x32 on %d int16 residual blocks, via the kvz_hip C ABI (batched 'hip' strategy entries)"
                                    % (F, blocks["sad_8x8"], blocks["dct_32x32"]),
-                       "frames_per_batch": F, "parallelism": "independent batches per GPU, no data-path collective (value); "
+                       "frames_per_batch": F,
+                       "untimed_before_warmup": "%.0f ms of the same launches (a burst on an idle device dips 5-10 %% between its 3rd and 7th "
+                                                "millisecond; KVZ_BENCH_SETTLE_S=0 switches it off)" % (SETTLE_S * 1e3),
+                       "parallelism": "independent batches per GPU, no data-path collective (value); "
                                                              "CTU-row shards of one fixed 4K batch + RCCL halo exchange (shard_4k)"},
             "kernels": kern,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -29,6 +29,9 @@ def main():
         du, ga = sorted(d["dur"]), sorted(d["gap"]) or [0.0]
         print("%-12s %9d %19.1f %7.1f %7.1f %7.1f %6.1f | %27.1f %7.1f %7.1f"
               % (k, len(du), sum(du) / len(du), du[len(du) // 2], du[0], du[-1], du[int(len(du) * 0.9)], sum(ga) / len(ga), ga[len(ga) // 2], ga[-1]))
+    # the launches in the order they ran (warm-up first): is the spread a drift, an alternation, or scattered?
+    for k, d in per.items():
+        print("%-10s in order: %s" % (k, " ".join("%.0f" % v for v in d["dur"])))
     if rows:
         first, last = rows[0][0], rows[-1][1]
         busy = sum(e - s for (s, e, _) in rows)
