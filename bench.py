@@ -200,7 +200,12 @@ class Env:
                 step(None)
             self.sync()
             per = max((time.perf_counter() - t0) / 4, 1e-5)
-            for _ in range(min(2000, int(SETTLE_S / per))):
+            n = min(2000, int(SETTLE_S / per))
+            if self.dist:                                # a step may hold an exchange: every rank runs the same number of them
+                t = self.torch.tensor([n], dtype=self.torch.int64, device=self.red_dev)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+                n = int(t.item())
+            for _ in range(n):
                 step(None)
         for _ in range(warmup):
             step(None)
