@@ -130,45 +130,45 @@ def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case,
         svc.close()
 
 
+@pytest.mark.parametrize("algorithm", [0, 3], ids=["hexbs", "full8"])
 @pytest.mark.parametrize("workers", [0, 64], ids=["launches", "resident_workers"])
-def test_pictures_replaced_between_requests_are_seen(api, workers):
-    """A slot's picture is overwritten between requests, dozens of times, while the same workgroups stay on the device: a search
-    posted after put_rect returned must read the new pixels (nothing stale in a CU's vector cache or an XCD's L2), whole pictures
-    and rectangles alike.  The same PUs every time, so the same addresses are read over and over."""
+def test_pictures_replaced_between_requests_are_seen(api, workers, algorithm):
+    """The pictures in the slots -- the one being coded and the reference -- are overwritten between requests, dozens of times, while the
+    same workgroups stay on the device: a search posted after put_rect returned must read the new pixels (nothing stale in a CU's vector
+    cache, in the scalar cache the exhaustive search reads the current block through, or in an XCD's L2), whole pictures and rectangles
+    alike.  The same PUs every time, so the same addresses are read over and over."""
     from kvazaar_amd import _lib
     for key, value in ((b"service_workers", workers), (b"service_linger_us", 5000)):
         _lib.check(_lib.load().kvz_hip_set_tuning(key, value), "tuning")
     w, h = 256, 192
-    prm = me_params(lambda_cost=21)
+    prm = me_params(lambda_cost=21, algorithm=algorithm, search_range=8)
     pics = [me_frames(w, h, 700 + k, motion) for k, motion in enumerate(((2, 1), (-4, 3), (6, -5)))]
-    pic = pics[0][0]
+    srcs = [pics[0][0], pics[1][0]]
     refs = [p[1] for p in pics]
-    pus = me_random_pus(w, h, 24, 5151, hint=(8, 4))
-    big = np.uint32(MAX_INT)
-    want = [np.asarray(O.search_pu_batch(pic, r, pus, prm, cost_to_beat=np.full(len(pus), big, np.uint32))).view(np.int32).reshape(len(pus), 8) for r in refs]
-    # a picture that is half one reference, half another (the lower part arrives as a rectangle later)
-    mixed = refs[0].copy()
+    mixed = refs[0].copy()                                      # half one reference, half another (the lower part arrives as a rectangle)
     mixed[96:] = refs[1][96:]
-    want_mixed = np.asarray(O.search_pu_batch(pic, mixed, pus, prm, cost_to_beat=np.full(len(pus), big, np.uint32))).view(np.int32).reshape(len(pus), 8)
+    refs.append(mixed)
+    pus = me_random_pus(w, h, 20, 5151, hint=(8, 4))
+    big = np.full(len(pus), MAX_INT, np.uint32)
+    want = {(a, b): np.asarray(O.search_pu_batch(srcs[a], refs[b], pus, prm, cost_to_beat=big)).view(np.int32).reshape(len(pus), 8)
+            for a in range(2) for b in range(4)}
     svc = api.MeService(w, h, max_pictures=3, max_threads=4)
     try:
-        svc.put_plane(0, pic)
         req = np.zeros(1, dtype=ME_REQUEST)
         req["pic_slot"], req["n_refs"], req["cost_to_beat"] = 0, 1, MAX_INT
         req["ref_slot"][0, 0] = 1
         req["params"] = prm[0]
-        for it in range(36):
-            k = it % 4
-            if k < 3:
-                svc.put_plane(1, refs[k])
-                expect = want[k]
+        for it in range(32):
+            a, b = (it // 2) % 2, (it * 3 + it // 5) % 4
+            svc.put_plane(0, srcs[a])
+            if b < 3:
+                svc.put_plane(1, refs[b])
             else:
                 svc.put_plane(1, refs[0])
                 svc.put_rect(1, refs[1], 0, 96, w, h - 96)
-                expect = want_mixed
             for i in range(len(pus)):
                 req["pu"][0, 0] = pus[i]
-                np.testing.assert_array_equal(svc.search(req)[0], expect[i], err_msg="iteration %d PU %d" % (it, i))
+                np.testing.assert_array_equal(svc.search(req)[0], want[(a, b)][i], err_msg="iteration %d (source %d, reference %d) PU %d" % (it, a, b, i))
     finally:
         for key in (b"service_workers", b"service_linger_us"):
             _lib.load().kvz_hip_set_tuning(key, -1)
