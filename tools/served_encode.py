@@ -56,7 +56,9 @@ def run(w, h, n, opts, threads, min_sizes, seed=5, repeat=1, shadow=False, probe
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
                 same = same and served == plain
-            row = dict(size="%dx%d" % (w, h), frames=n, opts=o, threads=t, min_pu_served=ms,
+            tune = dict(kv.split("=") for kv in os.environ.get("KVZ_HIP_TUNE", "").split(",") if "=" in kv)
+            way = "launch_per_batch" if tune.get("service_workers") == "0" else "resident_workers"   # (`launches` then counts worker start-ups)
+            row = dict(size="%dx%d" % (w, h), frames=n, opts=o, threads=t, min_pu_served=ms, service=way,
                        fps_untouched=round(n / best_plain, 3), fps_served=round(n / best, 3),
                        identical_bitstream=bool(same), searches_served=c["served"], searches_left_to_cpu=c["passed_on"], failed=c["failed"],
                        batches=c["batches"], launches=c["launches"],
