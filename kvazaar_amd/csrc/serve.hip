@@ -134,15 +134,21 @@ struct kvz_hip_me_service {
 namespace {
 
 std::atomic<uint64_t> g_service_ids{1};
+// A calling thread's place in each service it has used (a result area of its own, a row of statistics): remembered per thread for
+// the last few services, so that a thread that alternates between two encoder instances does not take a new place at every switch.
 struct thread_binding { uint64_t id; int slot; };
-thread_local thread_binding t_bind = { 0, -1 };
+constexpr int N_BINDINGS = 8;
+thread_local thread_binding t_bind[N_BINDINGS] = {};
+thread_local unsigned t_bind_next = 0;
 
 int thread_slot(kvz_hip_me_service *svc)
 {
-  if (t_bind.id == svc->id) return t_bind.slot;
+  for (int i = 0; i < N_BINDINGS; ++i)
+    if (t_bind[i].id == svc->id) return t_bind[i].slot;
   const int s = svc->next_thread.fetch_add(1);
   if (s >= svc->max_threads) return -1;
-  t_bind.id = svc->id; t_bind.slot = s;
+  thread_binding &b = t_bind[t_bind_next++ % N_BINDINGS];      // the oldest remembered service gives way (its place stays taken there)
+  b.id = svc->id; b.slot = s;
   prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);          // this thread's naps (see kvz_hip_me_service_search) end on time: 1 us of slack instead of 50
   return s;
 }

@@ -175,6 +175,47 @@ def test_pictures_replaced_between_requests_are_seen(api, workers, algorithm):
         svc.close()
 
 
+def test_two_services_at_once_and_the_fallback_for_many_threads(api):
+    """Two services alive on one device, each with its own resident workers, used alternately from several threads; a third one sized
+    for more calling threads than the ring serves (> 128) answers through a launch per batch by itself."""
+    prm = me_params(lambda_cost=17)
+    sizes = ((192, 128), (256, 192))
+    data = []
+    for k, (w, h) in enumerate(sizes):
+        pic, ref = me_frames(w, h, 810 + k, (3 - 5 * k, 2))
+        pus = me_random_pus(w, h, 16, 6000 + k, hint=(4, -4))
+        want = np.asarray(O.search_pu_batch(pic, ref, pus, prm, cost_to_beat=np.full(len(pus), MAX_INT, np.uint32))).view(np.int32).reshape(len(pus), 8)
+        data.append((pic, ref, pus, want))
+    svcs = [api.MeService(w, h, max_pictures=2, max_threads=8) for (w, h) in sizes]
+    big = api.MeService(192, 128, max_pictures=2, max_threads=200)
+    try:
+        for svc, (pic, ref, _, _) in zip(svcs + [big], data + [data[0]]):
+            svc.put_plane(0, pic)
+            svc.put_plane(1, ref)
+
+        def one(job):
+            which, i = job
+            svc = (svcs + [big])[which]
+            _, _, pus, want = data[which if which < 2 else 0]
+            req = np.zeros(1, dtype=ME_REQUEST)
+            req["pic_slot"], req["n_refs"], req["cost_to_beat"] = 0, 1, MAX_INT
+            req["ref_slot"][0, 0] = 1
+            req["params"] = prm[0]
+            req["pu"][0, 0] = pus[i]
+            np.testing.assert_array_equal(svc.search(req)[0], want[i], err_msg="service %d PU %d" % (which, i))
+            return which
+
+        jobs = [(which, i) for rep in range(6) for i in range(16) for which in range(3)]
+        with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+            assert sum(1 for _ in ex.map(one, jobs)) == len(jobs)
+        st = [s.stats() for s in svcs + [big]]
+        assert st[0]["max_batch_units"] == 0 and st[1]["max_batch_units"] == 0          # resident workers: no batches
+        assert st[2]["max_batch_units"] >= 1 and st[2]["launches"] >= 1                   # the fallback: a launch per batch
+    finally:
+        for s in svcs + [big]:
+            s.close()
+
+
 def test_service_refuses_bad_requests(api):
     from kvazaar_amd._lib import KvzHipError
     svc = api.MeService(64, 64, max_pictures=2, max_threads=2)
