@@ -53,12 +53,13 @@ SETTLE_S = float(os.environ.get("KVZ_BENCH_SETTLE_S", "0.03"))     # untimed lau
 
 
 def kernel_sources_digest():
-    """sha1 over the kernel sources: ties a committed PMC capture (profiles/pmc_traffic.json) to the code it was taken on"""
+    """sha1 over the sources of the three headline kernels (sad_nxn_kernel / satd8_kernel: picture.hip + satd_regs.h; dct32_mfma_kernel:
+    dct32_mfma.hip + dct32_mfma_core.h + transform_core.h; kvz_hip_internal.h): ties a committed PMC capture (profiles/pmc_traffic.json) to the code whose
+    traffic it measured -- an edit elsewhere in csrc/ cannot change what these kernels read and write"""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "kvazaar_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("dct32_mfma.hip", "dct32_mfma_core.h", "kvz_hip_internal.h", "picture.hip", "satd_regs.h", "transform_core.h"):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
