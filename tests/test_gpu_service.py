@@ -175,6 +175,35 @@ def test_pictures_replaced_between_requests_are_seen(api, workers, algorithm):
         svc.close()
 
 
+@pytest.mark.parametrize("workers", [0, 32], ids=["launches", "resident_workers"])
+def test_exhaustive_search_of_amp_and_smp_shapes(api, workers):
+    """the service's exhaustive search on the PU shapes of --smp / --amp (widths that are 4 mod 8: the any-width row loop, 4- and 12-pixel
+    rows) and on 48-wide ones, against the oracle"""
+    from kvazaar_amd import _lib
+    _lib.check(_lib.load().kvz_hip_set_tuning(b"service_workers", workers), "tuning")
+    w, h = 192, 128
+    shapes = ((12, 16), (16, 12), (4, 8), (8, 4), (16, 4), (4, 16), (48, 64), (64, 48), (24, 32), (32, 24), (64, 16), (16, 64))
+    pic, ref = me_frames(w, h, 911, (-3, 2))
+    svc = api.MeService(w, h, max_pictures=2, max_threads=4)
+    try:
+        svc.put_plane(0, pic)
+        svc.put_plane(1, ref)
+        for rng, fme in ((8, 4), (19, 1)):
+            prm = me_params(algorithm=3, search_range=rng, fme_level=fme, lambda_cost=23)
+            pus = me_random_pus(w, h, 48, 7300 + rng, hint=(-12, 8), sizes=shapes)
+            want = np.asarray(O.search_pu_batch(pic, ref, pus, prm, cost_to_beat=np.full(len(pus), MAX_INT, np.uint32))).view(np.int32).reshape(len(pus), 8)
+            req = np.zeros(1, dtype=ME_REQUEST)
+            req["pic_slot"], req["n_refs"], req["cost_to_beat"] = 0, 1, MAX_INT
+            req["ref_slot"][0, 0] = 1
+            req["params"] = prm[0]
+            for i in range(len(pus)):
+                req["pu"][0, 0] = pus[i]
+                np.testing.assert_array_equal(svc.search(req)[0], want[i], err_msg="range %d PU %d (%dx%d)" % (rng, i, pus[i]["width"], pus[i]["height"]))
+    finally:
+        _lib.load().kvz_hip_set_tuning(b"service_workers", -1)
+        svc.close()
+
+
 def test_two_services_at_once_and_the_fallback_for_many_threads(api):
     """Two services alive on one device, each with its own resident workers, used alternately from several threads; a third one sized
     for more calling threads than the ring serves (> 128) answers through a launch per batch by itself."""
