@@ -512,7 +512,8 @@ KVZ_HIP_API void kvz_hip_me_service_destroy(kvz_hip_me_service *svc);
  * return, so a request posted afterwards by any thread reads it. */
 KVZ_HIP_API int kvz_hip_me_service_put_rect(kvz_hip_me_service *svc, int slot, const kvz_hip_pixel *host, uint32_t host_stride,
                                             int x, int y, int w, int h);
-/* Blocks until the request's results[0 .. n_refs - 1] are there. */
+/* Blocks until the request's results[0 .. n_refs - 1] are there.  KVZ_HIP_ERR_INVALID for a malformed request (slots, n_refs, parameters,
+ * mv_rdo; with the exhaustive search a pu.x that is not a multiple of 4) or PU (outside the picture, impossible shape). */
 KVZ_HIP_API int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request *req, kvz_hip_me_result *results);
 KVZ_HIP_API int kvz_hip_me_service_get_stats(kvz_hip_me_service *svc, kvz_hip_me_service_stats *out);
 /* The device plane of a slot, for a host that wants to run another batched entry on the resident pictures. */

@@ -293,6 +293,10 @@ bool request_ok(const kvz_hip_me_service *svc, const kvz_hip_me_request *r)
   if (p.lambda_cost < 0 || p.lambda_cost > (1 << 20) || p.fme_level < 0 || p.fme_level > 4 || p.early_termination < 0 || p.early_termination > 2 ||
       p.algorithm < 0 || p.algorithm > 3 || (p.algorithm == 3 && (p.search_range < 1 || p.search_range > 64)) || p.mv_rdo) return false;
   if (p.mv_constraint < 0 || p.mv_constraint > 4) return false;
+  // the exhaustive search reads the current block with scalar loads: dword-aligned addresses, i.e. PUs at multiples of 4 (every HEVC PU is)
+  if (p.algorithm == 3)
+    for (int i = 0; i < r->n_refs; ++i)
+      if (r->pu[i].x & 3) return false;
   if (!(p.tile_w == 0 && p.tile_h == 0) &&
       (p.tile_x < 0 || p.tile_y < 0 || p.tile_w <= 0 || p.tile_h <= 0 || p.tile_x + p.tile_w > svc->w || p.tile_y + p.tile_h > svc->h ||
        (p.wpp_owf && ((p.tile_x & 63) || (p.tile_y & 63))))) return false;
@@ -461,7 +465,7 @@ int kvz_hip_me_service_put_rect(kvz_hip_me_service *svc, int slot, const kvz_hip
 int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request *req, kvz_hip_me_result *results)
 {
   if (!svc || !req || !results) return kvzhip::invalid_arg(__func__);
-  if (!request_ok(svc, req)) { set_error_msg("kvz_hip_me_service_search: bad request (slots, n_refs, parameters; mv_rdo is not served)"); return KVZ_HIP_ERR_INVALID; }
+  if (!request_ok(svc, req)) { set_error_msg("kvz_hip_me_service_search: bad request (slots, n_refs, parameters; mv_rdo is not served; the exhaustive search wants pu.x a multiple of 4)"); return KVZ_HIP_ERR_INVALID; }
   if (svc->failed.load()) { set_error_msg("kvz_hip_me_service_search: the service has failed earlier"); return KVZ_HIP_ERR_RUNTIME; }
   const int ts = thread_slot(svc);
   if (ts < 0) { set_error_msg("kvz_hip_me_service_search: more calling threads than max_threads"); return KVZ_HIP_ERR_INVALID; }

@@ -272,6 +272,12 @@ def test_service_refuses_bad_requests(api):
         with pytest.raises(KvzHipError):
             svc.search(bad)
         bad = req.copy()
+        bad["params"]["algorithm"], bad["params"]["search_range"] = 3, 8
+        assert svc.search(bad).shape == (1, 8)
+        bad["pu"][0, 0]["x"] = 2                                # the exhaustive search reads the block with dword-aligned scalar loads
+        with pytest.raises(KvzHipError):
+            svc.search(bad)
+        bad = req.copy()
         bad["pu"][0, 0]["x"] = 56                               # the PU leaves the picture: flagged by the kernel
         with pytest.raises(KvzHipError):
             svc.search(bad)
