@@ -387,7 +387,7 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
     kvz_hip_me_service_destroy(svc);
     return nullptr;
   }
-  (void)hipDeviceSynchronize();
+  (void)hipStreamSynchronize(nullptr);                 // the memsets above; not hipDeviceSynchronize: another service's resident workers may be running
   return svc;
 }
 
