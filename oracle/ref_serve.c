@@ -65,6 +65,7 @@ static struct {
   int (*init)(int);
   const char *(*last_error)(void);
   int w, h, min_size, shadow, probe;
+  int upload_only;                      /* flags bit 5: the pictures travel as usual, every search stays with the reference (what the uploads alone cost an encode) */
   int table_range;                      /* > 0: SAD-table mode (the search stays with the reference, kvz_image_calc_sad is answered from tables) */
   const uint32_t *(*sad_tables)(kvz_hip_me_service *, int, int, const int32_t *, int, int, int);
   long long tab_hits, tab_range_misses, tab_other, tab_ns;
@@ -119,6 +120,7 @@ int ref_service_begin(const char *lib_path, int w, int h, int max_threads, int m
   g_svc.svc = g_svc.create(&cfg);
   if (!g_svc.svc) { fprintf(stderr, "kvz_hip_me_service_create: %s\n", g_svc.last_error()); return -1; }
   g_svc.w = w; g_svc.h = h; g_svc.min_size = min_size; g_svc.shadow = flags & 1; g_svc.probe = (flags >> 1) & 1;
+  g_svc.upload_only = (flags >> 5) & 1;
   g_svc.table_range = (flags >> 8) & 0xff;
   g_svc.spec_probe = (flags >> 3) & 1;
   pthread_mutex_init(&g_svc.table_mu, NULL);
@@ -434,6 +436,11 @@ int svc_serve_cu_inter(encoder_state_t *state, int x, int y, int depth, lcu_t *l
   req.pic_slot = t_last_ctu.pic_slot;
   for (int i = 0; i < nref; ++i) req.ref_slot[i] = t_last_ctu.ref_slot[i];
   long long t1 = svc_now_ns();
+  if (g_svc.upload_only) {
+    if (new_ctu) __atomic_add_fetch(&g_svc.upload_ns, t1 - t0, __ATOMIC_RELAXED);
+    __atomic_add_fetch(&g_svc.passed_on, 1, __ATOMIC_RELAXED);
+    return 0;
+  }
   if (g_svc.table_range > 0) {
     /* SAD-table mode: the search stays with the reference; a new CTU gets its tables (every reference picture, +-range) first */
     if (new_ctu || !t_tab.valid) {

@@ -651,13 +651,15 @@ def encode_with_gpu_search(frames, w, h, opts, lib_path, strategy=None, deblock=
     return bitstream, c
 
 
-def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8, shadow=False, probe=False, table_range=0, spec_probe=False, host_only=False):
+def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8, shadow=False, probe=False, table_range=0, spec_probe=False, host_only=False,
+                        upload_only=False):
     """ref_encode with every 2Nx2N inter search of the encoder answered by the product's search service
     (kvz_hip_me_service_search; oracle/ref_serve.c), from all of the encoder's own worker threads at once.
     min_size: PUs narrower than this run the reference's own search.  shadow: every served search is repeated by the
     reference's search and compared (the reference's result is kept).  table_range > 0: nothing of the search is served; each worker
     fetches kvz_hip_me_service_sad_tables (+-table_range) when it starts a CTU and the encoder's kvz_image_calc_sad calls are answered
     from them (table_hits / table_range_misses / table_other_calls, tables, table_bytes, table_ns in the result).
+    upload_only: the pictures are uploaded as for a served run (at the first 2Nx2N search of at least min_size of a CTU), every search stays with the reference.
     host_only: no device library is opened and nothing is served (probe / spec_probe only; runs without a GPU).  spec_probe: per CU size, how
     many searches' candidates (merge list, AMVP pairs, start vectors) derived from the lcu as it was when the CTU started equal the real ones.
     -> (bitstream, dict(served, passed_on, failed, shadow_mismatch, upload_rects, search_wait_ns, upload_ns, cand_ns,
@@ -667,11 +669,14 @@ def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8
     L.ref_service_begin.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.ref_service_end.restype = None
     L.ref_service_end.argtypes = [C.POINTER(C.c_longlong)]
-    assert L.ref_service_begin(lib_path.encode(), w, h, max_threads, min_size, (1 if shadow else 0) | (2 if probe or host_only else 0) | (8 if spec_probe else 0) | (16 if host_only else 0) | (int(table_range) << 8)) == 0
+    assert L.ref_service_begin(lib_path.encode(), w, h, max_threads, min_size, (1 if shadow else 0) | (2 if probe or host_only else 0) | (8 if spec_probe else 0) | (16 if host_only else 0) | (32 if upload_only else 0) | (int(table_range) << 8)) == 0
     out = (C.c_longlong * 32)()
+    import time as _time
+    t_enc = _time.perf_counter()
     try:
         bitstream, _ = encode(frames, w, h, opts)
     finally:
+        t_enc = _time.perf_counter() - t_enc           # the encode alone: a session creates its service once (device planes, page-locked areas)
         L.ref_service_end(out)
     keys = ("served", "passed_on", "failed", "shadow_mismatch", "upload_rects", "search_wait_ns", "upload_ns", "cand_ns",
             "requests", "units", "batches", "launches", "max_batch_units", "rects", "rect_bytes", "wait_ns")
@@ -683,6 +688,7 @@ def encode_with_service(frames, w, h, opts, lib_path, max_threads=64, min_size=8
         c = {}
         c["spec_searches"] = {64 >> i: int(out[8 + i]) for i in range(4)}
         c["spec_same"] = {64 >> i: int(out[12 + i]) for i in range(4)}
+    c["encode_s"] = t_enc
     if probe or host_only:       # nothing served: the reference's own kvz_search_cu_inter timed per CU size
         c["probe_us_per_search"] = {64 >> i: round(out[16 + i] / 1e3 / max(1, out[20 + i]), 2) for i in range(4)}
         c["probe_searches"] = {64 >> i: int(out[20 + i]) for i in range(4)}

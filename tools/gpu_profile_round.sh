@@ -11,13 +11,14 @@
 #   5. every entry of the ABI: TAG_bench_all_kernels.txt
 #   6. (third argument `all`) front replay, frame pipeline, served encodes: TAG_front_replay.json, TAG_front_replay_kernel_stats.csv,
 #      TAG_frame_pipeline.txt, TAG_gpu_served_encode.txt
-# The program always follows `--` directly (no env / bash -c hop).  usage: tools/gpu_profile_round.sh TAG COMMIT [all | headline]
+# The program always follows `--` directly (no env / bash -c hop).  usage: tools/gpu_profile_round.sh TAG COMMIT [all | headline | service]
 set -e
 TAG=${1:-r02}
 COMMIT=${2:-unknown}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O/${TAG}_prof
+if [ "${3:-}" != "service" ]; then       # `service`: step 7 only (the search service and the served encodes)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_prof/bench.log
 ONLY="--no-shard-leg --no-reference-workload --no-encoder-leg"
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof/stats -o p --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 $ONLY > $O/${TAG}_bench_profiled.json 2> $O/${TAG}_prof/stats.log
@@ -55,17 +56,18 @@ if [ "${3:-}" = "all" ]; then
   rm -rf $O/${TAG}_prof/fr /tmp/kvz_case0.bin
   python3 -m pytest tests/test_gpu_dropin.py -m gpu -q -s -k "served or deblocked_by_one" 2>&1 | grep -E "frames: |frames, untouched|passed|failed" > $O/${TAG}_gpu_served_encode.txt
 fi
+fi
 #   7. the search service: C pthread hosts hammering it, and the reference encoder with its own thread pool served by it /
 #      with its SADs answered from tables, each next to the untouched encoder at the same thread count
 (for t in 1 4 16 48; do tests/c_host/service_stress $t 1500; done) > $O/${TAG}_service_stress.txt 2>&1 || true
 # 16 closed-loop C threads at 1080p, four pictures: resident workers against a launch per batch, without / with 60 us of work between a thread's requests
 (export KVZ_HIP_SERVICE_DEBUG=1; for wk in 64 0; do for think in 0 60; do echo "== service_workers=$wk think_us=$think"; KVZ_HIP_TUNE=service_workers=$wk tests/c_host/service_stress 16 8000 1920 1080 4 $think | grep -v "^single"; done; done) > $O/${TAG}_service_stress_1080p.txt 2>&1 || true
 python3 tools/service_latency.py --algos hexbs,full8,full16,full32 > $O/${TAG}_service_latency_by_size.jsonl 2> $O/${TAG}_prof/lat.err || true
-python3 tools/served_encode.py --size 1920x1080 --frames 16 --threads 16 --min-size 8,16,32,64 --tables 16 --probe > $O/${TAG}_served_encode_1080p_medium.jsonl 2> $O/${TAG}_prof/served1.err || true
+python3 tools/served_encode.py --size 1920x1080 --frames 16 --threads 16 --min-size 8,16,32,64 --tables 16 --probe --upload-only > $O/${TAG}_served_encode_1080p_medium.jsonl 2> $O/${TAG}_prof/served1.err || true
 KVZ_HIP_TUNE=service_workers=0 python3 tools/served_encode.py --size 1920x1080 --frames 16 --threads 16 --min-size 8,32 > $O/${TAG}_served_encode_1080p_medium_launches.jsonl 2> $O/${TAG}_prof/served1b.err || true
 KVZ_HIP_SERVICE_DEBUG=1 python3 tools/served_encode.py --size 1920x1080 --frames 16 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 8,16 --tables 16 --probe > $O/${TAG}_served_encode_1080p_full16.jsonl 2> $O/${TAG}_served_encode_1080p_full16_worker_stats.txt || true
 KVZ_HIP_TUNE=service_workers=0 python3 tools/served_encode.py --size 1920x1080 --frames 16 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 8 > $O/${TAG}_served_encode_1080p_full16_launches.jsonl 2> $O/${TAG}_prof/served2b.err || true
 python3 tools/served_encode.py --size 1920x1080 --frames 4 --opts preset=medium,qp=32,me=full32 --threads 16 --min-size 8 > $O/${TAG}_served_encode_1080p_full32.jsonl 2> $O/${TAG}_prof/served2c.err || true
 python3 tools/served_encode.py --size 3840x2160 --frames 8 --threads 16 --min-size 8,32,64 --probe > $O/${TAG}_served_encode_4k_medium.jsonl 2> $O/${TAG}_prof/served3.err || true
-python3 tools/served_encode.py --size 3840x2160 --frames 4 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 8 > $O/${TAG}_served_encode_4k_full16.jsonl 2> $O/${TAG}_prof/served4.err || true
+python3 tools/served_encode.py --size 3840x2160 --frames 8 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 8 > $O/${TAG}_served_encode_4k_full16.jsonl 2> $O/${TAG}_prof/served4.err || true
 echo "profile set $TAG done"
