@@ -15,6 +15,7 @@
 // reference pixels come from L2/HBM with the clamp addressing of image_interpolated_sad
 // (image.c:320-444).  The fractional stage is frac_core.h with the MV cost model plugged in.
 #include "kvz_hip_internal.h"
+#include "serve_seq.h"
 #include <type_traits>
 #include "frac_core.h"
 
@@ -1215,7 +1216,7 @@ __global__ __launch_bounds__(512) void serve_worker_kernel(const u8 *__restrict_
         u32 v = 0;
         if (tid <= UNIT_DWORDS) v = sys_load32(reinterpret_cast<const u32 *>(slot) + tid);      // dword UNIT_DWORDS is slot->seq
         const u32 seq = (u32)__shfl((int)v, UNIT_DWORDS, 64);
-        if (seq == (u32)(ticket + 1)) {
+        if (seq == serve_seq(ticket)) {
           if (tid < UNIT_DWORDS) s_unit[tid] = v;
           break;
         }

@@ -19,7 +19,7 @@
 //
 // Resident workers (tuning "service_workers" > 0): the same requests without a launch on their way.  Workgroups of
 // me_search.hip's serve_worker_kernel stay on the device and take units by ticket from a ring of slots in page-locked memory:
-//   host, under ring_mu:  wait until slot.seq == 0, write the unit, slot.seq = ticket + 1, ... ctl->tail += n      (publish)
+//   host, under ring_mu:  wait until slot.seq == 0, write the unit, slot.seq = serve_seq(ticket), ... ctl->tail += n      (publish)
 //   worker:               ticket = head++ while head < tail (device atomics; ctl->tail is read across PCIe by one worker at a
 //                         time and mirrored in device memory), copy the unit, slot.seq = 0, search, write the results and `done`.
 //   Workers leave when they have found no work for `service_linger_us`, or at the first idle moment after `service_life_ms`, or when
@@ -29,6 +29,7 @@
 //   by a caller that finds the worker gone.  alive[w] has one writer at a time: the host sets it when it launches worker w, which it
 //   only does when it reads 0; the worker clears it once.
 #include "kvz_hip_internal.h"
+#include "serve_seq.h"
 
 #include <sched.h>
 #include <sys/prctl.h>
@@ -275,7 +276,7 @@ int post_to_ring(kvz_hip_me_service *svc, const kvz_hip_me_request *r, thread_ar
     u.prm = r->params;
     u.prm.cost_to_beat = nullptr; u.prm.cabac = nullptr; u.prm.mv_rdo = 0; u.prm.size_classes = 0;
     if (u.prm.tile_w == 0 && u.prm.tile_h == 0) { u.prm.tile_x = 0; u.prm.tile_y = 0; u.prm.tile_w = svc->w; u.prm.tile_h = svc->h; }
-    __atomic_store_n(&slot->seq, (uint32_t)(t0 + (unsigned)i + 1), __ATOMIC_RELEASE);
+    __atomic_store_n(&slot->seq, serve_seq(t0 + (unsigned)i), __ATOMIC_RELEASE);
   }
   svc->wtail = t0 + (unsigned)r->n_refs;
   __atomic_store_n(&svc->ctl->tail, svc->wtail, __ATOMIC_RELEASE);
@@ -370,6 +371,16 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
     ok = ok && hipMalloc((void **)&svc->wdev, sizeof(serve_ring_dev)) == hipSuccess;
     ok = ok && hipMemset(svc->wdev, 0, sizeof(serve_ring_dev)) == hipSuccess;
     if (ok) { std::memset(svc->wring, 0, sizeof(serve_slot) * WRING_SLOTS); std::memset(svc->ctl, 0, sizeof(serve_ring_ctl)); }
+    // tickets normally start at 0; "service_ticket_base_k" (x 1024) starts them elsewhere, so that a test can walk the counters across
+    // 2^32 in seconds instead of an hour of full load
+    const unsigned long long base = 1024ull * (unsigned long long)kvzhip::tuning("service_ticket_base_k", 0);
+    if (ok && base) {
+      serve_ring_dev d0;
+      std::memset(&d0, 0, sizeof(d0));
+      d0.head = base; d0.tail = base;
+      ok = hipMemcpy(svc->wdev, &d0, sizeof(d0), hipMemcpyHostToDevice) == hipSuccess;
+      svc->wtail = base; svc->ctl->tail = base;
+    }
     int least = 0, greatest = 0;
     ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
     for (int i = 0; i < N_WSTREAMS && ok; ++i) ok = hipStreamCreateWithPriority(&svc->wstreams[i], hipStreamNonBlocking, greatest) == hipSuccess;

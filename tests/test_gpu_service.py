@@ -204,6 +204,42 @@ def test_exhaustive_search_of_amp_and_smp_shapes(api, workers):
         svc.close()
 
 
+def test_ring_tickets_across_two_to_the_32(api):
+    """the ring's ticket counters are 64-bit, the slots' sequence words 32-bit and never 0 ("free"): requests posted while the ticket count
+    passes 2^32 (the service started just below it) are answered like any other"""
+    from kvazaar_amd import _lib
+    _lib.check(_lib.load().kvz_hip_set_tuning(b"service_ticket_base_k", 4194303), "tuning")      # 2^32 - 1024
+    try:
+        w, h = 192, 128
+        prm = me_params(lambda_cost=19)
+        pic, ref = me_frames(w, h, 931, (2, -3))
+        pus = me_random_pus(w, h, 40, 7700, hint=(8, -12))
+        want = np.asarray(O.search_pu_batch(pic, ref, pus, prm, cost_to_beat=np.full(len(pus), MAX_INT, np.uint32))).view(np.int32).reshape(len(pus), 8)
+        svc = api.MeService(w, h, max_pictures=2, max_threads=8)
+        try:
+            svc.put_plane(0, pic)
+            svc.put_plane(1, ref)
+
+            def one(i):
+                req = np.zeros(1, dtype=ME_REQUEST)
+                req["pic_slot"], req["n_refs"], req["cost_to_beat"] = 0, 2, MAX_INT
+                req["ref_slot"][0, :2] = 1
+                req["params"] = prm[0]
+                req["pu"][0, 0] = pus[i % len(pus)]
+                req["pu"][0, 1] = pus[i % len(pus)]
+                got = svc.search(req)
+                np.testing.assert_array_equal(got[0], want[i % len(pus)], err_msg="request %d" % i)
+                return 1
+
+            with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+                assert sum(ex.map(one, range(1200))) == 1200            # 2400 units: tickets 2^32 - 1024 .. 2^32 + 1376
+            assert svc.stats()["units"] == 2400
+        finally:
+            svc.close()
+    finally:
+        _lib.load().kvz_hip_set_tuning(b"service_ticket_base_k", -1)
+
+
 def test_two_services_at_once_and_the_fallback_for_many_threads(api):
     """Two services alive on one device, each with its own resident workers, used alternately from several threads; a third one sized
     for more calling threads than the ring serves (> 128) answers through a launch per batch by itself."""
