@@ -98,8 +98,8 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * byte-aligned operands instead of four alignments per v_qsad_pk_u16_u8), "sample8_wave" (0: 8x8 luma blocks of the sampling entry
  * on the general path), "service_workers" (resident workgroups of the search service, 0: a launch per batch), "service_linger_us" /
  * "service_life_ms" (how long they stay without work / at most), "service_inflight" / "service_streams" (batches in the air and
- * launch streams of the launch-per-batch way), "service_spin_us" (how long a caller polls for its answer before it naps: 100 with a core
- * per caller, 40 otherwise), "service_ticket_base_k" (tests: first ticket of the ring x 1024); the service reads its knobs when it is created.  KVZ_HIP_SERVICE_DEBUG in the
+ * launch streams of the launch-per-batch way), "service_spin_us" / "service_spin_crowded_us" / "service_nap_us" (how long a caller polls for its answer
+ * before it naps: 100 us with a core per caller, 5 us and naps of 10 us with more callers than cores), "service_ticket_base_k" (tests: first ticket of the ring x 1024); the service reads its knobs when it is created.  KVZ_HIP_SERVICE_DEBUG in the
  * environment: a few lines of the workers' own timing on stderr when a service is destroyed.
  * Returns KVZ_HIP_OK or KVZ_HIP_ERR_INVALID (unknown key).  The environment variable KVZ_HIP_TUNE="key=value,..." presets
  * knobs at kvz_hip_init() for A/B runs of an unmodified host. */

@@ -52,11 +52,13 @@ constexpr int N_UPLOAD = 8;           // upload streams (put_rect)
 constexpr int N_WSTREAMS = 4;         // streams the worker generations rotate over (their own priority level, hence their own hardware queues)
 constexpr unsigned WRING_SLOTS = 4096;    // a power of two, more than any number of units in flight (max_threads x 16 is checked)
 constexpr int BATCH_CAP = 256;        // units per batch buffer (a larger batch leaves as several launches)
-// busy-polling phase of a caller's wait (tuning "service_spin_us"): a search takes 25-45 us, so a caller that has a core to itself polls
-// through it (1080p --me full16, 16 threads on 16 cores: 6.6 -> 7.5 frames/s against 40 us); with more callers than cores the core
-// is needed by somebody else (48 threads: 7.6 frames/s with 40 us, 6.9 with 100)
-constexpr uint64_t SPIN_NS = 100 * 1000, SPIN_CROWDED_NS = 40 * 1000;
-constexpr long NAP_NS = 5 * 1000;         // then naps of this length (the kernel rounds them up by the thread's timer slack)
+// How a caller waits for its answer (a search takes 25-45 us on the device).  With a core to itself it polls: 256 pauses, then
+// sched_yield until SPIN_NS ("service_spin_us"; 1080p --me full16, 16 threads on 16 cores: 6.6 -> 7.5 frames/s against 40 us).  With
+// more callers than cores the core is needed by somebody else: 16 pauses, sched_yield until SPIN_CROWDED_NS ("service_spin_crowded_us"),
+// then naps of NAP_NS ("service_nap_us"; the kernel adds the thread's timer slack, set to 1 us) -- measured with 32 encoder threads on
+// 16 cores: 8.3 frames/s polling for 40 us, 9.7 for 10 us, 11.6-13.1 for 0-5 us with naps of 5-10 us; 48 threads: 8.6 -> 10.6-11.2.
+constexpr uint64_t SPIN_NS = 100 * 1000, SPIN_CROWDED_NS = 5 * 1000;
+constexpr long NAP_NS = 10 * 1000;
 constexpr uint64_t WAIT_LIMIT_NS = 20ull * 1000 * 1000 * 1000;    // a request that is not answered in 20 s is a failure
 
 inline uint64_t now_ns()
@@ -109,6 +111,8 @@ struct kvz_hip_me_service {
   // resident workers
   int n_workers = 0;                                    // 0: a launch per batch
   uint64_t spin_ns = SPIN_NS;
+  long nap_ns = NAP_NS;
+  uint64_t spin_crowded_ns = SPIN_CROWDED_NS;
   bool spin_tuned = false;
   int host_cpus = 1;                                    // CPUs this process may run on
   serve_slot *wring = nullptr;                          // page-locked: WRING_SLOTS slots
@@ -340,6 +344,9 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
   // "service_workers" 0 selects the launches, and so does a service with more calling threads than the ring is sized for.
   svc->n_workers = kvzhip::tuning("service_workers", 64);
   svc->debug = getenv("KVZ_HIP_SERVICE_DEBUG") != nullptr;
+  svc->spin_crowded_ns = 1000ull * (uint64_t)kvzhip::tuning("service_spin_crowded_us", (int)(SPIN_CROWDED_NS / 1000));
+  svc->nap_ns = 1000L * kvzhip::tuning("service_nap_us", (int)(NAP_NS / 1000));
+  if (svc->nap_ns < 1000) svc->nap_ns = 1000;
   svc->spin_tuned = kvzhip::tuning("service_spin_us", -1) >= 0;
   svc->spin_ns = 1000ull * (uint64_t)kvzhip::tuning("service_spin_us", (int)(SPIN_NS / 1000));
   {
@@ -523,12 +530,13 @@ int kvz_hip_me_service_search(kvz_hip_me_service *svc, const kvz_hip_me_request 
     // A search takes tens of microseconds.  Spin through the first ones (a host with a core per worker loses nothing by it);
     // a worker that is still waiting then sleeps in short naps, so that on a host with more workers than cores the core
     // goes to a worker that has CPU work to do instead of to a poll loop.
-    if (++spins < 256) {
+    const bool crowded = !svc->spin_tuned && svc->next_thread.load(std::memory_order_relaxed) > svc->host_cpus;
+    if (++spins < (crowded ? 16 : 256)) {
       __builtin_ia32_pause();
-    } else if (now_ns() - t0 < (svc->spin_tuned || svc->next_thread.load(std::memory_order_relaxed) <= svc->host_cpus ? svc->spin_ns : SPIN_CROWDED_NS)) {
+    } else if (now_ns() - t0 < (crowded ? svc->spin_crowded_ns : svc->spin_ns)) {
       sched_yield();
     } else {
-      timespec nap = { 0, NAP_NS };
+      timespec nap = { 0, svc->nap_ns };
       nanosleep(&nap, nullptr);
       if ((spins & 255) == 0 && now_ns() - t0 > WAIT_LIMIT_NS) {
         svc->failed.store(1);
