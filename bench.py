@@ -606,6 +606,22 @@ def encoder_leg(frames=16, threads=16, timeout_s=280):
                 full_served["speedup"] = round(d["fps_served"] / d["fps_untouched"], 3) if d["fps_untouched"] else None
     except subprocess.TimeoutExpired:
         full = {"error": "timed out"}
+    # the same with twice as many encoder threads as the leg's cores: a caller that waits for the device naps, another one computes
+    full_served_2x = None
+    try:
+        r3 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "served_encode.py"), "--size", "1920x1080", "--frames", "8", "--threads", str(2 * threads),
+                             "--opts", "preset=medium,qp=32,me=full16", "--min-size", "8"],
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=150)
+        for line in r3.stdout.splitlines():
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            if "fps_served" in d:
+                full_served_2x = {k: d[k] for k in ("opts", "frames", "threads", "fps_untouched", "fps_served", "identical_bitstream", "mean_wait_us", "failed")}
+                full_served_2x["speedup"] = round(d["fps_served"] / d["fps_untouched"], 3) if d["fps_untouched"] else None
+    except subprocess.TimeoutExpired:
+        full_served_2x = {"error": "timed out"}
     out = {
         "what": "reference encoder (oracle/_ref) 1920x1080 preset medium qp 32, %d synthetic frames, threads=%d, owf auto: frames/s untouched (avx2 "
                 "strategies) and with its 2Nx2N inter searches of at least `min_pu_served` pixels answered by kvz_hip_me_service_search from all "
@@ -617,6 +633,7 @@ def encoder_leg(frames=16, threads=16, timeout_s=280):
                                         "mean_units_per_launch", "max_batch_units", "mean_wait_us", "upload_MB", "service_setup_s", "failed")} for row in rows],
         # what a served search has to beat: the reference's own kvz_search_cu_inter per CU size on this host (all reference pictures of the PU)
         "full_search_served": full_served,
+        "full_search_served_twice_the_threads": full_served_2x,
         "full_search_with_sad_tables": full,
         "cpu_search_us_per_cu": probe["cpu_search_us"] if probe else None,
         "cpu_searches_per_cu_size": probe["cpu_searches"] if probe else None,
