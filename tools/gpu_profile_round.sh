@@ -67,6 +67,8 @@ python3 tools/served_encode.py --size 1920x1080 --frames 16 --threads 16 --min-s
 KVZ_HIP_TUNE=service_workers=0 python3 tools/served_encode.py --size 1920x1080 --frames 16 --threads 16 --min-size 8,32 > $O/${TAG}_served_encode_1080p_medium_launches.jsonl 2> $O/${TAG}_prof/served1b.err || true
 KVZ_HIP_SERVICE_DEBUG=1 python3 tools/served_encode.py --size 1920x1080 --frames 16 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 8,16 --tables 16 --probe > $O/${TAG}_served_encode_1080p_full16.jsonl 2> $O/${TAG}_served_encode_1080p_full16_worker_stats.txt || true
 KVZ_HIP_TUNE=service_workers=0 python3 tools/served_encode.py --size 1920x1080 --frames 16 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 8 > $O/${TAG}_served_encode_1080p_full16_launches.jsonl 2> $O/${TAG}_prof/served2b.err || true
+python3 tools/served_encode.py --size 1920x1080 --frames 16 --opts preset=medium,qp=32,me=full16 --threads 32 --min-size 8 > $O/${TAG}_served_encode_1080p_full16_32threads.jsonl 2> $O/${TAG}_prof/served2d.err || true
+python3 tools/served_encode.py --size 1920x1080 --frames 32 --threads 32 --min-size 8,16,32 > $O/${TAG}_served_encode_1080p_medium_32threads.jsonl 2> $O/${TAG}_prof/served1c.err || true
 python3 tools/served_encode.py --size 1920x1080 --frames 4 --opts preset=medium,qp=32,me=full32 --threads 16 --min-size 8 > $O/${TAG}_served_encode_1080p_full32.jsonl 2> $O/${TAG}_prof/served2c.err || true
 python3 tools/served_encode.py --size 3840x2160 --frames 8 --threads 16 --min-size 8,32,64 --probe > $O/${TAG}_served_encode_4k_medium.jsonl 2> $O/${TAG}_prof/served3.err || true
 python3 tools/served_encode.py --size 3840x2160 --frames 8 --opts preset=medium,qp=32,me=full16 --threads 16 --min-size 8 > $O/${TAG}_served_encode_4k_full16.jsonl 2> $O/${TAG}_prof/served4.err || true
