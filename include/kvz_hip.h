@@ -96,7 +96,8 @@ KVZ_HIP_API int kvz_hip_abi_version(void);
  * iteration's first store), "pipe" / "dct_pipe" (1: the same hand placement in the 4x4 / 8x8 register kernels / the 32x32
  * transform, where it measured slower), "full_qsad" (0: the search service's exhaustive search prices positions with v_sad_u8 on
  * byte-aligned operands instead of four alignments per v_qsad_pk_u16_u8), "sample8_wave" (0: 8x8 luma blocks of the sampling entry
- * on the general path), "service_workers" (resident workgroups of the search service, 0: a launch per batch), "service_linger_us" /
+ * on the general path), "service_workers" (resident workgroups of the search service, 0: a launch per batch), "service_push" (0: the workers read the units from
+ * host memory even where the host could write them into device memory through a large BAR), "service_linger_us" /
  * "service_life_ms" (how long they stay without work / at most), "service_inflight" / "service_streams" (batches in the air and
  * launch streams of the launch-per-batch way), "service_spin_us" / "service_spin_crowded_us" / "service_nap_us" (how long a caller polls for its answer
  * before it naps: 100 us with a core per caller, 5 us and naps of 10 us with more callers than cores), "service_ticket_base_k" (tests: first ticket of the ring x 1024); the service reads its knobs when it is created.  KVZ_HIP_SERVICE_DEBUG in the

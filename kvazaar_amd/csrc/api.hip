@@ -38,7 +38,7 @@ static tune_entry g_tune[] = { { "sad_wgs_per_cu", {-1} }, { "satd8_wgs_per_cu",
                                { "sao_edge_fast", {-1} }, 
                                { "intra_rough_waves", {-1} }, { "pair_wave_kernel", {-1} }, { "qr4_wgs_per_cu", {-1} }, { "quant_wgs_per_cu", {-1} },
                                { "qr8_reg_kernel", {-1} }, { "qr8_wgs_per_cu", {-1} }, { "qr_tile_kernel", {-1} }, { "dct4_tile", {-1} }, { "dct4_wgs_per_cu", {-1} }, { "idct4_wgs_per_cu", {-1} },
-                               { "wg_chunk_min_wgs", {-1} }, { "pair_satd_threads", {-1} }, { "qr8_tile_kernel", {-1} }, { "qr_tile_pipe", {-1} }, { "pipe", {-1} }, { "dct_pipe", {-1} }, { "sample8_wave", {-1} }, { "pair_satd16_lanes", {-1} }, { "full_qsad", {-1} }, { "service_streams", {-1} }, { "service_inflight", {-1} }, { "service_workers", {-1} }, { "service_linger_us", {-1} }, { "service_life_ms", {-1} }, { "service_spin_us", {-1} }, { "service_ticket_base_k", {-1} }, { "service_nap_us", {-1} }, { "service_spin_crowded_us", {-1} } };
+                               { "wg_chunk_min_wgs", {-1} }, { "pair_satd_threads", {-1} }, { "qr8_tile_kernel", {-1} }, { "qr_tile_pipe", {-1} }, { "pipe", {-1} }, { "dct_pipe", {-1} }, { "sample8_wave", {-1} }, { "pair_satd16_lanes", {-1} }, { "full_qsad", {-1} }, { "service_streams", {-1} }, { "service_inflight", {-1} }, { "service_workers", {-1} }, { "service_linger_us", {-1} }, { "service_life_ms", {-1} }, { "service_spin_us", {-1} }, { "service_ticket_base_k", {-1} }, { "service_push", {-1} }, { "service_nap_us", {-1} }, { "service_spin_crowded_us", {-1} } };
 int tuning(const char *key, int dflt)
 {
   for (auto &e : g_tune) if (!std::strcmp(e.key, key)) { const int v = e.value.load(std::memory_order_relaxed); return v >= 0 ? v : dflt; }

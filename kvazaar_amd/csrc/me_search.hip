@@ -1111,7 +1111,7 @@ constexpr unsigned long long SERVE_SLOT_LIMIT_TICKS = 100000000ull;     // 1 s
 // thread 0 of a worker: the next ticket, or SERVE_NO_TICKET when it is time to leave (alive[me] is 0 by then).
 // ctl->tail lives in host memory; a worker reads it across PCIe every poll_period ticks (the period is the workers' number x 0.5 us
 // and their phases are spread, so SOMEBODY reads it every 0.5 us) and mirrors it in device memory, where everybody looks.
-__device__ __forceinline__ unsigned long long serve_take_ticket(serve_ring_ctl *ctl, serve_ring_dev *dev, u32 me, unsigned long long born,
+__device__ __forceinline__ unsigned long long serve_take_ticket(serve_ring_ctl *ctl, const serve_push *push, serve_ring_dev *dev, u32 me, unsigned long long born,
                                                                 unsigned long long linger_ticks, unsigned long long life_ticks,
                                                                 unsigned long long poll_period, unsigned long long &next_poll, bool &retired)
 {
@@ -1133,8 +1133,13 @@ __device__ __forceinline__ unsigned long long serve_take_ticket(serve_ring_ctl *
     if (retired) {
       from_host = sys_load64(&ctl->tail);                  // behind the store of alive[me] = 0 on the way to the host: see below
     } else if (now >= next_poll) {
-      from_host = sys_load64(&ctl->tail);
-      quit = sys_load32(&ctl->quit) != 0u;
+      if (push) {                                          // the host's copy in device memory: no PCIe read
+        from_host = sys_load64(&push->tail);
+        quit = sys_load32(&push->quit) != 0u;
+      } else {
+        from_host = sys_load64(&ctl->tail);
+        quit = sys_load32(&ctl->quit) != 0u;
+      }
       next_poll = now + poll_period;
     }
     unsigned long long tail = atomicMax(&dev->tail, from_host);
@@ -1174,8 +1179,8 @@ __device__ __forceinline__ unsigned long long serve_take_ticket(serve_ring_ctl *
 
 template <bool QSAD>
 __global__ __launch_bounds__(512) void serve_worker_kernel(const u8 *__restrict__ planes, size_t plane_bytes, int n_slots, u32 stride, int pic_w, int pic_h,
-                                                           serve_slot *ring, u32 ring_mask, serve_ring_ctl *ctl, serve_ring_dev *dev, serve_worker_ids ids,
-                                                           unsigned long long linger_ticks, unsigned long long life_ticks, unsigned long long poll_period)
+                                                           serve_slot *ring, serve_slot *host_ring, const serve_push *push, u32 ring_mask, serve_ring_ctl *ctl, serve_ring_dev *dev,
+                                                           serve_worker_ids ids, unsigned long long linger_ticks, unsigned long long life_ticks, unsigned long long poll_period)
 {
   __shared__ __attribute__((aligned(16))) u8 lds[frac_geom<64>::TOTAL];
   __shared__ me_shared sh;
@@ -1197,7 +1202,7 @@ __global__ __launch_bounds__(512) void serve_worker_kernel(const u8 *__restrict_
       // that never found an idle moment kept a whole new crowd waiting behind them).
       unsigned long long t = SERVE_NO_TICKET;
       if (!(retired && served_retired >= 2)) {
-        t = serve_take_ticket(ctl, dev, me, born, linger_ticks, life_ticks, poll_period, next_poll, retired);
+        t = serve_take_ticket(ctl, push, dev, me, born, linger_ticks, life_ticks, poll_period, next_poll, retired);
         if (t != SERVE_NO_TICKET && retired) ++served_retired;
       }
       s_ticket = t;
@@ -1234,7 +1239,7 @@ __global__ __launch_bounds__(512) void serve_worker_kernel(const u8 *__restrict_
     if (s_fail) return;
     unsigned long long t_fetched = 0;
     if (tid == 0) {
-      sys_store32(&slot->seq, 0u);                           // the host may write the slot again
+      sys_store32(&host_ring[ticket & ring_mask].seq, 0u);   // the host may write the slot again (its handshake word is the host ring's)
       t_fetched = wall_clock64();
     }
     serve_unit u;
@@ -1276,17 +1281,24 @@ __global__ __launch_bounds__(512) void serve_worker_kernel(const u8 *__restrict_
 
 }  // namespace
 
-int kvzhip::serve_workers_launch(const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h, serve_slot *ring, u32 ring_mask,
-                                 serve_ring_ctl *ctl, serve_ring_dev *dev, const serve_worker_ids &ids, int count,
+int kvzhip::serve_workers_launch_push(const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h, serve_slot *ring, serve_slot *host_ring,
+                                      const serve_push *push, u32 ring_mask, serve_ring_ctl *ctl, serve_ring_dev *dev, const serve_worker_ids &ids, int count,
                                  unsigned long long linger_ticks, unsigned long long life_ticks, unsigned long long poll_period, hipStream_t st)
 {
   if (count <= 0) return KVZ_HIP_OK;
   if (kvzhip::tuning("full_qsad", 1))
-    hipLaunchKernelGGL((serve_worker_kernel<true>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, ring, ring_mask, ctl, dev, ids, linger_ticks, life_ticks, poll_period);
+    hipLaunchKernelGGL((serve_worker_kernel<true>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, ring, host_ring, push, ring_mask, ctl, dev, ids, linger_ticks, life_ticks, poll_period);
   else
-    hipLaunchKernelGGL((serve_worker_kernel<false>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, ring, ring_mask, ctl, dev, ids, linger_ticks, life_ticks, poll_period);
+    hipLaunchKernelGGL((serve_worker_kernel<false>), dim3((unsigned)count), dim3(512), 0, st, planes, plane_bytes, n_slots, stride, w, h, ring, host_ring, push, ring_mask, ctl, dev, ids, linger_ticks, life_ticks, poll_period);
   KVZ_CHECK_LAUNCH("search service workers");
   return KVZ_HIP_OK;
+}
+
+int kvzhip::serve_workers_launch(const u8 *planes, size_t plane_bytes, int n_slots, u32 stride, int w, int h, serve_slot *ring, u32 ring_mask,
+                                 serve_ring_ctl *ctl, serve_ring_dev *dev, const serve_worker_ids &ids, int count,
+                                 unsigned long long linger_ticks, unsigned long long life_ticks, unsigned long long poll_period, hipStream_t st)
+{
+  return serve_workers_launch_push(planes, plane_bytes, n_slots, stride, w, h, ring, ring, nullptr, ring_mask, ctl, dev, ids, count, linger_ticks, life_ticks, poll_period, st);
 }
 
 // serve.hip's launch of one batch; `units` is device-visible host memory

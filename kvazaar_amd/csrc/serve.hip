@@ -31,6 +31,7 @@
 #include "kvz_hip_internal.h"
 #include "serve_seq.h"
 
+#include <immintrin.h>
 #include <sched.h>
 #include <sys/prctl.h>
 #include <time.h>
@@ -118,6 +119,8 @@ struct kvz_hip_me_service {
   serve_slot *wring = nullptr;                          // page-locked: WRING_SLOTS slots
   serve_ring_ctl *ctl = nullptr;                        // page-locked
   serve_ring_dev *wdev = nullptr;                       // device
+  serve_slot *dring = nullptr;                          // push mode: the ring's copy in fine-grained device memory, written through the BAR
+  serve_push *dpush = nullptr;                          // push mode: tail and quit for the workers, same
   std::mutex ring_mu;
   unsigned long long wtail = 0;                         // under ring_mu
   bool debug = false;                                   // KVZ_HIP_SERVICE_DEBUG: a line of worker statistics on stderr when the service is destroyed
@@ -247,8 +250,10 @@ int ensure_workers(kvz_hip_me_service *svc)
     std::atomic_thread_fence(std::memory_order_seq_cst);
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess || cur != svc->device) (void)hipSetDevice(svc->device);
-    rc = serve_workers_launch(svc->planes, svc->plane_bytes, svc->n_slots, (u32)svc->w, svc->w, svc->h, svc->wring, WRING_SLOTS - 1, ctl, svc->wdev,
-                              ids, n, svc->linger_ticks, svc->life_ticks, 50ull * (unsigned long long)svc->n_workers, svc->wstreams[svc->wnext++ % N_WSTREAMS]);
+    // poll period per worker: with the ticket count in device memory every worker looks every 0.5 us; across PCIe they take turns
+    rc = serve_workers_launch_push(svc->planes, svc->plane_bytes, svc->n_slots, (u32)svc->w, svc->w, svc->h, svc->dring ? svc->dring : svc->wring, svc->wring,
+                                   svc->dpush, WRING_SLOTS - 1, ctl, svc->wdev, ids, n, svc->linger_ticks, svc->life_ticks,
+                                   svc->dpush ? 50ull : 50ull * (unsigned long long)svc->n_workers, svc->wstreams[svc->wnext++ % N_WSTREAMS]);
     svc->st_launches.fetch_add(1, std::memory_order_relaxed);
     if (rc != KVZ_HIP_OK) {
       for (int i = 0; i < n; ++i) __atomic_store_n(&ctl->alive[ids.id[i]], 0u, __ATOMIC_RELAXED);
@@ -280,10 +285,20 @@ int post_to_ring(kvz_hip_me_service *svc, const kvz_hip_me_request *r, thread_ar
     u.prm = r->params;
     u.prm.cost_to_beat = nullptr; u.prm.cabac = nullptr; u.prm.mv_rdo = 0; u.prm.size_classes = 0;
     if (u.prm.tile_w == 0 && u.prm.tile_h == 0) { u.prm.tile_x = 0; u.prm.tile_y = 0; u.prm.tile_w = svc->w; u.prm.tile_h = svc->h; }
+    if (svc->dring) {                                     // push: the unit and its sequence word straight into device memory
+      serve_slot *ds = svc->dring + ((t0 + (unsigned)i) & (WRING_SLOTS - 1));
+      std::memcpy(&ds->u, &u, sizeof(serve_unit));
+      ds->seq = serve_seq(t0 + (unsigned)i);
+    }
     __atomic_store_n(&slot->seq, serve_seq(t0 + (unsigned)i), __ATOMIC_RELEASE);
   }
   svc->wtail = t0 + (unsigned)r->n_refs;
   __atomic_store_n(&svc->ctl->tail, svc->wtail, __ATOMIC_RELEASE);
+  if (svc->dpush) {
+    _mm_sfence();                                         // the units have left the write-combining buffers before the count that publishes them
+    *reinterpret_cast<volatile unsigned long long *>(&svc->dpush->tail) = svc->wtail;
+    _mm_sfence();
+  }
   svc->st_batches.fetch_add(1, std::memory_order_relaxed);
   svc->st_units.fetch_add((uint64_t)r->n_refs, std::memory_order_relaxed);
   return KVZ_HIP_OK;
@@ -387,6 +402,21 @@ kvz_hip_me_service *kvz_hip_me_service_create(const kvz_hip_me_service_config *c
       d0.head = base; d0.tail = base;
       ok = hipMemcpy(svc->wdev, &d0, sizeof(d0), hipMemcpyHostToDevice) == hipSuccess;
       svc->wtail = base; svc->ctl->tail = base;
+      if (svc->dpush) { *reinterpret_cast<volatile unsigned long long *>(&svc->dpush->tail) = base; _mm_sfence(); }
+    }
+    // push mode when the host can write device memory (large BAR); tuning "service_push" 0 keeps the workers reading host memory
+    int large_bar = 0;
+    if (ok && kvzhip::tuning("service_push", 1) != 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, svc->device) == hipSuccess && large_bar) {
+      bool got = hipExtMallocWithFlags((void **)&svc->dring, sizeof(serve_slot) * WRING_SLOTS, hipDeviceMallocFinegrained) == hipSuccess &&
+                 hipExtMallocWithFlags((void **)&svc->dpush, sizeof(serve_push), hipDeviceMallocFinegrained) == hipSuccess &&
+                 hipMemset(svc->dring, 0, sizeof(serve_slot) * WRING_SLOTS) == hipSuccess && hipMemset(svc->dpush, 0, sizeof(serve_push)) == hipSuccess &&
+                 hipDeviceSynchronize() == hipSuccess;
+      if (!got) {
+        (void)hipGetLastError();
+        if (svc->dring) (void)hipFree(svc->dring);
+        if (svc->dpush) (void)hipFree(svc->dpush);
+        svc->dring = nullptr; svc->dpush = nullptr;
+      }
     }
     int least = 0, greatest = 0;
     ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
@@ -416,6 +446,7 @@ void kvz_hip_me_service_destroy(kvz_hip_me_service *svc)
   if (hipGetDevice(&cur) == hipSuccess && cur != svc->device) (void)hipSetDevice(svc->device);
   if (svc->ctl) {                                       // the workers leave at their next idle moment
     __atomic_store_n(&svc->ctl->quit, 1u, __ATOMIC_SEQ_CST);
+    if (svc->dpush) { *reinterpret_cast<volatile uint32_t *>(&svc->dpush->quit) = 1u; _mm_sfence(); }
     for (int i = 0; i < N_WSTREAMS; ++i) if (svc->wstreams[i]) { (void)hipStreamSynchronize(svc->wstreams[i]); (void)hipStreamDestroy(svc->wstreams[i]); }
     if (svc->debug && svc->wdev) {
       if (svc->dbg_n_pick.load()) {
@@ -451,6 +482,8 @@ void kvz_hip_me_service_destroy(kvz_hip_me_service *svc)
   if (svc->wring) (void)hipHostFree(svc->wring);
   if (svc->ctl) (void)hipHostFree(svc->ctl);
   if (svc->wdev) (void)hipFree(svc->wdev);
+  if (svc->dring) (void)hipFree(svc->dring);
+  if (svc->dpush) (void)hipFree(svc->dpush);
   delete svc;
 }
 
