@@ -35,6 +35,7 @@ def test_c_host_runs():
 @pytest.mark.parametrize("threads,per_thread,extra,tune", [
     (4, 1500, (), ""), (16, 1500, (), ""), (48, 700, (), ""),
     (16, 1500, (), "service_workers=0"),                                  # a launch per batch instead of the resident workers
+    (16, 1500, (), "service_push=0"),                                     # resident workers that read the units from host memory (no large BAR)
     (16, 3000, ("640", "384", "4", "40"), "service_linger_us=30,service_life_ms=1"),    # workers come and go all the time
     (16, 600, ("640", "384", "4", "0", "16"), ""),                        # the exhaustive search on the whole workgroup
 ])

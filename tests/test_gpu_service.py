@@ -131,14 +131,14 @@ def test_service_requests_from_many_threads_equal_the_sequential_loop(api, case,
 
 
 @pytest.mark.parametrize("algorithm", [0, 3], ids=["hexbs", "full8"])
-@pytest.mark.parametrize("workers", [0, 64], ids=["launches", "resident_workers"])
+@pytest.mark.parametrize("workers", [0, 64, -64], ids=["launches", "resident_workers", "resident_workers_no_push"])
 def test_pictures_replaced_between_requests_are_seen(api, workers, algorithm):
     """The pictures in the slots -- the one being coded and the reference -- are overwritten between requests, dozens of times, while the
     same workgroups stay on the device: a search posted after put_rect returned must read the new pixels (nothing stale in a CU's vector
     cache, in the scalar cache the exhaustive search reads the current block through, or in an XCD's L2), whole pictures and rectangles
     alike.  The same PUs every time, so the same addresses are read over and over."""
     from kvazaar_amd import _lib
-    for key, value in ((b"service_workers", workers), (b"service_linger_us", 5000)):
+    for key, value in ((b"service_workers", abs(workers)), (b"service_linger_us", 5000), (b"service_push", 0 if workers < 0 else 1)):
         _lib.check(_lib.load().kvz_hip_set_tuning(key, value), "tuning")
     w, h = 256, 192
     prm = me_params(lambda_cost=21, algorithm=algorithm, search_range=8)
@@ -170,7 +170,7 @@ def test_pictures_replaced_between_requests_are_seen(api, workers, algorithm):
                 req["pu"][0, 0] = pus[i]
                 np.testing.assert_array_equal(svc.search(req)[0], want[(a, b)][i], err_msg="iteration %d (source %d, reference %d) PU %d" % (it, a, b, i))
     finally:
-        for key in (b"service_workers", b"service_linger_us"):
+        for key in (b"service_workers", b"service_linger_us", b"service_push"):
             _lib.load().kvz_hip_set_tuning(key, -1)
         svc.close()
 
